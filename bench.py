@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — users/sec of the CDAE training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] — ML-10M-shape synthetic (70K users x 10.6K items,
+~10M interactions, 80/20 per-user split), K=200, num_neg=5, sigmoid hidden, cross-entropy loss, AdaGrad.
+A step = one pass of the hot path (sample -> sort -> encode -> row-major decode -> hidden -> input rows)
+over one batch of `batch_users` users, cycling through the shard; with N > 1 every rank (one process per
+GPU, launched by torch.distributed.run) trains its OWN ML-10M-shaped shard (weak scaling: per-GPU work
+is fixed) and each step ends with one RCCL all-reduce of the shared-parameter deltas.
+Inputs (CSR, parameters) are resident in HBM before the timed region.  Timing: barrier +
+torch.cuda.synchronize() on both sides of exactly K steps, max over ranks; rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_user(K, n_u, n_in, num_neg):
+    """A_u = 4K[n_in + 4(n_u+m_u) + 4] + 4(n_in+n_u+m_u) + 16(n_u+m_u)."""
+    m_u = n_u * num_neg
+    return 4.0 * K * (n_in + 4.0 * (n_u + m_u) + 4.0) + 4.0 * (n_in + n_u + m_u) + 16.0 * (n_u + m_u)
+
+
+def decode_bytes_per_example(K):
+    """The decode kernel's share of A_u: per (user, output item) the reference streams the decoder row for
+    the dot and re-streams W, W_ag for the AdaGrad step (4 row streams of 4K bytes), plus the item id
+    (4 B) and b', b'_ag read+write (16 B)."""
+    return 4.0 * K * 4.0 + 4.0 + 16.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-users", type=int, default=int(os.environ.get("CDAE_BATCH_USERS", 4096)))
+    ap.add_argument("--shape", default="ml10m")
+    ap.add_argument("--num-dim", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-users", type=int, default=12000, help="users in the timed CPU-baseline sample")
+    ap.add_argument("--seed", type=int, default=20141119)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the CDAE hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import cdae_amd
+    from cdae_amd import synth
+    from cdae_amd.distributed import DeltaExchange
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # every rank owns one ML-10M-shaped shard of users over the same item space
+    data = synth.generate_shape(args.shape, seed=args.seed + 7919 * rank)
+    K, B = args.num_dim, min(args.batch_users, data.num_users)
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, num_corruptions=1,
+                              corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01,
+                              using_adagrad=True, user_factor=True, batch_users=B)
+    model = cdae_amd.CDAE(cfg, device=local_rank)
+    model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col,
+                           user_id_offset=rank * data.num_users)
+    model.init_params(args.seed)         # identical shared parameters on every rank; Wu differs but is private
+    exch = DeltaExchange(model, dist, world) if world > 1 else None
+
+    n_batches = (data.num_users + B - 1) // B
+
+    def step(i, acc):
+        b = i % n_batches
+        u0, u1 = b * B, min(data.num_users, (b + 1) * B)
+        if exch:
+            exch.begin()
+        st = model.train_users(args.seed, i // n_batches, u0, u1)
+        if exch:
+            exch.finish()
+        if acc is not None:
+            acc["users"] += st.users
+            acc["examples"] += st.examples
+            for k in ("ms_sample", "ms_sort", "ms_encode", "ms_decode", "ms_hidden", "ms_input"):
+                acc[k] += getattr(st, k)
+            acc["launches_decode"] += st.launches_decode
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, None)
+    model.set_profiling(True)             # HIP events on the library's own stream, around each kernel family
+    acc = dict(users=0, examples=0, ms_sample=0.0, ms_sort=0.0, ms_encode=0.0, ms_decode=0.0, ms_hidden=0.0,
+               ms_input=0.0, launches_decode=0)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i, acc)
+    sync()
+    elapsed = time.perf_counter() - t0
+    model.set_profiling(False)
+
+    users_total = float(acc["users"])
+    if dist is not None:
+        t = torch.tensor([elapsed, users_total], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, users_total = float(tmax[0]), float(t[1])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    n_u = data.nnz_train / data.num_users
+    n_in = n_u * (1.0 - cfg.corruption_ratio)
+    a_user = algorithmic_bytes_per_user(K, n_u, n_in, cfg.num_neg)
+    value = users_total / elapsed
+    # roofline of the dominant kernel (decode_rows_kernel), rank 0's launches
+    ex_per_launch = acc["examples"] / max(1, acc["launches_decode"])
+    ms_per_launch = acc["ms_decode"] / max(1, acc["launches_decode"])
+    alg_bytes_launch = decode_bytes_per_example(K) * ex_per_launch
+    achieved = alg_bytes_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    out = {
+        "metric": "users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity",
+        "value": value, "unit": "users/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, "
+                               f"nnz_train={data.nnz_train}, K={K}, num_neg=5, CE loss, AdaGrad, q=0.5 scaled",
+                   "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
+                   "exchange": "all-reduce of shared-parameter deltas every step" if args.gpus > 1 else "none"},
+        "roofline": {"bound": "hbm", "kernel": "decode_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": ms_per_launch,
+                     "whole_step_fraction_of_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS},
+        "kernel_ms_per_step": {k[3:]: acc[k] / args.steps for k in acc if k.startswith("ms_")},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(data, cfg, args)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(data, cfg, args):
+    """The reference's per-user sequential fp64 algorithm (oracle, literal schedule), ONE thread — the
+    reference training loop is single-threaded (cdae.hpp:136-146) — on a bounded sample."""
+    import oracle as orc
+    n = min(args.cpu_users, data.num_users)
+    ocfg = orc.OracleConfig(num_dim=cfg.num_dim, loss_type=cfg.lt, num_neg=cfg.num_neg,
+                            corruption_ratio=cfg.corruption_ratio, scaled=cfg.scaled, learn_rate=cfg.learn_rate,
+                            beta=cfg.beta, lambda_=cfg.lambda_)
+    o = orc.Oracle(ocfg, data.num_users, data.num_items, data.train_ptr, data.train_col)
+    o.init_params(args.seed)
+    o.train_literal(args.seed, 0, 0, min(200, n))     # warm caches
+    t0 = time.perf_counter()
+    o.train_literal(args.seed, 0, 0, n)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "users/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} users of the same shard, one pass of the literal cdae.hpp:136-358 restatement "
+                      f"(fp64, g++ -O3), {dt:.1f} s; host has {os.cpu_count()} logical cores"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,9 @@
+"""cdae_amd — MI355X-native CDAE training hot path (HIP kernels behind a C ABI) and its host mirror.
+
+Layout: csrc/ (gfx950 kernels + C ABI, built into lib/libcdae_hip.so), binding.py (ctypes + the
+libcf::CDAE-shaped host class), synth.py (BASELINE-shaped synthetic data), distributed.py (one process
+per GPU, RCCL all-reduce of the shared-parameter deltas).
+"""
+from .binding import (CDAE, CDAEConfig, CDAEError, CROSS_ENTROPY, SQUARE, LOGISTIC, Stats,  # noqa: F401
+                      load_library, LIB_PATH, EXPORTS)
+from . import synth  # noqa: F401

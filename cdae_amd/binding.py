@@ -1,0 +1,255 @@
+"""ctypes binding of libcdae_hip.so (include/cdae_hip.h) and a host-side mirror of libcf::CDAE.
+
+`CDAEConfig` / `CDAE` keep the field and method names of the reference's model class
+(/root/reference/src/model/recsys/cdae.hpp:13-31, 36-196) so that parity tests read like the reference's
+call sites (apps/yelp/yelp.cpp:168-199, src/solver/solver-inl.hpp:19,53,55).  There is NO CPU fallback:
+constructing a CDAE without the HIP library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcdae_hip.so")
+
+# libcf::LossType values (/root/reference/src/model/loss.hpp:10-18)
+SQUARE, LOGISTIC, LOG, HINGE, SQUARED_HINGE, CROSS_ENTROPY, LOGM = range(7)
+
+P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG = range(10)
+
+DEFAULT_BATCH_USERS = 1024
+
+
+class _Config(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "struct_size", "num_dim", "num_neg", "num_corruptions", "loss_type", "using_adagrad",
+        "asymmetric", "user_factor", "linear", "scaled", "tanh_act", "batch_users")] + [
+            (n, C.c_double) for n in ("lambda_", "learn_rate", "corruption_ratio", "beta")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("wall_seconds", C.c_double), ("users", C.c_uint64), ("examples", C.c_uint64),
+                ("batches", C.c_uint64), ("ms_sample", C.c_double), ("ms_sort", C.c_double),
+                ("ms_encode", C.c_double), ("ms_decode", C.c_double), ("ms_hidden", C.c_double),
+                ("ms_input", C.c_double), ("launches_decode", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = {
+    # name: (restype, argtypes) — every symbol include/cdae_hip.h declares
+    "cdae_hip_last_error": (C.c_char_p, []),
+    "cdae_hip_abi_version": (C.c_int, []),
+    "cdae_hip_create": (C.c_int, [C.POINTER(_Config), C.c_int, C.POINTER(C.c_void_p)]),
+    "cdae_hip_destroy": (C.c_int, [C.c_void_p]),
+    "cdae_hip_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "cdae_hip_row_stride": (C.c_uint32, [C.c_void_p]),
+    "cdae_hip_set_user_id_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cdae_hip_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cdae_hip_set_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "cdae_hip_get_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "cdae_hip_param_device_ptr": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "cdae_hip_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
+    "cdae_hip_train_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
+    "cdae_hip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "cdae_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "cdae_hip_encode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cdae_hip_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    "cdae_hip_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "cdae_hip_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "cdae_hip_delta_begin": (C.c_int, [C.c_void_p]),
+    "cdae_hip_delta_compute": (C.c_int, [C.c_void_p]),
+    "cdae_hip_delta_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "cdae_hip_delta_apply": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the C-ABI library and bind every declared export.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the CDAE hot path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class CDAEError(RuntimeError):
+    pass
+
+
+def _chk(lib, rc):
+    if rc != 0:
+        raise CDAEError(lib.cdae_hip_last_error().decode())
+
+
+@dataclass
+class CDAEConfig:
+    """libcf::CDAEConfig (/root/reference/src/model/recsys/cdae.hpp:13-31); defaults are the struct's."""
+    lambda_: float = 0.01
+    learn_rate: float = 0.1
+    lt: int = LOGISTIC
+    num_dim: int = 10
+    using_adagrad: bool = True
+    corruption_ratio: float = 0.5
+    num_corruptions: int = 1
+    asymmetric: bool = False
+    user_factor: bool = True
+    linear: bool = False
+    num_neg: int = 5
+    scaled: bool = True
+    beta: float = 0.0
+    linear_function: bool = False
+    tanh: bool = False
+    # not in the reference: users per parameter snapshot (1 == the reference's sequential schedule)
+    batch_users: int = DEFAULT_BATCH_USERS
+
+
+class CDAE:
+    """Host mirror of libcf::CDAE over the C ABI.
+
+    reset(train) ~ cdae.hpp:109-134, train_one_iteration ~ :136-146, current_loss ~ model_base.hpp:29-32,
+    pre_recommend/recommend ~ :162-196 (all users at once on the GPU, then table lookups).
+    """
+
+    def __init__(self, mcfg: CDAEConfig, device: int = 0):
+        if mcfg.linear_function:
+            raise CDAEError("linear_function (Uu) is not supported (cdae.sh:23 only ever passes false)")
+        self.lib = load_library()
+        self.cfg = mcfg
+        c = _Config(C.sizeof(_Config), mcfg.num_dim, mcfg.num_neg, mcfg.num_corruptions, mcfg.lt,
+                    int(mcfg.using_adagrad), int(mcfg.asymmetric), int(mcfg.user_factor), int(mcfg.linear),
+                    int(mcfg.scaled), int(mcfg.tanh), mcfg.batch_users, mcfg.lambda_, mcfg.learn_rate,
+                    mcfg.corruption_ratio, mcfg.beta)
+        self.h = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_create(C.byref(c), device, C.byref(self.h)))
+        self.num_users = self.num_items = 0
+        self._rec = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cdae_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ---- reset -------------------------------------------------------------------------------------
+    def set_interactions(self, num_users, num_items, row_ptr, col_idx, user_id_offset: int = 0):
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        if rp.size != num_users + 1 or ci.size != rp[-1]:
+            raise CDAEError("row_ptr / col_idx sizes do not match num_users")
+        _chk(self.lib, self.lib.cdae_hip_set_interactions(self.h, num_users, num_items, rp.ctypes.data, ci.ctypes.data))
+        _chk(self.lib, self.lib.cdae_hip_set_user_id_offset(self.h, user_id_offset))
+        self.num_users, self.num_items = int(num_users), int(num_items)
+
+    def reset(self, train, seed: int = 0):
+        """train: object with num_users, num_items, train_ptr, train_col (cdae_amd.synth.Interactions)."""
+        self.set_interactions(train.num_users, train.num_items, train.train_ptr, train.train_col)
+        self.init_params(seed)
+
+    def init_params(self, seed: int):
+        _chk(self.lib, self.lib.cdae_hip_init_params(self.h, seed))
+
+    # ---- parameters --------------------------------------------------------------------------------
+    def _shape(self, which):
+        K = self.cfg.num_dim
+        if which in (P_BP, P_BP_AG):
+            return (self.num_items,)
+        if which in (P_B, P_B_AG):
+            return (K,)
+        if which in (P_WU, P_WU_AG):
+            return (self.num_users, K)
+        return (self.num_items, K)
+
+    def get(self, which) -> np.ndarray:
+        out = np.empty(self._shape(which), dtype=np.float32)
+        _chk(self.lib, self.lib.cdae_hip_get_param(self.h, which, out.ctypes.data, out.size))
+        return out
+
+    def set(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32).reshape(self._shape(which))
+        _chk(self.lib, self.lib.cdae_hip_set_param(self.h, which, a.ctypes.data, a.size))
+
+    def param_device_ptr(self, which):
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(self.lib, self.lib.cdae_hip_param_device_ptr(self.h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- training ----------------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        _chk(self.lib, self.lib.cdae_hip_set_profiling(self.h, int(on)))
+
+    def train_one_iteration(self, seed: int, epoch: int) -> Stats:
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_train_epoch(self.h, seed, epoch, C.byref(st)))
+        return st
+
+    def train_users(self, seed: int, epoch: int, u_begin: int, u_end: int) -> Stats:
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_train_users(self.h, seed, epoch, u_begin, u_end, C.byref(st)))
+        return st
+
+    def get_hidden_values(self, uids, seed: int = 0, epoch: int = 0, mode: int = 0) -> np.ndarray:
+        u = np.ascontiguousarray(uids, dtype=np.uint32)
+        Z = np.empty((u.size, self.cfg.num_dim), dtype=np.float32)
+        _chk(self.lib, self.lib.cdae_hip_encode(self.h, seed, epoch, mode, u.ctypes.data, u.size, Z.ctypes.data))
+        return Z
+
+    def data_loss(self, seed: int, epoch: int) -> float:
+        v = C.c_double()
+        _chk(self.lib, self.lib.cdae_hip_data_loss(self.h, seed, epoch, C.byref(v)))
+        return v.value
+
+    def penalty_loss(self) -> float:
+        v = C.c_double()
+        _chk(self.lib, self.lib.cdae_hip_penalty_loss(self.h, C.byref(v)))
+        return v.value
+
+    def current_loss(self, seed: int, epoch: int) -> float:
+        return self.data_loss(seed, epoch) + self.penalty_loss()      # model_base.hpp:29-32
+
+    # ---- evaluation --------------------------------------------------------------------------------
+    def recommend_all(self, topk: int = 10, u_begin: int = 0, u_end: int | None = None) -> np.ndarray:
+        u_end = self.num_users if u_end is None else u_end
+        out = np.empty((u_end - u_begin, topk), dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_recommend_all(self.h, u_begin, u_end, topk, out.ctypes.data))
+        return out
+
+    def pre_recommend(self, topk: int = 10):
+        self._rec = self.recommend_all(topk)
+
+    def recommend(self, uid: int, topk: int = 10):
+        if self._rec is None or self._rec.shape[1] != topk:
+            self.pre_recommend(topk)
+        return self._rec[uid]
+
+    # ---- data-parallel exchange --------------------------------------------------------------------
+    def delta_begin(self):
+        _chk(self.lib, self.lib.cdae_hip_delta_begin(self.h))
+
+    def delta_compute(self):
+        _chk(self.lib, self.lib.cdae_hip_delta_compute(self.h))
+
+    def delta_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(self.lib, self.lib.cdae_hip_delta_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def delta_apply(self, world_size: int, rule: int = 0):
+        _chk(self.lib, self.lib.cdae_hip_delta_apply(self.h, world_size, rule))

@@ -1,0 +1,638 @@
+// cdae_hip.hip — host side of libcdae_hip.so: the C ABI of include/cdae_hip.h on top of the kernels
+// in cdae_kernels.hpp.  gfx950 only; no CPU fallback: every entry point needs a HIP device and fails
+// loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cstring>   // rocprim's texture_cache_iterator needs ::memset declared first
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/cdae_hip.h"
+#include "cdae_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIPCHK(expr)                                                                           \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+#define CHK(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+// launch `KERNEL<NI>` for the handle's NI (elements of a K-vector per lane)
+#define DISPATCH_NI(ni, KERNEL, grid, block, shmem, stream, ...)                                  \
+  do {                                                                                            \
+    switch (ni) {                                                                                 \
+      case 1: hipLaunchKernelGGL(KERNEL<1>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      case 2: hipLaunchKernelGGL(KERNEL<2>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      case 3: hipLaunchKernelGGL(KERNEL<3>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      case 4: hipLaunchKernelGGL(KERNEL<4>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      case 5: hipLaunchKernelGGL(KERNEL<5>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      case 6: hipLaunchKernelGGL(KERNEL<6>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      case 7: hipLaunchKernelGGL(KERNEL<7>, grid, block, shmem, stream, __VA_ARGS__); break;      \
+      default: hipLaunchKernelGGL(KERNEL<8>, grid, block, shmem, stream, __VA_ARGS__); break;     \
+    }                                                                                             \
+  } while (0)
+
+enum Family { F_SAMPLE = 0, F_SORT, F_ENCODE, F_DECODE, F_HIDDEN, F_INPUT, F_COUNT };
+
+struct Span { int family; hipEvent_t a, b; };
+
+}  // namespace
+
+struct cdae_hip {
+  cdae_hip_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t U = 0, I = 0;
+  uint32_t K = 0, Kp = 0, NI = 1, B = 0;
+  uint64_t uid_offset = 0;
+  cdae::HyperParams hp{};
+
+  std::vector<int64_t> h_row_ptr;
+  int64_t* d_row_ptr = nullptr;
+  uint32_t* d_col = nullptr;
+  uint32_t* d_item_order = nullptr;
+
+  // shared (item-side) parameters, one allocation: [W | W_ag | (V | V_ag) | bp | bp_ag | b | b_ag]
+  float* d_shared = nullptr;
+  size_t n_shared = 0, n_matrix = 0;
+  size_t off[CDAE_P_COUNT] = {0};
+  size_t cnt[CDAE_P_COUNT] = {0};   // padded element counts
+  float* d_Wu = nullptr;
+  float* d_Wu_ag = nullptr;
+
+  // batch workspace
+  uint64_t Ecap = 0;
+  uint32_t* d_ex_item = nullptr; uint32_t* d_ex_word = nullptr;
+  uint32_t* d_sorted_item = nullptr; uint32_t* d_sorted_word = nullptr;
+  void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  uint32_t* d_seg = nullptr;            // [2*I]: begin | end
+  float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
+  uint32_t* d_touched = nullptr;
+  double* d_scalar = nullptr;
+  uint32_t* d_uids = nullptr;
+  uint32_t* d_rec = nullptr; size_t rec_cap = 0;
+  int sort_bits = 1;
+
+  // data-parallel exchange
+  float* d_base = nullptr; float* d_delta = nullptr;
+
+  bool profiling = false;
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> pool;
+
+  float* P(uint32_t which) {
+    if (which == CDAE_P_WU) return d_Wu;
+    if (which == CDAE_P_WU_AG) return d_Wu_ag;
+    return cnt[which] ? d_shared + off[which] : nullptr;
+  }
+  float* dec() { return cfg.asymmetric ? P(CDAE_P_V) : P(CDAE_P_W); }
+  float* dec_ag() { return cfg.asymmetric ? P(CDAE_P_V_AG) : P(CDAE_P_W_AG); }
+};
+
+namespace {
+
+int get_event(cdae_hip* h, hipEvent_t* ev) {
+  if (!h->pool.empty()) { *ev = h->pool.back(); h->pool.pop_back(); return 0; }
+  HIPCHK(hipEventCreate(ev));
+  return 0;
+}
+struct Prof {   // RAII-less helper: begin()/end() around one kernel family launch
+  cdae_hip* h; Span s; bool on;
+  int begin(cdae_hip* hh, int family) {
+    h = hh; on = hh->profiling; if (!on) return 0;
+    s.family = family;
+    CHK(get_event(h, &s.a)); CHK(get_event(h, &s.b));
+    HIPCHK(hipEventRecord(s.a, h->stream));
+    return 0;
+  }
+  int end() {
+    if (!on) return 0;
+    HIPCHK(hipEventRecord(s.b, h->stream));
+    h->spans.push_back(s);
+    return 0;
+  }
+};
+
+int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
+  double ms[F_COUNT] = {0};
+  uint64_t launches[F_COUNT] = {0};
+  for (Span& s : h->spans) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, s.a, s.b));
+    ms[s.family] += t;
+    launches[s.family]++;
+    h->pool.push_back(s.a); h->pool.push_back(s.b);
+  }
+  h->spans.clear();
+  if (st) {
+    st->ms_sample = ms[F_SAMPLE]; st->ms_sort = ms[F_SORT]; st->ms_encode = ms[F_ENCODE];
+    st->ms_decode = ms[F_DECODE]; st->ms_hidden = ms[F_HIDDEN]; st->ms_input = ms[F_INPUT];
+    st->launches_decode = launches[F_DECODE];
+  }
+  return 0;
+}
+
+void free_all(cdae_hip* h) {
+  void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_ex_item,
+                  h->d_ex_word, h->d_sorted_item, h->d_sorted_word, h->d_sort_tmp, h->d_seg, h->d_Z, h->d_Dz,
+                  h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec, h->d_base, h->d_delta};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
+  for (Span& s : h->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+int free_interaction_state(cdae_hip* h) {
+  void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
+                   (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_ex_item, (void**)&h->d_ex_word,
+                   (void**)&h->d_sorted_item, (void**)&h->d_sorted_word, (void**)&h->d_sort_tmp, (void**)&h->d_seg,
+                   (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta};
+  for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+  h->rec_cap = 0;
+  return 0;
+}
+
+template <class T> int dev_alloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+  return 0;
+}
+
+// one batch of train_one_user_corruption for users [s0, s0+nb), corruption cidx
+int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch, uint64_t* n_ex_out) {
+  using namespace cdae;
+  const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
+  *n_ex_out = E;
+  if (E == 0) return 0;
+  if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I;
+  const dim3 blk(256);
+  const dim3 grid_users((nb + 3) / 4), grid_rows((I + 3) / 4);
+  Prof pr;
+
+  CHK(pr.begin(h, F_SAMPLE));
+  hipLaunchKernelGGL(sample_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, s0, nb, cidx, seed, epoch,
+                     h->d_ex_item, h->d_ex_word);
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_SORT));
+  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_word,
+                                   h->d_sorted_word, (size_t)E, 0u, (unsigned)h->sort_bits, st));
+  HIPCHK(hipMemsetAsync(h->d_seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(segment_kernel, dim3((uint32_t)((E + 255) / 256)), blk, 0, st, h->d_sorted_item, (uint32_t)E,
+                     h->d_seg, h->d_seg + I);
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_ENCODE));
+  DISPATCH_NI(h->NI, encode_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), h->d_Wu,
+              h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Z, h->d_Dz);
+  HIPCHK(hipMemsetAsync(h->d_HG, 0, (size_t)nb * h->Kp * sizeof(float), st));
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_DECODE));
+  DISPATCH_NI(h->NI, decode_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, h->d_seg, h->d_seg + I,
+              h->d_sorted_word, h->d_Z, h->dec(), h->dec_ag(), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G,
+              h->d_touched);
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_HIDDEN));
+  DISPATCH_NI(h->NI, hidden_user_kernel, grid_users, blk, 0, st, h->hp, s0, nb, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag);
+  hipLaunchKernelGGL(hidden_bias_kernel, dim3((h->K + 63) / 64), dim3(64), 0, st, h->hp, nb, h->d_HG, h->P(CDAE_P_B),
+                     h->P(CDAE_P_B_AG));
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_INPUT));
+  DISPATCH_NI(h->NI, input_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, h->d_seg, h->d_seg + I,
+              h->d_sorted_word, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched);
+  CHK(pr.end());
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream_id,
+                 uint32_t cidx, uint64_t seed, uint32_t epoch) {
+  DISPATCH_NI(h->NI, cdae::encode_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+              h->P(CDAE_P_W), h->d_Wu, h->P(CDAE_P_B), d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Z,
+              (float*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int copy_param_out(cdae_hip* h, uint32_t which, float* host, size_t count) {
+  float* d = h->P(which);
+  if (!d) return count == 0 ? 0 : fail("parameter %u is not allocated in this configuration", which);
+  const bool vec = (which == CDAE_P_BP || which == CDAE_P_BP_AG);
+  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
+  if (vec) {
+    if (count != h->I) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)h->I, count);
+    HIPCHK(hipMemcpyAsync(host, d, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
+    HIPCHK(hipMemcpy2DAsync(host, h->K * sizeof(float), d, h->Kp * sizeof(float), h->K * sizeof(float), rows,
+                            hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cdae_hip_last_error(void) { return g_err.c_str(); }
+int cdae_hip_abi_version(void) { return CDAE_HIP_ABI_VERSION; }
+
+int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out) {
+  if (!cfg || !out) return fail("null argument");
+  if (cfg->struct_size != sizeof(cdae_hip_config)) return fail("cdae_hip_config size mismatch: got %u, want %zu", cfg->struct_size, sizeof(cdae_hip_config));
+  if (cfg->num_dim == 0 || cfg->num_dim > 512) return fail("num_dim must be in [1, 512], got %u", cfg->num_dim);
+  if (cfg->loss_type != CDAE_LOSS_SQUARE && cfg->loss_type != CDAE_LOSS_CROSS_ENTROPY)
+    return fail("loss_type %u unsupported: CDAE's linear output only works with SQUARE (0) and CROSS_ENTROPY (5); "
+                "LOGISTIC aborts in the reference (loss.hpp:96)", cfg->loss_type);
+  if (cfg->num_corruptions == 0) return fail("num_corruptions must be >= 1");
+  if (cfg->scaled && !(cfg->corruption_ratio < 1.0)) return fail("scaled input needs corruption_ratio < 1");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail("device %d not available (%d HIP devices)", device_id, ndev);
+  HIPCHK(hipSetDevice(device_id));
+  cdae_hip* h = new cdae_hip();
+  h->cfg = *cfg;
+  h->device = device_id;
+  h->K = cfg->num_dim;
+  h->Kp = (cfg->num_dim + 3u) & ~3u;
+  h->NI = (cfg->num_dim + 63u) / 64u;
+  h->B = cfg->batch_users ? cfg->batch_users : 1024u;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
+  e = hipMalloc((void**)&h->d_scalar, 8 * sizeof(double));
+  if (e != hipSuccess) { free_all(h); delete h; return fail("hipMalloc failed: %s", hipGetErrorString(e)); }
+  cdae::HyperParams& hp = h->hp;
+  hp.lambda = (float)cfg->lambda; hp.lr = (float)cfg->learn_rate; hp.beta = (float)cfg->beta;
+  hp.scale = cfg->scaled ? (float)(1.0 / (1.0 - cfg->corruption_ratio)) : 1.f;     // cdae.hpp:202-205
+  hp.num_neg = cfg->num_neg; hp.loss_type = cfg->loss_type;
+  hp.adagrad = cfg->using_adagrad; hp.asymmetric = cfg->asymmetric; hp.user_factor = cfg->user_factor;
+  hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act;
+  hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
+  hp.uid_offset = 0; hp.num_items = 0; hp.K = h->K; hp.Kp = h->Kp;
+  *out = h;
+  return 0;
+}
+
+int cdae_hip_destroy(cdae_hip_t* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  free_all(h);
+  delete h;
+  return 0;
+}
+
+uint32_t cdae_hip_row_stride(const cdae_hip_t* h) { return h ? h->Kp : 0; }
+
+int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t offset) {
+  if (!h) return fail("null handle");
+  h->uid_offset = offset; h->hp.uid_offset = offset;
+  return 0;
+}
+
+int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64_t* row_ptr, const uint32_t* col) {
+  if (!h || !row_ptr || (!col && U && row_ptr[U])) return fail("null argument");
+  if (U == 0 || I == 0) return fail("empty interaction matrix (%llu users, %llu items)", (unsigned long long)U, (unsigned long long)I);
+  if (I >= (1ull << 30) || U >= (1ull << 30)) return fail("at most 2^30 users and items");
+  if (row_ptr[0] != 0) return fail("row_ptr[0] must be 0");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<uint64_t> pop(I, 0);
+  for (uint64_t u = 0; u < U; ++u) {
+    const int64_t a = row_ptr[u], b = row_ptr[u + 1];
+    if (b <= a) return fail("user %llu has no training item (the reference CHECK-fails too, cdae.hpp:139)", (unsigned long long)u);
+    if ((uint64_t)(b - a) >= I) return fail("user %llu rated every item: no negative can be sampled", (unsigned long long)u);
+    for (int64_t p = a; p < b; ++p) {
+      if (col[p] >= I) return fail("item id %u out of range at position %lld", col[p], (long long)p);
+      if (p > a && col[p] <= col[p - 1]) return fail("row %llu is not strictly ascending at position %lld", (unsigned long long)u, (long long)p);
+      pop[col[p]]++;
+    }
+  }
+  CHK(free_interaction_state(h));
+  h->U = U; h->I = I; h->hp.num_items = (uint32_t)I;
+  h->h_row_ptr.assign(row_ptr, row_ptr + U + 1);
+  const size_t nnz = (size_t)row_ptr[U];
+  CHK(dev_alloc(&h->d_row_ptr, U + 1));
+  CHK(dev_alloc(&h->d_col, nnz));
+  HIPCHK(hipMemcpy(h->d_row_ptr, row_ptr, (U + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(h->d_col, col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+  // decode launch order: most popular rows first (their example chains are the longest)
+  std::vector<uint32_t> order(I);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pop[a] > pop[b]; });
+  CHK(dev_alloc(&h->d_item_order, (size_t)I));
+  HIPCHK(hipMemcpy(h->d_item_order, order.data(), I * sizeof(uint32_t), hipMemcpyHostToDevice));
+
+  // parameters
+  const size_t IK = (size_t)I * h->Kp;
+  size_t o = 0;
+  std::memset(h->off, 0, sizeof h->off); std::memset(h->cnt, 0, sizeof h->cnt);
+  auto place = [&](uint32_t id, size_t n) { h->off[id] = o; h->cnt[id] = n; o += n; };
+  place(CDAE_P_W, IK); place(CDAE_P_W_AG, IK);
+  if (h->cfg.asymmetric) { place(CDAE_P_V, IK); place(CDAE_P_V_AG, IK); }
+  h->n_matrix = o;
+  place(CDAE_P_BP, I); place(CDAE_P_BP_AG, I);
+  place(CDAE_P_B, h->Kp); place(CDAE_P_B_AG, h->Kp);
+  h->n_shared = o;
+  CHK(dev_alloc(&h->d_shared, h->n_shared));
+  HIPCHK(hipMemset(h->d_shared, 0, h->n_shared * sizeof(float)));
+  h->cnt[CDAE_P_WU] = h->cnt[CDAE_P_WU_AG] = (size_t)U * h->Kp;
+  CHK(dev_alloc(&h->d_Wu, (size_t)U * h->Kp));
+  CHK(dev_alloc(&h->d_Wu_ag, (size_t)U * h->Kp));
+  HIPCHK(hipMemset(h->d_Wu, 0, (size_t)U * h->Kp * sizeof(float)));
+  HIPCHK(hipMemset(h->d_Wu_ag, 0, (size_t)U * h->Kp * sizeof(float)));
+
+  // batch workspace sized for the largest batch of B consecutive users
+  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, U);
+  uint64_t emax = 0;
+  for (uint64_t s0 = 0; s0 < U; ++s0) {   // any window [s0, s0+B) may be requested by train_users
+    const uint64_t s1 = std::min<uint64_t>(U, s0 + B);
+    emax = std::max<uint64_t>(emax, (uint64_t)(row_ptr[s1] - row_ptr[s0]));
+  }
+  h->Ecap = emax * (1u + h->cfg.num_neg);
+  if (h->Ecap > 0xFFFFFFF0ull) return fail("batch of %u users holds %llu examples (> 2^32); lower batch_users", B, (unsigned long long)h->Ecap);
+  CHK(dev_alloc(&h->d_ex_item, h->Ecap)); CHK(dev_alloc(&h->d_ex_word, h->Ecap));
+  CHK(dev_alloc(&h->d_sorted_item, h->Ecap)); CHK(dev_alloc(&h->d_sorted_word, h->Ecap));
+  CHK(dev_alloc(&h->d_G, h->Ecap));
+  h->sort_bits = 1;
+  while ((1ull << h->sort_bits) < I) h->sort_bits++;
+  h->sort_tmp_bytes = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_word,
+                                   h->d_sorted_word, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
+  CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
+  CHK(dev_alloc(&h->d_seg, 2 * (size_t)I));
+  const size_t BK = (size_t)B * h->Kp;
+  CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
+  CHK(dev_alloc(&h->d_touched, (size_t)I));
+  HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
+  CHK(dev_alloc(&h->d_uids, (size_t)B));
+  return 0;
+}
+
+int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  using namespace cdae;
+  const double init_scale = 4. * std::sqrt(6. / (double)(h->I + h->K));          // cdae.hpp:112
+  auto blocks = [](size_t n) { return dim3((uint32_t)((n + 255) / 256)); };
+  auto init = [&](float* M, size_t rows, uint32_t id) {
+    hipLaunchKernelGGL(init_matrix_kernel, blocks(rows * h->Kp), dim3(256), 0, h->stream, M, rows, h->K, h->Kp,
+                       cdae_rng_key(seed, 0, id, CDAE_STREAM_INIT), init_scale);
+  };
+  auto fill = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v) {
+    hipLaunchKernelGGL(fill_matrix_kernel, blocks(rows * Kp), dim3(256), 0, h->stream, M, rows, K, Kp, v);
+  };
+  init(h->P(CDAE_P_W), h->I, CDAE_P_W); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
+  if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
+  if (h->cfg.user_factor) { init(h->d_Wu, h->U, CDAE_P_WU); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }   // :119-122
+  else { fill(h->d_Wu, h->U, h->K, h->Kp, 0.f); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }
+  fill(h->P(CDAE_P_B), 1, h->K, h->Kp, 0.f); fill(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f);    // :123-124
+  fill(h->P(CDAE_P_BP), h->I, 1, 1, 0.f); fill(h->P(CDAE_P_BP_AG), h->I, 1, 1, 1e-4f);          // :125-126
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t count) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if (which >= CDAE_P_COUNT || !host) return fail("bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  float* d = h->P(which);
+  if (!d) return fail("parameter %u is not allocated in this configuration", which);
+  if (which == CDAE_P_BP || which == CDAE_P_BP_AG) {
+    if (count != h->I) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)h->I, count);
+    HIPCHK(hipMemcpy(d, host, count * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+  }
+  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
+  if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
+  HIPCHK(hipMemset(d, 0, rows * h->Kp * sizeof(float)));
+  HIPCHK(hipMemcpy2D(d, h->Kp * sizeof(float), host, h->K * sizeof(float), h->K * sizeof(float), rows, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int cdae_hip_get_param(cdae_hip_t* h, uint32_t which, float* host, size_t count) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if (which >= CDAE_P_COUNT || !host) return fail("bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  return copy_param_out(h, which, host, count);
+}
+
+int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, size_t* padded_count) {
+  if (!h || !h->d_shared || which >= CDAE_P_COUNT || !device_ptr) return fail("bad argument");
+  *device_ptr = h->P(which);
+  if (padded_count) *padded_count = h->cnt[which];
+  return 0;
+}
+
+int cdae_hip_set_profiling(cdae_hip_t* h, int enabled) {
+  if (!h) return fail("null handle");
+  h->profiling = enabled != 0;
+  return 0;
+}
+
+int cdae_hip_synchronize(cdae_hip_t* h) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end, cdae_hip_stats* stats) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if (u_begin > u_end || u_end > h->U) return fail("bad user range [%llu, %llu)", (unsigned long long)u_begin, (unsigned long long)u_end);
+  HIPCHK(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  uint64_t examples = 0, batches = 0, users = 0;
+  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
+  for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
+    for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) {       // cdae.hpp:141
+      uint64_t e = 0;
+      CHK(run_batch(h, s0, nb, c, seed, epoch, &e));
+      examples += e; batches++; users += nb;
+    }
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->users = users; stats->examples = examples; stats->batches = batches;
+  }
+  if (h->profiling) CHK(collect_profile(h, stats));
+  if (stats) stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats) {
+  if (!h) return fail("null handle");
+  return cdae_hip_train_users(h, seed, epoch, 0, h->U, stats);
+}
+
+int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, const uint32_t* uids, size_t n, float* Z) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if ((!uids || !Z) && n) return fail("null argument");
+  if (mode != 0 && mode != 1) return fail("mode must be 0 or 1");
+  HIPCHK(hipSetDevice(h->device));
+  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
+  for (size_t i = 0; i < n; ++i) if (uids[i] >= h->U) return fail("user id %u out of range", uids[i]);
+  for (size_t c0 = 0; c0 < n; c0 += B) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(B, n - c0);
+    HIPCHK(hipMemcpyAsync(h->d_uids, uids + c0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    CHK(encode_chunk(h, h->d_uids, 0, nb, mode, CDAE_STREAM_CORRUPT, 0, seed, epoch));
+    HIPCHK(hipMemcpy2DAsync(Z + c0 * h->K, h->K * sizeof(float), h->d_Z, h->Kp * sizeof(float), h->K * sizeof(float), nb,
+                            hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out) {
+  if (!h || !h->d_shared || !out) return fail("bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
+  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
+  for (uint64_t s0 = 0; s0 < h->U; s0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, h->U - s0);
+    for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) {       // cdae.hpp:86
+      CHK(encode_chunk(h, nullptr, s0, nb, 1, CDAE_STREAM_LOSS_CORRUPT, c, seed, epoch));
+      DISPATCH_NI(h->NI, cdae::data_loss_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+                  s0, nb, h->d_Z, h->dec(), h->P(CDAE_P_BP), h->d_scalar);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  double v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *out = v / (double)h->cfg.num_corruptions;                      // cdae.hpp:98
+  return 0;
+}
+
+int cdae_hip_penalty_loss(cdae_hip_t* h, double* out) {
+  if (!h || !h->d_shared || !out) return fail("bad argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
+  auto add = [&](const float* p, size_t n) {
+    if (p && n) hipLaunchKernelGGL(cdae::sqnorm_kernel, dim3((uint32_t)std::min<size_t>(2048, (n + 255) / 256)), dim3(256), 0,
+                                   h->stream, p, n, h->d_scalar);
+  };
+  // cdae.hpp:104-106: W, V, Wu, b, b_prime (pad lanes are zero)
+  add(h->P(CDAE_P_W), h->cnt[CDAE_P_W]);
+  add(h->P(CDAE_P_V), h->cnt[CDAE_P_V]);
+  if (h->cfg.user_factor) add(h->d_Wu, h->cnt[CDAE_P_WU]);
+  add(h->P(CDAE_P_B), h->cnt[CDAE_P_B]);
+  add(h->P(CDAE_P_BP), h->cnt[CDAE_P_BP]);
+  HIPCHK(hipGetLastError());
+  double v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *out = 0.5 * h->cfg.lambda * v;
+  return 0;
+}
+
+int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out) {
+  if (!h || !h->d_shared || !out) return fail("bad argument");
+  if (u_begin > u_end || u_end > h->U) return fail("bad user range");
+  if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
+  HIPCHK(hipSetDevice(h->device));
+  const size_t shmem = (size_t)h->I * sizeof(float) + 64;
+  if (shmem > 160 * 1024) return fail("recommend: %llu items exceed the 160 KiB LDS score buffer", (unsigned long long)h->I);
+  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
+  if (h->rec_cap < (size_t)B * topk) {
+    if (h->d_rec) HIPCHK(hipFree(h->d_rec));
+    h->d_rec = nullptr;
+    CHK(dev_alloc(&h->d_rec, (size_t)B * topk));
+    h->rec_cap = (size_t)B * topk;
+  }
+#define SET_SHMEM(NI_) HIPCHK(hipFuncSetAttribute((const void*)cdae::recommend_kernel<NI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+  switch (h->NI) { case 1: SET_SHMEM(1); break; case 2: SET_SHMEM(2); break; case 3: SET_SHMEM(3); break; case 4: SET_SHMEM(4); break;
+                   case 5: SET_SHMEM(5); break; case 6: SET_SHMEM(6); break; case 7: SET_SHMEM(7); break; default: SET_SHMEM(8); break; }
+#undef SET_SHMEM
+  for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
+    CHK(encode_chunk(h, nullptr, s0, nb, 0, CDAE_STREAM_CORRUPT, 0, 0, 0));      // cdae.hpp:167-172
+    DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, s0,
+                h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+// ---- data-parallel exchange ---------------------------------------------------------------------
+int cdae_hip_delta_begin(cdae_hip_t* h) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_base) { CHK(dev_alloc(&h->d_base, h->n_shared)); CHK(dev_alloc(&h->d_delta, h->n_shared + h->I)); }
+  HIPCHK(hipMemcpyAsync(h->d_base, h->d_shared, h->n_shared * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_touched, 0, h->I * sizeof(uint32_t), h->stream));
+  return 0;
+}
+
+int cdae_hip_delta_compute(cdae_hip_t* h) {
+  if (!h || !h->d_base) return fail("delta_begin must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(cdae::delta_kernel, dim3((uint32_t)((h->n_shared + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
+                     h->d_base, h->d_delta, h->n_shared);
+  hipLaunchKernelGGL(cdae::touch_to_float_kernel, dim3((uint32_t)((h->I + 255) / 256)), dim3(256), 0, h->stream, h->d_touched,
+                     h->d_delta + h->n_shared, (uint32_t)h->I);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats) {
+  if (!h || !h->d_delta || !device_ptr) return fail("delta_begin must be called first");
+  *device_ptr = h->d_delta;
+  if (count_floats) *count_floats = h->n_shared + h->I;
+  return 0;
+}
+
+int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
+  if (!h || !h->d_delta) return fail("delta_begin must be called first");
+  if (world_size == 0) return fail("world_size must be >= 1");
+  if (rule > CDAE_DELTA_TOUCH_MEAN) return fail("unknown delta rule %u", rule);
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(cdae::apply_delta_kernel, dim3((uint32_t)((h->n_shared + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
+                     h->d_base, h->d_delta, h->d_delta + h->n_shared, h->n_matrix, h->Kp, (uint32_t)h->I, h->n_shared, world_size, rule);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+}  // extern "C"

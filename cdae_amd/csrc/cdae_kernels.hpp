@@ -1,0 +1,562 @@
+// cdae_kernels.hpp — gfx950 device kernels of the CDAE training hot path.
+//
+// Replaces, per batch of users, the body of CDAE::train_one_iteration
+// (/root/reference/src/model/recsys/cdae.hpp:136-146) and train_one_user_corruption (cdae.hpp:198-358).
+// The reference's loop nest is   for user: { encode; for output item: {dot, loss', row step} ; hidden ; input rows }.
+// Here the decode loop nest is TRANSPOSED: for item row: for (user, target) example of the batch in
+// user order: {dot, loss', row step}.  A row lives in the registers of one wavefront for the whole
+// batch, every dot product sees every earlier update of that row exactly as in the reference, and W /
+// W_ag cross HBM once per batch instead of once per (user, item) touch.  Only the encode (z_u) and the
+// hidden gradient are computed from the batch-start snapshot (DESIGN.md "Schedule").
+//
+// Register layout of a K-vector: lane l of a 64-wide wavefront holds elements k = l + 64*i, i < NI
+// (each load/atomic instruction of the wave then covers 256 contiguous bytes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cdae_rng.h"
+
+namespace cdae {
+
+constexpr int WAVE = 64;
+constexpr uint32_t SLOT_MASK = 0x3FFFFFFFu;   // example word: slot | target << 30 | is_input << 31
+constexpr uint32_t TARGET_BIT = 1u << 30;
+constexpr uint32_t INPUT_BIT = 1u << 31;
+
+struct HyperParams {
+  float lambda, lr, beta, scale;
+  uint32_t num_neg;
+  uint32_t loss_type;        // 0 SQUARE, 5 CROSS_ENTROPY (loss.hpp:10-18)
+  uint32_t adagrad, asymmetric, user_factor, linear, tanh_act;
+  uint64_t keep_thr;         // cdae_keep_threshold(q)
+  uint64_t uid_offset;       // global id of local user 0 (data-parallel shards keep global random streams)
+  uint32_t num_items;
+  uint32_t K, Kp;            // num_dim and row stride (floats)
+};
+
+// ------------------------------------------------------------------------------------------------
+// scalar math (fp32, hardware transcendental units)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+// loss.hpp:53-55 (SQUARE), loss.hpp:141-147 (CROSS_ENTROPY)
+__device__ __forceinline__ float loss_grad(uint32_t loss_type, float pred, float truth) {
+  if (loss_type == 0u) return -2.f * (truth - pred);
+  if (pred < -18.f) return fast_exp(pred) - truth;
+  if (pred > 18.f) return 1.f - truth;
+  return fast_rcp(1.f + fast_exp(-pred)) - truth;
+}
+// loss.hpp:48-51, 132-139
+__device__ __forceinline__ float loss_eval(uint32_t loss_type, float pred, float truth) {
+  if (loss_type == 0u) { float e = truth - pred; return e * e; }
+  float ret = (1.f - truth) * pred;
+  if (pred > 18.f) return ret + fast_exp(-pred);
+  if (pred < -18.f) return ret - pred;
+  return ret + log1pf(fast_exp(-pred));
+}
+// cdae.hpp:391-414
+__device__ __forceinline__ float activate(const HyperParams& hp, float x) {
+  if (hp.linear) return x;
+  if (!hp.tanh_act) return x > 18.f ? 1.f : (x < -18.f ? 0.f : fast_rcp(1.f + fast_exp(-x)));
+  if (x > 9.f) return 1.f;
+  if (x < -9.f) return -1.f;
+  float r = fast_exp(-2.f * x);
+  return (1.f - r) * fast_rcp(1.f + r);
+}
+// cdae.hpp:208-215
+__device__ __forceinline__ float act_deriv(const HyperParams& hp, float z) {
+  return hp.linear ? 1.f : (hp.tanh_act ? 1.f - z * z : z - z * z);
+}
+// one coordinate of every `if (using_adagrad_) {...} p -= lr*grad` block (e.g. cdae.hpp:252-257)
+__device__ __forceinline__ void ada_step(const HyperParams& hp, float& p, float& acc, float grad) {
+  if (hp.adagrad) {
+    acc = fmaf(grad, grad, acc);
+    grad = grad * fast_rcp(fast_sqrt(acc) + hp.beta);
+  }
+  p = fmaf(-hp.lr, grad, p);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  sample: dropout keep-mask + rejection-sampled negatives -> example list of the batch.
+// get_corrputed_input (cdae.hpp:361-371) and sample_negative_item (recsys_model_base.hpp:46-57,
+// call site cdae.hpp:217-220).  One wavefront per user; integer-only.
+// Example e of user slot s sits at ex_base(s) + j, j < n_u positives then j - n_u < n_u*num_neg negatives.
+__global__ void __launch_bounds__(256)
+sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+              uint64_t u0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch,
+              uint32_t* __restrict__ ex_item, uint32_t* __restrict__ ex_word) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint32_t m = n * hp.num_neg;
+  const uint32_t* row = col + r0;
+  const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
+  const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
+  const uint64_t key_n = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_NEGATIVE);
+  for (uint32_t p = lane; p < n; p += WAVE) {
+    const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+    ex_item[base + p] = row[p];
+    ex_word[base + p] = slot | TARGET_BIT | ((keep && !hp.asymmetric) ? INPUT_BIT : 0u);
+  }
+  for (uint32_t i = lane; i < m; i += WAVE) {
+    ex_item[base + n + i] = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
+    ex_word[base + n + i] = slot;
+  }
+}
+
+// first / one-past-last sorted position of every item that has examples (others keep 0,0)
+__global__ void __launch_bounds__(256)
+segment_kernel(const uint32_t* __restrict__ sorted_item, uint32_t n_ex, uint32_t* __restrict__ seg_begin,
+               uint32_t* __restrict__ seg_end) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_ex) return;
+  const uint32_t it = sorted_item[p];
+  if (p == 0 || sorted_item[p - 1] != it) seg_begin[it] = p;
+  if (p + 1 == n_ex || sorted_item[p + 1] != it) seg_end[it] = p + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  encode: z_u = act(scale * sum_{i in In(u)} W[i] + b + Wu[u])   (get_hidden_values, cdae.hpp:373-416)
+// One wavefront per user.  mode 0: all train items, scale 1 (inference, cdae.hpp:169);
+// mode 1: dropout mask of stream `stream`, scale hp.scale (training cdae.hpp:207, data_loss cdae.hpp:92).
+// HBM-bound coalesced gather: each kept row is NI x 256-byte wave loads; four rows in flight.
+template <int NI>
+__global__ void __launch_bounds__(256)
+encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+              const float* __restrict__ W, const float* __restrict__ Wu, const float* __restrict__ b,
+              const uint32_t* __restrict__ uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream,
+              uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Z, float* __restrict__ Dz) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = uids ? (uint64_t)uids[slot] : u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint32_t* row = col + r0;
+  const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, stream);
+  const bool none = (mode == 0 && hp.keep_thr == 0x100000000ull);   // cdae.hpp:168-172 (q == 1 -> empty input)
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  for (uint32_t p0 = 0; p0 < n && !none; p0 += WAVE) {
+    const uint32_t p = p0 + lane;
+    uint32_t item = 0;
+    int keep = 0;
+    if (p < n) {
+      item = row[p];
+      keep = mode == 0 ? 1 : cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+    }
+    unsigned long long mask = __ballot(keep);
+    while (mask) {
+      // up to four kept rows per trip, summed in ascending item order
+      uint32_t it[4];
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (mask) {
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          it[j] = __shfl(item, src, WAVE);
+          cnt = j + 1;
+        } else {
+          it[j] = 0;
+        }
+      }
+      float v[4][NI];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const uint32_t k = lane + WAVE * i;
+          v[j][i] = (j < cnt && k < hp.K) ? W[(size_t)it[j] * hp.Kp + k] : 0.f;
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += v[j][i];
+    }
+  }
+  const float sc = mode == 0 ? 1.f : hp.scale;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    if (k < hp.K) {
+      float h = acc[i] * sc + b[k];
+      if (hp.user_factor) h += Wu[(size_t)uid * hp.Kp + k];
+      const float z = activate(hp, h);
+      Z[(size_t)slot * hp.Kp + k] = z;
+      if (Dz) Dz[(size_t)slot * hp.Kp + k] = act_deriv(hp, z);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  decode, row-major: positives loop cdae.hpp:225-260 and negatives loop cdae.hpp:262-293, for all
+// users of the batch at once.  One wavefront owns item row j: D[j], D_ag[j], b'[j], b'_ag[j] stay in
+// registers while it walks the row's examples in user order:
+//   y = D[j].z_u + b'[j] (cdae.hpp:227/263, 418-426);  g = loss'(y, t) (:228/:265);
+//   b'[j] step (:230-237/:267-274);  hg_u += g * D[j] with the pre-update row (:240,:248/:277,:285);
+//   row step grad = g z_u + lambda D[j] (:241-246,:252-257/:278-283,:286-291), or, when j is one of u's
+//   kept inputs in tied mode, defer g for the merged input-row step (:249-250).
+// D = V when asymmetric else W.  Rows are visited in `item_order` (popular rows first: their chains
+// are the longest).
+template <int NI>
+__global__ void __launch_bounds__(256)
+decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
+                   const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                   const uint32_t* __restrict__ sorted_word, const float* __restrict__ Z,
+                   float* __restrict__ D, float* __restrict__ D_ag, float* __restrict__ bp,
+                   float* __restrict__ bp_ag, float* __restrict__ HG, float* __restrict__ Gdefer,
+                   uint32_t* __restrict__ touched) {
+  const uint32_t rank = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (rank >= hp.num_items) return;
+  const uint32_t item = item_order[rank];
+  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  if (beg == end) return;
+  float w[NI], a[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    w[i] = k < hp.K ? D[(size_t)item * hp.Kp + k] : 0.f;
+    a[i] = k < hp.K ? D_ag[(size_t)item * hp.Kp + k] : 1.f;
+  }
+  float bias = bp[item], bias_ag = bp_ag[item];
+  // one-ahead prefetch of the example word and of z
+  uint32_t word = sorted_word[beg];
+  float z[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    z[i] = k < hp.K ? Z[(size_t)(word & SLOT_MASK) * hp.Kp + k] : 0.f;
+  }
+  for (uint32_t p = beg; p < end; ++p) {
+    const uint32_t cur = word;
+    float zc[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) zc[i] = z[i];
+    if (p + 1 < end) {
+      word = sorted_word[p + 1];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t k = lane + WAVE * i;
+        z[i] = k < hp.K ? Z[(size_t)(word & SLOT_MASK) * hp.Kp + k] : 0.f;
+      }
+    }
+    const uint32_t slot = cur & SLOT_MASK;
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dot = fmaf(w[i], zc[i], dot);
+    const float y = wave_sum(dot) + bias;
+    const float g = loss_grad(hp.loss_type, y, (cur & TARGET_BIT) ? 1.f : 0.f);
+    ada_step(hp, bias, bias_ag, g + hp.lambda * bias);
+    float* hg = HG + (size_t)slot * hp.Kp;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t k = lane + WAVE * i;
+      if (k < hp.K) unsafeAtomicAdd(hg + k, g * w[i]);
+    }
+    if (cur & INPUT_BIT) {
+      if (lane == 0) Gdefer[p] = g;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, zc[i], hp.lambda * w[i]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    if (k < hp.K) {
+      D[(size_t)item * hp.Kp + k] = w[i];
+      D_ag[(size_t)item * hp.Kp + k] = a[i];
+    }
+  }
+  if (lane == 0) {
+    bp[item] = bias;
+    bp_ag[item] = bias_ag;
+    if (touched) touched[item] = 1u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4a  delta_u = hg_u (.) act'(z_u)  and the private user-node step (cdae.hpp:317-331), one wave/user
+template <int NI>
+__global__ void __launch_bounds__(256)
+hidden_user_kernel(HyperParams hp, uint64_t u0, uint32_t nb, const float* __restrict__ Dz,
+                   float* __restrict__ HG /* in: hg, out: delta */, float* __restrict__ Wu,
+                   float* __restrict__ Wu_ag) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = u0 + slot;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    if (k < hp.K) {
+      const size_t o = (size_t)slot * hp.Kp + k;
+      const float delta = HG[o] * Dz[o];
+      HG[o] = delta;
+      if (hp.user_factor) {
+        const size_t ou = (size_t)uid * hp.Kp + k;
+        float p = Wu[ou], acc = Wu_ag[ou];
+        ada_step(hp, p, acc, delta + hp.lambda * p);
+        Wu[ou] = p;
+        Wu_ag[ou] = acc;
+      }
+    }
+  }
+}
+
+// K4b  hidden bias b: the one parameter every user updates, strictly in user order (cdae.hpp:301-315).
+// One thread per coordinate; the recurrence is elementwise, the delta loads are independent of it.
+__global__ void __launch_bounds__(1024)
+hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA, float* __restrict__ b,
+                   float* __restrict__ b_ag) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= hp.K) return;
+  float p = b[k], acc = b_ag[k];
+  uint32_t s = 0;
+  for (; s + 8 <= nb; s += 8) {
+    float d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = DELTA[(size_t)(s + j) * hp.Kp + k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ada_step(hp, p, acc, d[j] + hp.lambda * p);
+  }
+  for (; s < nb; ++s) ada_step(hp, p, acc, DELTA[(size_t)s * hp.Kp + k] + hp.lambda * p);
+  b[k] = p;
+  b_ag[k] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  input rows, row-major (cdae.hpp:333-349): for every kept input (u, j) in user order
+//     grad = scale * delta_u + lambda W[j] + g_uj z_u   (the last term is the deferred decoder
+//     gradient input_gradient[j], cdae.hpp:249-250, 342-343; absent when asymmetric)
+template <int NI>
+__global__ void __launch_bounds__(256)
+input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
+                  const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                  const uint32_t* __restrict__ sorted_word, const float* __restrict__ Z,
+                  const float* __restrict__ DELTA, const float* __restrict__ Gdefer,
+                  float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched) {
+  const uint32_t rank = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (rank >= hp.num_items) return;
+  const uint32_t item = item_order[rank];
+  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  if (beg == end) return;
+  float w[NI], a[NI];
+  bool loaded = false;
+  for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
+    const uint32_t p = p0 + lane;
+    const uint32_t word = p < end ? sorted_word[p] : 0u;
+    unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
+    if (mask && !loaded) {
+      loaded = true;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t k = lane + WAVE * i;
+        w[i] = k < hp.K ? W[(size_t)item * hp.Kp + k] : 0.f;
+        a[i] = k < hp.K ? W_ag[(size_t)item * hp.Kp + k] : 1.f;
+      }
+    }
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const uint32_t slot = __shfl(word, src, WAVE) & SLOT_MASK;
+      const float g = hp.asymmetric ? 0.f : Gdefer[p0 + src];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint32_t k = lane + WAVE * i;
+        if (k < hp.K) {
+          const size_t o = (size_t)slot * hp.Kp + k;
+          const float grad = fmaf(hp.scale, DELTA[o], fmaf(g, Z[o], hp.lambda * w[i]));
+          ada_step(hp, w[i], a[i], grad);
+        }
+      }
+    }
+  }
+  if (loaded) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t k = lane + WAVE * i;
+      if (k < hp.K) {
+        W[(size_t)item * hp.Kp + k] = w[i];
+        W_ag[(size_t)item * hp.Kp + k] = a[i];
+      }
+    }
+    if (lane == 0 && touched) touched[item] = 1u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6  data_loss (cdae.hpp:78-101): per user  sum_{i in P(u)} loss(D[i].z_u + b'[i], 1) ; Z from K2
+template <int NI>
+__global__ void __launch_bounds__(256)
+data_loss_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                 uint64_t u0, uint32_t nb, const float* __restrict__ Z, const float* __restrict__ D,
+                 const float* __restrict__ bp, double* __restrict__ out) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  float z[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    z[i] = k < hp.K ? Z[(size_t)slot * hp.Kp + k] : 0.f;
+  }
+  double total = 0.;
+  for (uint32_t p = 0; p < n; ++p) {
+    const uint32_t item = col[r0 + p];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t k = lane + WAVE * i;
+      dot = fmaf(k < hp.K ? D[(size_t)item * hp.Kp + k] : 0.f, z[i], dot);
+    }
+    const float y = wave_sum(dot) + bp[item];
+    total += (double)loss_eval(hp.loss_type, y, 1.f);
+  }
+  if (lane == 0) atomicAdd(out, total);
+}
+
+// sum of squares of a float array into a double (penalty.hpp:36-39)
+__global__ void __launch_bounds__(256)
+sqnorm_kernel(const float* __restrict__ x, size_t n, double* __restrict__ out) {
+  double s = 0.;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double v = x[i];
+    s += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, WAVE);
+  if (threadIdx.x % WAVE == 0) atomicAdd(out, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7  recommend (cdae.hpp:162-196): scores of all items for one user per block, rated items masked,
+// top-k by repeated block arg-max (k = 10, evaluation.hpp:145).  Ties resolve to the lower item id.
+// One block (256 threads) per user: each wavefront scores items wave-strided; scores go to LDS.
+template <int NI>
+__global__ void __launch_bounds__(256)
+recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                 uint64_t u0, const float* __restrict__ Z, const float* __restrict__ D,
+                 const float* __restrict__ bp, uint32_t topk, uint32_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* score = reinterpret_cast<float*>(smem_raw);                         // [num_items]
+  float* red_v = score + hp.num_items;                                       // [4]
+  uint32_t* red_i = reinterpret_cast<uint32_t*>(red_v + 4);                  // [4]
+  const uint32_t slot = blockIdx.x;
+  const uint64_t uid = u0 + slot;
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+  float z[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const uint32_t k = lane + WAVE * i;
+    z[i] = k < hp.K ? Z[(size_t)slot * hp.Kp + k] : 0.f;
+  }
+  for (uint32_t item = wid; item < hp.num_items; item += nw) {
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t k = lane + WAVE * i;
+      dot = fmaf(k < hp.K ? D[(size_t)item * hp.Kp + k] : 0.f, z[i], dot);
+    }
+    const float y = wave_sum(dot) + bp[item];
+    if (lane == 0) score[item] = y;
+  }
+  __syncthreads();
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) score[col[r0 + p]] = -INFINITY;   // cdae.hpp:177-179
+  __syncthreads();
+  for (uint32_t t = 0; t < topk; ++t) {
+    float best = -INFINITY;
+    uint32_t best_i = 0xFFFFFFFFu;
+    for (uint32_t item = threadIdx.x; item < hp.num_items; item += blockDim.x) {
+      const float v = score[item];
+      if (v > best || (v == best && item < best_i)) { best = v; best_i = item; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, WAVE);
+      const uint32_t oi = __shfl_xor(best_i, off, WAVE);
+      if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    if (lane == 0) { red_v[wid] = best; red_i[wid] = best_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float bv = red_v[0];
+      uint32_t bi = red_i[0];
+      for (uint32_t w2 = 1; w2 < nw; ++w2)
+        if (red_v[w2] > bv || (red_v[w2] == bv && red_i[w2] < bi)) { bv = red_v[w2]; bi = red_i[w2]; }
+      out[(size_t)slot * topk + t] = bi;
+      if (bi != 0xFFFFFFFFu) score[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter init (cdae.hpp:109-134) from the CDAE_STREAM_INIT counter stream
+__global__ void __launch_bounds__(256)
+init_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, uint64_t key, double init_scale) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * Kp) return;
+  const size_t r = idx / Kp;
+  const uint32_t k = (uint32_t)(idx % Kp);
+  M[idx] = k < K ? (float)(cdae_init_uniform(key, r * K + k) * init_scale) : 0.f;
+}
+__global__ void __launch_bounds__(256)
+fill_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, float value) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * Kp) return;
+  M[idx] = (uint32_t)(idx % Kp) < K ? value : 0.f;
+}
+
+// data-parallel exchange helpers (no reference counterpart; DESIGN.md "Multi-GPU")
+__global__ void __launch_bounds__(256)
+delta_kernel(const float* __restrict__ cur, const float* __restrict__ base, float* __restrict__ delta, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) delta[i] = cur[i] - base[i];
+}
+__global__ void __launch_bounds__(256)
+touch_to_float_kernel(const uint32_t* __restrict__ touched, float* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = touched[i] ? 1.f : 0.f;
+}
+// cur = base + sum_delta * weight.  rule 0 (CDAE_DELTA_SUM): weight 1 — the all-reduced sum of every
+// rank's accumulated steps, i.e. what summing gradients does.  rule 1 (CDAE_DELTA_TOUCH_MEAN): item rows are
+// divided by the number of ranks that touched them, the hidden bias by world_size.
+// Shared block layout: [I x Kp matrices ...][bp | bp_ag (I each)][b | b_ag (Kp each)].
+__global__ void __launch_bounds__(256)
+apply_delta_kernel(float* __restrict__ cur, const float* __restrict__ base, const float* __restrict__ sum,
+                   const float* __restrict__ touch_sum, size_t n_matrix, uint32_t Kp, uint32_t num_items,
+                   size_t n_total, uint32_t world_size, uint32_t rule) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  float wgt = 1.f;
+  if (rule == 1u) {
+    if (i < n_matrix) wgt = 1.f / fmaxf(1.f, touch_sum[(uint32_t)((i / Kp) % num_items)]);
+    else if (i < n_total - 2u * Kp) wgt = 1.f / fmaxf(1.f, touch_sum[(uint32_t)((i - n_matrix) % num_items)]);
+    else wgt = 1.f / (float)world_size;
+  }
+  cur[i] = fmaf(sum[i], wgt, base[i]);
+}
+
+}  // namespace cdae

@@ -1,0 +1,81 @@
+"""Data-parallel exchange for the CDAE hot path: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference is single-process and strictly sequential (cdae.hpp:136-146), so this layer has no
+reference counterpart.  Users are sharded across ranks (each rank holds only its own rows of the
+interaction matrix and its own Wu / Wu_ag rows — the north star's "V_u stays local"); the item-side
+parameters W, W_ag, (V, V_ag), b', b'_ag, b, b_ag are replicated.  One exchange step:
+
+    begin()   snapshot the shared block                                  (cdae_hip_delta_begin)
+    ...       every rank trains its batch of users from that snapshot    (cdae_hip_train_users)
+    finish()  delta = current - snapshot                                 (cdae_hip_delta_compute)
+              all-reduce(sum) of ONE contiguous fp32 buffer [delta | touch]   <- the only collective
+              current = snapshot + combine(sum)                          (cdae_hip_delta_apply)
+
+The delta of W is the accumulated -lr * AdaGrad-preconditioned gradient of the rank's examples and the
+delta of W_ag the accumulated squared gradient, so summing them is the data-parallel "all-reduce of the
+shared gradients"; with world_size == 1 the step is the identity.  `combine_reference` restates the
+device kernel in torch ops: the gloo CPU tests run it, the GPU test checks the HIP kernel against it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RULE_SUM = 0
+RULE_TOUCH_MEAN = 1
+
+
+def shard_bounds(num_users: int, world: int, rank: int, row_ptr=None):
+    """Contiguous user range of `rank`.  With row_ptr, ranges are balanced by interactions (nnz), not by
+    user count."""
+    if row_ptr is None:
+        per = (num_users + world - 1) // world
+        return min(num_users, rank * per), min(num_users, (rank + 1) * per)
+    nnz = int(row_ptr[num_users])
+    cuts = [int(np.searchsorted(row_ptr, nnz * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, num_users
+    return cuts[rank], cuts[rank + 1]
+
+
+def combine_reference(base, summed, touch_sum, n_matrix: int, Kp: int, num_items: int, world: int, rule: int):
+    """torch restatement of apply_delta_kernel (cdae_amd/csrc/cdae_kernels.hpp)."""
+    import torch
+    if rule == RULE_SUM:
+        return base + summed
+    w = torch.ones_like(summed)
+    t = torch.clamp(touch_sum, min=1.0)
+    n_total = base.numel()
+    n_mats = n_matrix // (num_items * Kp)
+    w[:n_matrix] = (1.0 / t).repeat_interleave(Kp).repeat(n_mats)
+    w[n_matrix:n_total - 2 * Kp] = (1.0 / t).repeat(2)
+    w[n_total - 2 * Kp:] = 1.0 / world
+    return base + summed * w
+
+
+class _DeviceBuffer:
+    """Zero-copy view of library-owned device memory for torch.as_tensor."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class DeltaExchange:
+    """GPU path: the delta buffer lives in the library; torch only wraps it for the RCCL all-reduce."""
+
+    def __init__(self, model, dist, world: int, rule: int = RULE_SUM):
+        import torch
+        self.model, self.dist, self.world, self.rule = model, dist, world, rule
+        model.delta_begin()
+        ptr, count = model.delta_device_ptr()
+        self.buf = torch.as_tensor(_DeviceBuffer(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+        assert self.buf.data_ptr() == ptr, "torch copied the delta buffer instead of wrapping it"
+        self.torch = torch
+
+    def begin(self):
+        self.model.delta_begin()
+
+    def finish(self):
+        self.model.delta_compute()                       # stream-synchronised by the library
+        if self.world > 1:
+            self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM)
+            self.torch.cuda.current_stream().synchronize()
+        self.model.delta_apply(self.world, self.rule)

@@ -1,0 +1,165 @@
+/* cdae_hip.h — C ABI of libcdae_hip.so, the MI355X (gfx950) implementation of the CDAE training hot path.
+ *
+ * The reference (jasonyaw/CDAE, "libcf") has no FFI: its boundary is C++ template duck-typing —
+ * Solver<Model> and Evaluation<Model> instantiated with Model = libcf::CDAE
+ * (/root/reference/src/solver/solver.hpp:11-46, src/model/evaluation.hpp:113-181,
+ * apps/yelp/yelp.cpp:168-199).  This header is the plain-C surface that sits *underneath* that
+ * class: the repo's own host C++ (src/model/recsys/cdae.hpp, same class name and methods as the
+ * reference) forwards each Model-concept call to exactly one entry point below, and CHECKs the status
+ * so that the reference's abort-on-error convention (glog CHECK / LOG(FATAL)) is preserved.
+ *
+ *   reference interface (file:line)                         entry point
+ *   -------------------------------------------------------------------------------------------
+ *   CDAE::CDAE(const CDAEConfig&)        cdae.hpp:39-74      cdae_hip_create
+ *   RecsysModelBase::reset               recsys_model_base.hpp:29-34
+ *                                                            cdae_hip_set_interactions
+ *   CDAE::reset (parameter init)         cdae.hpp:109-134    cdae_hip_init_params / cdae_hip_set_param
+ *   CDAE::train_one_iteration            cdae.hpp:136-146    cdae_hip_train_epoch
+ *     get_corrputed_input                cdae.hpp:361-371      (device, include/cdae_rng.h)
+ *     sample_negative_item               recsys_model_base.hpp:46-57  (device, include/cdae_rng.h)
+ *     train_one_user_corruption          cdae.hpp:198-358      (device kernels)
+ *   CDAE::get_hidden_values              cdae.hpp:373-416    cdae_hip_encode
+ *   CDAE::data_loss                      cdae.hpp:78-101     cdae_hip_data_loss
+ *   CDAE::penalty_loss                   cdae.hpp:103-107    cdae_hip_penalty_loss
+ *   CDAE::recommend (all users, top-k)   cdae.hpp:162-196    cdae_hip_recommend_all
+ *   (data-parallel exchange; no reference counterpart)       cdae_hip_delta_* / cdae_hip_shared_*
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure; cdae_hip_last_error()
+ * returns a thread-local message for the last failure.  No exceptions cross the boundary.  All
+ * pointers are HOST pointers unless the name says `device`.  The library owns all device memory.
+ * A handle is used from one host thread at a time.  Parameters are fp32 row-major with the row
+ * stride returned by cdae_hip_row_stride() (num_dim rounded up to a multiple of 4; pad lanes are 0).
+ */
+#ifndef CDAE_HIP_H_
+#define CDAE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDAE_HIP_ABI_VERSION 1
+
+/* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
+#define CDAE_LOSS_SQUARE 0u
+#define CDAE_LOSS_CROSS_ENTROPY 5u
+
+/* parameter ids (/root/reference/src/model/recsys/cdae.hpp:430-439) */
+#define CDAE_P_W 0u      /* items x K  : input embedding and, when !asymmetric, tied decoder  */
+#define CDAE_P_W_AG 1u   /* AdaGrad accumulator of W                                          */
+#define CDAE_P_V 2u      /* items x K  : decoder when asymmetric                              */
+#define CDAE_P_V_AG 3u
+#define CDAE_P_WU 4u     /* users x K  : per-user input node (north-star "V_u"), cdae.hpp:434 */
+#define CDAE_P_WU_AG 5u
+#define CDAE_P_B 6u      /* K          : hidden bias                                          */
+#define CDAE_P_B_AG 7u
+#define CDAE_P_BP 8u     /* items      : output bias b_prime                                  */
+#define CDAE_P_BP_AG 9u
+#define CDAE_P_COUNT 10u
+
+typedef struct cdae_hip_config {
+  uint32_t struct_size;      /* sizeof(cdae_hip_config), for ABI checking                  */
+  uint32_t num_dim;          /* CDAEConfig::num_dim          cdae.hpp:19                   */
+  uint32_t num_neg;          /* CDAEConfig::num_neg          cdae.hpp:26                   */
+  uint32_t num_corruptions;  /* CDAEConfig::num_corruptions  cdae.hpp:22                   */
+  uint32_t loss_type;        /* CDAE_LOSS_*                  cdae.hpp:17                   */
+  uint32_t using_adagrad;    /* cdae.hpp:20 (0 -> plain SGD with L2)                       */
+  uint32_t asymmetric;       /* cdae.hpp:23                                                */
+  uint32_t user_factor;      /* cdae.hpp:24                                                */
+  uint32_t linear;           /* cdae.hpp:25 (identity hidden activation)                   */
+  uint32_t scaled;           /* cdae.hpp:27 (input scale 1/(1-q))                          */
+  uint32_t tanh_act;         /* cdae.hpp:30                                                */
+  uint32_t batch_users;      /* users whose encode sees the same parameter snapshot; 1 ==  */
+                             /* the reference's strictly sequential schedule; 0 -> default */
+  double lambda;             /* cdae.hpp:15 */
+  double learn_rate;         /* cdae.hpp:16 */
+  double corruption_ratio;   /* cdae.hpp:21 */
+  double beta;               /* cdae.hpp:28 */
+} cdae_hip_config;
+
+typedef struct cdae_hip_stats {
+  double wall_seconds;       /* host wall-clock of the call, stream-synchronised            */
+  uint64_t users;            /* user-corruption units trained                               */
+  uint64_t examples;         /* (user, output item) pairs decoded = sum (1+num_neg) n_u     */
+  uint64_t batches;
+  /* accumulated HIP-event milliseconds per kernel family; filled only when profiling is on */
+  double ms_sample, ms_sort, ms_encode, ms_decode, ms_hidden, ms_input;
+  uint64_t launches_decode;
+} cdae_hip_stats;
+
+typedef struct cdae_hip cdae_hip_t;
+
+const char* cdae_hip_last_error(void);
+int cdae_hip_abi_version(void);
+
+int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out);
+int cdae_hip_destroy(cdae_hip_t* h);
+
+/* CSR of the training interactions: row_ptr[num_users+1], col_idx[nnz] sorted ascending and unique
+ * inside each row (the reference's uid -> {iid -> label} hashtable, data-inl.hpp:414-429, with the
+ * always-1 labels of yelp.cpp:60-66 dropped).  Copied; the caller keeps its arrays. */
+int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t num_users, uint64_t num_items,
+                              const int64_t* row_ptr, const uint32_t* col_idx);
+
+uint32_t cdae_hip_row_stride(const cdae_hip_t* h);
+
+/* A data-parallel rank holds only its own users (rows re-based to 0).  The random streams of
+ * include/cdae_rng.h are keyed by GLOBAL user id = offset + local row, so a sharded run draws the
+ * same masks and negatives as a single-GPU run over all users.  Default 0. */
+int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t global_id_of_local_user_0);
+
+/* reset(): W, V, Wu ~ U(-1,1) * 4*sqrt(6/(I+K)), accumulators 1e-4, biases 0 (cdae.hpp:109-134),
+ * drawn from the CDAE_STREAM_INIT counter stream of include/cdae_rng.h. */
+int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed);
+
+/* dense [rows x num_dim] (or [n]) fp32 host arrays, unpadded */
+int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t count);
+int cdae_hip_get_param(cdae_hip_t* h, uint32_t which, float* host, size_t count);
+int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, size_t* padded_count);
+
+/* One pass over users [u_begin, u_end) x num_corruptions in batches of batch_users
+ * (train_one_iteration, cdae.hpp:136-146).  train_epoch == train_users over all users. */
+int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
+int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin,
+                         uint64_t u_end, cdae_hip_stats* stats);
+int cdae_hip_set_profiling(cdae_hip_t* h, int enabled);
+int cdae_hip_synchronize(cdae_hip_t* h);
+
+/* z for `n` users (get_hidden_values, cdae.hpp:373-416).  mode 0: full train row, scale 1 (the
+ * inference form, cdae.hpp:169); mode 1: training corruption of (seed, epoch, corruption 0) with the
+ * configured scale.  Z is [n x num_dim] fp32 on the host. */
+int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, const uint32_t* uids,
+                    size_t n, float* Z);
+
+/* data_loss (cdae.hpp:78-101) with the CDAE_STREAM_LOSS_CORRUPT masks; penalty_loss (cdae.hpp:103-107) */
+int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out);
+int cdae_hip_penalty_loss(cdae_hip_t* h, double* out);
+
+/* recommend() for users [u_begin, u_end): top-k unrated items by W'[i].z + b'[i], descending score,
+ * ties -> lower item id first (heap.hpp:44-52 + utils.hpp:16-19 with ascending scan order).
+ * out is [(u_end-u_begin) x topk] uint32 on the host. */
+int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint32_t topk,
+                           uint32_t* out);
+
+/* ---- data-parallel exchange (north star: RCCL all-reduce of the shared W / W' / bias gradients;
+ * Wu never leaves its GPU).  Each rank trains its own users from a common snapshot, then
+ *   cdae_hip_delta_begin   : snapshot the shared parameters
+ *   ... cdae_hip_train_users ...
+ *   cdae_hip_delta_compute : delta = current - snapshot, packed in one device buffer together with a
+ *                            per-row touch indicator
+ *   <all-reduce(sum) of that buffer by the caller, e.g. torch.distributed over RCCL>
+ *   cdae_hip_delta_apply   : current = snapshot + combine(summed delta)
+ * Layout of the buffer: cdae_hip_delta_device_ptr(). */
+int cdae_hip_delta_begin(cdae_hip_t* h);
+int cdae_hip_delta_compute(cdae_hip_t* h);
+int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);
+#define CDAE_DELTA_SUM 0u         /* current = snapshot + sum over ranks (summed gradients; default)      */
+#define CDAE_DELTA_TOUCH_MEAN 1u  /* item rows / #ranks that touched them, hidden bias / world_size      */
+int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDAE_HIP_H_ */

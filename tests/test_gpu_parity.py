@@ -1,0 +1,128 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle on identical inputs.
+
+Tolerances: the reference computes in fp64 (src/base/mat.hpp:12,19-22); the HIP path stores and
+computes in fp32 with hardware rcp/sqrt/exp (1 ulp).  Integer work (masks, negatives, top-k ids) is
+bit-exact.  fp tolerances are written next to each assert.
+"""
+import numpy as np
+import pytest
+
+import cdae_amd
+from cdae_amd import synth
+import oracle as orc
+from helpers import make_pair, max_param_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny(built):
+    return synth.generate_shape("tiny", seed=5)
+
+
+@pytest.fixture(scope="module")
+def small(built):
+    return synth.generate(1200, 500, 60_000, seed=9)
+
+
+def test_init_params_match_counter_stream(tiny):
+    model, o = make_pair(tiny, K=10)
+    o.init_params(11)     # oracle's own init (fp64) vs the device init kernel (fp32 of the same fp64 value)
+    for which in (0, 4):
+        ref = o.get(which).astype(np.float32)
+        np.testing.assert_array_equal(model.get(which).ravel(), ref)
+    assert np.all(model.get(1) == np.float32(1e-4)) and np.all(model.get(8) == 0)
+
+
+@pytest.mark.parametrize("K", [1, 10, 50, 64, 65, 200])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_encode_matches_oracle(tiny, K, mode):
+    model, o = make_pair(tiny, K=K)
+    uids = np.arange(tiny.num_users, dtype=np.uint32)[::-1].copy()      # any order, all users
+    z_gpu = model.get_hidden_values(uids, seed=3, epoch=2, mode=mode)
+    z_ref = o.encode(3, 2, mode, uids)
+    # sigmoid outputs in (0,1): absolute tolerance 2e-6 (fp32 sum of <= ~100 rows + 1-ulp exp/rcp)
+    assert np.abs(z_gpu - z_ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("variant", [
+    dict(), dict(loss=cdae_amd.SQUARE), dict(asymmetric=True), dict(using_adagrad=False, learn_rate=0.01),
+    dict(tanh=True), dict(linear=True, learn_rate=0.02), dict(user_factor=False), dict(scaled=False),
+    dict(corruption_ratio=0.0, scaled=False), dict(corruption_ratio=1.0, scaled=False), dict(num_neg=1),
+    dict(num_corruptions=2), dict(beta=0.0),
+])
+def test_sequential_schedule_tracks_reference_literal(tiny, variant):
+    """batch_users = 1 is the reference's schedule: compare with the LITERAL restatement of cdae.hpp:136-358."""
+    model, o = make_pair(tiny, K=24, B=1, **variant)
+    for ep in range(2):
+        model.train_one_iteration(seed=7, epoch=ep)
+        o.train_literal(7, ep)
+    err, which = max_param_err(model, o)
+    # two epochs x 300 users of fp32 AdaGrad steps vs fp64: relative 2e-4 of the parameter's range
+    assert err < 2e-4, (err, which)
+
+
+@pytest.mark.parametrize("B", [7, 64, 300])
+@pytest.mark.parametrize("variant", [dict(), dict(loss=cdae_amd.SQUARE, asymmetric=True)])
+def test_batched_schedule_matches_oracle(tiny, B, variant):
+    model, o = make_pair(tiny, K=40, B=B, **variant)
+    for ep in range(2):
+        model.train_one_iteration(seed=1, epoch=ep)
+        o.train_batched(1, ep, B)
+    err, which = max_param_err(model, o)
+    assert err < 2e-4, (err, which)
+
+
+def test_loss_and_recommend_match_oracle(small):
+    model, o = make_pair(small, K=50, B=256)
+    for ep in range(3):
+        model.train_one_iteration(seed=2, epoch=ep)
+        o.train_batched(2, ep, 256)
+    lg, lo = model.data_loss(5, 0), o.data_loss(5, 0)
+    assert abs(lg - lo) < 2e-4 * abs(lo)                      # sum over ~48k positives, fp32 vs fp64
+    pg, po = model.penalty_loss(), o.penalty_loss()
+    assert abs(pg - po) < 2e-4 * abs(po)
+    rec_g = model.recommend_all(10)
+    rec_o, sc_o = o.recommend(10, with_scores=True)
+    # ids must agree wherever the oracle's neighbouring scores are separated by more than fp32 noise
+    gap = np.abs(np.diff(sc_o, axis=1)).min(axis=1)
+    clear = gap > 1e-4
+    assert clear.mean() > 0.9
+    np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
+    m_g = orc.eval_topn(rec_g, small.test_ptr, small.test_col)
+    m_o = orc.eval_topn(rec_o, small.test_ptr, small.test_col)
+    assert np.abs(m_g - m_o).max() < 2e-3                     # a near-tie may swap one id
+
+
+def test_user_range_and_offset_equal_full_run(tiny):
+    """A shard with a global-id offset draws the same random streams as the full run."""
+    full, _ = make_pair(tiny, K=16, B=50)
+    full.train_users(seed=4, epoch=0, u_begin=100, u_end=200)
+    shard_data = tiny.user_range(100, 200)
+    cfg = full.cfg
+    shard = cdae_amd.CDAE(cfg)
+    shard.set_interactions(shard_data.num_users, shard_data.num_items, shard_data.train_ptr, shard_data.train_col,
+                           user_id_offset=100)
+    shard.init_params(11)
+    for which in (0, 1, 6, 7, 8, 9):
+        shard.set(which, make_pair(tiny, K=16, B=50)[0].get(which))
+    wu = make_pair(tiny, K=16, B=50)[0]
+    shard.set(4, wu.get(4)[100:200]); shard.set(5, wu.get(5)[100:200])
+    shard.train_one_iteration(seed=4, epoch=0)
+    for which in (0, 8, 6):
+        np.testing.assert_allclose(shard.get(which), full.get(which), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(shard.get(4), full.get(4)[100:200], rtol=0, atol=1e-6)
+
+
+def test_errors_are_reported_not_swallowed(tiny):
+    with pytest.raises(cdae_amd.CDAEError, match="LOGISTIC aborts"):
+        cdae_amd.CDAE(cdae_amd.CDAEConfig(lt=cdae_amd.LOGISTIC))
+    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(lt=cdae_amd.SQUARE))
+    with pytest.raises(cdae_amd.CDAEError, match="set_interactions"):
+        m.train_one_iteration(0, 0)
+    ptr = np.array([0, 2, 2], dtype=np.int64)       # user 1 has no item: the reference CHECK-fails (cdae.hpp:139)
+    with pytest.raises(cdae_amd.CDAEError, match="no training item"):
+        m.set_interactions(2, 5, ptr, np.array([0, 1], dtype=np.uint32))
+    ptr = np.array([0, 2], dtype=np.int64)
+    with pytest.raises(cdae_amd.CDAEError, match="ascending"):
+        m.set_interactions(1, 5, ptr, np.array([3, 1], dtype=np.uint32))
