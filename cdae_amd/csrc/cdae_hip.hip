@@ -53,11 +53,7 @@ int fail(const char* fmt, ...) {
     switch (ni) {                                                                                 \
       case 1: hipLaunchKernelGGL(KERNEL<1>, grid, block, shmem, stream, __VA_ARGS__); break;      \
       case 2: hipLaunchKernelGGL(KERNEL<2>, grid, block, shmem, stream, __VA_ARGS__); break;      \
-      case 3: hipLaunchKernelGGL(KERNEL<3>, grid, block, shmem, stream, __VA_ARGS__); break;      \
       case 4: hipLaunchKernelGGL(KERNEL<4>, grid, block, shmem, stream, __VA_ARGS__); break;      \
-      case 5: hipLaunchKernelGGL(KERNEL<5>, grid, block, shmem, stream, __VA_ARGS__); break;      \
-      case 6: hipLaunchKernelGGL(KERNEL<6>, grid, block, shmem, stream, __VA_ARGS__); break;      \
-      case 7: hipLaunchKernelGGL(KERNEL<7>, grid, block, shmem, stream, __VA_ARGS__); break;      \
       default: hipLaunchKernelGGL(KERNEL<8>, grid, block, shmem, stream, __VA_ARGS__); break;     \
     }                                                                                             \
   } while (0)
@@ -92,8 +88,11 @@ struct cdae_hip {
 
   // batch workspace
   uint64_t Ecap = 0;
-  uint32_t* d_ex_item = nullptr; uint32_t* d_ex_word = nullptr;
-  uint32_t* d_sorted_item = nullptr; uint32_t* d_sorted_word = nullptr;
+  uint32_t* d_ex_item = nullptr; uint64_t* d_ex_val = nullptr;
+  uint32_t* d_sorted_item = nullptr; uint64_t* d_sorted_val = nullptr;
+  float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
+  hipStream_t side = nullptr;           // hidden-bias recurrence runs beside the input-row kernel
+  hipEvent_t ev_delta = nullptr, ev_bias = nullptr;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   uint32_t* d_seg = nullptr;            // [2*I]: begin | end
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
@@ -164,18 +163,21 @@ int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
 
 void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_ex_item,
-                  h->d_ex_word, h->d_sorted_item, h->d_sorted_word, h->d_sort_tmp, h->d_seg, h->d_Z, h->d_Dz,
+                  h->d_ex_val, h->d_sorted_item, h->d_sorted_val, h->d_D0, h->d_sort_tmp, h->d_seg, h->d_Z, h->d_Dz,
                   h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec, h->d_base, h->d_delta};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (Span& s : h->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  if (h->ev_delta) (void)hipEventDestroy(h->ev_delta);
+  if (h->ev_bias) (void)hipEventDestroy(h->ev_bias);
+  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
 int free_interaction_state(cdae_hip* h) {
   void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
-                   (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_ex_item, (void**)&h->d_ex_word,
-                   (void**)&h->d_sorted_item, (void**)&h->d_sorted_word, (void**)&h->d_sort_tmp, (void**)&h->d_seg,
+                   (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_ex_item, (void**)&h->d_ex_val,
+                   (void**)&h->d_sorted_item, (void**)&h->d_sorted_val, (void**)&h->d_D0, (void**)&h->d_sort_tmp, (void**)&h->d_seg,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta};
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
@@ -203,39 +205,48 @@ int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t see
 
   CHK(pr.begin(h, F_SAMPLE));
   hipLaunchKernelGGL(sample_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, s0, nb, cidx, seed, epoch,
-                     h->d_ex_item, h->d_ex_word);
+                     h->d_ex_item, h->d_ex_val);
   CHK(pr.end());
 
   CHK(pr.begin(h, F_SORT));
-  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_word,
-                                   h->d_sorted_word, (size_t)E, 0u, (unsigned)h->sort_bits, st));
+  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_val,
+                                   h->d_sorted_val, (size_t)E, 0u, (unsigned)h->sort_bits, st));
   HIPCHK(hipMemsetAsync(h->d_seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
   hipLaunchKernelGGL(segment_kernel, dim3((uint32_t)((E + 255) / 256)), blk, 0, st, h->d_sorted_item, (uint32_t)E,
                      h->d_seg, h->d_seg + I);
   CHK(pr.end());
 
   CHK(pr.begin(h, F_ENCODE));
+  HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));             // b of the previous batch (side stream)
   DISPATCH_NI(h->NI, encode_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), h->d_Wu,
               h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Z, h->d_Dz);
   HIPCHK(hipMemsetAsync(h->d_HG, 0, (size_t)nb * h->Kp * sizeof(float), st));
+  HIPCHK(hipMemcpyAsync(h->d_D0, h->dec(), (size_t)I * h->Kp * sizeof(float), hipMemcpyDeviceToDevice, st));
   CHK(pr.end());
 
   CHK(pr.begin(h, F_DECODE));
   DISPATCH_NI(h->NI, decode_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, h->d_seg, h->d_seg + I,
-              h->d_sorted_word, h->d_Z, h->dec(), h->dec_ag(), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G,
+              h->d_sorted_val, h->d_Z, h->dec(), h->dec_ag(), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G,
               h->d_touched);
   CHK(pr.end());
 
   CHK(pr.begin(h, F_HIDDEN));
-  DISPATCH_NI(h->NI, hidden_user_kernel, grid_users, blk, 0, st, h->hp, s0, nb, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag);
-  hipLaunchKernelGGL(hidden_bias_kernel, dim3((h->K + 63) / 64), dim3(64), 0, st, h->hp, nb, h->d_HG, h->P(CDAE_P_B),
-                     h->P(CDAE_P_B_AG));
+  DISPATCH_NI(h->NI, hidden_gather_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, s0, nb, h->d_ex_item, h->d_G,
+              h->d_D0, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag);
   CHK(pr.end());
+  // the strictly sequential hidden-bias recurrence needs only delta: run it beside the input rows
+  HIPCHK(hipEventRecord(h->ev_delta, st));
+  HIPCHK(hipStreamWaitEvent(h->side, h->ev_delta, 0));
+  hipLaunchKernelGGL(hidden_bias_kernel, dim3(h->Kp / 64), dim3(64), 0, h->side, h->hp, nb, h->d_HG, h->P(CDAE_P_B),
+                     h->P(CDAE_P_B_AG));
+  HIPCHK(hipEventRecord(h->ev_bias, h->side));
 
   CHK(pr.begin(h, F_INPUT));
   DISPATCH_NI(h->NI, input_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, h->d_seg, h->d_seg + I,
-              h->d_sorted_word, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched);
+              h->d_sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched);
   CHK(pr.end());
+  // delta (d_HG) is overwritten by the next batch's memset: that batch must not start before the bias kernel read it
+  HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -290,11 +301,16 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->cfg = *cfg;
   h->device = device_id;
   h->K = cfg->num_dim;
-  h->Kp = (cfg->num_dim + 3u) & ~3u;
-  h->NI = (cfg->num_dim + 63u) / 64u;
+  h->NI = cfg->num_dim <= 64 ? 1 : (cfg->num_dim <= 128 ? 2 : (cfg->num_dim <= 256 ? 4 : 8));
+  h->Kp = 64u * h->NI;
   h->B = cfg->batch_users ? cfg->batch_users : 1024u;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_bias, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(h->ev_bias, h->side);
+  if (e != hipSuccess) { free_all(h); delete h; return fail("stream/event setup failed: %s", hipGetErrorString(e)); }
   e = hipMalloc((void**)&h->d_scalar, 8 * sizeof(double));
   if (e != hipSuccess) { free_all(h); delete h; return fail("hipMalloc failed: %s", hipGetErrorString(e)); }
   cdae::HyperParams& hp = h->hp;
@@ -386,14 +402,15 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   }
   h->Ecap = emax * (1u + h->cfg.num_neg);
   if (h->Ecap > 0xFFFFFFF0ull) return fail("batch of %u users holds %llu examples (> 2^32); lower batch_users", B, (unsigned long long)h->Ecap);
-  CHK(dev_alloc(&h->d_ex_item, h->Ecap)); CHK(dev_alloc(&h->d_ex_word, h->Ecap));
-  CHK(dev_alloc(&h->d_sorted_item, h->Ecap)); CHK(dev_alloc(&h->d_sorted_word, h->Ecap));
+  CHK(dev_alloc(&h->d_ex_item, h->Ecap)); CHK(dev_alloc(&h->d_ex_val, h->Ecap));
+  CHK(dev_alloc(&h->d_sorted_item, h->Ecap)); CHK(dev_alloc(&h->d_sorted_val, h->Ecap));
+  CHK(dev_alloc(&h->d_D0, IK));
   CHK(dev_alloc(&h->d_G, h->Ecap));
   h->sort_bits = 1;
   while ((1ull << h->sort_bits) < I) h->sort_bits++;
   h->sort_tmp_bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_word,
-                                   h->d_sorted_word, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_val,
+                                   h->d_sorted_val, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
   CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
   CHK(dev_alloc(&h->d_seg, 2 * (size_t)I));
   const size_t BK = (size_t)B * h->Kp;
@@ -401,6 +418,19 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(dev_alloc(&h->d_touched, (size_t)I));
   HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
   CHK(dev_alloc(&h->d_uids, (size_t)B));
+  // weights 0, accumulators 1e-4 (cdae.hpp:114,...), accumulator pad lanes 1: a well-defined state even
+  // before init_params / set_param (a zero accumulator pad would make beta == 0 divide 0 by 0)
+  auto fillm = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v, float pad) {
+    if (M) hipLaunchKernelGGL(cdae::fill_matrix_kernel, dim3((uint32_t)((rows * Kp + 255) / 256)), dim3(256), 0, h->stream, M, rows,
+                              K, Kp, v, pad);
+  };
+  fillm(h->P(CDAE_P_W_AG), I, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->P(CDAE_P_V_AG), I, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->d_Wu_ag, U, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->P(CDAE_P_BP_AG), I, 1, 1, 1e-4f, 1.f);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -414,8 +444,8 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
     hipLaunchKernelGGL(init_matrix_kernel, blocks(rows * h->Kp), dim3(256), 0, h->stream, M, rows, h->K, h->Kp,
                        cdae_rng_key(seed, 0, id, CDAE_STREAM_INIT), init_scale);
   };
-  auto fill = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v) {
-    hipLaunchKernelGGL(fill_matrix_kernel, blocks(rows * Kp), dim3(256), 0, h->stream, M, rows, K, Kp, v);
+  auto fill = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v) {     // accumulator pads are 1, others 0
+    hipLaunchKernelGGL(fill_matrix_kernel, blocks(rows * Kp), dim3(256), 0, h->stream, M, rows, K, Kp, v, v == 0.f ? 0.f : 1.f);
   };
   init(h->P(CDAE_P_W), h->I, CDAE_P_W); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
   if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
@@ -441,7 +471,11 @@ int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t 
   }
   const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
   if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
-  HIPCHK(hipMemset(d, 0, rows * h->Kp * sizeof(float)));
+  const bool is_acc = (which & 1u) != 0u;                 // odd ids are the *_AG accumulators: pad lanes stay 1
+  hipLaunchKernelGGL(cdae::fill_matrix_kernel, dim3((uint32_t)((rows * h->Kp + 255) / 256)), dim3(256), 0, h->stream, d, rows,
+                     h->K, h->Kp, 0.f, is_acc ? 1.f : 0.f);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipMemcpy2D(d, h->Kp * sizeof(float), host, h->K * sizeof(float), h->K * sizeof(float), rows, hipMemcpyHostToDevice));
   return 0;
 }

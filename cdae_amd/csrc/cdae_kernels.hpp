@@ -2,15 +2,19 @@
 //
 // Replaces, per batch of users, the body of CDAE::train_one_iteration
 // (/root/reference/src/model/recsys/cdae.hpp:136-146) and train_one_user_corruption (cdae.hpp:198-358).
-// The reference's loop nest is   for user: { encode; for output item: {dot, loss', row step} ; hidden ; input rows }.
+// The reference's loop nest is   for user: { encode; for output item: {dot, loss', row step}; hidden; input rows }.
 // Here the decode loop nest is TRANSPOSED: for item row: for (user, target) example of the batch in
 // user order: {dot, loss', row step}.  A row lives in the registers of one wavefront for the whole
 // batch, every dot product sees every earlier update of that row exactly as in the reference, and W /
-// W_ag cross HBM once per batch instead of once per (user, item) touch.  Only the encode (z_u) and the
-// hidden gradient are computed from the batch-start snapshot (DESIGN.md "Schedule").
+// W_ag cross HBM once per batch instead of once per (user, item) touch.  The hidden layer of a user
+// (z_u, and the hidden gradient hg_u = sum_e g_e D[j_e]) is evaluated against the batch-start snapshot
+// of the parameters plus the user's own duplicate-negative updates (DESIGN.md "Schedule"); with
+// batch_users == 1 that is exactly the reference.
 //
-// Register layout of a K-vector: lane l of a 64-wide wavefront holds elements k = l + 64*i, i < NI
-// (each load/atomic instruction of the wave then covers 256 contiguous bytes).
+// Register layout of a K-vector: rows are padded to Kp = 64*NI floats (NI in {1,2,4,8}); lane l of a
+// 64-wide wavefront holds the NI contiguous elements k = NI*l .. NI*l+NI-1, so one row is ONE
+// global_load_dwordx{NI} per lane = a fully coalesced 256*NI-byte wave access, with no tail predication.
+// Pad elements are 0 in every parameter / activation (accumulators: 1) and provably stay there.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,8 +37,38 @@ struct HyperParams {
   uint64_t keep_thr;         // cdae_keep_threshold(q)
   uint64_t uid_offset;       // global id of local user 0 (data-parallel shards keep global random streams)
   uint32_t num_items;
-  uint32_t K, Kp;            // num_dim and row stride (floats)
+  uint32_t K, Kp;            // num_dim and row stride (floats, = 64 * NI)
 };
+
+// ------------------------------------------------------------------------------------------------
+// vector access: NI contiguous floats per lane
+template <int NI>
+__device__ __forceinline__ void vload(float (&d)[NI], const float* __restrict__ p) {
+  if constexpr (NI == 1) {
+    d[0] = p[0];
+  } else if constexpr (NI == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    d[0] = t.x; d[1] = t.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NI / 4; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(p)[q];
+      d[4 * q] = t.x; d[4 * q + 1] = t.y; d[4 * q + 2] = t.z; d[4 * q + 3] = t.w;
+    }
+  }
+}
+template <int NI>
+__device__ __forceinline__ void vstore(float* __restrict__ p, const float (&d)[NI]) {
+  if constexpr (NI == 1) {
+    p[0] = d[0];
+  } else if constexpr (NI == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NI / 4; ++q)
+      reinterpret_cast<float4*>(p)[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // scalar math (fp32, hardware transcendental units)
@@ -79,21 +113,33 @@ __device__ __forceinline__ void ada_step(const HyperParams& hp, float& p, float&
   p = fmaf(-hp.lr, grad, p);
 }
 
+// Wavefront all-reduce on the VALU's DPP lanes (no LDS crossbar): quad swaps, row mirrors, then the two
+// row broadcasts; lane 63 ends up with the full sum and is read back as a scalar.  ~7 dependent VALU ops
+// instead of six ds_bpermute round trips — this sits on the critical path of every decoded example.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, /*bound_ctrl*/ true);
+  return v + __builtin_bit_cast(float, moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-  return v;
+  v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);           // row_half_mirror
+  v = dpp_add<0x140>(v);           // row_mirror        -> every lane holds its 16-lane row sum
+  v = dpp_add<0x142, 0xA>(v);      // row_bcast:15 into rows 1,3
+  v = dpp_add<0x143, 0xC>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ------------------------------------------------------------------------------------------------
 // K1  sample: dropout keep-mask + rejection-sampled negatives -> example list of the batch.
 // get_corrputed_input (cdae.hpp:361-371) and sample_negative_item (recsys_model_base.hpp:46-57,
 // call site cdae.hpp:217-220).  One wavefront per user; integer-only.
-// Example e of user slot s sits at ex_base(s) + j, j < n_u positives then j - n_u < n_u*num_neg negatives.
+// Example e of user slot s sits at ex_base(s) + j: j < n_u positives, then n_u*num_neg negatives.
 __global__ void __launch_bounds__(256)
 sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
               uint64_t u0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch,
-              uint32_t* __restrict__ ex_item, uint32_t* __restrict__ ex_word) {
+              uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -107,12 +153,14 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint64_t key_n = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_NEGATIVE);
   for (uint32_t p = lane; p < n; p += WAVE) {
     const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
-    ex_item[base + p] = row[p];
-    ex_word[base + p] = slot | TARGET_BIT | ((keep && !hp.asymmetric) ? INPUT_BIT : 0u);
+    const uint64_t e = base + p;
+    ex_item[e] = row[p];
+    ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
   for (uint32_t i = lane; i < m; i += WAVE) {
-    ex_item[base + n + i] = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
-    ex_word[base + n + i] = slot;
+    const uint64_t e = base + n + i;
+    ex_item[e] = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
+    ex_val[e] = (e << 32) | (uint64_t)slot;
   }
 }
 
@@ -131,7 +179,7 @@ segment_kernel(const uint32_t* __restrict__ sorted_item, uint32_t n_ex, uint32_t
 // K2  encode: z_u = act(scale * sum_{i in In(u)} W[i] + b + Wu[u])   (get_hidden_values, cdae.hpp:373-416)
 // One wavefront per user.  mode 0: all train items, scale 1 (inference, cdae.hpp:169);
 // mode 1: dropout mask of stream `stream`, scale hp.scale (training cdae.hpp:207, data_loss cdae.hpp:92).
-// HBM-bound coalesced gather: each kept row is NI x 256-byte wave loads; four rows in flight.
+// Coalesced gather: each kept row is one 256*NI-byte wave load; eight rows in flight per wave.
 template <int NI>
 __global__ void __launch_bounds__(256)
 encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
@@ -147,9 +195,11 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint32_t* row = col + r0;
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, stream);
   const bool none = (mode == 0 && hp.keep_thr == 0x100000000ull);   // cdae.hpp:168-172 (q == 1 -> empty input)
+  const uint32_t lo = lane * NI;
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  constexpr int UN = 8;
   for (uint32_t p0 = 0; p0 < n && !none; p0 += WAVE) {
     const uint32_t p = p0 + lane;
     uint32_t item = 0;
@@ -160,46 +210,41 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     }
     unsigned long long mask = __ballot(keep);
     while (mask) {
-      // up to four kept rows per trip, summed in ascending item order
-      uint32_t it[4];
-      int cnt = 0;
+      // up to UN kept rows per trip, summed in ascending item order
+      float v[UN][NI];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (mask) {
+      for (int j = 0; j < UN; ++j) {
+        if (mask) {                                          // wave-uniform
           const int src = __ffsll((long long)mask) - 1;
           mask &= mask - 1;
-          it[j] = __shfl(item, src, WAVE);
-          cnt = j + 1;
+          const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)item, src);
+          vload<NI>(v[j], W + (size_t)it * hp.Kp + lo);
         } else {
-          it[j] = 0;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[j][i] = 0.f;
         }
       }
-      float v[4][NI];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const uint32_t k = lane + WAVE * i;
-          v[j][i] = (j < cnt && k < hp.K) ? W[(size_t)it[j] * hp.Kp + k] : 0.f;
-        }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < UN; ++j)
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] += v[j][i];
     }
   }
   const float sc = mode == 0 ? 1.f : hp.scale;
+  float bb[NI], wu[NI], z[NI], dz[NI];
+  vload<NI>(bb, b + lo);
+  if (hp.user_factor) vload<NI>(wu, Wu + (size_t)uid * hp.Kp + lo);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    if (k < hp.K) {
-      float h = acc[i] * sc + b[k];
-      if (hp.user_factor) h += Wu[(size_t)uid * hp.Kp + k];
-      const float z = activate(hp, h);
-      Z[(size_t)slot * hp.Kp + k] = z;
-      if (Dz) Dz[(size_t)slot * hp.Kp + k] = act_deriv(hp, z);
-    }
+    float h = fmaf(acc[i], sc, bb[i]);
+    if (hp.user_factor) h += wu[i];
+    const float zz = activate(hp, h);
+    const bool live = lo + i < hp.K;                         // pad elements of z must be 0
+    z[i] = live ? zz : 0.f;
+    dz[i] = live ? act_deriv(hp, zz) : 0.f;
   }
+  vstore<NI>(Z + (size_t)slot * hp.Kp + lo, z);
+  if (Dz) vstore<NI>(Dz + (size_t)slot * hp.Kp + lo, dz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,82 +252,92 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
 // users of the batch at once.  One wavefront owns item row j: D[j], D_ag[j], b'[j], b'_ag[j] stay in
 // registers while it walks the row's examples in user order:
 //   y = D[j].z_u + b'[j] (cdae.hpp:227/263, 418-426);  g = loss'(y, t) (:228/:265);
-//   b'[j] step (:230-237/:267-274);  hg_u += g * D[j] with the pre-update row (:240,:248/:277,:285);
+//   b'[j] step (:230-237/:267-274);
 //   row step grad = g z_u + lambda D[j] (:241-246,:252-257/:278-283,:286-291), or, when j is one of u's
-//   kept inputs in tied mode, defer g for the merged input-row step (:249-250).
-// D = V when asymmetric else W.  Rows are visited in `item_order` (popular rows first: their chains
-// are the longest).
+//   kept inputs in tied mode, no step: g is deferred into the merged input-row step (:249-250).
+// g is written to G[e] (user-major) for the hidden-gradient gather (K4) and the input rows (K5).
+// hg_u += g D[j] (:240,:248/:277,:285) is NOT accumulated here with one atomic per element (measured:
+// 150 G atomics/s saturates the L2 atomic units, 3.7 ms per 4096-user batch); K4 gathers it from the
+// batch-start snapshot D0 instead, and this kernel only adds the exact correction for a user's own
+// duplicate negatives — g * (row now - row at the user's first visit) — which is what makes
+// batch_users == 1 reproduce the reference in exact arithmetic.
+// D = V when asymmetric else W.  Rows are visited in `item_order` (popular rows first: their example
+// chains are the longest and bound the kernel).  z and the example words run PF examples ahead.
 template <int NI>
 __global__ void __launch_bounds__(256)
 decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                    const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
-                   const uint32_t* __restrict__ sorted_word, const float* __restrict__ Z,
+                   const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
                    float* __restrict__ D, float* __restrict__ D_ag, float* __restrict__ bp,
-                   float* __restrict__ bp_ag, float* __restrict__ HG, float* __restrict__ Gdefer,
+                   float* __restrict__ bp_ag, float* __restrict__ HGcorr, float* __restrict__ G,
                    uint32_t* __restrict__ touched) {
-  const uint32_t rank = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   if (beg == end) return;
-  float w[NI], a[NI];
+  const uint32_t lo = lane * NI;
+  float w[NI], a[NI], wref[NI];
+  vload<NI>(w, D + (size_t)item * hp.Kp + lo);
+  vload<NI>(a, D_ag + (size_t)item * hp.Kp + lo);
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    w[i] = k < hp.K ? D[(size_t)item * hp.Kp + k] : 0.f;
-    a[i] = k < hp.K ? D_ag[(size_t)item * hp.Kp + k] : 1.f;
-  }
+  for (int i = 0; i < NI; ++i) wref[i] = w[i];
   float bias = bp[item], bias_ag = bp_ag[item];
-  // one-ahead prefetch of the example word and of z
-  uint32_t word = sorted_word[beg];
-  float z[NI];
+
+  constexpr int PF = 4;
+  uint64_t val[PF];
+  float z[PF][NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    z[i] = k < hp.K ? Z[(size_t)(word & SLOT_MASK) * hp.Kp + k] : 0.f;
+  for (int j = 0; j < PF; ++j) {
+    val[j] = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) z[j][i] = 0.f;
+    if (beg + j < end) {
+      val[j] = sorted_val[beg + j];
+      vload<NI>(z[j], Z + (size_t)((uint32_t)val[j] & SLOT_MASK) * hp.Kp + lo);
+    }
   }
-  for (uint32_t p = beg; p < end; ++p) {
-    const uint32_t cur = word;
-    float zc[NI];
+  uint32_t prev_slot = 0xFFFFFFFFu;
+  for (uint32_t p = beg; p < end; p += PF) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) zc[i] = z[i];
-    if (p + 1 < end) {
-      word = sorted_word[p + 1];
+    for (int j = 0; j < PF; ++j) {
+      if (p + j < end) {                                     // wave-uniform
+        const uint64_t cur = val[j];
+        float zc[NI];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const uint32_t k = lane + WAVE * i;
-        z[i] = k < hp.K ? Z[(size_t)(word & SLOT_MASK) * hp.Kp + k] : 0.f;
+        for (int i = 0; i < NI; ++i) zc[i] = z[j][i];
+        if (p + j + PF < end) {                              // refill this ring slot, PF examples ahead
+          val[j] = sorted_val[p + j + PF];
+          vload<NI>(z[j], Z + (size_t)((uint32_t)val[j] & SLOT_MASK) * hp.Kp + lo);
+        }
+        const uint32_t word = (uint32_t)cur;
+        const uint32_t slot = word & SLOT_MASK;
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) dot = fmaf(w[i], zc[i], dot);
+        const float y = wave_sum(dot) + bias;
+        const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
+        ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
+        if (lane == 0) G[cur >> 32] = g;
+        if (slot == prev_slot) {                             // duplicate negative of the same user (rare)
+          float* hc = HGcorr + (size_t)slot * hp.Kp + lo;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, g * (w[i] - wref[i]));
+        } else {
+          prev_slot = slot;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) wref[i] = w[i];
+        }
+        if (!(word & INPUT_BIT) || hp.asymmetric) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, zc[i], hp.lambda * w[i]));
+        }
       }
     }
-    const uint32_t slot = cur & SLOT_MASK;
-    float dot = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) dot = fmaf(w[i], zc[i], dot);
-    const float y = wave_sum(dot) + bias;
-    const float g = loss_grad(hp.loss_type, y, (cur & TARGET_BIT) ? 1.f : 0.f);
-    ada_step(hp, bias, bias_ag, g + hp.lambda * bias);
-    float* hg = HG + (size_t)slot * hp.Kp;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const uint32_t k = lane + WAVE * i;
-      if (k < hp.K) unsafeAtomicAdd(hg + k, g * w[i]);
-    }
-    if (cur & INPUT_BIT) {
-      if (lane == 0) Gdefer[p] = g;
-    } else {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, zc[i], hp.lambda * w[i]));
-    }
   }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    if (k < hp.K) {
-      D[(size_t)item * hp.Kp + k] = w[i];
-      D_ag[(size_t)item * hp.Kp + k] = a[i];
-    }
-  }
+  vstore<NI>(D + (size_t)item * hp.Kp + lo, w);
+  vstore<NI>(D_ag + (size_t)item * hp.Kp + lo, a);
   if (lane == 0) {
     bp[item] = bias;
     bp_ag[item] = bias_ag;
@@ -291,51 +346,87 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4a  delta_u = hg_u (.) act'(z_u)  and the private user-node step (cdae.hpp:317-331), one wave/user
+// K4a  hidden gradient + user node, one wavefront per user:
+//   hg_u = sum_e g_e D0[j_e] (+ the duplicate corrections K3 left in HG)     cdae.hpp:240,248,277,285
+//   delta_u = hg_u (.) act'(z_u)                                             cdae.hpp:305,321,337
+//   Wu[u] step (private row, no reduction)                                   cdae.hpp:317-331
+// D0 is the decoder matrix as it was at batch start.  Gather of (1+num_neg) n_u rows per user out of
+// L2 / Infinity Cache; 8 rows in flight per wave, g and item ids staged 64 at a time.
 template <int NI>
 __global__ void __launch_bounds__(256)
-hidden_user_kernel(HyperParams hp, uint64_t u0, uint32_t nb, const float* __restrict__ Dz,
-                   float* __restrict__ HG /* in: hg, out: delta */, float* __restrict__ Wu,
-                   float* __restrict__ Wu_ag) {
+hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64_t u0, uint32_t nb,
+                     const uint32_t* __restrict__ ex_item, const float* __restrict__ G,
+                     const float* __restrict__ D0, const float* __restrict__ Dz,
+                     float* __restrict__ HG /* in: corrections, out: delta */, float* __restrict__ Wu,
+                     float* __restrict__ Wu_ag) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const uint64_t uid = u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n_ex = (uint32_t)(row_ptr[uid + 1] - r0) * (1u + hp.num_neg);
+  const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
+  const uint32_t lo = lane * NI;
+  float acc[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    if (k < hp.K) {
-      const size_t o = (size_t)slot * hp.Kp + k;
-      const float delta = HG[o] * Dz[o];
-      HG[o] = delta;
-      if (hp.user_factor) {
-        const size_t ou = (size_t)uid * hp.Kp + k;
-        float p = Wu[ou], acc = Wu_ag[ou];
-        ada_step(hp, p, acc, delta + hp.lambda * p);
-        Wu[ou] = p;
-        Wu_ag[ou] = acc;
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  constexpr int UN = 8;
+  for (uint32_t c0 = 0; c0 < n_ex; c0 += WAVE) {
+    const uint32_t e = c0 + lane;
+    const uint32_t my_item = e < n_ex ? ex_item[base + e] : 0u;
+    const float my_g = e < n_ex ? G[base + e] : 0.f;         // lanes past the end carry g = 0, item 0
+    const uint32_t cnt = min((uint32_t)WAVE, n_ex - c0);
+    for (uint32_t j0 = 0; j0 < cnt; j0 += UN) {              // WAVE % UN == 0: j0 + t < WAVE
+      float v[UN][NI], gg[UN];
+#pragma unroll
+      for (int t = 0; t < UN; ++t) {
+        const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)my_item, j0 + t);
+        gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), j0 + t));
+        vload<NI>(v[t], D0 + (size_t)it * hp.Kp + lo);
       }
+#pragma unroll
+      for (int t = 0; t < UN; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] = fmaf(gg[t], v[t][i], acc[i]);
     }
+  }
+  const size_t o = (size_t)slot * hp.Kp + lo;
+  float corr[NI], dz[NI], delta[NI];
+  vload<NI>(corr, HG + o);
+  vload<NI>(dz, Dz + o);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) delta[i] = (acc[i] + corr[i]) * dz[i];
+  vstore<NI>(HG + o, delta);
+  if (hp.user_factor) {
+    const size_t ou = (size_t)uid * hp.Kp + lo;
+    float p[NI], pa[NI];
+    vload<NI>(p, Wu + ou);
+    vload<NI>(pa, Wu_ag + ou);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ada_step(hp, p[i], pa[i], fmaf(hp.lambda, p[i], delta[i]));
+    vstore<NI>(Wu + ou, p);
+    vstore<NI>(Wu_ag + ou, pa);
   }
 }
 
 // K4b  hidden bias b: the one parameter every user updates, strictly in user order (cdae.hpp:301-315).
-// One thread per coordinate; the recurrence is elementwise, the delta loads are independent of it.
-__global__ void __launch_bounds__(1024)
+// One thread per coordinate; the recurrence is elementwise, the delta loads run 16 users ahead of it.
+__global__ void __launch_bounds__(64)
 hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA, float* __restrict__ b,
                    float* __restrict__ b_ag) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= hp.K) return;
+  if (k >= hp.Kp) return;
   float p = b[k], acc = b_ag[k];
+  constexpr int UN = 16;
   uint32_t s = 0;
-  for (; s + 8 <= nb; s += 8) {
-    float d[8];
+  for (; s + UN <= nb; s += UN) {
+    float d[UN];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = DELTA[(size_t)(s + j) * hp.Kp + k];
+    for (int j = 0; j < UN; ++j) d[j] = DELTA[(size_t)(s + j) * hp.Kp + k];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ada_step(hp, p, acc, d[j] + hp.lambda * p);
+    for (int j = 0; j < UN; ++j) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
   }
-  for (; s < nb; ++s) ada_step(hp, p, acc, DELTA[(size_t)s * hp.Kp + k] + hp.lambda * p);
+  for (; s < nb; ++s) ada_step(hp, p, acc, fmaf(hp.lambda, p, DELTA[(size_t)s * hp.Kp + k]));
   b[k] = p;
   b_ag[k] = acc;
 }
@@ -344,59 +435,71 @@ hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA,
 // K5  input rows, row-major (cdae.hpp:333-349): for every kept input (u, j) in user order
 //     grad = scale * delta_u + lambda W[j] + g_uj z_u   (the last term is the deferred decoder
 //     gradient input_gradient[j], cdae.hpp:249-250, 342-343; absent when asymmetric)
+// The row's example words are scanned 64 at a time; the kept inputs among them are processed in groups
+// of UN with all their delta/z/g loads issued before the (elementwise, reduction-free) AdaGrad chain.
 template <int NI>
 __global__ void __launch_bounds__(256)
 input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                   const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
-                  const uint32_t* __restrict__ sorted_word, const float* __restrict__ Z,
-                  const float* __restrict__ DELTA, const float* __restrict__ Gdefer,
+                  const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
+                  const float* __restrict__ DELTA, const float* __restrict__ G,
                   float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched) {
-  const uint32_t rank = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   if (beg == end) return;
+  const uint32_t lo = lane * NI;
   float w[NI], a[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { w[i] = 0.f; a[i] = 1.f; }
   bool loaded = false;
+  constexpr int UN = 4;
   for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
     const uint32_t p = p0 + lane;
-    const uint32_t word = p < end ? sorted_word[p] : 0u;
+    const uint64_t val = p < end ? sorted_val[p] : 0ull;
+    const uint32_t word = (uint32_t)val;
+    const uint32_t ex = (uint32_t)(val >> 32);
     unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
     if (mask && !loaded) {
       loaded = true;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const uint32_t k = lane + WAVE * i;
-        w[i] = k < hp.K ? W[(size_t)item * hp.Kp + k] : 0.f;
-        a[i] = k < hp.K ? W_ag[(size_t)item * hp.Kp + k] : 1.f;
-      }
+      vload<NI>(w, W + (size_t)item * hp.Kp + lo);
+      vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
     }
     while (mask) {
-      const int src = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const uint32_t slot = __shfl(word, src, WAVE) & SLOT_MASK;
-      const float g = hp.asymmetric ? 0.f : Gdefer[p0 + src];
+      float dl[UN][NI], zz[UN][NI], gg[UN];
+      bool on[UN];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const uint32_t k = lane + WAVE * i;
-        if (k < hp.K) {
-          const size_t o = (size_t)slot * hp.Kp + k;
-          const float grad = fmaf(hp.scale, DELTA[o], fmaf(g, Z[o], hp.lambda * w[i]));
-          ada_step(hp, w[i], a[i], grad);
+      for (int t = 0; t < UN; ++t) {
+        on[t] = mask != 0ull;                                // wave-uniform
+        gg[t] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { dl[t][i] = 0.f; zz[t][i] = 0.f; }
+        if (on[t]) {
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, src) & SLOT_MASK;
+          const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ex, src);
+          const size_t o = (size_t)slot * hp.Kp + lo;
+          vload<NI>(dl[t], DELTA + o);
+          vload<NI>(zz[t], Z + o);
+          if (!hp.asymmetric) gg[t] = G[e];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UN; ++t) {
+        if (on[t]) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i)
+            ada_step(hp, w[i], a[i], fmaf(hp.scale, dl[t][i], fmaf(gg[t], zz[t][i], hp.lambda * w[i])));
         }
       }
     }
   }
   if (loaded) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const uint32_t k = lane + WAVE * i;
-      if (k < hp.K) {
-        W[(size_t)item * hp.Kp + k] = w[i];
-        W_ag[(size_t)item * hp.Kp + k] = a[i];
-      }
-    }
+    vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
+    vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
     if (lane == 0 && touched) touched[item] = 1u;
   }
 }
@@ -414,21 +517,17 @@ data_loss_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
   const uint64_t uid = u0 + slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint32_t lo = lane * NI;
   float z[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    z[i] = k < hp.K ? Z[(size_t)slot * hp.Kp + k] : 0.f;
-  }
+  vload<NI>(z, Z + (size_t)slot * hp.Kp + lo);
   double total = 0.;
   for (uint32_t p = 0; p < n; ++p) {
     const uint32_t item = col[r0 + p];
+    float d[NI];
+    vload<NI>(d, D + (size_t)item * hp.Kp + lo);
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const uint32_t k = lane + WAVE * i;
-      dot = fmaf(k < hp.K ? D[(size_t)item * hp.Kp + k] : 0.f, z[i], dot);
-    }
+    for (int i = 0; i < NI; ++i) dot = fmaf(d[i], z[i], dot);
     const float y = wave_sum(dot) + bp[item];
     total += (double)loss_eval(hp.loss_type, y, 1.f);
   }
@@ -464,19 +563,15 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
   const uint32_t slot = blockIdx.x;
   const uint64_t uid = u0 + slot;
   const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+  const uint32_t lo = lane * NI;
   float z[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const uint32_t k = lane + WAVE * i;
-    z[i] = k < hp.K ? Z[(size_t)slot * hp.Kp + k] : 0.f;
-  }
+  vload<NI>(z, Z + (size_t)slot * hp.Kp + lo);
   for (uint32_t item = wid; item < hp.num_items; item += nw) {
+    float d[NI];
+    vload<NI>(d, D + (size_t)item * hp.Kp + lo);
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const uint32_t k = lane + WAVE * i;
-      dot = fmaf(k < hp.K ? D[(size_t)item * hp.Kp + k] : 0.f, z[i], dot);
-    }
+    for (int i = 0; i < NI; ++i) dot = fmaf(d[i], z[i], dot);
     const float y = wave_sum(dot) + bp[item];
     if (lane == 0) score[item] = y;
   }
@@ -513,7 +608,7 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
 }
 
 // ------------------------------------------------------------------------------------------------
-// parameter init (cdae.hpp:109-134) from the CDAE_STREAM_INIT counter stream
+// parameter init (cdae.hpp:109-134) from the CDAE_STREAM_INIT counter stream; pad elements get `pad`
 __global__ void __launch_bounds__(256)
 init_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, uint64_t key, double init_scale) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,10 +618,10 @@ init_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, 
   M[idx] = k < K ? (float)(cdae_init_uniform(key, r * K + k) * init_scale) : 0.f;
 }
 __global__ void __launch_bounds__(256)
-fill_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, float value) {
+fill_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, float value, float pad) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * Kp) return;
-  M[idx] = (uint32_t)(idx % Kp) < K ? value : 0.f;
+  M[idx] = (uint32_t)(idx % Kp) < K ? value : pad;
 }
 
 // data-parallel exchange helpers (no reference counterpart; DESIGN.md "Multi-GPU")

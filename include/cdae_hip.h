@@ -28,7 +28,8 @@
  * returns a thread-local message for the last failure.  No exceptions cross the boundary.  All
  * pointers are HOST pointers unless the name says `device`.  The library owns all device memory.
  * A handle is used from one host thread at a time.  Parameters are fp32 row-major with the row
- * stride returned by cdae_hip_row_stride() (num_dim rounded up to a multiple of 4; pad lanes are 0).
+ * stride returned by cdae_hip_row_stride() (64, 128, 256 or 512 floats — the smallest that holds
+ * num_dim; pad lanes are 0, or 1 in the AdaGrad accumulators, and stay so).
  */
 #ifndef CDAE_HIP_H_
 #define CDAE_HIP_H_

@@ -14,12 +14,14 @@
  * Two schedules:
  *   literal  — train_one_iteration exactly as cdae.hpp:136-146 + 198-358: users strictly in order,
  *              every row updated the moment the reference updates it.
- *   batched  — the schedule the HIP path executes: users are taken in blocks of B; all B encodes see
- *              the block-start parameters; the decode runs row-major (for each item row, its
- *              (user, target) examples in user order — every dot product sees every earlier update of
- *              that row, exactly like the reference), then hidden-layer/bias/user-node steps in user
- *              order, then the input-row steps row-major.  With B = 1 the two schedules perform the
- *              same floating-point operations in the same order (tests assert bit equality).
+ *   batched  — the schedule the HIP path executes: users are taken in blocks of B; the hidden layer of
+ *              every user of a block (z_u and the hidden gradient sum_e g_e D[j_e]) is evaluated against
+ *              the block-start parameters (plus the user's own duplicate-negative updates); the decode
+ *              runs row-major (for each item row, its (user, target) examples in user order — every dot
+ *              product sees every earlier update of that row, exactly like the reference), then
+ *              hidden-bias/user-node steps in user order, then the input-row steps row-major.  With
+ *              B = 1 the two schedules are the same algorithm (tests assert agreement to 1e-12; only
+ *              the summation order of the hidden gradient differs).
  * Randomness: include/cdae_rng.h counter streams (the reference's global mt19937_64 / rand() are
  * order-dependent and cannot be shared with a parallel implementation; see that header).
  */
@@ -252,10 +254,13 @@ struct Oracle {
           for (size_t i = 0; i < neg.size(); ++i) ex.push_back(Ex{neg[i], (uint32_t)s, 0, 0, (uint32_t)ex.size()});
         }
         G.assign(ex.size(), 0.);
+        const std::vector<double> D0(D);     // decoder rows at block start (hidden-gradient snapshot)
         // row-major order: stable by item (order == user order, positives before negatives)
         std::vector<Ex> sorted(ex);
         std::stable_sort(sorted.begin(), sorted.end(), [](const Ex& a, const Ex& b) { return a.item < b.item; });
         // phase B: decode, every row sequential over its examples
+        std::vector<double> wref(K);
+        uint32_t prev_item = 0xFFFFFFFFu, prev_slot = 0xFFFFFFFFu;
         for (const Ex& e : sorted) {
           size_t iid = e.item;
           const double* z = &Z[(size_t)e.slot * K];
@@ -263,11 +268,24 @@ struct Oracle {
           double g = loss_grad(y, e.target ? 1. : 0.);
           ada1(bp[iid], bp_ag[iid], g + c.lambda * bp[iid]);
           double* row = &D[iid * K];
-          double* hg = &HG[(size_t)e.slot * K];
-          for (size_t k = 0; k < K; ++k) hg[k] += g * row[k];
-          if (!c.asymmetric && e.is_in) { G[e.order] = g; continue; }
+          G[e.order] = g;
+          if (e.item == prev_item && e.slot == prev_slot) {
+            // the same user's duplicate negative: its hidden gradient sees its own earlier update of the row
+            double* hg = &HG[(size_t)e.slot * K];
+            for (size_t k = 0; k < K; ++k) hg[k] += g * (row[k] - wref[k]);
+          } else {
+            prev_item = e.item; prev_slot = e.slot;
+            for (size_t k = 0; k < K; ++k) wref[k] = row[k];
+          }
+          if (!c.asymmetric && e.is_in) continue;
           for (size_t k = 0; k < K; ++k) grad[k] = g * z[k] + c.lambda * row[k];
           ada_row(row, &D_ag[iid * K], grad.data());
+        }
+        // hidden gradient against the block-start decoder rows (+ the duplicate corrections above)
+        for (const Ex& e : ex) {
+          double* hg = &HG[(size_t)e.slot * K];
+          const double* row0 = &D0[(size_t)e.item * K];
+          for (size_t k = 0; k < K; ++k) hg[k] += G[e.order] * row0[k];
         }
         // phase C: hidden bias + user node, user order
         std::vector<double> DELTA(nb * K);
