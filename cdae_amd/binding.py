@@ -56,6 +56,7 @@ EXPORTS = {
     "cdae_hip_param_device_ptr": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
     "cdae_hip_train_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
+    "cdae_hip_train_one_user_corruption": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "cdae_hip_synchronize": (C.c_int, [C.c_void_p]),
     "cdae_hip_encode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -204,6 +205,12 @@ class CDAE:
         st = Stats()
         _chk(self.lib, self.lib.cdae_hip_train_users(self.h, seed, epoch, u_begin, u_end, C.byref(st)))
         return st
+
+    def train_one_user_corruption(self, uid: int, input_items, negative_items):
+        """cdae.hpp:198-200 with explicit input set; negatives as the reference would have drawn them."""
+        i = np.ascontiguousarray(input_items, dtype=np.uint32)
+        n = np.ascontiguousarray(negative_items, dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_train_one_user_corruption(self.h, uid, i.ctypes.data, i.size, n.ctypes.data, n.size))
 
     def get_hidden_values(self, uids, seed: int = 0, epoch: int = 0, mode: int = 0) -> np.ndarray:
         u = np.ascontiguousarray(uids, dtype=np.uint32)

@@ -191,9 +191,12 @@ template <class T> int dev_alloc(T** p, size_t n) {
 }
 
 // one batch of train_one_user_corruption for users [s0, s0+nb), corruption cidx
-int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch, uint64_t* n_ex_out) {
+// explicit_in != nullptr: single user (nb == 1) whose example list and input set were written by the caller
+int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch, uint64_t* n_ex_out,
+              const uint32_t* explicit_in = nullptr, uint32_t n_explicit = 0, uint64_t explicit_examples = 0) {
   using namespace cdae;
-  const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
+  const uint64_t E = explicit_in ? explicit_examples
+                                 : (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
   *n_ex_out = E;
   if (E == 0) return 0;
   if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
@@ -204,8 +207,9 @@ int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t see
   Prof pr;
 
   CHK(pr.begin(h, F_SAMPLE));
-  hipLaunchKernelGGL(sample_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, s0, nb, cidx, seed, epoch,
-                     h->d_ex_item, h->d_ex_val);
+  if (!explicit_in)
+    hipLaunchKernelGGL(sample_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, s0, nb, cidx, seed, epoch,
+                       h->d_ex_item, h->d_ex_val);
   CHK(pr.end());
 
   CHK(pr.begin(h, F_SORT));
@@ -219,20 +223,32 @@ int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t see
   CHK(pr.begin(h, F_ENCODE));
   HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));             // b of the previous batch (side stream)
   DISPATCH_NI(h->NI, encode_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), h->d_Wu,
-              h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Z, h->d_Dz);
+              h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Z, h->d_Dz, explicit_in, n_explicit);
   HIPCHK(hipMemsetAsync(h->d_HG, 0, (size_t)nb * h->Kp * sizeof(float), st));
   HIPCHK(hipMemcpyAsync(h->d_D0, h->dec(), (size_t)I * h->Kp * sizeof(float), hipMemcpyDeviceToDevice, st));
   CHK(pr.end());
 
   CHK(pr.begin(h, F_DECODE));
-  DISPATCH_NI(h->NI, decode_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, h->d_seg, h->d_seg + I,
-              h->d_sorted_val, h->d_Z, h->dec(), h->dec_ag(), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G,
-              h->d_touched);
+#define DECODE_ARGS h->hp, h->d_item_order, h->d_seg, h->d_seg + I, h->d_sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
+                    h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_touched
+#define DECODE_NI(NI_)                                                                                              \
+  do {                                                                                                              \
+    if (ce && ada) hipLaunchKernelGGL((decode_rows_kernel<NI_, 5, true>), grid_rows, blk, 0, st, DECODE_ARGS);      \
+    else if (ce) hipLaunchKernelGGL((decode_rows_kernel<NI_, 5, false>), grid_rows, blk, 0, st, DECODE_ARGS);       \
+    else if (ada) hipLaunchKernelGGL((decode_rows_kernel<NI_, 0, true>), grid_rows, blk, 0, st, DECODE_ARGS);       \
+    else hipLaunchKernelGGL((decode_rows_kernel<NI_, 0, false>), grid_rows, blk, 0, st, DECODE_ARGS);               \
+  } while (0)
+  {
+    const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY, ada = h->cfg.using_adagrad != 0;
+    switch (h->NI) { case 1: DECODE_NI(1); break; case 2: DECODE_NI(2); break; case 4: DECODE_NI(4); break; default: DECODE_NI(8); break; }
+  }
+#undef DECODE_NI
+#undef DECODE_ARGS
   CHK(pr.end());
 
   CHK(pr.begin(h, F_HIDDEN));
   DISPATCH_NI(h->NI, hidden_gather_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, s0, nb, h->d_ex_item, h->d_G,
-              h->d_D0, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag);
+              h->d_D0, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, explicit_in ? (uint32_t)E : 0u);
   CHK(pr.end());
   // the strictly sequential hidden-bias recurrence needs only delta: run it beside the input rows
   HIPCHK(hipEventRecord(h->ev_delta, st));
@@ -255,7 +271,7 @@ int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, 
                  uint32_t cidx, uint64_t seed, uint32_t epoch) {
   DISPATCH_NI(h->NI, cdae::encode_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
               h->P(CDAE_P_W), h->d_Wu, h->P(CDAE_P_B), d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Z,
-              (float*)nullptr);
+              (float*)nullptr, (const uint32_t*)nullptr, 0u);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -625,6 +641,50 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
     HIPCHK(hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
+  return 0;
+}
+
+int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32_t* input_items, size_t n_in,
+                                       const uint32_t* negative_items, size_t n_neg) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if (uid >= h->U) return fail("user id %llu out of range", (unsigned long long)uid);
+  if ((n_in && !input_items) || (n_neg && !negative_items)) return fail("null argument");
+  HIPCHK(hipSetDevice(h->device));
+  const int64_t r0 = h->h_row_ptr[uid];
+  const size_t n_pos = (size_t)(h->h_row_ptr[uid + 1] - r0);
+  const size_t E = n_pos + n_neg;
+  if (E > h->Ecap) return fail("%zu examples exceed the batch capacity %llu", E, (unsigned long long)h->Ecap);
+  std::vector<uint32_t> pos(n_pos), items(E), in_sorted(input_items, input_items + n_in);
+  HIPCHK(hipMemcpy(pos.data(), h->d_col + r0, n_pos * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  std::sort(in_sorted.begin(), in_sorted.end());
+  for (size_t i = 0; i < n_in; ++i) {
+    if (!std::binary_search(pos.begin(), pos.end(), in_sorted[i])) return fail("input item %u is not a training item of user %llu", in_sorted[i], (unsigned long long)uid);
+    if (i && in_sorted[i] == in_sorted[i - 1]) return fail("duplicate input item %u", in_sorted[i]);
+  }
+  std::vector<uint64_t> vals(E);
+  for (size_t p = 0; p < n_pos; ++p) {
+    const bool kept = std::binary_search(in_sorted.begin(), in_sorted.end(), pos[p]);
+    items[p] = pos[p];
+    vals[p] = ((uint64_t)p << 32) | (uint64_t)(cdae::TARGET_BIT | (kept ? cdae::INPUT_BIT : 0u));    // slot 0
+  }
+  for (size_t i = 0; i < n_neg; ++i) {
+    if (negative_items[i] >= h->I) return fail("negative item %u out of range", negative_items[i]);
+    if (std::binary_search(pos.begin(), pos.end(), negative_items[i])) return fail("negative item %u is a training item", negative_items[i]);
+    items[n_pos + i] = negative_items[i];
+    vals[n_pos + i] = (uint64_t)(n_pos + i) << 32;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_ex_item, items.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_ex_val, vals.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  uint32_t* d_in = h->d_uids;                     // reuse: capacity B >= 1 ... inputs can be longer: own buffer
+  uint32_t* d_in_owned = nullptr;
+  if (n_in > std::min<uint64_t>(h->B, h->U)) { CHK(dev_alloc(&d_in_owned, n_in)); d_in = d_in_owned; }
+  if (n_in) HIPCHK(hipMemcpyAsync(d_in, in_sorted.data(), n_in * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  uint64_t e = 0;
+  int rc = run_batch(h, uid, 1, 0, 0, 0, &e, d_in, (uint32_t)n_in, E);
+  hipError_t se = hipStreamSynchronize(h->stream);
+  if (d_in_owned) (void)hipFree(d_in_owned);
+  if (rc) return rc;
+  if (se != hipSuccess) return fail("stream synchronize failed: %s", hipGetErrorString(se));
   return 0;
 }
 

@@ -185,14 +185,17 @@ __global__ void __launch_bounds__(256)
 encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
               const float* __restrict__ W, const float* __restrict__ Wu, const float* __restrict__ b,
               const uint32_t* __restrict__ uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream,
-              uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Z, float* __restrict__ Dz) {
+              uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Z, float* __restrict__ Dz,
+              const uint32_t* __restrict__ explicit_in, uint32_t n_explicit) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const uint64_t uid = uids ? (uint64_t)uids[slot] : u0 + slot;
   const int64_t r0 = row_ptr[uid];
-  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
-  const uint32_t* row = col + r0;
+  // explicit_in: the caller supplies the corrupted input set itself, like the reference's public
+  // train_one_user_corruption(uid, input_set, output_set) (cdae.hpp:198-200); mode 1 scale, no mask
+  const uint32_t n = explicit_in ? n_explicit : (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint32_t* row = explicit_in ? explicit_in : col + r0;
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, stream);
   const bool none = (mode == 0 && hp.keep_thr == 0x100000000ull);   // cdae.hpp:168-172 (q == 1 -> empty input)
   const uint32_t lo = lane * NI;
@@ -206,7 +209,7 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     int keep = 0;
     if (p < n) {
       item = row[p];
-      keep = mode == 0 ? 1 : cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+      keep = (mode == 0 || explicit_in) ? 1 : cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
     }
     unsigned long long mask = __ballot(keep);
     while (mask) {
@@ -262,8 +265,15 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
 // duplicate negatives — g * (row now - row at the user's first visit) — which is what makes
 // batch_users == 1 reproduce the reference in exact arithmetic.
 // D = V when asymmetric else W.  Rows are visited in `item_order` (popular rows first: their example
-// chains are the longest and bound the kernel).  z and the example words run PF examples ahead.
-template <int NI>
+// chains are the longest and bound the kernel).
+// Memory pipeline: the row's example words are fetched 64 at a time (one coalesced 512-byte load, next
+// chunk in flight), broadcast with v_readlane; z_u rows run PF examples ahead in a register ring; g is
+// parked in lane (p mod 64) of one VGPR and written once per chunk.  The inner loop therefore issues
+// loads only, which is what lets s_waitcnt vmcnt(N) be counted instead of drained (on gfx9 stores share
+// the counter and complete out of order with loads).
+constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15 = don't care), gfx9 encoding
+
+template <int NI, int LOSS, bool ADAGRAD>
 __global__ void __launch_bounds__(256)
 decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                    const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
@@ -277,7 +287,10 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   if (beg == end) return;
+  hp.loss_type = LOSS;                 // compile-time specialisation of the per-example branches
+  hp.adagrad = ADAGRAD;
   const uint32_t lo = lane * NI;
+  const bool tied = !hp.asymmetric;
   float w[NI], a[NI], wref[NI];
   vload<NI>(w, D + (size_t)item * hp.Kp + lo);
   vload<NI>(a, D_ag + (size_t)item * hp.Kp + lo);
@@ -286,55 +299,71 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   float bias = bp[item], bias_ag = bp_ag[item];
 
   constexpr int PF = 4;
-  uint64_t val[PF];
+  // cur / nxt: this lane's example word (slot | flags) and example index of the current / next chunk
+  uint64_t v0 = beg + lane < end ? sorted_val[beg + lane] : 0ull;
+  uint32_t cur_w = (uint32_t)v0, cur_e = (uint32_t)(v0 >> 32), nxt_w = 0, nxt_e = 0;
   float z[PF][NI];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
-    val[j] = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) z[j][i] = 0.f;
     if (beg + j < end) {
-      val[j] = sorted_val[beg + j];
-      vload<NI>(z[j], Z + (size_t)((uint32_t)val[j] & SLOT_MASK) * hp.Kp + lo);
+      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, j) & SLOT_MASK;
+      vload<NI>(z[j], Z + (size_t)s * hp.Kp + lo);
     }
   }
   uint32_t prev_slot = 0xFFFFFFFFu;
-  for (uint32_t p = beg; p < end; p += PF) {
+  for (uint32_t c0 = beg; c0 < end; c0 += WAVE) {
+    {
+      const uint32_t q = c0 + WAVE + lane;
+      const uint64_t vn = q < end ? sorted_val[q] : 0ull;
+      nxt_w = (uint32_t)vn; nxt_e = (uint32_t)(vn >> 32);
+    }
+    const uint32_t cnt = min((uint32_t)WAVE, end - c0);
+    float gbuf = 0.f;
+    for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
-      if (p + j < end) {                                     // wave-uniform
-        const uint64_t cur = val[j];
-        float zc[NI];
+      for (int t = 0; t < PF; ++t) {
+        const uint32_t idx = j0 + t;
+        if (idx < cnt) {                                       // wave-uniform
+          const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
+          const uint32_t slot = word & SLOT_MASK;
+          float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) zc[i] = z[j][i];
-        if (p + j + PF < end) {                              // refill this ring slot, PF examples ahead
-          val[j] = sorted_val[p + j + PF];
-          vload<NI>(z[j], Z + (size_t)((uint32_t)val[j] & SLOT_MASK) * hp.Kp + lo);
+          for (int i = 0; i < NI; ++i) dot = fmaf(w[i], z[t][i], dot);
+          const float y = wave_sum(dot) + bias;
+          const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
+          ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
+          gbuf = lane == idx ? g : gbuf;
+          if (slot == prev_slot) {                             // duplicate negative of the same user (rare)
+            float* hc = HGcorr + (size_t)slot * hp.Kp + lo;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, g * (w[i] - wref[i]));
+            __builtin_amdgcn_s_waitcnt(WAIT_VM0);              // keep the loop's VMEM stream loads-only
+          } else {
+            prev_slot = slot;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wref[i] = w[i];
+          }
+          if (!(word & INPUT_BIT) || !tied) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
+          }
         }
-        const uint32_t word = (uint32_t)cur;
-        const uint32_t slot = word & SLOT_MASK;
-        float dot = 0.f;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) dot = fmaf(w[i], zc[i], dot);
-        const float y = wave_sum(dot) + bias;
-        const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
-        ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
-        if (lane == 0) G[cur >> 32] = g;
-        if (slot == prev_slot) {                             // duplicate negative of the same user (rare)
-          float* hc = HGcorr + (size_t)slot * hp.Kp + lo;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, g * (w[i] - wref[i]));
-        } else {
-          prev_slot = slot;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) wref[i] = w[i];
-        }
-        if (!(word & INPUT_BIT) || hp.asymmetric) {
-#pragma unroll
-          for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, zc[i], hp.lambda * w[i]));
+        // refill ring slot t with the example PF ahead (clamped to the row's last example; the value is
+        // never consumed past the end).  Issued after the slot's last use so that the load lands in the
+        // same registers and the compiler can wait with a counted vmcnt instead of draining.
+        {
+          const uint32_t rel = min(c0 + idx + PF, end - 1u) - c0;
+          const uint32_t nw = rel < (uint32_t)WAVE ? (uint32_t)__builtin_amdgcn_readlane((int)cur_w, rel & 63u)
+                                                   : (uint32_t)__builtin_amdgcn_readlane((int)nxt_w, rel & 63u);
+          vload<NI>(z[t], Z + (size_t)(nw & SLOT_MASK) * hp.Kp + lo);
         }
       }
     }
+    if (lane < cnt) G[cur_e] = gbuf;
+    __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    cur_w = nxt_w; cur_e = nxt_e;
   }
   vstore<NI>(D + (size_t)item * hp.Kp + lo, w);
   vstore<NI>(D_ag + (size_t)item * hp.Kp + lo, a);
@@ -358,13 +387,13 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64
                      const uint32_t* __restrict__ ex_item, const float* __restrict__ G,
                      const float* __restrict__ D0, const float* __restrict__ Dz,
                      float* __restrict__ HG /* in: corrections, out: delta */, float* __restrict__ Wu,
-                     float* __restrict__ Wu_ag) {
+                     float* __restrict__ Wu_ag, uint32_t explicit_examples /* != 0: one user, that many examples */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const uint64_t uid = u0 + slot;
   const int64_t r0 = row_ptr[uid];
-  const uint32_t n_ex = (uint32_t)(row_ptr[uid + 1] - r0) * (1u + hp.num_neg);
+  const uint32_t n_ex = explicit_examples ? explicit_examples : (uint32_t)(row_ptr[uid + 1] - r0) * (1u + hp.num_neg);
   const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
   const uint32_t lo = lane * NI;
   float acc[NI];

@@ -79,3 +79,32 @@ class DeltaExchange:
             self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM)
             self.torch.cuda.current_stream().synchronize()
         self.model.delta_apply(self.world, self.rule)
+
+
+class HostDeltaExchange:
+    """The same exchange protocol over host tensors (any torch.distributed backend, e.g. gloo).
+
+    `get_shared()` / `set_shared(t)` move the flat shared block [matrices | bp | bp_ag | b | b_ag]; `touched()`
+    returns the per-item 0/1 indicator of this step.  Used by the multi-process CPU tests to exercise the
+    sharding + all-reduce + combine logic without a GPU; the GPU path (DeltaExchange) runs the identical
+    protocol with the buffers and the combine kernel inside libcdae_hip.so.
+    """
+
+    def __init__(self, get_shared, set_shared, touched, dist, world: int, n_matrix: int, Kp: int, num_items: int,
+                 rule: int = RULE_SUM):
+        self.get_shared, self.set_shared, self.touched = get_shared, set_shared, touched
+        self.dist, self.world, self.rule = dist, world, rule
+        self.n_matrix, self.Kp, self.I = n_matrix, Kp, num_items
+        self.base = None
+
+    def begin(self):
+        self.base = self.get_shared().clone()
+
+    def finish(self):
+        import torch
+        cur = self.get_shared()
+        buf = torch.cat([cur - self.base, self.touched().to(cur.dtype)])
+        if self.world > 1:
+            self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+        n = cur.numel()
+        self.set_shared(combine_reference(self.base, buf[:n], buf[n:], self.n_matrix, self.Kp, self.I, self.world, self.rule))

@@ -6,9 +6,10 @@ shuffled instances going to test (/root/reference/src/base/data-inl.hpp:231-272)
 network here, so bench.py and the tests generate data of the same shape:
 
   * user activity n_u ~ log-normal, clipped to [min_items, I/4], mean set by `nnz`
-  * item popularity Zipf(s); half of every user's draws come from a global ranking, half from the
-    ranking of the user's latent group (a per-group permutation of the head), so that a model which
-    learns user structure beats the popularity baseline and Recall@10 is a meaningful parity signal
+  * item popularity Zipf(s); 20 % of every user's draws come from a global ranking, 80 % from the
+    ranking of the user's latent group (a per-group permutation of the items), so that a model which
+    learns user structure beats the popularity baseline by a wide margin (Recall@10 ~0.23 vs ~0.09 at
+    4000 x 1500) and Recall@10 is a meaningful parity signal
   * ids dense 0..U-1 / 0..I-1, rows sorted ascending and unique
   * per-user split: floor(test_ratio * n) random items to test, the rest to train
 
@@ -65,8 +66,8 @@ def _csr_from_pairs(users: np.ndarray, items: np.ndarray, num_users: int):
 
 
 def generate(num_users: int, num_items: int, nnz: int, seed: int = 20141119, zipf_s: float = 1.0,
-             groups: int = 32, min_items: int = 20, test_ratio: float = 0.2,
-             group_mix: float = 0.5) -> Interactions:
+             groups: int = 16, min_items: int = 20, test_ratio: float = 0.2,
+             group_mix: float = 0.8) -> Interactions:
     rng = np.random.default_rng(seed)
     max_items = max(min_items + 1, num_items // 4)
     mean_target = nnz / num_users

@@ -17,7 +17,8 @@
  *   CDAE::train_one_iteration            cdae.hpp:136-146    cdae_hip_train_epoch
  *     get_corrputed_input                cdae.hpp:361-371      (device, include/cdae_rng.h)
  *     sample_negative_item               recsys_model_base.hpp:46-57  (device, include/cdae_rng.h)
- *     train_one_user_corruption          cdae.hpp:198-358      (device kernels)
+ *     train_one_user_corruption          cdae.hpp:198-358      (device kernels; explicit-input form:
+ *                                                           cdae_hip_train_one_user_corruption)
  *   CDAE::get_hidden_values              cdae.hpp:373-416    cdae_hip_encode
  *   CDAE::data_loss                      cdae.hpp:78-101     cdae_hip_data_loss
  *   CDAE::penalty_loss                   cdae.hpp:103-107    cdae_hip_penalty_loss
@@ -125,6 +126,12 @@ int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, 
 int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
 int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin,
                          uint64_t u_end, cdae_hip_stats* stats);
+/* The reference's public per-user step with the caller's own corrupted input set,
+ * train_one_user_corruption(uid, input_set, output_set) (cdae.hpp:198-200; output_set is the user's
+ * train row), plus the negatives the reference would draw at cdae.hpp:217-220.  Known-answer tests use it
+ * to feed fixed masks and negatives (duplicates allowed, processed in the given order). */
+int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32_t* input_items,
+                                       size_t n_input, const uint32_t* negative_items, size_t n_negative);
 int cdae_hip_set_profiling(cdae_hip_t* h, int enabled);
 int cdae_hip_synchronize(cdae_hip_t* h);
 

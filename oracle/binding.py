@@ -99,6 +99,10 @@ def _load():
     lib.oracle_heap_size.restype = u64
     lib.oracle_heap_size.argtypes = [vp]
     lib.oracle_heap_sorted.argtypes = [vp, vp, vp]
+    lib.oracle_heap_front.restype = u64
+    lib.oracle_heap_front.argtypes = [vp]
+    lib.oracle_heap_pop.restype = u64
+    lib.oracle_heap_pop.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -230,6 +234,12 @@ class OracleHeap:
 
     def size(self):
         return self.lib.oracle_heap_size(self.h)
+
+    def front(self):
+        return self.lib.oracle_heap_front(self.h)
+
+    def pop(self):
+        return self.lib.oracle_heap_pop(self.h)
 
     def sorted(self):
         n = self.size()

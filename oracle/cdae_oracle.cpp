@@ -526,6 +526,11 @@ void oracle_heap_push_and_pop(void* p, uint64_t id, double v) {            // he
   if (ocomp(t, h->d.front())) { std::pop_heap(h->d.begin(), h->d.end(), ocomp); h->d.pop_back(); h->d.push_back(t); std::push_heap(h->d.begin(), h->d.end(), ocomp); }
 }
 uint64_t oracle_heap_size(void* p) { return ((OHeap*)p)->d.size(); }
+uint64_t oracle_heap_front(void* p) { return ((OHeap*)p)->d.front().first; }
+uint64_t oracle_heap_pop(void* p) {                                         // heap.hpp:34-42
+  auto* h = (OHeap*)p; std::pop_heap(h->d.begin(), h->d.end(), ocomp);
+  uint64_t r = h->d.back().first; h->d.pop_back(); return r;
+}
 void oracle_heap_sorted(void* p, uint64_t* ids, double* vals) {             // heap.hpp:66-69
   auto* h = (OHeap*)p; auto c = h->d; std::sort_heap(c.begin(), c.end(), ocomp);
   for (size_t i = 0; i < c.size(); ++i) { ids[i] = c[i].first; vals[i] = c[i].second; }

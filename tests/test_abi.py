@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library cross-compiles, loads, and exports exactly what include/cdae_hip.h declares.
+No compute is attempted here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import cdae_amd
+from cdae_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cdae_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_exported_and_bound(built):
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    lib = ctypes.CDLL(cdae_amd.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/cdae_hip.h but not exported"
+    assert sorted(binding.EXPORTS) == syms, "binding.EXPORTS and the header disagree"
+
+
+def test_abi_version_and_config_layout(built):
+    lib = cdae_amd.load_library()
+    assert lib.cdae_hip_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
+    assert "#define CDAE_HIP_ABI_VERSION 1" in hdr
+    # 12 uint32 + 4 double, naturally aligned
+    assert ctypes.sizeof(binding._Config) == 12 * 4 + 4 * 8
+    assert ctypes.sizeof(binding.Stats) == 8 * 11
+
+
+def test_no_cpu_fallback_without_a_device(built):
+    """Without a HIP device the product path must fail loudly, not compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(cdae_amd.CDAEError):
+        cdae_amd.CDAE(cdae_amd.CDAEConfig(lt=cdae_amd.SQUARE))
+
+
+def test_library_is_gfx950_code_object(built):
+    blob = open(cdae_amd.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"decode_rows_kernel" in blob and b"hidden_gather_kernel" in blob
+
+
+def test_product_sources_do_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing shipped may include, import or link it."""
+    bad = []
+    for base in ("cdae_amd", "include", "src"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".cc")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"(^|\W)(import|from)\s+oracle\b|#include\s*[\"<][^\">]*oracle", text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -126,3 +126,33 @@ def test_errors_are_reported_not_swallowed(tiny):
     ptr = np.array([0, 2], dtype=np.int64)
     with pytest.raises(cdae_amd.CDAEError, match="ascending"):
         m.set_interactions(1, 5, ptr, np.array([3, 1], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
+    """World of one process emulating two identical ranks: the all-reduced buffer is 2 x this rank's."""
+    import torch
+    from cdae_amd.distributed import DeltaExchange, combine_reference
+    model, _ = make_pair(tiny, K=20, B=64)
+    ex = DeltaExchange(model, None, 1, rule)
+    shared_ids = (0, 1, 8, 9, 6, 7)
+    ex.begin()
+    before = {w: model.get(w).astype(np.float64) for w in shared_ids}
+    model.train_users(seed=2, epoch=0, u_begin=0, u_end=64)
+    after = {w: model.get(w).astype(np.float64) for w in shared_ids}
+    model.delta_compute()
+    assert ex.buf.is_cuda and ex.buf.numel() == model.delta_device_ptr()[1]
+    ex.buf.mul_(2.0)                                   # "all-reduce" of two identical ranks
+    torch.cuda.synchronize()
+    model.delta_apply(2, rule)
+    touched = (np.abs(after[1] - before[1]).sum(1) + np.abs(after[9] - before[9])) > 0
+    for w in shared_ids:
+        d = after[w] - before[w]
+        if rule == 0:
+            want = before[w] + 2 * d
+        elif w in (6, 7):
+            want = before[w] + 2 * d / 2
+        else:
+            wgt = np.where(touched, 0.5, 1.0)
+            want = before[w] + 2 * d * (wgt[:, None] if d.ndim == 2 else wgt)
+        np.testing.assert_allclose(model.get(w), want, rtol=0, atol=2e-6)
