@@ -86,7 +86,7 @@ def test_oracle_reproduces_loss_kat(built):
 @pytest.mark.parametrize("name", list(VARIANTS))
 def test_hip_reproduces_step_kat(built, name):
     """One explicit-input train_one_user_corruption (fixed mask, negatives with a duplicate) vs the golden
-    post-step parameters.  fp32 path vs fp64 golden: |diff| <= 2e-6 on parameters of magnitude <= 0.7."""
+    post-step parameters.  fp32 path vs fp64 golden: |diff| <= 2e-6 + 3e-6 |ref| (a few fp32 ulps)."""
     g = G("step_kat.npz")
     loss, lr, kw = _flags(VARIANTS[name])
     K, U, I = int(g["K"]), int(g["U"]), int(g["I"])
@@ -101,7 +101,7 @@ def test_hip_reproduces_step_kat(built, name):
     assert np.isfinite(z).all()
     m.train_one_user_corruption(int(g["uid"]), g["kept"], g["neg"])
     for k in present:
-        np.testing.assert_allclose(m.get(k).ravel(), g[f"{name}_after_{k}"].ravel(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(m.get(k).ravel(), g[f"{name}_after_{k}"].ravel(), rtol=3e-6, atol=2e-6)
 
 
 @pytest.mark.gpu
