@@ -1,0 +1,77 @@
+// Compile-and-link check of the host layer, and a tiny end-to-end driver used by the tests:
+//   host_check                      -> exercises the CPU-only pieces (flags, logging, Data, split, cache, heap, metrics)
+//   host_check --run_cdae=true ...  -> trains CDAE through Solver<CDAE> on a GPU (needs libcdae_hip.so + a device)
+#include <glog/logging.h>
+#include <gflags/gflags.h>
+
+#include <base/data.hpp>
+#include <base/heap.hpp>
+#include <base/io.hpp>
+#include <base/random.hpp>
+#include <model/recsys/cdae.hpp>
+#include <model/recsys/popularity.hpp>
+#include <solver/solver.hpp>
+
+DEFINE_string(input_file, "", "user item text file (header line skipped)");
+DEFINE_bool(run_cdae, false, "train CDAE on the GPU");
+DEFINE_int32(num_dim, 8, "latent dimensions");
+DEFINE_int32(iters, 2, "epochs");
+DEFINE_string(loss_type, "CE", "SQUARE or CE");
+DEFINE_double(cratio, 0.5, "corruption ratio");
+
+int main(int argc, char* argv[]) {
+  using namespace libcf;
+  gflags::ParseCommandLineFlags(&argc, &argv, true);
+
+  // heap semantics (reference test/heap_test.hpp:66-86)
+  Heap<std::pair<size_t, double>> h(sort_by_second_desc<size_t, double>);
+  const std::pair<size_t, double> items[] = {{10, 10.}, {20, 20.}, {30, 30.}, {5, 5.}, {15, 15.}};
+  for (auto& p : items) { if (h.size() < 3) h.push(p); else h.push_and_pop(p); }
+  auto sorted = h.get_sorted_data_copy();
+  CHECK_EQ(sorted[0].first, size_t(30)); CHECK_EQ(sorted[1].first, size_t(20)); CHECK_EQ(sorted[2].first, size_t(15));
+  CHECK_EQ(split_line("a  b c ", " ").size(), size_t(3));
+
+  // metrics (reference evaluation.hpp:183-219)
+  std::unordered_map<size_t, double> truth{{9, 1.}, {3, 1.}, {100, 1.}};
+  auto r = TOPN_Evaluation<Popularity>::evaluate_rec_list({5, 9, 1, 7, 3, 2, 8, 4, 6, 0}, truth);
+  CHECK(r[2] > 0.199 && r[2] < 0.201) << r[2];
+  CHECK(r[5] > 0.666 && r[5] < 0.667) << r[5];
+
+  if (FLAGS_input_file.empty()) { LOG(INFO) << "host layer OK (no input file given)"; return 0; }
+
+  auto parser = [&](const std::string& line) {
+    auto f = split_line(line, " ");
+    CHECK_EQ(f.size(), size_t(2));
+    return std::vector<std::string>{f[0], f[1], "1"};
+  };
+  Data data;
+  data.load(FLAGS_input_file, RECSYS, parser, true);
+  const std::string cache = FLAGS_input_file + ".bin";
+  save(data, cache);
+  Data again;
+  load(cache, again);
+  CHECK_EQ(again.size(), data.size());
+  CHECK_EQ(again.feature_group_total_dimension(1), data.feature_group_total_dimension(1));
+  Random::seed(20141119);
+  Data train, test;
+  again.random_split_by_feature_group(train, test, 0, 0.2);
+  CHECK_EQ(train.size() + test.size(), data.size());
+  {
+    Popularity pop;
+    Solver<Popularity> solver(pop);
+    solver.train(train, test, {TOPN});
+  }
+  if (FLAGS_run_cdae) {
+    CDAEConfig cfg;
+    cfg.num_dim = FLAGS_num_dim;
+    cfg.corruption_ratio = FLAGS_cratio;
+    cfg.scaled = FLAGS_cratio > 0;
+    cfg.beta = 1.;
+    cfg.lt = FLAGS_loss_type == "SQUARE" ? SQUARE : CROSS_ENTROPY;
+    CDAE model(cfg);
+    Solver<CDAE> solver(model, FLAGS_iters);
+    solver.train(train, test, {TOPN});
+  }
+  LOG(INFO) << "host layer OK";
+  return 0;
+}

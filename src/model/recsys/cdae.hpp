@@ -1,0 +1,195 @@
+// libcf::CDAE on MI355X: the reference's model class (src/model/recsys/cdae.hpp:13-31 CDAEConfig, :36-454
+// CDAE) re-provided with the same names, constructor, public methods and abort-on-error behaviour, so that
+// Solver<CDAE>, Evaluation<CDAE> and apps/yelp/yelp.cpp:168-199 compile and run unchanged — but every method of
+// the hot path forwards to one entry point of libcdae_hip.so (include/cdae_hip.h), where the per-user
+// forward/backward and the AdaGrad/SGD update run as HIP kernels on gfx950.  No CPU fallback: without the
+// library or a GPU the first call CHECK-fails.
+//
+//   method (reference lines)                         -> C ABI
+//   reset (109-134, recsys_model_base.hpp:29-34)      cdae_hip_create, _set_interactions, _init_params
+//   train_one_iteration (136-146)                     cdae_hip_train_epoch
+//   train_one_user_corruption (198-358)               cdae_hip_train_one_user_corruption
+//   data_loss (78-101) / penalty_loss (103-107)       cdae_hip_data_loss / cdae_hip_penalty_loss
+//   pre_recommend + recommend (162-196)               cdae_hip_recommend_all, then lock-free table reads
+//   get_user_representations (148-159)                cdae_hip_encode
+//
+// Environment knobs (not in the reference): CDAE_BATCH_USERS (users per parameter snapshot; 1 = the
+// reference's strictly sequential schedule), CDAE_SEED (fixes the counter-stream seed; default: one draw of
+// libcf::Random, i.e. time-seeded like yelp.cpp:107), CDAE_DEVICE (HIP device index).
+#ifndef CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
+#define CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
+
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include <cdae_hip.h>
+
+#include <base/data.hpp>
+#include <base/instance.hpp>
+#include <base/mat.hpp>
+#include <base/parallel.hpp>
+#include <base/random.hpp>
+#include <model/recsys/recsys_model_base.hpp>
+
+#define CDAE_HIP_CHECK(call) CHECK_EQ((call), 0) << "libcdae_hip: " << cdae_hip_last_error() << " "
+
+namespace libcf {
+
+struct CDAEConfig {
+  CDAEConfig() = default;
+  double lambda = 0.01;
+  double learn_rate = 0.1;
+  LossType lt = LOGISTIC;
+  PenaltyType pt = L2;
+  size_t num_dim = 10;
+  bool using_adagrad = true;
+  double corruption_ratio = 0.5;
+  size_t num_corruptions = 1;
+  bool asymmetric = false;
+  bool user_factor = true;
+  bool linear = false;
+  size_t num_neg = 5;
+  bool scaled = true;
+  double beta = 0.;
+  bool linear_function = false;
+  bool tanh = false;
+};
+
+class CDAE : public RecsysModelBase {
+ public:
+  CDAE(const CDAEConfig& mcfg) : cfg_(mcfg) {
+    loss_ = Loss::create(mcfg.lt);
+    penalty_ = Penalty::create(mcfg.pt);
+    LOG(INFO) << "CDAE Configure (MI355X / HIP): \n"
+              << "\t{lambda: " << cfg_.lambda << "}, {Loss: " << loss_->loss_type() << "}, {Penalty: " << penalty_->penalty_type() << "}\n"
+              << "\t{Dim: " << cfg_.num_dim << "}, {LearnRate: " << cfg_.learn_rate << "}, {Using AdaGrad: " << cfg_.using_adagrad << "}\n"
+              << "\t{Corruption Ratio: " << cfg_.corruption_ratio << "}, {Num Corruptions: " << cfg_.num_corruptions
+              << "}, {Asymmetric: " << cfg_.asymmetric << "}\n"
+              << "\t{UserFactor: " << cfg_.user_factor << "}, {Linear: " << cfg_.linear << "}, {Num Negative: " << cfg_.num_neg
+              << "}, {Scaled: " << cfg_.scaled << "}\n"
+              << "\t{Beta: " << cfg_.beta << "}, {LinearFunction: " << cfg_.linear_function << "}, {tanh: " << cfg_.tanh << "}";
+  }
+  CDAE() : CDAE(CDAEConfig()) {}
+
+  // ---- reset: cdae.hpp:109-134 -------------------------------------------------------------------------
+  void reset(const Data& data_set) {
+    ModelBase::reset(data_set);
+    num_users_ = data_->feature_group_total_dimension(0);
+    num_items_ = data_->feature_group_total_dimension(1);
+    CHECK(!cfg_.linear_function) << "linear_function (Uu) is not provided by the HIP path (cdae.sh only ever passes false)";
+    CHECK(cfg_.pt == L2) << "CDAE's gradient hard-codes the L2 term (cdae.hpp:231)";
+    cdae_hip_config c;
+    c.struct_size = sizeof(c);
+    c.num_dim = static_cast<uint32_t>(cfg_.num_dim);
+    c.num_neg = static_cast<uint32_t>(cfg_.num_neg);
+    c.num_corruptions = static_cast<uint32_t>(cfg_.num_corruptions);
+    c.loss_type = static_cast<uint32_t>(cfg_.lt);          // the C ABI rejects losses CDAE cannot train with
+    c.using_adagrad = cfg_.using_adagrad; c.asymmetric = cfg_.asymmetric; c.user_factor = cfg_.user_factor;
+    c.linear = cfg_.linear; c.scaled = cfg_.scaled; c.tanh_act = cfg_.tanh;
+    c.batch_users = static_cast<uint32_t>(env_u64("CDAE_BATCH_USERS", 0));
+    c.lambda = cfg_.lambda; c.learn_rate = cfg_.learn_rate; c.corruption_ratio = cfg_.corruption_ratio; c.beta = cfg_.beta;
+    cdae_hip_t* raw = nullptr;
+    CDAE_HIP_CHECK(cdae_hip_create(&c, static_cast<int>(env_u64("CDAE_DEVICE", 0)), &raw));
+    dev_.reset(raw, [](cdae_hip_t* h) { cdae_hip_destroy(h); });
+    std::vector<int64_t> row_ptr;
+    std::vector<uint32_t> col;
+    data_->to_csr(0, 1, row_ptr, col);                     // uid -> sorted {iid}; labels are all 1 (yelp.cpp:66)
+    CDAE_HIP_CHECK(cdae_hip_set_interactions(dev_.get(), num_users_, num_items_, row_ptr.data(), col.data()));
+    seed_ = std::getenv("CDAE_SEED") ? env_u64("CDAE_SEED", 0) : Random::next_u64();
+    CDAE_HIP_CHECK(cdae_hip_init_params(dev_.get(), seed_));
+    epoch_ = 0;
+    rec_.reset();
+  }
+
+  // ---- training: cdae.hpp:136-146 -----------------------------------------------------------------------
+  void train_one_iteration(const Data&) {
+    CHECK(dev_ != nullptr) << "reset() must be called first";
+    cdae_hip_stats st;
+    CDAE_HIP_CHECK(cdae_hip_train_epoch(dev_.get(), seed_, epoch_++, &st));
+    LOG(INFO) << "CDAE epoch " << epoch_ << ": " << st.users << " users in " << st.wall_seconds << " s ("
+              << static_cast<double>(st.users) / st.wall_seconds << " users/s, " << st.batches << " batches)";
+    rec_.reset();
+  }
+
+  // cdae.hpp:198-358 with the caller's corrupted input set; negatives drawn like cdae.hpp:217-220
+  void train_one_user_corruption(size_t uid, const std::unordered_map<size_t, double>& input_set,
+                                 const std::unordered_map<size_t, double>& output_set) {
+    CHECK(dev_ != nullptr) << "reset() must be called first";
+    std::vector<uint32_t> in, neg(output_set.size() * cfg_.num_neg);
+    for (auto& p : input_set) in.push_back(static_cast<uint32_t>(p.first));
+    for (auto& n : neg) n = static_cast<uint32_t>(sample_negative_item(output_set));
+    CDAE_HIP_CHECK(cdae_hip_train_one_user_corruption(dev_.get(), uid, in.data(), in.size(), neg.data(), neg.size()));
+    rec_.reset();
+  }
+
+  // ---- reported loss: cdae.hpp:78-107 -------------------------------------------------------------------
+  double data_loss(const Data&, size_t = 0) const {
+    CHECK(dev_ != nullptr) << "reset() must be called first";
+    double v = 0;
+    CDAE_HIP_CHECK(cdae_hip_data_loss(dev_.get(), seed_, epoch_, &v));
+    return v;
+  }
+  double penalty_loss() const {
+    double v = 0;
+    CDAE_HIP_CHECK(cdae_hip_penalty_loss(dev_.get(), &v));
+    return v;
+  }
+
+  // cdae.hpp:148-159
+  DMatrix get_user_representations() {
+    std::vector<uint32_t> uids(num_users_);
+    for (size_t u = 0; u < num_users_; ++u) uids[u] = static_cast<uint32_t>(u);
+    std::vector<float> z(num_users_ * cfg_.num_dim);
+    CDAE_HIP_CHECK(cdae_hip_encode(dev_.get(), seed_, epoch_, 0, uids.data(), uids.size(), z.data()));
+    DMatrix out(num_users_, cfg_.num_dim);
+    for (size_t i = 0; i < z.size(); ++i) out.data()[i] = z[i];
+    return out;
+  }
+
+  // ---- evaluation: cdae.hpp:162-196 ---------------------------------------------------------------------
+  // All users are scored and top-k'd on the GPU once (evaluation.hpp:135 calls this before the thread pool
+  // starts); recommend() is then a read of an immutable table and safe to call concurrently (evaluation.hpp:137).
+  void pre_recommend() { ensure_table(10); }
+
+  std::vector<size_t> recommend(size_t uid, size_t topk, const std::unordered_map<size_t, double>& /*rated_item_set*/) const {
+    CHECK_LT(uid, num_users_);
+    std::shared_ptr<const Table> t = ensure_table(topk);
+    std::vector<size_t> out(topk);
+    for (size_t i = 0; i < topk; ++i) out[i] = t->ids[uid * topk + i];
+    return out;
+  }
+
+ private:
+  struct Table { size_t topk; std::vector<uint32_t> ids; };
+
+  std::shared_ptr<const Table> ensure_table(size_t topk) const {
+    std::lock_guard<std::mutex> lk(*mu_);
+    if (!rec_ || rec_->topk != topk) {
+      CHECK(dev_ != nullptr) << "reset() must be called first";
+      auto t = std::make_shared<Table>();
+      t->topk = topk;
+      t->ids.resize(num_users_ * topk);
+      CDAE_HIP_CHECK(cdae_hip_recommend_all(dev_.get(), 0, num_users_, static_cast<uint32_t>(topk), t->ids.data()));
+      rec_ = t;
+    }
+    return rec_;
+  }
+  static uint64_t env_u64(const char* name, uint64_t dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::strtoull(v, nullptr, 10) : dflt;
+  }
+
+  CDAEConfig cfg_;
+  std::shared_ptr<cdae_hip_t> dev_;                  // shared by copies: Solver copies the model (solver.hpp:17)
+  std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
+  mutable std::shared_ptr<const Table> rec_;
+  uint64_t seed_ = 0;
+  uint32_t epoch_ = 0;
+};
+
+}  // namespace libcf
+
+#endif  // CDAE_HOST_MODEL_RECSYS_CDAE_HPP_

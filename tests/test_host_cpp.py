@@ -1,0 +1,109 @@
+"""The host C++ layer (src/): libcf-shaped headers over the C ABI.
+
+CPU: the headers compile; the reference's apps/yelp/yelp.cpp builds UNMODIFIED and IN PLACE against them
+(only where /root/reference exists — nothing of it is copied here) and runs BASELINE config 1's plumbing
+prepare -> split -> test up to the Popularity row.
+GPU: the same binaries train CDAE through Solver<CDAE> on the device.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from cdae_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "build")
+REF_YELP = "/root/reference/apps/yelp/yelp.cpp"
+
+
+def write_ratings(path, seed=5):
+    d = synth.generate(300, 120, 9000, seed=seed)
+    rng = np.random.default_rng(0)
+    pairs = []
+    for u in range(d.num_users):
+        for ptr, col in ((d.train_ptr, d.train_col), (d.test_ptr, d.test_col)):
+            pairs += [(u, int(i)) for i in col[ptr[u]:ptr[u + 1]]]
+    rng.shuffle(pairs)
+    with open(path, "w") as f:
+        f.write("user item\n")
+        for u, i in pairs:
+            f.write(f"u{u} i{i}\n")
+    return len(pairs)
+
+
+def run(cmd, cwd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run(cmd, cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    return p.returncode, p.stdout
+
+
+@pytest.fixture(scope="module")
+def host_bins(built):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "src"), "-s", "check"])
+    if os.path.exists(REF_YELP):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "src"), "-s", "yelp"])
+    return BUILD
+
+
+def test_host_layer_compiles_and_cpu_pieces_work(host_bins, tmp_path):
+    n = write_ratings(tmp_path / "ratings.txt")
+    rc, out = run([os.path.join(host_bins, "host_check"), f"--input_file={tmp_path / 'ratings.txt'}"], tmp_path)
+    assert rc == 0, out
+    assert f"Num of Instance: {n}" in out and "host layer OK" in out
+    assert re.search(r"\|\s*P@10\|", out) and "Popularity Model" in out
+
+
+def test_reference_yelp_app_builds_unmodified_and_runs_config1_plumbing(host_bins, tmp_path):
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("reference sources not present on this box and no prebuilt build/yelp")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    # every task except "test" ends in yelp.cpp:102-104's `else { return -1; }` after doing its work
+    assert run([yelp, "--task=prepare"], tmp_path)[0] == 255
+    assert os.path.exists(tmp_path / "yelp.bin")
+    assert run([yelp, "--task=split"], tmp_path)[0] == 255
+    assert os.path.exists(tmp_path / "yelp.train.bin") and os.path.exists(tmp_path / "yelp.test.bin")
+    rc, out = run([yelp, "--task=test", "--method=NONE"], tmp_path)
+    assert rc == 0, out
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+    assert len(rows) == 2                                  # iteration 0 and 1 of Solver<Popularity>
+    recall10 = float(rows[-1].split("|")[8])
+    assert 0.05 < recall10 < 0.6
+    # the reference's --task=train falls through to `return -1` (yelp.cpp:88-104)
+    assert run([yelp, "--task=train"], tmp_path)[0] != 0
+
+
+@pytest.mark.gpu
+def test_solver_cdae_trains_on_gpu_through_host_layer(host_bins, tmp_path):
+    write_ratings(tmp_path / "ratings.txt")
+    rc, out = run([os.path.join(host_bins, "host_check"), f"--input_file={tmp_path / 'ratings.txt'}", "--run_cdae=true",
+                   "--num_dim=16", "--iters=6"], tmp_path, env={"CDAE_SEED": "7", "CDAE_BATCH_USERS": "64"})
+    assert rc == 0, out
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+    cdae_rows = rows[2:]                                   # after the two Popularity rows
+    assert len(cdae_rows) == 7
+    losses = [float(r.split("|")[2]) for r in cdae_rows[1:]]
+    assert losses[-1] < losses[0]
+    assert float(cdae_rows[-1].split("|")[8]) > float(cdae_rows[0].split("|")[8])     # Recall@10 improves over untrained
+
+
+@pytest.mark.gpu
+def test_reference_yelp_app_trains_cdae_on_gpu(host_bins, tmp_path):
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.4", "--scaled=true",
+                   "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "64"})
+    assert rc == 0, out[-3000:]
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+    assert len(rows) == 2 + 51                             # Popularity (0,1) + CDAE iterations 0..50 (yelp.cpp:197)
+    pop_r10 = float(rows[1].split("|")[8])
+    best = max(float(r.split("|")[8]) for r in rows[2:])
+    assert best > pop_r10, (best, pop_r10)
