@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=12000, help="users in the timed CPU-baseline sample")
     ap.add_argument("--seed", type=int, default=20141119)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
+                    "code path on a single-GPU box together with --share-device")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -65,6 +68,8 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the CDAE hot path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import cdae_amd
     from cdae_amd import synth
@@ -74,7 +79,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     # every rank owns one ML-10M-shaped shard of users over the same item space
     data = synth.generate_shape(args.shape, seed=args.seed + 7919 * rank)

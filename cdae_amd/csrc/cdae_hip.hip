@@ -88,13 +88,19 @@ struct cdae_hip {
 
   // batch workspace
   uint64_t Ecap = 0;
-  uint32_t* d_ex_item = nullptr; uint64_t* d_ex_val = nullptr;
-  uint32_t* d_sorted_item = nullptr; uint64_t* d_sorted_val = nullptr;
+  // example lists are double-buffered: batch t+1 is sampled and sorted on the `prep` stream while batch t trains
+  struct ExBuf {
+    uint32_t* item = nullptr; uint64_t* val = nullptr;            // user-major example list
+    uint32_t* sorted_item = nullptr; uint64_t* sorted_val = nullptr;   // the same, stably sorted by item
+    uint32_t* seg = nullptr;                                      // [2*I]: first | one-past-last sorted position per item
+    hipEvent_t ready = nullptr, released = nullptr;
+  } ex[2];
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
+  float* d_HGpart = nullptr;            // [8][B][Kp] per-XCD partial hidden gradients
   hipStream_t side = nullptr;           // hidden-bias recurrence runs beside the input-row kernel
+  hipStream_t prep = nullptr;           // sampling + sorting of the next batch
   hipEvent_t ev_delta = nullptr, ev_bias = nullptr;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
-  uint32_t* d_seg = nullptr;            // [2*I]: begin | end
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
   uint32_t* d_touched = nullptr;
   double* d_scalar = nullptr;
@@ -125,18 +131,18 @@ int get_event(cdae_hip* h, hipEvent_t* ev) {
   HIPCHK(hipEventCreate(ev));
   return 0;
 }
-struct Prof {   // RAII-less helper: begin()/end() around one kernel family launch
-  cdae_hip* h; Span s; bool on;
-  int begin(cdae_hip* hh, int family) {
-    h = hh; on = hh->profiling; if (!on) return 0;
+struct Prof {   // RAII-less helper: begin()/end() around one kernel family launch, on the stream it is launched on
+  cdae_hip* h; Span s; bool on; hipStream_t st;
+  int begin(cdae_hip* hh, int family, hipStream_t stream) {
+    h = hh; on = hh->profiling; st = stream; if (!on) return 0;
     s.family = family;
     CHK(get_event(h, &s.a)); CHK(get_event(h, &s.b));
-    HIPCHK(hipEventRecord(s.a, h->stream));
+    HIPCHK(hipEventRecord(s.a, st));
     return 0;
   }
   int end() {
     if (!on) return 0;
-    HIPCHK(hipEventRecord(s.b, h->stream));
+    HIPCHK(hipEventRecord(s.b, st));
     h->spans.push_back(s);
     return 0;
   }
@@ -162,10 +168,17 @@ int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
 }
 
 void free_all(cdae_hip* h) {
-  void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_ex_item,
-                  h->d_ex_val, h->d_sorted_item, h->d_sorted_val, h->d_D0, h->d_sort_tmp, h->d_seg, h->d_Z, h->d_Dz,
-                  h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec, h->d_base, h->d_delta};
+  void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
+                  h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
+                  h->d_base, h->d_delta};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& b : h->ex) {
+    void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg};
+    for (void* p : q) if (p) (void)hipFree(p);
+    if (b.ready) (void)hipEventDestroy(b.ready);
+    if (b.released) (void)hipEventDestroy(b.released);
+  }
+  if (h->prep) (void)hipStreamDestroy(h->prep);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (Span& s : h->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   if (h->ev_delta) (void)hipEventDestroy(h->ev_delta);
@@ -176,10 +189,12 @@ void free_all(cdae_hip* h) {
 
 int free_interaction_state(cdae_hip* h) {
   void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
-                   (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_ex_item, (void**)&h->d_ex_val,
-                   (void**)&h->d_sorted_item, (void**)&h->d_sorted_val, (void**)&h->d_D0, (void**)&h->d_sort_tmp, (void**)&h->d_seg,
+                   (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_D0, (void**)&h->d_HGpart, (void**)&h->d_sort_tmp,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta,
+                   (void**)&h->ex[0].item, (void**)&h->ex[0].val, (void**)&h->ex[0].sorted_item, (void**)&h->ex[0].sorted_val,
+                   (void**)&h->ex[0].seg, (void**)&h->ex[1].item, (void**)&h->ex[1].val, (void**)&h->ex[1].sorted_item,
+                   (void**)&h->ex[1].sorted_val, (void**)&h->ex[1].seg};
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   h->rec_cap = 0;
   return 0;
@@ -191,45 +206,57 @@ template <class T> int dev_alloc(T** p, size_t n) {
 }
 
 // one batch of train_one_user_corruption for users [s0, s0+nb), corruption cidx
-// explicit_in != nullptr: single user (nb == 1) whose example list and input set were written by the caller
-int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch, uint64_t* n_ex_out,
-              const uint32_t* explicit_in = nullptr, uint32_t n_explicit = 0, uint64_t explicit_examples = 0) {
+struct Batch { uint64_t s0; uint32_t nb; uint32_t cidx; uint64_t E; };
+
+// K1 + sort on the prep stream into example-buffer set `b`
+int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
   using namespace cdae;
-  const uint64_t E = explicit_in ? explicit_examples
-                                 : (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
-  *n_ex_out = E;
-  if (E == 0) return 0;
-  if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
-  hipStream_t st = h->stream;
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->prep;
   const uint32_t I = (uint32_t)h->I;
+  Prof pr;
+  HIPCHK(hipStreamWaitEvent(st, x.released, 0));               // the batch that last used this set is done with it
+  CHK(pr.begin(h, F_SAMPLE, st));
+  hipLaunchKernelGGL(sample_kernel, dim3((bt.nb + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col, bt.s0, bt.nb,
+                     bt.cidx, seed, epoch, x.item, x.val);
+  CHK(pr.end());
+  CHK(pr.begin(h, F_SORT, st));
+  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
+                                   (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
+  HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(segment_kernel, dim3((uint32_t)((bt.E + 255) / 256)), dim3(256), 0, st, x.sorted_item, (uint32_t)bt.E,
+                     x.seg, x.seg + I);
+  CHK(pr.end());
+  HIPCHK(hipEventRecord(x.ready, st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// K2..K5 on the main stream from example-buffer set `b`.
+// explicit_in != nullptr: single user whose example list (already sorted into set b) and input set come from the caller
+int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch,
+                  const uint32_t* explicit_in = nullptr, uint32_t n_explicit = 0) {
+  using namespace cdae;
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I, nb = bt.nb;
+  const uint64_t s0 = bt.s0;
   const dim3 blk(256);
   const dim3 grid_users((nb + 3) / 4), grid_rows((I + 3) / 4);
   Prof pr;
 
-  CHK(pr.begin(h, F_SAMPLE));
-  if (!explicit_in)
-    hipLaunchKernelGGL(sample_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, s0, nb, cidx, seed, epoch,
-                       h->d_ex_item, h->d_ex_val);
-  CHK(pr.end());
-
-  CHK(pr.begin(h, F_SORT));
-  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_val,
-                                   h->d_sorted_val, (size_t)E, 0u, (unsigned)h->sort_bits, st));
-  HIPCHK(hipMemsetAsync(h->d_seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(segment_kernel, dim3((uint32_t)((E + 255) / 256)), blk, 0, st, h->d_sorted_item, (uint32_t)E,
-                     h->d_seg, h->d_seg + I);
-  CHK(pr.end());
-
-  CHK(pr.begin(h, F_ENCODE));
+  CHK(pr.begin(h, F_ENCODE, st));
   HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));             // b of the previous batch (side stream)
   DISPATCH_NI(h->NI, encode_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), h->d_Wu,
-              h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Z, h->d_Dz, explicit_in, n_explicit);
+              h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Z, h->d_Dz,
+              explicit_in, n_explicit);
   HIPCHK(hipMemsetAsync(h->d_HG, 0, (size_t)nb * h->Kp * sizeof(float), st));
   HIPCHK(hipMemcpyAsync(h->d_D0, h->dec(), (size_t)I * h->Kp * sizeof(float), hipMemcpyDeviceToDevice, st));
   CHK(pr.end());
 
-  CHK(pr.begin(h, F_DECODE));
-#define DECODE_ARGS h->hp, h->d_item_order, h->d_seg, h->d_seg + I, h->d_sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
+  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  CHK(pr.begin(h, F_DECODE, st));
+#define DECODE_ARGS h->hp, h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
                     h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_touched
 #define DECODE_NI(NI_)                                                                                              \
   do {                                                                                                              \
@@ -246,9 +273,11 @@ int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t see
 #undef DECODE_ARGS
   CHK(pr.end());
 
-  CHK(pr.begin(h, F_HIDDEN));
-  DISPATCH_NI(h->NI, hidden_gather_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, s0, nb, h->d_ex_item, h->d_G,
-              h->d_D0, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, explicit_in ? (uint32_t)E : 0u);
+  CHK(pr.begin(h, F_HIDDEN, st));
+  DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((nb + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, s0, nb, x.item, h->d_G,
+              h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u);
+  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu,
+              h->d_Wu_ag);
   CHK(pr.end());
   // the strictly sequential hidden-bias recurrence needs only delta: run it beside the input rows
   HIPCHK(hipEventRecord(h->ev_delta, st));
@@ -257,10 +286,11 @@ int run_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, uint64_t see
                      h->P(CDAE_P_B_AG));
   HIPCHK(hipEventRecord(h->ev_bias, h->side));
 
-  CHK(pr.begin(h, F_INPUT));
-  DISPATCH_NI(h->NI, input_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, h->d_seg, h->d_seg + I,
-              h->d_sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched);
+  CHK(pr.begin(h, F_INPUT, st));
+  DISPATCH_NI(h->NI, input_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z,
+              h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched);
   CHK(pr.end());
+  HIPCHK(hipEventRecord(x.released, st));
   // delta (d_HG) is overwritten by the next batch's memset: that batch must not start before the bias kernel read it
   HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));
   HIPCHK(hipGetLastError());
@@ -323,6 +353,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_bias, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventRecord(h->ev_bias, h->side);
@@ -418,19 +449,24 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   }
   h->Ecap = emax * (1u + h->cfg.num_neg);
   if (h->Ecap > 0xFFFFFFF0ull) return fail("batch of %u users holds %llu examples (> 2^32); lower batch_users", B, (unsigned long long)h->Ecap);
-  CHK(dev_alloc(&h->d_ex_item, h->Ecap)); CHK(dev_alloc(&h->d_ex_val, h->Ecap));
-  CHK(dev_alloc(&h->d_sorted_item, h->Ecap)); CHK(dev_alloc(&h->d_sorted_val, h->Ecap));
+  for (auto& b : h->ex) {
+    CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));
+    CHK(dev_alloc(&b.sorted_item, h->Ecap)); CHK(dev_alloc(&b.sorted_val, h->Ecap));
+    CHK(dev_alloc(&b.seg, 2 * (size_t)I));
+    if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b.released, hipEventDisableTiming)); }
+    HIPCHK(hipEventRecord(b.released, h->stream));
+  }
   CHK(dev_alloc(&h->d_D0, IK));
   CHK(dev_alloc(&h->d_G, h->Ecap));
   h->sort_bits = 1;
   while ((1ull << h->sort_bits) < I) h->sort_bits++;
   h->sort_tmp_bytes = 0;
-  HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->d_ex_item, h->d_sorted_item, h->d_ex_val,
-                                   h->d_sorted_val, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->ex[0].item, h->ex[0].sorted_item, h->ex[0].val,
+                                   h->ex[0].sorted_val, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
   CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
-  CHK(dev_alloc(&h->d_seg, 2 * (size_t)I));
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
+  CHK(dev_alloc(&h->d_HGpart, 8 * BK));
   CHK(dev_alloc(&h->d_touched, (size_t)I));
   HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
   CHK(dev_alloc(&h->d_uids, (size_t)B));
@@ -530,13 +566,19 @@ int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t 
   const auto t0 = std::chrono::steady_clock::now();
   uint64_t examples = 0, batches = 0, users = 0;
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
+  std::vector<Batch> plan;
   for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
-    for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) {       // cdae.hpp:141
-      uint64_t e = 0;
-      CHK(run_batch(h, s0, nb, c, seed, epoch, &e));
-      examples += e; batches++; users += nb;
-    }
+    const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
+    if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
+    for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) plan.push_back(Batch{s0, nb, c, E});       // cdae.hpp:141
+  }
+  // software pipeline over batches: sample + sort of batch t+1 (prep stream) overlaps the training of batch t
+  if (!plan.empty()) CHK(prep_batch(h, 0, plan[0], seed, epoch));
+  for (size_t t = 0; t < plan.size(); ++t) {
+    if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((t + 1) & 1), plan[t + 1], seed, epoch));
+    CHK(compute_batch(h, (int)(t & 1), plan[t], seed, epoch));
+    examples += plan[t].E; batches++; users += plan[t].nb;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   if (stats) {
@@ -673,14 +715,21 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
     items[n_pos + i] = negative_items[i];
     vals[n_pos + i] = (uint64_t)(n_pos + i) << 32;
   }
-  HIPCHK(hipMemcpyAsync(h->d_ex_item, items.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_ex_val, vals.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-  uint32_t* d_in = h->d_uids;                     // reuse: capacity B >= 1 ... inputs can be longer: own buffer
+  cdae_hip::ExBuf& x = h->ex[0];
+  HIPCHK(hipStreamSynchronize(h->prep));
+  HIPCHK(hipMemcpyAsync(x.item, items.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(x.val, vals.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val, E, 0u,
+                                   (unsigned)h->sort_bits, h->stream));
+  HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)h->I * sizeof(uint32_t), h->stream));
+  hipLaunchKernelGGL(cdae::segment_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, h->stream, x.sorted_item, (uint32_t)E,
+                     x.seg, x.seg + h->I);
+  HIPCHK(hipEventRecord(x.ready, h->stream));
+  uint32_t* d_in = h->d_uids;                     // capacity min(B, U) >= 1; longer input sets get their own buffer
   uint32_t* d_in_owned = nullptr;
   if (n_in > std::min<uint64_t>(h->B, h->U)) { CHK(dev_alloc(&d_in_owned, n_in)); d_in = d_in_owned; }
   if (n_in) HIPCHK(hipMemcpyAsync(d_in, in_sorted.data(), n_in * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-  uint64_t e = 0;
-  int rc = run_batch(h, uid, 1, 0, 0, 0, &e, d_in, (uint32_t)n_in, E);
+  int rc = compute_batch(h, 0, Batch{uid, 1, 0, E}, 0, 0, d_in, (uint32_t)n_in);
   hipError_t se = hipStreamSynchronize(h->stream);
   if (d_in_owned) (void)hipFree(d_in_owned);
   if (rc) return rc;

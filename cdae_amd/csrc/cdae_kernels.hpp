@@ -77,10 +77,11 @@ __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sq
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
 // loss.hpp:53-55 (SQUARE), loss.hpp:141-147 (CROSS_ENTROPY)
+// The reference switches to e^y - t below -18 and to 1 - t above +18 (loss.hpp:142-145).  In fp32 the plain
+// form is already those limits to within 1 ulp (|sigmoid(y) - e^y| <= e^{2y} < 3e-16 for y < -18; 1/(1+e^-y)
+// rounds to 1 for y > 18; e^-y overflowing to +inf gives rcp(inf) = 0), so the hot loop stays branch-free.
 __device__ __forceinline__ float loss_grad(uint32_t loss_type, float pred, float truth) {
   if (loss_type == 0u) return -2.f * (truth - pred);
-  if (pred < -18.f) return fast_exp(pred) - truth;
-  if (pred > 18.f) return 1.f - truth;
   return fast_rcp(1.f + fast_exp(-pred)) - truth;
 }
 // loss.hpp:48-51, 132-139
@@ -136,11 +137,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 // get_corrputed_input (cdae.hpp:361-371) and sample_negative_item (recsys_model_base.hpp:46-57,
 // call site cdae.hpp:217-220).  One wavefront per user; integer-only.
 // Example e of user slot s sits at ex_base(s) + j: j < n_u positives, then n_u*num_neg negatives.
+// membership test in a sorted row staged in LDS (device twin of cdae_row_contains)
+__device__ __forceinline__ int lds_row_contains(const uint32_t* row, uint32_t n, uint32_t item) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (row[mid] < item) lo = mid + 1; else hi = mid;
+  }
+  return lo < n && row[lo] == item;
+}
+constexpr uint32_t SAMPLE_LDS_ROW = 2048;   // items of a user's row staged per wavefront (8 KiB); longer rows search global memory
+
 __global__ void __launch_bounds__(256)
 sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
               uint64_t u0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch,
               uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
+  const uint32_t wid = threadIdx.x / WAVE;
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const uint64_t uid = u0 + slot;
@@ -151,15 +165,39 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
   const uint64_t key_n = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_NEGATIVE);
+  const bool staged = n <= SAMPLE_LDS_ROW;
+  uint32_t* lrow = lds_rows[wid];
   for (uint32_t p = lane; p < n; p += WAVE) {
+    const uint32_t it = row[p];
+    if (staged) lrow[p] = it;
     const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
     const uint64_t e = base + p;
-    ex_item[e] = row[p];
+    ex_item[e] = it;
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
+  // the wavefront's own LDS writes are visible to it after the LDS counter drains (no cross-wave sharing)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   for (uint32_t i = lane; i < m; i += WAVE) {
     const uint64_t e = base + n + i;
-    ex_item[e] = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
+    uint32_t cand;
+    if (staged) {
+      // recsys_model_base.hpp:46-57 on the LDS copy of the row; identical draws to cdae_sample_negative
+      const uint64_t draw = (uint64_t)cidx * m + i;
+      bool found = false;
+      cand = 0;
+      for (uint32_t t = 0; t < CDAE_NEG_MAX_TRY && !found; ++t) {
+        cand = cdae_item_from_draw(cdae_rng_draw(key_n, draw * CDAE_NEG_MAX_TRY + t), hp.num_items);
+        found = !lds_row_contains(lrow, n, cand);
+      }
+      for (uint32_t t = 0; t < hp.num_items && !found; ++t) {
+        cand = cand + 1u == hp.num_items ? 0u : cand + 1u;
+        found = !lds_row_contains(lrow, n, cand);
+      }
+    } else {
+      cand = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
+    }
+    ex_item[e] = cand;
     ex_val[e] = (e << 32) | (uint64_t)slot;
   }
 }
@@ -299,17 +337,22 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   float bias = bp[item], bias_ag = bp_ag[item];
 
   constexpr int PF = 4;
-  // cur / nxt: this lane's example word (slot | flags) and example index of the current / next chunk
+  // cur / nxt: this lane's example word (slot | flags), example index and z-row byte offset of the current /
+  // next chunk.  The byte offset is computed once per chunk by all 64 lanes, so the per-example address is a
+  // v_readlane + a scalar add onto the Z base (32-bit: the batch's Z is at most 4 GiB).
+  const uint32_t row_bytes = hp.Kp * 4u;
+  const char* Zb = reinterpret_cast<const char*>(Z) + (size_t)lo * 4u;
   uint64_t v0 = beg + lane < end ? sorted_val[beg + lane] : 0ull;
-  uint32_t cur_w = (uint32_t)v0, cur_e = (uint32_t)(v0 >> 32), nxt_w = 0, nxt_e = 0;
+  uint32_t cur_w = (uint32_t)v0, cur_e = (uint32_t)(v0 >> 32), cur_o = (cur_w & SLOT_MASK) * row_bytes;
+  uint32_t nxt_w = 0, nxt_e = 0, nxt_o = 0;
   float z[PF][NI];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) z[j][i] = 0.f;
     if (beg + j < end) {
-      const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, j) & SLOT_MASK;
-      vload<NI>(z[j], Z + (size_t)s * hp.Kp + lo);
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)cur_o, j);
+      vload<NI>(z[j], reinterpret_cast<const float*>(Zb + off));
     }
   }
   uint32_t prev_slot = 0xFFFFFFFFu;
@@ -317,7 +360,7 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
     {
       const uint32_t q = c0 + WAVE + lane;
       const uint64_t vn = q < end ? sorted_val[q] : 0ull;
-      nxt_w = (uint32_t)vn; nxt_e = (uint32_t)(vn >> 32);
+      nxt_w = (uint32_t)vn; nxt_e = (uint32_t)(vn >> 32); nxt_o = (nxt_w & SLOT_MASK) * row_bytes;
     }
     const uint32_t cnt = min((uint32_t)WAVE, end - c0);
     float gbuf = 0.f;
@@ -355,15 +398,15 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
         // same registers and the compiler can wait with a counted vmcnt instead of draining.
         {
           const uint32_t rel = min(c0 + idx + PF, end - 1u) - c0;
-          const uint32_t nw = rel < (uint32_t)WAVE ? (uint32_t)__builtin_amdgcn_readlane((int)cur_w, rel & 63u)
-                                                   : (uint32_t)__builtin_amdgcn_readlane((int)nxt_w, rel & 63u);
-          vload<NI>(z[t], Z + (size_t)(nw & SLOT_MASK) * hp.Kp + lo);
+          const uint32_t off = rel < (uint32_t)WAVE ? (uint32_t)__builtin_amdgcn_readlane((int)cur_o, rel & 63u)
+                                                    : (uint32_t)__builtin_amdgcn_readlane((int)nxt_o, rel & 63u);
+          vload<NI>(z[t], reinterpret_cast<const float*>(Zb + off));
         }
       }
     }
     if (lane < cnt) G[cur_e] = gbuf;
     __builtin_amdgcn_s_waitcnt(WAIT_VM0);
-    cur_w = nxt_w; cur_e = nxt_e;
+    cur_w = nxt_w; cur_e = nxt_e; cur_o = nxt_o;
   }
   vstore<NI>(D + (size_t)item * hp.Kp + lo, w);
   vstore<NI>(D_ag + (size_t)item * hp.Kp + lo, a);
@@ -375,20 +418,22 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4a  hidden gradient + user node, one wavefront per user:
-//   hg_u = sum_e g_e D0[j_e] (+ the duplicate corrections K3 left in HG)     cdae.hpp:240,248,277,285
-//   delta_u = hg_u (.) act'(z_u)                                             cdae.hpp:305,321,337
-//   Wu[u] step (private row, no reduction)                                   cdae.hpp:317-331
-// D0 is the decoder matrix as it was at batch start.  Gather of (1+num_neg) n_u rows per user out of
-// L2 / Infinity Cache; 8 rows in flight per wave, g and item ids staged 64 at a time.
+// K4a  hidden gradient, XCD-partitioned gather:  hg_u = sum_e g_e D0[j_e]     cdae.hpp:240,248,277,285
+// D0 is the decoder matrix as it was at batch start (I x Kp fp32, 10.8 MB at ML-10M/K=200: larger than one
+// XCD's 4 MiB L2).  Workgroup b serves item partition x = b mod 8 — the dispatcher places consecutive
+// workgroups round-robin on the 8 XCDs (a speed assumption only; any placement gives the same result) —
+// and gathers, for its 4 users, only the rows with (item mod 8) == x.  Each XCD's L2 then holds 1/8 of
+// D0 (1.35 MB) and the 684 row reads per user hit L2 instead of the fabric.  The 8 partial sums per user
+// are combined by hidden_finish_kernel.  One wavefront per (user, partition); ids and g staged 64 at a
+// time, matching rows compacted with a ballot, 8 row loads in flight.
 template <int NI>
 __global__ void __launch_bounds__(256)
 hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64_t u0, uint32_t nb,
                      const uint32_t* __restrict__ ex_item, const float* __restrict__ G,
-                     const float* __restrict__ D0, const float* __restrict__ Dz,
-                     float* __restrict__ HG /* in: corrections, out: delta */, float* __restrict__ Wu,
-                     float* __restrict__ Wu_ag, uint32_t explicit_examples /* != 0: one user, that many examples */) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+                     const float* __restrict__ D0, float* __restrict__ HGpart /* [8][nb][Kp] */,
+                     uint32_t explicit_examples /* != 0: one user, that many examples */) {
+  const uint32_t part = blockIdx.x & 7u;
+  const uint32_t slot = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const uint64_t uid = u0 + slot;
@@ -402,16 +447,24 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64
   constexpr int UN = 8;
   for (uint32_t c0 = 0; c0 < n_ex; c0 += WAVE) {
     const uint32_t e = c0 + lane;
-    const uint32_t my_item = e < n_ex ? ex_item[base + e] : 0u;
-    const float my_g = e < n_ex ? G[base + e] : 0.f;         // lanes past the end carry g = 0, item 0
-    const uint32_t cnt = min((uint32_t)WAVE, n_ex - c0);
-    for (uint32_t j0 = 0; j0 < cnt; j0 += UN) {              // WAVE % UN == 0: j0 + t < WAVE
+    const uint32_t my_item = e < n_ex ? ex_item[base + e] : 0xFFFFFFFFu;
+    const float my_g = e < n_ex ? G[base + e] : 0.f;
+    unsigned long long mask = __ballot(e < n_ex && (my_item & 7u) == part);
+    while (mask) {
       float v[UN][NI], gg[UN];
 #pragma unroll
       for (int t = 0; t < UN; ++t) {
-        const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)my_item, j0 + t);
-        gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), j0 + t));
-        vload<NI>(v[t], D0 + (size_t)it * hp.Kp + lo);
+        if (mask) {                                            // wave-uniform
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)my_item, src);
+          gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), src));
+          vload<NI>(v[t], D0 + (size_t)it * hp.Kp + lo);
+        } else {
+          gg[t] = 0.f;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[t][i] = 0.f;
+        }
       }
 #pragma unroll
       for (int t = 0; t < UN; ++t)
@@ -419,12 +472,34 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64
         for (int i = 0; i < NI; ++i) acc[i] = fmaf(gg[t], v[t][i], acc[i]);
     }
   }
+  vstore<NI>(HGpart + ((size_t)part * nb + slot) * hp.Kp + lo, acc);
+}
+
+// K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
+//       and the private user-node step Wu[u]                                      cdae.hpp:317-331
+template <int NI>
+__global__ void __launch_bounds__(256)
+hidden_finish_kernel(HyperParams hp, uint64_t u0, uint32_t nb, const float* __restrict__ HGpart,
+                     const float* __restrict__ Dz, float* __restrict__ HG /* in: corrections, out: delta */,
+                     float* __restrict__ Wu, float* __restrict__ Wu_ag) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = u0 + slot;
+  const uint32_t lo = lane * NI;
   const size_t o = (size_t)slot * hp.Kp + lo;
-  float corr[NI], dz[NI], delta[NI];
-  vload<NI>(corr, HG + o);
+  float hg[NI], dz[NI], delta[NI];
+  vload<NI>(hg, HG + o);
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {                                 // fixed order: deterministic
+    float part[NI];
+    vload<NI>(part, HGpart + ((size_t)x * nb + slot) * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) hg[i] += part[i];
+  }
   vload<NI>(dz, Dz + o);
 #pragma unroll
-  for (int i = 0; i < NI; ++i) delta[i] = (acc[i] + corr[i]) * dz[i];
+  for (int i = 0; i < NI; ++i) delta[i] = hg[i] * dz[i];
   vstore<NI>(HG + o, delta);
   if (hp.user_factor) {
     const size_t ou = (size_t)uid * hp.Kp + lo;
@@ -464,8 +539,15 @@ hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA,
 // K5  input rows, row-major (cdae.hpp:333-349): for every kept input (u, j) in user order
 //     grad = scale * delta_u + lambda W[j] + g_uj z_u   (the last term is the deferred decoder
 //     gradient input_gradient[j], cdae.hpp:249-250, 342-343; absent when asymmetric)
-// The row's example words are scanned 64 at a time; the kept inputs among them are processed in groups
-// of UN with all their delta/z/g loads issued before the (elementwise, reduction-free) AdaGrad chain.
+// The row's example words are scanned 64 at a time; the kept inputs among them are taken in groups of UN.
+// Two groups are kept in registers: while the (elementwise, reduction-free) AdaGrad chain of group A runs,
+// the delta / z / g loads of group B are in flight (loads-only loop => counted vmcnt, see K3).
+template <int NI, int UN>
+struct InputGroup {
+  float dl[UN][NI], zz[UN][NI], gg[UN];
+  bool on[UN];
+};
+
 template <int NI>
 __global__ void __launch_bounds__(256)
 input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
@@ -480,51 +562,71 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   if (beg == end) return;
   const uint32_t lo = lane * NI;
+  constexpr int UN = 4;
   float w[NI], a[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) { w[i] = 0.f; a[i] = 1.f; }
   bool loaded = false;
-  constexpr int UN = 4;
-  for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
-    const uint32_t p = p0 + lane;
-    const uint64_t val = p < end ? sorted_val[p] : 0ull;
-    const uint32_t word = (uint32_t)val;
-    const uint32_t ex = (uint32_t)(val >> 32);
-    unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
-    if (mask && !loaded) {
+
+  // stream state: next chunk start, and the kept-input mask / words / example ids of the current chunk
+  uint32_t next_chunk = beg;
+  unsigned long long mask = 0ull;
+  uint32_t word = 0u, ex = 0u;
+
+  auto fetch = [&](InputGroup<NI, UN>& grp) -> bool {
+    bool any = false;
+#pragma unroll
+    for (int t = 0; t < UN; ++t) {
+      while (mask == 0ull && next_chunk < end) {               // wave-uniform: refill from the next 64 example words
+        const uint32_t p = next_chunk + lane;
+        const uint64_t val = p < end ? sorted_val[p] : 0ull;
+        word = (uint32_t)val;
+        ex = (uint32_t)(val >> 32);
+        mask = __ballot((word & INPUT_BIT) != 0u);
+        next_chunk += WAVE;
+      }
+      grp.on[t] = mask != 0ull;
+      grp.gg[t] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) { grp.dl[t][i] = 0.f; grp.zz[t][i] = 0.f; }
+      if (grp.on[t]) {
+        any = true;
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, src) & SLOT_MASK;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ex, src);
+        const size_t o = (size_t)slot * hp.Kp + lo;
+        vload<NI>(grp.dl[t], DELTA + o);
+        vload<NI>(grp.zz[t], Z + o);
+        if (!hp.asymmetric) grp.gg[t] = G[e];
+      }
+    }
+    return any;
+  };
+  auto apply = [&](const InputGroup<NI, UN>& grp) {
+    if (!loaded) {
       loaded = true;
       vload<NI>(w, W + (size_t)item * hp.Kp + lo);
       vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
     }
-    while (mask) {
-      float dl[UN][NI], zz[UN][NI], gg[UN];
-      bool on[UN];
 #pragma unroll
-      for (int t = 0; t < UN; ++t) {
-        on[t] = mask != 0ull;                                // wave-uniform
-        gg[t] = 0.f;
+    for (int t = 0; t < UN; ++t) {
+      if (grp.on[t]) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { dl[t][i] = 0.f; zz[t][i] = 0.f; }
-        if (on[t]) {
-          const int src = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, src) & SLOT_MASK;
-          const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ex, src);
-          const size_t o = (size_t)slot * hp.Kp + lo;
-          vload<NI>(dl[t], DELTA + o);
-          vload<NI>(zz[t], Z + o);
-          if (!hp.asymmetric) gg[t] = G[e];
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < UN; ++t) {
-        if (on[t]) {
-#pragma unroll
-          for (int i = 0; i < NI; ++i)
-            ada_step(hp, w[i], a[i], fmaf(hp.scale, dl[t][i], fmaf(gg[t], zz[t][i], hp.lambda * w[i])));
-        }
+        for (int i = 0; i < NI; ++i)
+          ada_step(hp, w[i], a[i], fmaf(hp.scale, grp.dl[t][i], fmaf(grp.gg[t], grp.zz[t][i], hp.lambda * w[i])));
       }
     }
+  };
+
+  InputGroup<NI, UN> A, B;
+  bool hasA = fetch(A);
+  while (hasA) {
+    const bool hasB = fetch(B);
+    apply(A);
+    if (!hasB) break;
+    hasA = fetch(A);
+    apply(B);
   }
   if (loaded) {
     vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
