@@ -98,37 +98,50 @@ def main():
 
     n_batches = (data.num_users + B - 1) // B
 
-    def step(i, acc):
+    def batch_of(i):
         b = i % n_batches
-        u0, u1 = b * B, min(data.num_users, (b + 1) * B)
+        return i // n_batches, b * B, min(data.num_users, (b + 1) * B)
+
+    KEYS = ("users", "examples", "ms_sample", "ms_sort", "ms_encode", "ms_decode", "ms_hidden", "ms_input", "launches_decode")
+    acc = {k: 0 for k in KEYS}
+
+    def add(st):
+        for k in KEYS:
+            acc[k] += getattr(st, k)
+
+    def step(i):
+        ep, u0, u1 = batch_of(i)
         if exch:
             exch.begin()
-        st = model.train_users(args.seed, i // n_batches, u0, u1)
-        if exch:
+            add(model.train_users(args.seed, ep, u0, u1))
+            nep, n0, n1 = batch_of(i + 1)
+            model.prefetch_users(args.seed, nep, n0, n1)   # next batch's sampling + sort overlaps the all-reduce
             exch.finish()
-        if acc is not None:
-            acc["users"] += st.users
-            acc["examples"] += st.examples
-            for k in ("ms_sample", "ms_sort", "ms_encode", "ms_decode", "ms_hidden", "ms_input"):
-                acc[k] += getattr(st, k)
-            acc["launches_decode"] += st.launches_decode
+        else:
+            # single GPU: steps queue asynchronously on the library's stream; the next batch is sampled and
+            # sorted on the side stream while this one trains
+            model.enqueue_users(args.seed, ep, u0, u1)
+            nep, n0, n1 = batch_of(i + 1)
+            model.prefetch_users(args.seed, nep, n0, n1)
 
     def sync():
         if dist is not None:
             dist.barrier()
+        model.synchronize()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i, None)
-    model.set_profiling(True)             # HIP events on the library's own stream, around each kernel family
-    acc = dict(users=0, examples=0, ms_sample=0.0, ms_sort=0.0, ms_encode=0.0, ms_decode=0.0, ms_hidden=0.0,
-               ms_input=0.0, launches_decode=0)
+        step(i)
+    model.collect_stats()
+    acc = {k: 0 for k in KEYS}
+    model.set_profiling(True)             # HIP events on the library's own streams, around each kernel family
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        step(i, acc)
+        step(i)
     sync()
     elapsed = time.perf_counter() - t0
+    add(model.collect_stats())
     model.set_profiling(False)
 
     users_total = float(acc["users"])

@@ -56,6 +56,9 @@ EXPORTS = {
     "cdae_hip_param_device_ptr": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
     "cdae_hip_train_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
+    "cdae_hip_enqueue_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "cdae_hip_prefetch_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "cdae_hip_collect_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "cdae_hip_train_one_user_corruption": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "cdae_hip_synchronize": (C.c_int, [C.c_void_p]),
@@ -205,6 +208,20 @@ class CDAE:
         st = Stats()
         _chk(self.lib, self.lib.cdae_hip_train_users(self.h, seed, epoch, u_begin, u_end, C.byref(st)))
         return st
+
+    def enqueue_users(self, seed: int, epoch: int, u_begin: int, u_end: int):
+        _chk(self.lib, self.lib.cdae_hip_enqueue_users(self.h, seed, epoch, u_begin, u_end))
+
+    def prefetch_users(self, seed: int, epoch: int, u_begin: int, u_end: int):
+        _chk(self.lib, self.lib.cdae_hip_prefetch_users(self.h, seed, epoch, u_begin, u_end))
+
+    def collect_stats(self) -> Stats:
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_collect_stats(self.h, C.byref(st)))
+        return st
+
+    def synchronize(self):
+        _chk(self.lib, self.lib.cdae_hip_synchronize(self.h))
 
     def train_one_user_corruption(self, uid: int, input_items, negative_items):
         """cdae.hpp:198-200 with explicit input set; negatives as the reference would have drawn them."""

@@ -77,6 +77,11 @@ struct cdae_hip {
   int64_t* d_row_ptr = nullptr;
   uint32_t* d_col = nullptr;
   uint32_t* d_item_order = nullptr;
+  std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
+  uint32_t* d_unit_ptr = nullptr;
+  uint32_t unit_cap = 0;                // most units in any window of batch_users users
+  float* d_Hpart = nullptr;             // [unit_cap][Kp] encode partial sums
+  uint32_t* d_uptr_tmp = nullptr;       // per-call prefix for cdae_hip_encode's arbitrary user lists
 
   // shared (item-side) parameters, one allocation: [W | W_ag | (V | V_ag) | bp | bp_ag | b | b_ag]
   float* d_shared = nullptr;
@@ -111,6 +116,10 @@ struct cdae_hip {
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr;
 
+  uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q & 1
+  bool pre_valid = false;               // set (seq & 1) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
+  uint64_t pre_s0 = 0, pre_seed = 0; uint32_t pre_nb = 0, pre_cidx = 0, pre_epoch = 0;
+  uint64_t acc_users = 0, acc_examples = 0, acc_batches = 0;   // since the last stats collection
   bool profiling = false;
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
@@ -169,7 +178,7 @@ int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
 
 void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
-                  h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
+                  h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
@@ -190,6 +199,7 @@ void free_all(cdae_hip* h) {
 int free_interaction_state(cdae_hip* h) {
   void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
                    (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_D0, (void**)&h->d_HGpart, (void**)&h->d_sort_tmp,
+                   (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta,
                    (void**)&h->ex[0].item, (void**)&h->ex[0].val, (void**)&h->ex[0].sorted_item, (void**)&h->ex[0].sorted_val,
@@ -208,6 +218,8 @@ template <class T> int dev_alloc(T** p, size_t n) {
 // one batch of train_one_user_corruption for users [s0, s0+nb), corruption cidx
 struct Batch { uint64_t s0; uint32_t nb; uint32_t cidx; uint64_t E; };
 
+inline uint32_t units_of(const cdae_hip* h, const Batch& b) { return h->h_unit_ptr[b.s0 + b.nb] - h->h_unit_ptr[b.s0]; }
+
 // K1 + sort on the prep stream into example-buffer set `b`
 int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
   using namespace cdae;
@@ -217,8 +229,9 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   Prof pr;
   HIPCHK(hipStreamWaitEvent(st, x.released, 0));               // the batch that last used this set is done with it
   CHK(pr.begin(h, F_SAMPLE, st));
-  hipLaunchKernelGGL(sample_kernel, dim3((bt.nb + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col, bt.s0, bt.nb,
-                     bt.cidx, seed, epoch, x.item, x.val);
+  const uint32_t n_units = units_of(h, bt);
+  hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
+                     h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st));
   HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
@@ -247,9 +260,14 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
 
   CHK(pr.begin(h, F_ENCODE, st));
   HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));             // b of the previous batch (side stream)
-  DISPATCH_NI(h->NI, encode_kernel, grid_users, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), h->d_Wu,
-              h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Z, h->d_Dz,
-              explicit_in, n_explicit);
+  // explicit mode: one user, one unit (the caller's lists need not follow the num_neg proportion)
+  const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
+  const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
+  const dim3 grid_units((n_units + 3) / 4);
+  DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
+              (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit);
+  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
+              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz);
   HIPCHK(hipMemsetAsync(h->d_HG, 0, (size_t)nb * h->Kp * sizeof(float), st));
   HIPCHK(hipMemcpyAsync(h->d_D0, h->dec(), (size_t)I * h->Kp * sizeof(float), hipMemcpyDeviceToDevice, st));
   CHK(pr.end());
@@ -274,10 +292,10 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   CHK(pr.end());
 
   CHK(pr.begin(h, F_HIDDEN, st));
-  DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((nb + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, s0, nb, x.item, h->d_G,
-              h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u);
-  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu,
-              h->d_Wu_ag);
+  DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
+              x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u);
+  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
+              h->d_Wu, h->d_Wu_ag);
   CHK(pr.end());
   // the strictly sequential hidden-bias recurrence needs only delta: run it beside the input rows
   HIPCHK(hipEventRecord(h->ev_delta, st));
@@ -297,11 +315,17 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   return 0;
 }
 
+// z for nb users: a contiguous range [u0, u0+nb) (d_uids == nullptr) or the list d_uids (prefix in d_uptr_tmp)
 int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream_id,
-                 uint32_t cidx, uint64_t seed, uint32_t epoch) {
-  DISPATCH_NI(h->NI, cdae::encode_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
-              h->P(CDAE_P_W), h->d_Wu, h->P(CDAE_P_B), d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Z,
-              (float*)nullptr, (const uint32_t*)nullptr, 0u);
+                 uint32_t cidx, uint64_t seed, uint32_t epoch, uint32_t n_units_list = 0) {
+  const uint32_t n_units = d_uids ? n_units_list : h->h_unit_ptr[u0 + nb] - h->h_unit_ptr[u0];
+  const uint32_t* uptr = d_uids ? h->d_uptr_tmp : h->d_unit_ptr + u0;
+  if (n_units > h->unit_cap) return fail("%u work units exceed the capacity %u", n_units, h->unit_cap);
+  DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+              h->P(CDAE_P_W), uptr, n_units, d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Hpart,
+              (const uint32_t*)nullptr, 0u);
+  DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, h->d_Wu,
+              h->P(CDAE_P_B), d_uids, u0, nb, mode, h->d_Z, (float*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -448,6 +472,32 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     emax = std::max<uint64_t>(emax, (uint64_t)(row_ptr[s1] - row_ptr[s0]));
   }
   h->Ecap = emax * (1u + h->cfg.num_neg);
+  h->seq = 0; h->pre_valid = false;
+  h->h_unit_ptr.assign(U + 1, 0u);
+  for (uint64_t u = 0; u < U; ++u)
+    h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + cdae::UNIT_POS - 1) / cdae::UNIT_POS);
+  h->unit_cap = 0;
+  for (uint64_t s0 = 0; s0 < U; ++s0) {
+    const uint64_t s1 = std::min<uint64_t>(U, s0 + B);
+    h->unit_cap = std::max(h->unit_cap, h->h_unit_ptr[s1] - h->h_unit_ptr[s0]);
+  }
+  // cdae_hip_encode takes arbitrary user lists of up to B users: the heaviest B users bound its unit count
+  {
+    std::vector<uint32_t> per(U);
+    for (uint64_t u = 0; u < U; ++u) per[u] = h->h_unit_ptr[u + 1] - h->h_unit_ptr[u];
+    std::partial_sort(per.begin(), per.begin() + B, per.end(), std::greater<uint32_t>());
+    uint64_t top = 0;
+    for (uint32_t i = 0; i < B; ++i) top += per[i];
+    h->unit_cap = (uint32_t)std::max<uint64_t>(h->unit_cap, top);
+  }
+  CHK(dev_alloc(&h->d_unit_ptr, U + 1));
+  HIPCHK(hipMemcpy(h->d_unit_ptr, h->h_unit_ptr.data(), (U + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  CHK(dev_alloc(&h->d_Hpart, (size_t)h->unit_cap * h->Kp));
+  CHK(dev_alloc(&h->d_uptr_tmp, (size_t)B + 1));
+  {
+    const uint32_t one_unit[2] = {0u, 1u};          // explicit-input step: one user, one unit
+    HIPCHK(hipMemcpy(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice));
+  }
   if (h->Ecap > 0xFFFFFFF0ull) return fail("batch of %u users holds %llu examples (> 2^32); lower batch_users", B, (unsigned long long)h->Ecap);
   for (auto& b : h->ex) {
     CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));
@@ -466,7 +516,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
-  CHK(dev_alloc(&h->d_HGpart, 8 * BK));
+  CHK(dev_alloc(&h->d_HGpart, 8 * (size_t)h->unit_cap * h->Kp));
   CHK(dev_alloc(&h->d_touched, (size_t)I));
   HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
   CHK(dev_alloc(&h->d_uids, (size_t)B));
@@ -559,35 +609,92 @@ int cdae_hip_synchronize(cdae_hip_t* h) {
   return 0;
 }
 
-int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end, cdae_hip_stats* stats) {
-  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+}  // extern "C"
+
+namespace {
+
+int make_plan(cdae_hip* h, uint64_t u_begin, uint64_t u_end, std::vector<Batch>& plan) {
   if (u_begin > u_end || u_end > h->U) return fail("bad user range [%llu, %llu)", (unsigned long long)u_begin, (unsigned long long)u_end);
-  HIPCHK(hipSetDevice(h->device));
-  const auto t0 = std::chrono::steady_clock::now();
-  uint64_t examples = 0, batches = 0, users = 0;
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
-  std::vector<Batch> plan;
   for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
     const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
     if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
     for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) plan.push_back(Batch{s0, nb, c, E});       // cdae.hpp:141
   }
-  // software pipeline over batches: sample + sort of batch t+1 (prep stream) overlaps the training of batch t
-  if (!plan.empty()) CHK(prep_batch(h, 0, plan[0], seed, epoch));
+  return 0;
+}
+
+bool is_prefetched(const cdae_hip* h, const Batch& b, uint64_t seed, uint32_t epoch) {
+  return h->pre_valid && h->pre_s0 == b.s0 && h->pre_nb == b.nb && h->pre_cidx == b.cidx && h->pre_seed == seed && h->pre_epoch == epoch;
+}
+
+// Enqueue (no host synchronisation) one pass over users [u_begin, u_end): a software pipeline in which the
+// sampling + sorting of batch t+1 (prep stream) overlaps the training of batch t (main stream).
+int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end) {
+  std::vector<Batch> plan;
+  CHK(make_plan(h, u_begin, u_end, plan));
+  if (plan.empty()) return 0;
+  if (!is_prefetched(h, plan[0], seed, epoch)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
+  h->pre_valid = false;
   for (size_t t = 0; t < plan.size(); ++t) {
-    if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((t + 1) & 1), plan[t + 1], seed, epoch));
-    CHK(compute_batch(h, (int)(t & 1), plan[t], seed, epoch));
-    examples += plan[t].E; batches++; users += plan[t].nb;
+    if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
+    CHK(compute_batch(h, (int)(h->seq & 1), plan[t], seed, epoch));
+    h->seq++;
+    h->acc_examples += plan[t].E; h->acc_batches++; h->acc_users += plan[t].nb;
   }
-  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int fill_stats(cdae_hip* h, cdae_hip_stats* stats) {
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
-    stats->users = users; stats->examples = examples; stats->batches = batches;
+    stats->users = h->acc_users; stats->examples = h->acc_examples; stats->batches = h->acc_batches;
   }
+  h->acc_users = h->acc_examples = h->acc_batches = 0;
   if (h->profiling) CHK(collect_profile(h, stats));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end, cdae_hip_stats* stats) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  CHK(enqueue_users(h, seed, epoch, u_begin, u_end));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  CHK(fill_stats(h, stats));
   if (stats) stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;
+}
+
+int cdae_hip_enqueue_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  return enqueue_users(h, seed, epoch, u_begin, u_end);
+}
+
+int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  std::vector<Batch> plan;
+  CHK(make_plan(h, u_begin, u_end, plan));
+  if (plan.empty()) return 0;
+  if (is_prefetched(h, plan[0], seed, epoch)) return 0;
+  CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
+  h->pre_valid = true;
+  h->pre_s0 = plan[0].s0; h->pre_nb = plan[0].nb; h->pre_cidx = plan[0].cidx; h->pre_seed = seed; h->pre_epoch = epoch;
+  return 0;
+}
+
+int cdae_hip_collect_stats(cdae_hip_t* h, cdae_hip_stats* stats) {
+  if (!h) return fail("null handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return fill_stats(h, stats);
 }
 
 int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats) {
@@ -605,7 +712,11 @@ int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, cons
   for (size_t c0 = 0; c0 < n; c0 += B) {
     const uint32_t nb = (uint32_t)std::min<size_t>(B, n - c0);
     HIPCHK(hipMemcpyAsync(h->d_uids, uids + c0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    CHK(encode_chunk(h, h->d_uids, 0, nb, mode, CDAE_STREAM_CORRUPT, 0, seed, epoch));
+    std::vector<uint32_t> prefix(nb + 1, 0u);
+    for (uint32_t i = 0; i < nb; ++i) prefix[i + 1] = prefix[i] + (h->h_unit_ptr[uids[c0 + i] + 1] - h->h_unit_ptr[uids[c0 + i]]);
+    HIPCHK(hipMemcpyAsync(h->d_uptr_tmp, prefix.data(), (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));                     // `prefix` is a stack temporary
+    CHK(encode_chunk(h, h->d_uids, 0, nb, mode, CDAE_STREAM_CORRUPT, 0, seed, epoch, prefix[nb]));
     HIPCHK(hipMemcpy2DAsync(Z + c0 * h->K, h->K * sizeof(float), h->d_Z, h->Kp * sizeof(float), h->K * sizeof(float), nb,
                             hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -715,8 +826,11 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
     items[n_pos + i] = negative_items[i];
     vals[n_pos + i] = (uint64_t)(n_pos + i) << 32;
   }
-  cdae_hip::ExBuf& x = h->ex[0];
+  h->pre_valid = false;
+  HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipStreamSynchronize(h->prep));
+  const int set = (int)(h->seq & 1);
+  cdae_hip::ExBuf& x = h->ex[set];
   HIPCHK(hipMemcpyAsync(x.item, items.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(x.val, vals.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val, E, 0u,
@@ -725,11 +839,15 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   hipLaunchKernelGGL(cdae::segment_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, h->stream, x.sorted_item, (uint32_t)E,
                      x.seg, x.seg + h->I);
   HIPCHK(hipEventRecord(x.ready, h->stream));
+  const uint32_t one_unit[2] = {0u, 1u};                         // one user, one unit
+  HIPCHK(hipMemcpyAsync(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
   uint32_t* d_in = h->d_uids;                     // capacity min(B, U) >= 1; longer input sets get their own buffer
   uint32_t* d_in_owned = nullptr;
   if (n_in > std::min<uint64_t>(h->B, h->U)) { CHK(dev_alloc(&d_in_owned, n_in)); d_in = d_in_owned; }
   if (n_in) HIPCHK(hipMemcpyAsync(d_in, in_sorted.data(), n_in * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-  int rc = compute_batch(h, 0, Batch{uid, 1, 0, E}, 0, 0, d_in, (uint32_t)n_in);
+  int rc = compute_batch(h, set, Batch{uid, 1, 0, E}, 0, 0, d_in, (uint32_t)n_in);
+  h->seq++;
   hipError_t se = hipStreamSynchronize(h->stream);
   if (d_in_owned) (void)hipFree(d_in_owned);
   if (rc) return rc;

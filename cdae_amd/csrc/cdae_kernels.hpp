@@ -133,6 +133,30 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Work units.  User activity is heavy-tailed (n_u from 16 to 1468 at ML-10M shape), and a kernel that gives
+// every user one wavefront takes as long as its longest user.  The user-parallel kernels therefore run on
+// UNITS of at most UNIT_POS positives of one user: unit k of a user covers positives [k*UNIT_POS, ...) and the
+// num_neg x as many negatives that belong to them.  `uptr` is the batch's prefix array (nb + 1 entries, any
+// base): user slot s owns units uptr[s] .. uptr[s+1]-1.
+constexpr uint32_t UNIT_POS = 128;
+
+struct UnitRef { uint32_t slot, p0, p1; };   // user slot and the positive range [p0, p1) of the unit
+
+__device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g, uint32_t n_pos_fn_unused) {
+  (void)n_pos_fn_unused;
+  uint32_t lo = 0, hi = nb;                      // largest slot with uptr[slot] <= g
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (uptr[mid] <= g) lo = mid; else hi = mid;
+  }
+  UnitRef r;
+  r.slot = lo;
+  r.p0 = (g - uptr[lo]) * UNIT_POS;
+  r.p1 = r.p0 + UNIT_POS;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1  sample: dropout keep-mask + rejection-sampled negatives -> example list of the batch.
 // get_corrputed_input (cdae.hpp:361-371) and sample_negative_item (recsys_model_base.hpp:46-57,
 // call site cdae.hpp:217-220).  One wavefront per user; integer-only.
@@ -150,35 +174,38 @@ constexpr uint32_t SAMPLE_LDS_ROW = 2048;   // items of a user's row staged per 
 
 __global__ void __launch_bounds__(256)
 sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-              uint64_t u0, uint32_t nb, uint32_t cidx, uint64_t seed, uint32_t epoch,
-              uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val) {
+              const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb, uint32_t cidx,
+              uint64_t seed, uint32_t epoch, uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   const uint32_t wid = threadIdx.x / WAVE;
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + wid;
+  const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
+  if (unit >= n_units) return;
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, 0);
+  const uint32_t slot = ur.slot;
   const uint64_t uid = u0 + slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
   const uint32_t m = n * hp.num_neg;
+  const uint32_t p0 = ur.p0, p1 = min(ur.p1, n);
   const uint32_t* row = col + r0;
   const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
   const uint64_t key_n = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_NEGATIVE);
   const bool staged = n <= SAMPLE_LDS_ROW;
   uint32_t* lrow = lds_rows[wid];
-  for (uint32_t p = lane; p < n; p += WAVE) {
-    const uint32_t it = row[p];
-    if (staged) lrow[p] = it;
+  if (staged)
+    for (uint32_t p = lane; p < n; p += WAVE) lrow[p] = row[p];           // the whole row: negatives are tested against it
+  for (uint32_t p = p0 + lane; p < p1; p += WAVE) {
     const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
     const uint64_t e = base + p;
-    ex_item[e] = it;
+    ex_item[e] = row[p];
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
-  // the wavefront's own LDS writes are visible to it after the LDS counter drains (no cross-wave sharing)
+  // the wavefront's own LDS writes are visible to it once they are issued in order (no cross-wave sharing)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < m; i += WAVE) {
+  for (uint32_t i = p0 * hp.num_neg + lane; i < p1 * hp.num_neg; i += WAVE) {
     const uint64_t e = base + n + i;
     uint32_t cand;
     if (staged) {
@@ -215,25 +242,30 @@ segment_kernel(const uint32_t* __restrict__ sorted_item, uint32_t n_ex, uint32_t
 
 // ------------------------------------------------------------------------------------------------
 // K2  encode: z_u = act(scale * sum_{i in In(u)} W[i] + b + Wu[u])   (get_hidden_values, cdae.hpp:373-416)
-// One wavefront per user.  mode 0: all train items, scale 1 (inference, cdae.hpp:169);
-// mode 1: dropout mask of stream `stream`, scale hp.scale (training cdae.hpp:207, data_loss cdae.hpp:92).
-// Coalesced gather: each kept row is one 256*NI-byte wave load; eight rows in flight per wave.
+// Two launches: encode_partial_kernel — one wavefront per unit sums the kept rows of its <= 128 positives
+// (coalesced gather: each row is one 256*NI-byte wave load, eight rows in flight) — and
+// encode_finish_kernel — one wavefront per user adds its units' partial sums in order, applies scale, b,
+// Wu[u] and the activation.
+// mode 0: all train items, scale 1 (inference, cdae.hpp:169); mode 1: dropout mask of stream `stream`, scale
+// hp.scale (training cdae.hpp:207, data_loss cdae.hpp:92).  explicit_in: the caller supplies the corrupted
+// input set itself, like the reference's public train_one_user_corruption(uid, input_set, output_set)
+// (cdae.hpp:198-200): one user, one unit, mode-1 scale, no mask.
 template <int NI>
 __global__ void __launch_bounds__(256)
-encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-              const float* __restrict__ W, const float* __restrict__ Wu, const float* __restrict__ b,
-              const uint32_t* __restrict__ uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream,
-              uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Z, float* __restrict__ Dz,
-              const uint32_t* __restrict__ explicit_in, uint32_t n_explicit) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                      const float* __restrict__ W, const uint32_t* __restrict__ uptr, uint32_t n_units,
+                      const uint32_t* __restrict__ uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream,
+                      uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Hpart,
+                      const uint32_t* __restrict__ explicit_in, uint32_t n_explicit) {
+  const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
-  const uint64_t uid = uids ? (uint64_t)uids[slot] : u0 + slot;
+  if (unit >= n_units) return;
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, 0);
+  const uint64_t uid = uids ? (uint64_t)uids[ur.slot] : u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
-  // explicit_in: the caller supplies the corrupted input set itself, like the reference's public
-  // train_one_user_corruption(uid, input_set, output_set) (cdae.hpp:198-200); mode 1 scale, no mask
   const uint32_t n = explicit_in ? n_explicit : (uint32_t)(row_ptr[uid + 1] - r0);
   const uint32_t* row = explicit_in ? explicit_in : col + r0;
+  const uint32_t p_begin = explicit_in ? 0u : ur.p0, p_end = explicit_in ? n : min(ur.p1, n);
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, stream);
   const bool none = (mode == 0 && hp.keep_thr == 0x100000000ull);   // cdae.hpp:168-172 (q == 1 -> empty input)
   const uint32_t lo = lane * NI;
@@ -241,11 +273,11 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   constexpr int UN = 8;
-  for (uint32_t p0 = 0; p0 < n && !none; p0 += WAVE) {
-    const uint32_t p = p0 + lane;
+  for (uint32_t q0 = p_begin; q0 < p_end && !none; q0 += WAVE) {
+    const uint32_t p = q0 + lane;
     uint32_t item = 0;
     int keep = 0;
-    if (p < n) {
+    if (p < p_end) {
       item = row[p];
       keep = (mode == 0 || explicit_in) ? 1 : cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
     }
@@ -270,6 +302,29 @@ encode_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] += v[j][i];
     }
+  }
+  vstore<NI>(Hpart + (size_t)unit * hp.Kp + lo, acc);
+}
+
+template <int NI>
+__global__ void __launch_bounds__(256)
+encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t* __restrict__ uptr,
+                     const float* __restrict__ Wu, const float* __restrict__ b, const uint32_t* __restrict__ uids,
+                     uint64_t u0, uint32_t nb, int mode, float* __restrict__ Z, float* __restrict__ Dz) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = uids ? (uint64_t)uids[slot] : u0 + slot;
+  const uint32_t lo = lane * NI;
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  for (uint32_t u = ub; u < ue; ++u) {                          // unit order == item order: deterministic sum
+    float part[NI];
+    vload<NI>(part, Hpart + (size_t)u * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] += part[i];
   }
   const float sc = mode == 0 ? 1.f : hp.scale;
   float bb[NI], wu[NI], z[NI], dz[NI];
@@ -424,34 +479,43 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
 // workgroups round-robin on the 8 XCDs (a speed assumption only; any placement gives the same result) —
 // and gathers, for its 4 users, only the rows with (item mod 8) == x.  Each XCD's L2 then holds 1/8 of
 // D0 (1.35 MB) and the 684 row reads per user hit L2 instead of the fabric.  The 8 partial sums per user
-// are combined by hidden_finish_kernel.  One wavefront per (user, partition); ids and g staged 64 at a
-// time, matching rows compacted with a ballot, 8 row loads in flight.
+// per unit are combined by hidden_finish_kernel.  One wavefront per (unit, partition); ids and g staged 64
+// at a time, matching rows compacted with a ballot, 8 row loads in flight.
 template <int NI>
 __global__ void __launch_bounds__(256)
-hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64_t u0, uint32_t nb,
-                     const uint32_t* __restrict__ ex_item, const float* __restrict__ G,
-                     const float* __restrict__ D0, float* __restrict__ HGpart /* [8][nb][Kp] */,
-                     uint32_t explicit_examples /* != 0: one user, that many examples */) {
+hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ uptr,
+                     uint32_t n_units, uint64_t u0, uint32_t nb, const uint32_t* __restrict__ ex_item,
+                     const float* __restrict__ G, const float* __restrict__ D0,
+                     float* __restrict__ HGpart /* [8][n_units][Kp] */,
+                     uint32_t explicit_examples /* != 0: one user, one unit, that many examples */) {
   const uint32_t part = blockIdx.x & 7u;
-  const uint32_t slot = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
-  const uint64_t uid = u0 + slot;
+  if (unit >= n_units) return;
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, 0);
+  const uint64_t uid = u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
-  const uint32_t n_ex = explicit_examples ? explicit_examples : (uint32_t)(row_ptr[uid + 1] - r0) * (1u + hp.num_neg);
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
   const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
+  // the unit's examples: positives [p0, p1) then negatives [num_neg*p0, num_neg*p1) (stored after the n positives)
+  const uint32_t p0 = explicit_examples ? 0u : ur.p0, p1 = explicit_examples ? n : min(ur.p1, n);
+  const uint32_t n_posu = p1 - p0;
+  const uint32_t n_negu = explicit_examples ? explicit_examples - n : n_posu * hp.num_neg;
+  const uint32_t neg0 = n + p0 * hp.num_neg;
+  const uint32_t n_ex = n_posu + n_negu;
   const uint32_t lo = lane * NI;
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   constexpr int UN = 8;
   for (uint32_t c0 = 0; c0 < n_ex; c0 += WAVE) {
-    const uint32_t e = c0 + lane;
-    const uint32_t my_item = e < n_ex ? ex_item[base + e] : 0xFFFFFFFFu;
-    const float my_g = e < n_ex ? G[base + e] : 0.f;
-    unsigned long long mask = __ballot(e < n_ex && (my_item & 7u) == part);
+    const uint32_t v = c0 + lane;
+    const uint32_t e = v < n_posu ? p0 + v : neg0 + (v - n_posu);
+    const uint32_t my_item = v < n_ex ? ex_item[base + e] : 0xFFFFFFFFu;
+    const float my_g = v < n_ex ? G[base + e] : 0.f;
+    unsigned long long mask = __ballot(v < n_ex && (my_item & 7u) == part);
     while (mask) {
-      float v[UN][NI], gg[UN];
+      float vv[UN][NI], gg[UN];
 #pragma unroll
       for (int t = 0; t < UN; ++t) {
         if (mask) {                                            // wave-uniform
@@ -459,29 +523,30 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, uint64
           mask &= mask - 1;
           const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)my_item, src);
           gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), src));
-          vload<NI>(v[t], D0 + (size_t)it * hp.Kp + lo);
+          vload<NI>(vv[t], D0 + (size_t)it * hp.Kp + lo);
         } else {
           gg[t] = 0.f;
 #pragma unroll
-          for (int i = 0; i < NI; ++i) v[t][i] = 0.f;
+          for (int i = 0; i < NI; ++i) vv[t][i] = 0.f;
         }
       }
 #pragma unroll
       for (int t = 0; t < UN; ++t)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] = fmaf(gg[t], v[t][i], acc[i]);
+        for (int i = 0; i < NI; ++i) acc[i] = fmaf(gg[t], vv[t][i], acc[i]);
     }
   }
-  vstore<NI>(HGpart + ((size_t)part * nb + slot) * hp.Kp + lo, acc);
+  vstore<NI>(HGpart + ((size_t)part * n_units + unit) * hp.Kp + lo, acc);
 }
 
 // K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
 //       and the private user-node step Wu[u]                                      cdae.hpp:317-331
 template <int NI>
 __global__ void __launch_bounds__(256)
-hidden_finish_kernel(HyperParams hp, uint64_t u0, uint32_t nb, const float* __restrict__ HGpart,
-                     const float* __restrict__ Dz, float* __restrict__ HG /* in: corrections, out: delta */,
-                     float* __restrict__ Wu, float* __restrict__ Wu_ag) {
+hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb,
+                     const float* __restrict__ HGpart, const float* __restrict__ Dz,
+                     float* __restrict__ HG /* in: corrections, out: delta */, float* __restrict__ Wu,
+                     float* __restrict__ Wu_ag) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -490,12 +555,15 @@ hidden_finish_kernel(HyperParams hp, uint64_t u0, uint32_t nb, const float* __re
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
   vload<NI>(hg, HG + o);
+  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  for (uint32_t u = ub; u < ue; ++u) {                          // fixed order: deterministic
 #pragma unroll
-  for (int x = 0; x < 8; ++x) {                                 // fixed order: deterministic
-    float part[NI];
-    vload<NI>(part, HGpart + ((size_t)x * nb + slot) * hp.Kp + lo);
+    for (int x = 0; x < 8; ++x) {
+      float part[NI];
+      vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) hg[i] += part[i];
+      for (int i = 0; i < NI; ++i) hg[i] += part[i];
+    }
   }
   vload<NI>(dz, Dz + o);
 #pragma unroll

@@ -126,6 +126,16 @@ int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, 
 int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
 int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin,
                          uint64_t u_end, cdae_hip_stats* stats);
+/* Asynchronous forms.  enqueue_users = train_users without the final host synchronisation (several calls
+ * queue back to back on the library's stream); prefetch_users runs only the sampling + sorting of the first
+ * batch of a range on the side stream, so that it overlaps whatever the caller does next (e.g. the RCCL
+ * all-reduce of the data-parallel exchange) — a later train/enqueue call for the same (seed, epoch, range)
+ * picks the prepared batch up.  collect_stats synchronises and returns the counters (and, with profiling
+ * on, the HIP-event kernel times) accumulated since the previous train_users / collect_stats. */
+int cdae_hip_enqueue_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end);
+int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end);
+int cdae_hip_collect_stats(cdae_hip_t* h, cdae_hip_stats* stats);
+
 /* The reference's public per-user step with the caller's own corrupted input set,
  * train_one_user_corruption(uid, input_set, output_set) (cdae.hpp:198-200; output_set is the user's
  * train row), plus the negatives the reference would draw at cdae.hpp:217-220.  Known-answer tests use it
