@@ -127,8 +127,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]
   v = dpp_add<0x141>(v);           // row_half_mirror
   v = dpp_add<0x140>(v);           // row_mirror        -> every lane holds its 16-lane row sum
-  v = dpp_add<0x142, 0xA>(v);      // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xC>(v);      // row_bcast:31 into rows 2,3 -> lane 63 = total
+  // row_bcast with the full row mask: rows that have no source lane add 0 (bound_ctrl), rows 0-2 end up with
+  // partial sums nobody reads, and the instruction folds into one v_add_f32_dpp like the stages above
+  v = dpp_add<0x142>(v);           // row_bcast:15 -> row r += sum(row r-1)
+  v = dpp_add<0x143>(v);           // row_bcast:31 -> rows 2,3 += lane 31 (= rows 0+1) -> lane 63 = total
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 

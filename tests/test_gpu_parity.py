@@ -156,3 +156,27 @@ def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
             wgt = np.where(touched, 0.5, 1.0)
             want = before[w] + 2 * d * (wgt[:, None] if d.ndim == 2 else wgt)
         np.testing.assert_allclose(model.get(w), want, rtol=0, atol=2e-6)
+
+
+def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):
+    """enqueue_users / prefetch_users only change WHEN work is queued, never the result.  (Equality up to the
+    order of the few fp32 atomics that carry duplicate-negative corrections: a few fp32 ulps.)"""
+    a, _ = make_pair(tiny, K=32, B=40)
+    b, _ = make_pair(tiny, K=32, B=40)
+    a.train_one_iteration(seed=9, epoch=0)
+    a.train_users(seed=9, epoch=1, u_begin=0, u_end=120)
+    # same work, queued batch by batch with the next batch prefetched, one synchronisation at the end
+    bounds = [(0, s, min(tiny.num_users, s + 40)) for s in range(0, tiny.num_users, 40)] + [(1, 0, 40), (1, 40, 80), (1, 80, 120)]
+    for i, (ep, u0, u1) in enumerate(bounds):
+        b.enqueue_users(9, ep, u0, u1)
+        if i + 1 < len(bounds):
+            b.prefetch_users(9, *bounds[i + 1])
+    st = b.collect_stats()
+    assert st.users == tiny.num_users + 120 and st.batches == len(bounds)
+    for which in (0, 1, 4, 5, 6, 7, 8, 9):
+        np.testing.assert_allclose(a.get(which), b.get(which), rtol=5e-6, atol=1e-6)
+    # a prefetch that is never consumed (different range next) must not corrupt anything
+    b.prefetch_users(9, 2, 0, 40)
+    b.train_users(9, 2, 40, 80)
+    a.train_users(9, 2, 40, 80)
+    np.testing.assert_allclose(a.get(0), b.get(0), rtol=5e-6, atol=1e-6)
