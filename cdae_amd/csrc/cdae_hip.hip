@@ -267,26 +267,30 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
               (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit);
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz);
-  HIPCHK(hipMemsetAsync(h->d_HG, 0, (size_t)nb * h->Kp * sizeof(float), st));
-  HIPCHK(hipMemcpyAsync(h->d_D0, h->dec(), (size_t)I * h->Kp * sizeof(float), hipMemcpyDeviceToDevice, st));
+              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG);
   CHK(pr.end());
 
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   CHK(pr.begin(h, F_DECODE, st));
 #define DECODE_ARGS h->hp, h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
-                    h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_touched
-#define DECODE_NI(NI_)                                                                                              \
-  do {                                                                                                              \
-    if (ce && ada) hipLaunchKernelGGL((decode_rows_kernel<NI_, 5, true>), grid_rows, blk, 0, st, DECODE_ARGS);      \
-    else if (ce) hipLaunchKernelGGL((decode_rows_kernel<NI_, 5, false>), grid_rows, blk, 0, st, DECODE_ARGS);       \
-    else if (ada) hipLaunchKernelGGL((decode_rows_kernel<NI_, 0, true>), grid_rows, blk, 0, st, DECODE_ARGS);       \
-    else hipLaunchKernelGGL((decode_rows_kernel<NI_, 0, false>), grid_rows, blk, 0, st, DECODE_ARGS);               \
+                    h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_D0, h->d_touched
+#define DECODE_LA(NI_, L_, A_)                                                                                       \
+  do {                                                                                                               \
+    if (pad) hipLaunchKernelGGL((decode_rows_kernel<NI_, L_, A_, true>), grid_rows, blk, 0, st, DECODE_ARGS);        \
+    else hipLaunchKernelGGL((decode_rows_kernel<NI_, L_, A_, false>), grid_rows, blk, 0, st, DECODE_ARGS);           \
+  } while (0)
+#define DECODE_NI(NI_)                                          \
+  do {                                                          \
+    if (ce && ada) DECODE_LA(NI_, 5, true);                     \
+    else if (ce) DECODE_LA(NI_, 5, false);                      \
+    else if (ada) DECODE_LA(NI_, 0, true);                      \
+    else DECODE_LA(NI_, 0, false);                              \
   } while (0)
   {
-    const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY, ada = h->cfg.using_adagrad != 0;
+    const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY, ada = h->cfg.using_adagrad != 0, pad = h->K < h->Kp;
     switch (h->NI) { case 1: DECODE_NI(1); break; case 2: DECODE_NI(2); break; case 4: DECODE_NI(4); break; default: DECODE_NI(8); break; }
   }
+#undef DECODE_LA
 #undef DECODE_NI
 #undef DECODE_ARGS
   CHK(pr.end());
@@ -325,7 +329,7 @@ int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, 
               h->P(CDAE_P_W), uptr, n_units, d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Hpart,
               (const uint32_t*)nullptr, 0u);
   DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, h->d_Wu,
-              h->P(CDAE_P_B), d_uids, u0, nb, mode, h->d_Z, (float*)nullptr);
+              h->P(CDAE_P_B), d_uids, u0, nb, mode, h->d_Z, (float*)nullptr, (float*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -312,7 +312,8 @@ template <int NI>
 __global__ void __launch_bounds__(256)
 encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t* __restrict__ uptr,
                      const float* __restrict__ Wu, const float* __restrict__ b, const uint32_t* __restrict__ uids,
-                     uint64_t u0, uint32_t nb, int mode, float* __restrict__ Z, float* __restrict__ Dz) {
+                     uint64_t u0, uint32_t nb, int mode, float* __restrict__ Z, float* __restrict__ Dz,
+                     float* __restrict__ HGzero /* training: the batch's duplicate-correction rows start at 0 */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -343,6 +344,11 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
   }
   vstore<NI>(Z + (size_t)slot * hp.Kp + lo, z);
   if (Dz) vstore<NI>(Dz + (size_t)slot * hp.Kp + lo, dz);
+  if (HGzero) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) z[i] = 0.f;
+    vstore<NI>(HGzero + (size_t)slot * hp.Kp + lo, z);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,14 +374,18 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
 // the counter and complete out of order with loads).
 constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15 = don't care), gfx9 encoding
 
-template <int NI, int LOSS, bool ADAGRAD>
+// BIAS_IN_PAD (K < Kp, e.g. K = 200 or 50): b'[j] rides in the last pad element of the row registers with a
+// constant 1 as its "z": its AdaGrad step grad = g*1 + lambda*b' (cdae.hpp:230-237) is then the row step's own
+// arithmetic and y = D[j].z + b'[j] needs no separate add — the per-example chain loses the scalar bias
+// recurrence (two transcendentals).  Memory images of D and D0 keep their pad elements 0.
+template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
 __global__ void __launch_bounds__(256)
 decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                    const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
                    const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
                    float* __restrict__ D, float* __restrict__ D_ag, float* __restrict__ bp,
                    float* __restrict__ bp_ag, float* __restrict__ HGcorr, float* __restrict__ G,
-                   uint32_t* __restrict__ touched) {
+                   float* __restrict__ D0, uint32_t* __restrict__ touched) {
   const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
@@ -389,11 +399,18 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   float w[NI], a[NI], wref[NI];
   vload<NI>(w, D + (size_t)item * hp.Kp + lo);
   vload<NI>(a, D_ag + (size_t)item * hp.Kp + lo);
+  vstore<NI>(D0 + (size_t)item * hp.Kp + lo, w);     // batch-start snapshot of this row for the hidden-gradient gather
+  float bias = bp[item], bias_ag = bp_ag[item];
+  const bool pad_lane = BIAS_IN_PAD && lane == WAVE - 1;
+  const float pad_one = pad_lane ? 1.f : 0.f;
+  if (pad_lane) { w[NI - 1] = bias; a[NI - 1] = bias_ag; }
 #pragma unroll
   for (int i = 0; i < NI; ++i) wref[i] = w[i];
-  float bias = bp[item], bias_ag = bp_ag[item];
 
-  constexpr int PF = 4;
+#ifndef CDAE_DECODE_PF
+#define CDAE_DECODE_PF 8
+#endif
+  constexpr int PF = CDAE_DECODE_PF;   // z rows in flight per wavefront (must divide 64)
   // cur / nxt: this lane's example word (slot | flags), example index and z-row byte offset of the current /
   // next chunk.  The byte offset is computed once per chunk by all 64 lanes, so the per-example address is a
   // v_readlane + a scalar add onto the Z base (32-bit: the batch's Z is at most 4 GiB).
@@ -428,17 +445,20 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
         if (idx < cnt) {                                       // wave-uniform
           const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
           const uint32_t slot = word & SLOT_MASK;
+          if (BIAS_IN_PAD) z[t][NI - 1] += pad_one;            // the bias element's "z" is 1 (Z's pad elements are 0)
           float dot = 0.f;
 #pragma unroll
           for (int i = 0; i < NI; ++i) dot = fmaf(w[i], z[t][i], dot);
-          const float y = wave_sum(dot) + bias;
+          float y = wave_sum(dot);
+          if (!BIAS_IN_PAD) y += bias;
           const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
-          ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
+          if (!BIAS_IN_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
           gbuf = lane == idx ? g : gbuf;
           if (slot == prev_slot) {                             // duplicate negative of the same user (rare)
             float* hc = HGcorr + (size_t)slot * hp.Kp + lo;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, g * (w[i] - wref[i]));
+            for (int i = 0; i < NI; ++i)
+              if (!(pad_lane && i == NI - 1)) unsafeAtomicAdd(hc + i, g * (w[i] - wref[i]));
             __builtin_amdgcn_s_waitcnt(WAIT_VM0);              // keep the loop's VMEM stream loads-only
           } else {
             prev_slot = slot;
@@ -448,6 +468,10 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
           if (!(word & INPUT_BIT) || !tied) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
+          } else if (BIAS_IN_PAD) {                            // deferred row step (cdae.hpp:249-250): b' still steps now
+            float bw = w[NI - 1], ba = a[NI - 1];
+            ada_step(hp, bw, ba, fmaf(hp.lambda, bw, g));
+            if (pad_lane) { w[NI - 1] = bw; a[NI - 1] = ba; }
           }
         }
         // refill ring slot t with the example PF ahead (clamped to the row's last example; the value is
@@ -465,13 +489,19 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
     __builtin_amdgcn_s_waitcnt(WAIT_VM0);
     cur_w = nxt_w; cur_e = nxt_e; cur_o = nxt_o;
   }
-  vstore<NI>(D + (size_t)item * hp.Kp + lo, w);
-  vstore<NI>(D_ag + (size_t)item * hp.Kp + lo, a);
-  if (lane == 0) {
+  if (BIAS_IN_PAD) {
+    if (pad_lane) {
+      bp[item] = w[NI - 1];
+      bp_ag[item] = a[NI - 1];
+      w[NI - 1] = 0.f; a[NI - 1] = 1.f;                     // pad images in memory: weight 0, accumulator 1
+    }
+  } else if (lane == 0) {
     bp[item] = bias;
     bp_ag[item] = bias_ag;
-    if (touched) touched[item] = 1u;
   }
+  vstore<NI>(D + (size_t)item * hp.Kp + lo, w);
+  vstore<NI>(D_ag + (size_t)item * hp.Kp + lo, a);
+  if (lane == 0 && touched) touched[item] = 1u;
 }
 
 // ------------------------------------------------------------------------------------------------
