@@ -115,16 +115,13 @@ def main():
         ep, u0, u1 = batch_of(i)
         if exch:
             exch.begin()
-            add(model.train_users(args.seed, ep, u0, u1))
-            nep, n0, n1 = batch_of(i + 1)
-            model.prefetch_users(args.seed, nep, n0, n1)   # next batch's sampling + sort overlaps the all-reduce
+        # steps queue asynchronously on the library's stream; the next batch is sampled and sorted on the side
+        # stream while this one trains (and, with N > 1, while its deltas are all-reduced)
+        model.enqueue_users(args.seed, ep, u0, u1)
+        nep, n0, n1 = batch_of(i + 1)
+        model.prefetch_users(args.seed, nep, n0, n1)
+        if exch:
             exch.finish()
-        else:
-            # single GPU: steps queue asynchronously on the library's stream; the next batch is sampled and
-            # sorted on the side stream while this one trains
-            model.enqueue_users(args.seed, ep, u0, u1)
-            nep, n0, n1 = batch_of(i + 1)
-            model.prefetch_users(args.seed, nep, n0, n1)
 
     def sync():
         if dist is not None:

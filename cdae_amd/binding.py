@@ -66,6 +66,7 @@ EXPORTS = {
     "cdae_hip_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "cdae_hip_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "cdae_hip_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "cdae_hip_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cdae_hip_delta_begin": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_compute": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -264,6 +265,11 @@ class CDAE:
         return self._rec[uid]
 
     # ---- data-parallel exchange --------------------------------------------------------------------
+    def stream_handle(self) -> int:
+        p = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_stream(self.h, C.byref(p)))
+        return p.value
+
     def delta_begin(self):
         _chk(self.lib, self.lib.cdae_hip_delta_begin(self.h))
 

@@ -869,6 +869,12 @@ int cdae_hip_delta_begin(cdae_hip_t* h) {
   return 0;
 }
 
+int cdae_hip_stream(cdae_hip_t* h, void** hip_stream) {
+  if (!h || !hip_stream) return fail("bad argument");
+  *hip_stream = (void*)h->stream;
+  return 0;
+}
+
 int cdae_hip_delta_compute(cdae_hip_t* h) {
   if (!h || !h->d_base) return fail("delta_begin must be called first");
   HIPCHK(hipSetDevice(h->device));
@@ -877,8 +883,7 @@ int cdae_hip_delta_compute(cdae_hip_t* h) {
   hipLaunchKernelGGL(cdae::touch_to_float_kernel, dim3((uint32_t)((h->I + 255) / 256)), dim3(256), 0, h->stream, h->d_touched,
                      h->d_delta + h->n_shared, (uint32_t)h->I);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
+  return 0;                                  // stream-ordered: callers that read the buffer on another stream synchronise
 }
 
 int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats) {
@@ -896,7 +901,6 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
   hipLaunchKernelGGL(cdae::apply_delta_kernel, dim3((uint32_t)((h->n_shared + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                      h->d_base, h->d_delta, h->d_delta + h->n_shared, h->n_matrix, h->Kp, (uint32_t)h->I, h->n_shared, world_size, rule);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
 

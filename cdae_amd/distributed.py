@@ -59,25 +59,29 @@ class _DeviceBuffer:
 
 
 class DeltaExchange:
-    """GPU path: the delta buffer lives in the library; torch only wraps it for the RCCL all-reduce."""
+    """GPU path: the delta buffer lives in the library; torch only wraps it (zero copy) for the RCCL all-reduce,
+    which is enqueued on the library's own HIP stream (torch.cuda.ExternalStream) — the whole step
+    snapshot -> train -> delta -> all-reduce -> apply is stream-ordered and never blocks the host."""
 
     def __init__(self, model, dist, world: int, rule: int = RULE_SUM):
         import torch
         self.model, self.dist, self.world, self.rule = model, dist, world, rule
         model.delta_begin()
         ptr, count = model.delta_device_ptr()
-        self.buf = torch.as_tensor(_DeviceBuffer(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.buf = torch.as_tensor(_DeviceBuffer(ptr, count), device=dev)
         assert self.buf.data_ptr() == ptr, "torch copied the delta buffer instead of wrapping it"
+        self.stream = torch.cuda.ExternalStream(model.stream_handle(), device=dev)
         self.torch = torch
 
     def begin(self):
         self.model.delta_begin()
 
     def finish(self):
-        self.model.delta_compute()                       # stream-synchronised by the library
+        self.model.delta_compute()
         if self.world > 1:
-            self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM)
-            self.torch.cuda.current_stream().synchronize()
+            with self.torch.cuda.stream(self.stream):
+                self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM)
         self.model.delta_apply(self.world, self.rule)
 
 

@@ -170,6 +170,10 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
  *   <all-reduce(sum) of that buffer by the caller, e.g. torch.distributed over RCCL>
  *   cdae_hip_delta_apply   : current = snapshot + combine(summed delta)
  * Layout of the buffer: cdae_hip_delta_device_ptr(). */
+/* All four delta calls are stream-ordered on the library's HIP stream (cdae_hip_stream) and do not block the
+ * host; run the all-reduce on that stream, or synchronise (cdae_hip_synchronize) before touching the buffer
+ * from another one. */
+int cdae_hip_stream(cdae_hip_t* h, void** hip_stream);
 int cdae_hip_delta_begin(cdae_hip_t* h);
 int cdae_hip_delta_compute(cdae_hip_t* h);
 int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);

@@ -141,9 +141,10 @@ def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
     model.train_users(seed=2, epoch=0, u_begin=0, u_end=64)
     after = {w: model.get(w).astype(np.float64) for w in shared_ids}
     model.delta_compute()
+    model.synchronize()                                # the delta calls are stream-ordered on the library's stream
     assert ex.buf.is_cuda and ex.buf.numel() == model.delta_device_ptr()[1]
-    ex.buf.mul_(2.0)                                   # "all-reduce" of two identical ranks
-    torch.cuda.synchronize()
+    with torch.cuda.stream(ex.stream):                 # the stream the real all-reduce is enqueued on
+        ex.buf.mul_(2.0)                               # "all-reduce" of two identical ranks
     model.delta_apply(2, rule)
     touched = (np.abs(after[1] - before[1]).sum(1) + np.abs(after[9] - before[9])) > 0
     for w in shared_ids:
