@@ -102,9 +102,7 @@ struct cdae_hip {
   } ex[2];
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
   float* d_HGpart = nullptr;            // [8][B][Kp] per-XCD partial hidden gradients
-  hipStream_t side = nullptr;           // hidden-bias recurrence runs beside the input-row kernel
   hipStream_t prep = nullptr;           // sampling + sorting of the next batch
-  hipEvent_t ev_delta = nullptr, ev_bias = nullptr;
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
   uint32_t* d_touched = nullptr;
@@ -190,9 +188,6 @@ void free_all(cdae_hip* h) {
   if (h->prep) (void)hipStreamDestroy(h->prep);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (Span& s : h->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
-  if (h->ev_delta) (void)hipEventDestroy(h->ev_delta);
-  if (h->ev_bias) (void)hipEventDestroy(h->ev_bias);
-  if (h->side) (void)hipStreamDestroy(h->side);
   if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -259,7 +254,6 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   Prof pr;
 
   CHK(pr.begin(h, F_ENCODE, st));
-  HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));             // b of the previous batch (side stream)
   // explicit mode: one user, one unit (the caller's lists need not follow the num_neg proportion)
   const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
   const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
@@ -301,20 +295,16 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
               h->d_Wu, h->d_Wu_ag);
   CHK(pr.end());
-  // the strictly sequential hidden-bias recurrence needs only delta: run it beside the input rows
-  HIPCHK(hipEventRecord(h->ev_delta, st));
-  HIPCHK(hipStreamWaitEvent(h->side, h->ev_delta, 0));
-  hipLaunchKernelGGL(hidden_bias_kernel, dim3(h->Kp / 64), dim3(64), 0, h->side, h->hp, nb, h->d_HG, h->P(CDAE_P_B),
-                     h->P(CDAE_P_B_AG));
-  HIPCHK(hipEventRecord(h->ev_bias, h->side));
-
+  // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
   CHK(pr.begin(h, F_INPUT, st));
-  DISPATCH_NI(h->NI, input_rows_kernel, grid_rows, blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z,
-              h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched);
+  {
+    const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
+    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
+                x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched, nb, h->P(CDAE_P_B),
+                h->P(CDAE_P_B_AG));
+  }
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
-  // delta (d_HG) is overwritten by the next batch's memset: that batch must not start before the bias kernel read it
-  HIPCHK(hipStreamWaitEvent(st, h->ev_bias, 0));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -380,11 +370,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->B = cfg->batch_users ? cfg->batch_users : 1024u;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_bias, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(h->ev_bias, h->side);
   if (e != hipSuccess) { free_all(h); delete h; return fail("stream/event setup failed: %s", hipGetErrorString(e)); }
   e = hipMalloc((void**)&h->d_scalar, 8 * sizeof(double));
   if (e != hipSuccess) { free_all(h); delete h; return fail("hipMalloc failed: %s", hipGetErrorString(e)); }

@@ -615,10 +615,11 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
 
 // K4b  hidden bias b: the one parameter every user updates, strictly in user order (cdae.hpp:301-315).
 // One thread per coordinate; the recurrence is elementwise, the delta loads run 16 users ahead of it.
-__global__ void __launch_bounds__(64)
-hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA, float* __restrict__ b,
-                   float* __restrict__ b_ag) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+// It needs only delta, like the input rows, so it runs as the leading workgroup(s) of input_rows_kernel
+// instead of a launch of its own.
+__device__ __forceinline__ void hidden_bias_role(const HyperParams& hp, uint32_t k, uint32_t nb,
+                                                 const float* __restrict__ DELTA, float* __restrict__ b,
+                                                 float* __restrict__ b_ag) {
   if (k >= hp.Kp) return;
   float p = b[k], acc = b_ag[k];
   constexpr int UN = 16;
@@ -654,8 +655,14 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                   const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
                   const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
                   const float* __restrict__ DELTA, const float* __restrict__ G,
-                  float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched) {
-  const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+                  float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched,
+                  uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag) {
+  const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
+  if (blockIdx.x < bias_blocks) {
+    hidden_bias_role(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
+    return;
+  }
+  const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
