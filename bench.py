@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--shape", default="ml10m")
     ap.add_argument("--num-dim", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-users", type=int, default=12000, help="users in the timed CPU-baseline sample")
+    ap.add_argument("--cpu-users", type=int, default=40000, help="users in the timed CPU-baseline sample (~20 s)")
     ap.add_argument("--seed", type=int, default=20141119)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
                     "code path on a single-GPU box together with --share-device")
@@ -165,6 +165,7 @@ def main():
     ms_per_launch = acc["ms_decode"] / max(1, acc["launches_decode"])
     alg_bytes_launch = decode_bytes_per_example(K) * ex_per_launch
     achieved = alg_bytes_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    traffic = measured_traffic(args.shape, K, B)
     out = {
         "metric": "users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity",
         "value": value, "unit": "users/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
@@ -175,7 +176,7 @@ def main():
                    "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
                    "exchange": "all-reduce of shared-parameter deltas every step" if args.gpus > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": "decode_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": ms_per_launch,
                      "whole_step_fraction_of_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS},
         "kernel_ms_per_step": {k[3:]: acc[k] / args.steps for k in acc if k.startswith("ms_")},
@@ -185,6 +186,21 @@ def main():
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_traffic(shape, K, B):
+    """HBM bytes per decode launch from the committed rocprofv3 PMC passes (profiles/*_decode_traffic.json), or None
+    when no pass was taken for this exact workload.  bench.py cannot collect PMC counters on itself."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_decode_traffic.json"))):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if t.get("shape") == shape and t.get("num_dim") == K and t.get("batch_users") == B:
+            best = t.get("traffic_bytes_per_launch")
+    return best
 
 
 def cpu_baseline(data, cfg, args):
