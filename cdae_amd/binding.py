@@ -85,6 +85,14 @@ def load_library(path: str = LIB_PATH):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the CDAE hot path.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64 (ROCm 7.0) next
+    # to the system's (7.2).  If this library pulled the system copies in first, a later `import torch` (needed
+    # only for torch.distributed) finds a foreign runtime already loaded and reports "No HIP GPUs are available".
+    # Loading torch first makes both share torch's copy, which the kernels run on unchanged.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported

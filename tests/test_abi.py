@@ -21,7 +21,7 @@ def declared_symbols():
 def test_header_symbols_are_all_exported_and_bound(built):
     syms = declared_symbols()
     assert len(syms) >= 20
-    lib = ctypes.CDLL(cdae_amd.LIB_PATH)
+    lib = cdae_amd.load_library()      # (loads torch first: one HIP runtime per process, see binding.py)
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/cdae_hip.h but not exported"
     assert sorted(binding.EXPORTS) == syms, "binding.EXPORTS and the header disagree"

@@ -181,3 +181,57 @@ def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):
     b.train_users(9, 2, 40, 80)
     a.train_users(9, 2, 40, 80)
     np.testing.assert_allclose(a.get(0), b.get(0), rtol=5e-6, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def ragged(built):
+    """Heavy-tailed rows: 1 item, a few, > 128 (several work units), > 2048 (sampler's global-memory path)."""
+    rng = np.random.default_rng(3)
+    I = 9000
+    sizes = [1, 2, 3, 127, 128, 129, 300, 700, 2047, 2048, 2049, 2600] + list(rng.integers(5, 60, size=52))
+    rows = [np.sort(rng.choice(I, size=int(n), replace=False)).astype(np.uint32) for n in sizes]
+    ptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
+    col = np.concatenate(rows)
+    empty = np.zeros(len(rows) + 1, dtype=np.int64)
+    return synth.Interactions(len(rows), I, ptr, col, empty, np.zeros(0, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("B,K", [(1, 16), (5, 200), (64, 72)])
+def test_ragged_rows_multi_unit_users_and_long_rows(ragged, B, K):
+    model, o = make_pair(ragged, K=K, B=B, num_neg=2)
+    uids = np.arange(ragged.num_users, dtype=np.uint32)
+    for mode in (0, 1):
+        assert np.abs(model.get_hidden_values(uids, seed=5, epoch=1, mode=mode) - o.encode(5, 1, mode, uids)).max() < 5e-6
+    model.train_one_iteration(seed=5, epoch=0)
+    o.train_batched(5, 0, B)
+    err, which = max_param_err(model, o)
+    assert err < 2e-4, (err, which)
+    lg, lo = model.data_loss(6, 0), o.data_loss(6, 0)
+    assert abs(lg - lo) < 2e-4 * abs(lo)
+    rec_g = model.recommend_all(10)
+    rec_o, sc_o = o.recommend(10, with_scores=True)
+    clear = np.abs(np.diff(sc_o, axis=1)).min(axis=1) > 1e-4
+    np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
+
+
+@pytest.mark.parametrize("K", [100, 256, 300, 512])
+def test_wide_rows(tiny, K):
+    """NI = 2, 4 (no pad element: separate bias path), 8."""
+    model, o = make_pair(tiny, K=K, B=32)
+    model.train_one_iteration(seed=3, epoch=0)
+    o.train_batched(3, 0, 32)
+    err, which = max_param_err(model, o)
+    assert err < 2e-4, (err, which)
+
+
+def test_single_user_single_item_dataset(built):
+    ptr = np.array([0, 1], dtype=np.int64)
+    col = np.array([2], dtype=np.uint32)
+    d = synth.Interactions(1, 12, ptr, col, np.zeros(2, dtype=np.int64), np.zeros(0, dtype=np.uint32))
+    model, o = make_pair(d, K=8, B=1)
+    for ep in range(3):
+        model.train_one_iteration(seed=1, epoch=ep)
+        o.train_literal(1, ep)
+    err, which = max_param_err(model, o)
+    assert err < 1e-4, (err, which)
+    assert model.recommend_all(10).shape == (1, 10) and 2 not in model.recommend_all(10)[0]
