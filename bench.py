@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=40000, help="users in the timed CPU-baseline sample (~20 s)")
     ap.add_argument("--seed", type=int, default=20141119)
+    ap.add_argument("--full-output", action="store_true", help="BASELINE configs[1]/[4]: every unrated item is a negative; "
+                    "dense decode on the bf16 MFMA cores (roofline bound: mfma)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
                     "code path on a single-GPU box together with --share-device")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
@@ -91,7 +93,7 @@ def main():
     K, B = args.num_dim, min(args.batch_users, data.num_users)
     cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, num_corruptions=1,
                               corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01,
-                              using_adagrad=True, user_factor=True, batch_users=B)
+                              using_adagrad=True, user_factor=True, batch_users=B, full_output=args.full_output)
     model = cdae_amd.CDAE(cfg, device=local_rank)
     model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col,
                            user_id_offset=rank * data.num_users)
@@ -166,19 +168,31 @@ def main():
     alg_bytes_launch = decode_bytes_per_example(K) * ex_per_launch
     achieved = alg_bytes_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
     traffic = measured_traffic(args.shape, K, B)
+    if args.full_output:
+        # dominant kernels: the three bf16 MFMA contractions, 6 K I flop per user, timed as one family
+        MFMA_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+        flops_launch = 6.0 * K * data.num_items * (acc["users"] / max(1, acc["launches_decode"]))
+        achieved_tf = flops_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel x3 (+ bf16 operand copies, target fix-up)",
+                    "achieved": achieved_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_PEAK_TFLOPS,
+                    "traffic": None, "algorithmic_flops_per_launch": flops_launch, "avg_launch_ms": ms_per_launch}
+        workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "
+                    f"FULL-OUTPUT decode (every unrated item a negative), CE loss, AdaGrad, q=0.5 scaled")
+    else:
+        roofline = {"bound": "hbm", "kernel": "decode_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": ms_per_launch,
+                    "whole_step_fraction_of_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS}
+        workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "
+                    f"num_neg=5, CE loss, AdaGrad, q=0.5 scaled")
     out = {
         "metric": "users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity",
         "value": value, "unit": "users/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, "
-                               f"nnz_train={data.nnz_train}, K={K}, num_neg=5, CE loss, AdaGrad, q=0.5 scaled",
-                   "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
+        "vs_baseline": None, "dtype": "bf16" if args.full_output else "f32", "data": "synthetic",
+        "config": {"workload": workload, "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
                    "exchange": "all-reduce of shared-parameter deltas every step" if args.gpus > 1 else "none"},
-        "roofline": {"bound": "hbm", "kernel": "decode_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": ms_per_launch,
-                     "whole_step_fraction_of_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS},
+        "roofline": roofline,
         "kernel_ms_per_step": {k[3:]: acc[k] / args.steps for k in acc if k.startswith("ms_")},
     }
     if not args.no_cpu_baseline:

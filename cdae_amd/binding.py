@@ -27,7 +27,7 @@ DEFAULT_BATCH_USERS = 1024
 class _Config(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "struct_size", "num_dim", "num_neg", "num_corruptions", "loss_type", "using_adagrad",
-        "asymmetric", "user_factor", "linear", "scaled", "tanh_act", "batch_users")] + [
+        "asymmetric", "user_factor", "linear", "scaled", "tanh_act", "batch_users", "full_output")] + [
             (n, C.c_double) for n in ("lambda_", "learn_rate", "corruption_ratio", "beta")]
 
 
@@ -131,6 +131,8 @@ class CDAEConfig:
     tanh: bool = False
     # not in the reference: users per parameter snapshot (1 == the reference's sequential schedule)
     batch_users: int = DEFAULT_BATCH_USERS
+    # not in the reference: full-output decode — every unrated item is a negative once (MFMA path)
+    full_output: bool = False
 
 
 class CDAE:
@@ -147,7 +149,7 @@ class CDAE:
         self.cfg = mcfg
         c = _Config(C.sizeof(_Config), mcfg.num_dim, mcfg.num_neg, mcfg.num_corruptions, mcfg.lt,
                     int(mcfg.using_adagrad), int(mcfg.asymmetric), int(mcfg.user_factor), int(mcfg.linear),
-                    int(mcfg.scaled), int(mcfg.tanh), mcfg.batch_users, mcfg.lambda_, mcfg.learn_rate,
+                    int(mcfg.scaled), int(mcfg.tanh), mcfg.batch_users, int(mcfg.full_output), mcfg.lambda_, mcfg.learn_rate,
                     mcfg.corruption_ratio, mcfg.beta)
         self.h = C.c_void_p()
         _chk(self.lib, self.lib.cdae_hip_create(C.byref(c), device, C.byref(self.h)))

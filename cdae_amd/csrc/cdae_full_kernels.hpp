@@ -1,0 +1,241 @@
+// cdae_full_kernels.hpp — full-output decode on the MFMA matrix cores (BASELINE.json configs[1], configs[4]).
+//
+// The reference's training decode is always sampled (cdae.hpp:217-293); its only dense decode over all items
+// is recommend() (cdae.hpp:176-186).  The north star extends training to "every unrated item is a negative with
+// target 0".  Per block of B users, from the block-start parameters (oracle: Oracle::train_users_full):
+//     Y  = Z D^T + b'            [B x I]    GEMM 1, loss' fused in the epilogue -> G (and G^T), bf16
+//     hg = G D                   [B x K]    GEMM 2, split along the item dimension, fp32 atomics
+//     dD = G^T Z                 [I x K]    GEMM 3
+// then one AdaGrad/SGD step per decoder row with dD[j] + lambda D[j] (+ the summed input gradient in tied mode),
+// one per b'[j], and the hidden-layer steps of the sampled path.  With B = 1 this is exactly the reference loop
+// fed all unrated items.  This is the compute-bound end of the path (6 K I flop per user), so it runs on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the operands are bf16 copies made per batch.
+//
+// All three products are "NT" GEMMs  C[m][n] = sum_k A[m][k] * Bm[n][k]  over row-major bf16 operands with the
+// contraction index contiguous (the per-batch transposed copies D^T, Z^T, G^T make that true), so an MFMA
+// fragment is one 16-byte global load per lane: lane l holds A[m0 + (l & 31)][k0 + 8 (l >> 5) .. +7] and the same
+// slice of Bm's row n0 + (l & 31).  A wavefront owns a 64 x 64 tile of C (2 x 2 MFMA tiles, 64 accumulator
+// VGPRs), a 256-thread workgroup 128 x 128.  Round 1 feeds the fragments straight from L1/L2 (no LDS staging).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cdae_kernels.hpp"
+
+namespace cdae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// fp32 [R x C] (row stride ld_src) -> bf16 [Rp x C] with rows >= R zero, and its transpose [C x Rp].
+// 64 x 64 tiles through LDS so that both images are written in coalesced runs.
+__global__ void __launch_bounds__(256)
+to_bf16_transpose_kernel(const float* __restrict__ src, uint32_t R, uint32_t C, uint32_t ld_src, uint32_t Rp,
+                         __bf16* __restrict__ dst, __bf16* __restrict__ dstT) {
+  __shared__ float tile[64][65];
+  const uint32_t r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const uint32_t r = r0 + i / 64, c = c0 + i % 64;
+    const float v = (r < R && c < C) ? src[(size_t)r * ld_src + c] : 0.f;
+    tile[i / 64][i % 64] = v;
+    if (r < Rp && c < C) dst[(size_t)r * C + c] = (__bf16)v;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const uint32_t c = c0 + i / 64, r = r0 + i % 64;
+    if (r < Rp && c < C) dstT[(size_t)c * Rp + r] = (__bf16)tile[i % 64][i / 64];
+  }
+}
+
+enum { EPI_LOSS = 0, EPI_ATOMIC = 1, EPI_STORE = 2 };
+
+struct GemmEpilogue {
+  // EPI_LOSS: g = loss'(acc + bp[n], 0) for m < rows_live, n < cols_live, else 0; G[m][n] and GT[n][m] (bf16)
+  const float* bp;
+  __bf16* G; uint32_t ldg;
+  __bf16* GT; uint32_t ldgt;
+  uint32_t rows_live, cols_live, loss_type;
+  // EPI_ATOMIC / EPI_STORE: fp32 C with row stride ldc (ATOMIC: only rows < rows_live)
+  float* Cout; uint32_t ldc;
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(256)
+gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
+                    uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep) {
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;
+  const uint32_t m_base = blockIdx.y * 128 + (wid >> 1) * 64;
+  const uint32_t n_base = blockIdx.x * 128 + (wid & 1) * 64;
+  if (m_base >= M || n_base >= N) return;
+  const uint32_t k_begin = blockIdx.z * k_per_split;
+  const uint32_t k_end = min(Kd, k_begin + k_per_split);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const uint32_t frag_row = lane & 31, frag_k = (lane >> 5) * 8;
+  const __bf16* a0 = A + (size_t)(m_base + frag_row) * lda + frag_k;
+  const __bf16* a1 = a0 + (size_t)32 * lda;
+  const __bf16* b0 = Bm + (size_t)(n_base + frag_row) * ldb + frag_k;
+  const __bf16* b1 = b0 + (size_t)32 * ldb;
+  for (uint32_t k = k_begin; k < k_end; k += 16) {
+    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(a0 + k);
+    const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a1 + k);
+    const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(b0 + k);
+    const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(b1 + k);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t n = n_base + j * 32 + (lane & 31);
+      if constexpr (EPI == EPI_LOSS) {
+        const float bias = n < ep.cols_live ? ep.bp[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                          // rows m0 .. m0+3 are consecutive: one 8-byte G^T store
+          const uint32_t m0 = m_base + i * 32 + 8 * q + 4 * (lane >> 5);
+          bf16x4 gt;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t m = m0 + r;
+            float g = 0.f;
+            if (m < ep.rows_live && n < ep.cols_live) g = loss_grad(ep.loss_type, acc[i][j][4 * q + r] + bias, 0.f);
+            gt[r] = (__bf16)g;
+            ep.G[(size_t)m * ep.ldg + n] = (__bf16)g;
+          }
+          *reinterpret_cast<bf16x4*>(ep.GT + (size_t)n * ep.ldgt + m0) = gt;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if constexpr (EPI == EPI_ATOMIC) {
+            if (m < ep.rows_live) unsafeAtomicAdd(ep.Cout + (size_t)m * ep.ldc + n, acc[i][j][r]);
+          } else {
+            ep.Cout[(size_t)m * ep.ldc + n] = acc[i][j][r];
+          }
+        }
+      }
+    }
+}
+
+// Targets: GEMM 1 computed every g against target 0.  For a positive, loss'(y, 1) = loss'(y, 0) - c with
+// c = 1 (cross-entropy: sigmoid(y) - t) or 2 (square: -2 (t - y)), so the batch's positives are patched in place.
+__global__ void __launch_bounds__(256)
+full_positive_fixup_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __restrict__ ex_val, uint32_t n_ex,
+                           float c, __bf16* __restrict__ G, uint32_t ldg, __bf16* __restrict__ GT, uint32_t ldgt) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ex) return;
+  const uint32_t item = ex_item[e];
+  const uint32_t slot = (uint32_t)ex_val[e] & SLOT_MASK;
+  const float g = (float)G[(size_t)slot * ldg + item] - c;
+  G[(size_t)slot * ldg + item] = (__bf16)g;
+  GT[(size_t)item * ldgt + slot] = (__bf16)g;
+}
+
+// Row steps of the full-output schedule (+ the hidden-bias recurrence as the leading workgroups, like K5):
+//   b'[j]: grad = sum_u G[u][j] + lambda b'[j]                                 cdae.hpp:230-237, summed over the block
+//   tied : W[j]: grad = dD[j] + scale * sum_{u: j kept} delta_u + lambda W[j]     cdae.hpp:252-257 + 337-348 merged
+//   asym : V[j]: grad = dD[j] + lambda V[j];  W[j] (only if some user kept j): scale * sum delta_u + lambda W[j]
+// One wavefront per item row; the kept inputs of the row come from the item-sorted positives list.
+template <int NI>
+__global__ void __launch_bounds__(256)
+full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                 const uint64_t* __restrict__ sorted_val, const float* __restrict__ DELTA,
+                 const float* __restrict__ dD, const __bf16* __restrict__ GT, uint32_t ldgt, uint32_t nb,
+                 float* __restrict__ W, float* __restrict__ W_ag, float* __restrict__ V, float* __restrict__ V_ag,
+                 float* __restrict__ bp, float* __restrict__ bp_ag, float* __restrict__ b, float* __restrict__ b_ag,
+                 uint32_t* __restrict__ touched) {
+  const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;
+  if (blockIdx.x < bias_blocks) {
+    hidden_bias_role(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
+    return;
+  }
+  const uint32_t item = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (item >= hp.num_items) return;
+  const uint32_t lo = lane * NI;
+  // summed input gradient of the row
+  float din[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) din[i] = 0.f;
+  bool has_in = false;
+  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  constexpr int UN = 8;
+  for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
+    const uint32_t p = p0 + lane;
+    const uint32_t word = p < end ? (uint32_t)sorted_val[p] : 0u;
+    unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
+    has_in = has_in || mask != 0ull;
+    while (mask) {
+      float v[UN][NI];
+#pragma unroll
+      for (int t = 0; t < UN; ++t) {
+        if (mask) {
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, src) & SLOT_MASK;
+          vload<NI>(v[t], DELTA + (size_t)slot * hp.Kp + lo);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[t][i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UN; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) din[i] += v[t][i];        // user order: deterministic
+    }
+  }
+  // b'[j]
+  float gsum = 0.f;
+  for (uint32_t u = lane; u < nb; u += WAVE) gsum += (float)GT[(size_t)item * ldgt + u];
+  gsum = wave_sum(gsum);
+  {
+    float p = bp[item], pa = bp_ag[item];
+    ada_step(hp, p, pa, fmaf(hp.lambda, p, gsum));
+    if (lane == 0) { bp[item] = p; bp_ag[item] = pa; }
+  }
+  float dd[NI];
+  vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);
+  const bool live0 = true;
+  (void)live0;
+  if (!hp.asymmetric) {
+    float w[NI], a[NI];
+    vload<NI>(w, W + (size_t)item * hp.Kp + lo);
+    vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
+    vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
+    vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+  } else {
+    float w[NI], a[NI];
+    vload<NI>(w, V + (size_t)item * hp.Kp + lo);
+    vload<NI>(a, V_ag + (size_t)item * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.lambda, w[i], dd[i]));
+    vstore<NI>(V + (size_t)item * hp.Kp + lo, w);
+    vstore<NI>(V_ag + (size_t)item * hp.Kp + lo, a);
+    if (has_in) {
+      vload<NI>(w, W + (size_t)item * hp.Kp + lo);
+      vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], hp.lambda * w[i]));
+      vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
+      vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+    }
+  }
+  if (lane == 0 && touched) touched[item] = 1u;
+}
+
+}  // namespace cdae

@@ -19,6 +19,7 @@
 
 #include "../../include/cdae_hip.h"
 #include "cdae_kernels.hpp"
+#include "cdae_full_kernels.hpp"
 
 namespace {
 
@@ -102,6 +103,10 @@ struct cdae_hip {
   } ex[2];
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
   float* d_HGpart = nullptr;            // [8][B][Kp] per-XCD partial hidden gradients
+  // full-output decode (MFMA path): bf16 operand copies and the dense gradient, padded to 128-multiples
+  uint32_t Bp = 0, Ip = 0;
+  __bf16 *d_Zb = nullptr, *d_ZTb = nullptr, *d_Db = nullptr, *d_DTb = nullptr, *d_Gb = nullptr, *d_GTb = nullptr;
+  float* d_dD = nullptr;
   hipStream_t prep = nullptr;           // sampling + sorting of the next batch
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
@@ -176,7 +181,8 @@ int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
 
 void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
-                  h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
+                  h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
+                  h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
@@ -194,7 +200,8 @@ void free_all(cdae_hip* h) {
 int free_interaction_state(cdae_hip* h) {
   void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
                    (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_D0, (void**)&h->d_HGpart, (void**)&h->d_sort_tmp,
-                   (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp,
+                   (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
+                   (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta,
                    (void**)&h->ex[0].item, (void**)&h->ex[0].val, (void**)&h->ex[0].sorted_item, (void**)&h->ex[0].sorted_val,
@@ -293,7 +300,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
               x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
-              h->d_Wu, h->d_Wu_ag);
+              h->d_Wu, h->d_Wu_ag, 1u);
   CHK(pr.end());
   // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
   CHK(pr.begin(h, F_INPUT, st));
@@ -302,6 +309,75 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
     DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
                 x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched, nb, h->P(CDAE_P_B),
                 h->P(CDAE_P_B_AG));
+  }
+  CHK(pr.end());
+  HIPCHK(hipEventRecord(x.released, st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Full-output decode of one batch (MFMA path, cdae_full_kernels.hpp).  The example list holds the positives only.
+int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
+  using namespace cdae;
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I, nb = bt.nb, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
+  const uint64_t s0 = bt.s0;
+  const dim3 blk(256);
+  const dim3 grid_users((nb + 3) / 4);
+  const uint32_t n_units = units_of(h, bt);
+  const uint32_t* uptr = h->d_unit_ptr + s0;
+  Prof pr;
+
+  CHK(pr.begin(h, F_ENCODE, st));
+  DISPATCH_NI(h->NI, encode_partial_kernel, dim3((n_units + 3) / 4), blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr,
+              n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart,
+              (const uint32_t*)nullptr, 0u);
+  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
+              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG);
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_DECODE, st));
+  // bf16 operand copies of this batch: Z, Z^T (rows >= nb zero) and D, D^T (rows >= I zero)
+  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
+  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  GemmEpilogue ep{};
+  ep.bp = h->P(CDAE_P_BP); ep.G = h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
+  ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
+  // GEMM 1: Y = Z D^T (+ b'), g = loss'(y, 0) -> G [Bp x Ip], G^T [Ip x Bp]
+  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
+                     Kp, ep);
+  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
+                     h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
+  // GEMM 2: hg = G D  (contraction over items, split; fp32 atomics into the zeroed HG)
+  {
+    const uint32_t kps = 2048;
+    GemmEpilogue e2{};
+    e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
+                       h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
+  }
+  // GEMM 3: dD = G^T Z  (contraction over the batch's users)
+  {
+    GemmEpilogue e3{};
+    e3.Cout = h->d_dD; e3.ldc = Kp;
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 128, 1), blk, 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
+                       Bp, Bp, Bp, Bp, e3);
+  }
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_HIDDEN, st));
+  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
+              h->d_Wu, h->d_Wu_ag, 0u);
+  CHK(pr.end());
+
+  CHK(pr.begin(h, F_INPUT, st));
+  {
+    const uint32_t bias_blocks = (Kp + 255u) / 256u;
+    DISPATCH_NI(h->NI, full_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->d_HG,
+                h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
+                h->P(CDAE_P_BP_AG), h->P(CDAE_P_B), h->P(CDAE_P_B_AG), h->d_touched);
   }
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
@@ -377,7 +453,8 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   cdae::HyperParams& hp = h->hp;
   hp.lambda = (float)cfg->lambda; hp.lr = (float)cfg->learn_rate; hp.beta = (float)cfg->beta;
   hp.scale = cfg->scaled ? (float)(1.0 / (1.0 - cfg->corruption_ratio)) : 1.f;     // cdae.hpp:202-205
-  hp.num_neg = cfg->num_neg; hp.loss_type = cfg->loss_type;
+  hp.num_neg = cfg->full_output ? 0u : cfg->num_neg;     // full output: the example list holds the positives only
+  hp.loss_type = cfg->loss_type;
   hp.adagrad = cfg->using_adagrad; hp.asymmetric = cfg->asymmetric; hp.user_factor = cfg->user_factor;
   hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act;
   hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
@@ -461,7 +538,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint64_t s1 = std::min<uint64_t>(U, s0 + B);
     emax = std::max<uint64_t>(emax, (uint64_t)(row_ptr[s1] - row_ptr[s0]));
   }
-  h->Ecap = emax * (1u + h->cfg.num_neg);
+  h->Ecap = emax * (1u + h->hp.num_neg);
   h->seq = 0; h->pre_valid = false;
   h->h_unit_ptr.assign(U + 1, 0u);
   for (uint64_t u = 0; u < U; ++u)
@@ -507,6 +584,14 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
   CHK(dev_alloc(&h->d_HGpart, 8 * (size_t)h->unit_cap * h->Kp));
+  if (h->cfg.full_output) {
+    h->Bp = (B + 127u) & ~127u;
+    h->Ip = ((uint32_t)I + 127u) & ~127u;
+    CHK(dev_alloc(&h->d_Zb, (size_t)h->Bp * h->Kp)); CHK(dev_alloc(&h->d_ZTb, (size_t)h->Kp * h->Bp));
+    CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
+    CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
+    CHK(dev_alloc(&h->d_dD, (size_t)h->Ip * h->Kp));
+  }
   CHK(dev_alloc(&h->d_touched, (size_t)I));
   HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
   CHK(dev_alloc(&h->d_uids, (size_t)B));
@@ -608,7 +693,7 @@ int make_plan(cdae_hip* h, uint64_t u_begin, uint64_t u_end, std::vector<Batch>&
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
   for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
-    const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->cfg.num_neg);
+    const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->hp.num_neg);
     if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
     for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) plan.push_back(Batch{s0, nb, c, E});       // cdae.hpp:141
   }
@@ -629,7 +714,8 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
   h->pre_valid = false;
   for (size_t t = 0; t < plan.size(); ++t) {
     if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
-    CHK(compute_batch(h, (int)(h->seq & 1), plan[t], seed, epoch));
+    if (h->cfg.full_output) CHK(compute_batch_full(h, (int)(h->seq & 1), plan[t], seed, epoch));
+    else CHK(compute_batch(h, (int)(h->seq & 1), plan[t], seed, epoch));
     h->seq++;
     h->acc_examples += plan[t].E; h->acc_batches++; h->acc_users += plan[t].nb;
   }
@@ -791,6 +877,7 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
                                        const uint32_t* negative_items, size_t n_neg) {
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (uid >= h->U) return fail("user id %llu out of range", (unsigned long long)uid);
+  if (h->cfg.full_output) return fail("train_one_user_corruption takes an explicit negative list; it is not available in full_output mode");
   if ((n_in && !input_items) || (n_neg && !negative_items)) return fail("null argument");
   HIPCHK(hipSetDevice(h->device));
   const int64_t r0 = h->h_row_ptr[uid];

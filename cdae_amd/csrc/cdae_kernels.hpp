@@ -577,8 +577,9 @@ template <int NI>
 __global__ void __launch_bounds__(256)
 hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb,
                      const float* __restrict__ HGpart, const float* __restrict__ Dz,
-                     float* __restrict__ HG /* in: corrections, out: delta */, float* __restrict__ Wu,
-                     float* __restrict__ Wu_ag) {
+                     float* __restrict__ HG /* in: corrections (or the whole hg), out: delta */,
+                     float* __restrict__ Wu, float* __restrict__ Wu_ag,
+                     uint32_t use_parts /* 0: HG already holds hg (full-output path) */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -587,7 +588,7 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
   vload<NI>(hg, HG + o);
-  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  const uint32_t ub = use_parts ? uptr[slot] - uptr[0] : 0u, ue = use_parts ? uptr[slot + 1] - uptr[0] : 0u;
   for (uint32_t u = ub; u < ue; ++u) {                          // fixed order: deterministic
 #pragma unroll
     for (int x = 0; x < 8; ++x) {

@@ -75,6 +75,9 @@ typedef struct cdae_hip_config {
   uint32_t tanh_act;         /* cdae.hpp:30                                                */
   uint32_t batch_users;      /* users whose encode sees the same parameter snapshot; 1 ==  */
                              /* the reference's strictly sequential schedule; 0 -> default */
+  uint32_t full_output;      /* 1: every unrated item is a negative with target 0 (north-star */
+                             /* extension; num_neg is ignored): dense decode on the MFMA cores, */
+                             /* per-block summed decoder gradient            */
   double lambda;             /* cdae.hpp:15 */
   double learn_rate;         /* cdae.hpp:16 */
   double corruption_ratio;   /* cdae.hpp:21 */

@@ -77,6 +77,7 @@ def _load():
     lib.oracle_set_param.argtypes = [vp, u32, vp, C.c_size_t]
     lib.oracle_train_users_literal.argtypes = [vp, u64, u32, u64, u64]
     lib.oracle_train_users_batched.argtypes = [vp, u64, u32, u64, u64, u64]
+    lib.oracle_train_users_full.argtypes = [vp, u64, u32, u64, u64, u64]
     lib.oracle_step_user.argtypes = [vp, u64, vp, u64, vp, u64, vp, vp, vp, vp]
     lib.oracle_draw_inputs.argtypes = [vp, u64, u32, u64, u32, u32, vp, vp]
     lib.oracle_draw_negatives.argtypes = [vp, u64, u32, u64, u32, vp]
@@ -145,6 +146,10 @@ class Oracle:
 
     def train_batched(self, seed: int, epoch: int, batch_users: int, u0: int = 0, u1: int | None = None):
         self.lib.oracle_train_users_batched(self.h, seed, epoch, u0, self.U if u1 is None else u1, batch_users)
+
+    def train_full(self, seed: int, epoch: int, batch_users: int, u0: int = 0, u1: int | None = None):
+        """Full-output decode (every unrated item is a negative once), block-summed gradients."""
+        self.lib.oracle_train_users_full(self.h, seed, epoch, u0, self.U if u1 is None else u1, batch_users)
 
     def step_user(self, uid: int, in_items, neg_items):
         i = np.ascontiguousarray(in_items, dtype=np.uint32)

@@ -319,6 +319,86 @@ struct Oracle {
     }
   }
 
+  // ---- full-output decode (north-star extension) ----
+  // Every non-positive item is a negative with target 0, each exactly once per user.  The reference has no
+  // such training mode (its decode is always sampled, cdae.hpp:217-293); this is the limit of that loop with
+  // the negative list = all unrated items, restated in the dense form the MFMA path computes per block of B
+  // users from the block-start parameters:
+  //   Y = Z D^T + b' ;  G = loss'(Y, T) ;  hg = G D ;  dD = G^T Z ;  db' = column sums of G
+  //   one step per decoder row with the block's summed gradient dD[j] + lambda D[j] (+, tied mode, the summed
+  //   input gradient scale * sum_{u: j kept} delta_u, merged like cdae.hpp:337-343), one step per b'[j],
+  //   b and Wu[u] steps in user order as in the sampled schedule.
+  // With B = 1 every row is touched once per user and this IS the reference loop (tests compare it with
+  // train_user_literal fed all unrated items as negatives).
+  void train_users_full(uint64_t seed, uint32_t epoch, size_t u0, size_t u1, size_t B) {
+    if (B == 0) B = 1;
+    const double sc = scale();
+    std::vector<double>& D = c.asymmetric ? V : W;
+    std::vector<double>& D_ag = c.asymmetric ? V_ag : W_ag;
+    std::vector<uint32_t> in;
+    std::vector<double> grad(K);
+    for (size_t s0 = u0; s0 < u1; s0 += B) {
+      const size_t s1 = std::min(u1, s0 + B), nb = s1 - s0;
+      for (uint32_t ci = 0; ci < c.num_corruptions; ++ci) {
+        std::vector<double> Z(nb * K), Dv(nb * K), HG(nb * K, 0.), DELTA(nb * K);
+        std::vector<double> dD(I * K, 0.), dbp(I, 0.), dIn(I * K, 0.);
+        std::vector<char> has_in(I, 0);
+        std::vector<std::vector<uint32_t>> kept(nb);
+        for (size_t s = 0; s < nb; ++s) {
+          const size_t uid = s0 + s;
+          draw_inputs(seed, epoch, uid, ci, CDAE_STREAM_CORRUPT, in);
+          kept[s] = in;
+          hidden(uid, in.data(), in.size(), sc, &Z[s * K]);
+          act_deriv(&Z[s * K], &Dv[s * K]);
+        }
+        for (size_t s = 0; s < nb; ++s) {                      // dense decode against the block-start rows
+          const size_t uid = s0 + s;
+          const uint32_t* pos = &col[row_ptr[uid]];
+          const size_t n_pos = row_ptr[uid + 1] - row_ptr[uid];
+          const double* z = &Z[s * K];
+          size_t t = 0;
+          for (size_t j = 0; j < I; ++j) {
+            while (t < n_pos && pos[t] < j) ++t;
+            const double truth = (t < n_pos && pos[t] == j) ? 1. : 0.;
+            const double g = loss_grad(output(z, j), truth);
+            const double* row = &D[j * K];
+            for (size_t k = 0; k < K; ++k) { HG[s * K + k] += g * row[k]; dD[j * K + k] += g * z[k]; }
+            dbp[j] += g;
+          }
+        }
+        for (size_t s = 0; s < nb; ++s) {                      // hidden layer: delta, b (user order), Wu[u]
+          const size_t uid = s0 + s;
+          double* delta = &DELTA[s * K];
+          for (size_t k = 0; k < K; ++k) delta[k] = HG[s * K + k] * Dv[s * K + k];
+          for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * b[k];
+          ada_row(b.data(), b_ag.data(), grad.data());
+          if (c.user_factor) {
+            double* wu = &Wu[uid * K];
+            for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * wu[k];
+            ada_row(wu, &Wu_ag[uid * K], grad.data());
+          }
+          for (uint32_t j : kept[s]) { has_in[j] = 1; for (size_t k = 0; k < K; ++k) dIn[(size_t)j * K + k] += sc * delta[k]; }
+        }
+        for (size_t j = 0; j < I; ++j) {                       // one step per row with the block's summed gradient
+          ada1(bp[j], bp_ag[j], dbp[j] + c.lambda * bp[j]);
+          double* drow = &D[j * K];
+          if (!c.asymmetric) {
+            for (size_t k = 0; k < K; ++k) grad[k] = dD[j * K + k] + dIn[j * K + k] + c.lambda * drow[k];
+            ada_row(drow, &D_ag[j * K], grad.data());
+          } else {
+            for (size_t k = 0; k < K; ++k) grad[k] = dD[j * K + k] + c.lambda * drow[k];
+            ada_row(drow, &D_ag[j * K], grad.data());
+            if (has_in[j]) {
+              double* wrow = &W[j * K];
+              for (size_t k = 0; k < K; ++k) grad[k] = dIn[j * K + k] + c.lambda * wrow[k];
+              ada_row(wrow, &W_ag[j * K], grad.data());
+            }
+          }
+        }
+      }
+    }
+  }
+
   // ---- data_loss, cdae.hpp:78-101 ; penalty_loss, cdae.hpp:103-107 + penalty.hpp:36-39 ----
   double data_loss(uint64_t seed, uint32_t epoch) const {
     double rets = 0.;
@@ -454,6 +534,9 @@ void oracle_train_users_literal(void* h, uint64_t seed, uint32_t epoch, uint64_t
 }
 void oracle_train_users_batched(void* h, uint64_t seed, uint32_t epoch, uint64_t u0, uint64_t u1, uint64_t B) {
   ((Oracle*)h)->train_users_batched(seed, epoch, u0, u1, B);
+}
+void oracle_train_users_full(void* h, uint64_t seed, uint32_t epoch, uint64_t u0, uint64_t u1, uint64_t B) {
+  ((Oracle*)h)->train_users_full(seed, epoch, u0, u1, B);
 }
 // explicit-input single step with taps (known-answer fixtures)
 void oracle_step_user(void* h, uint64_t uid, const uint32_t* in, uint64_t n_in, const uint32_t* neg,

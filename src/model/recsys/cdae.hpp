@@ -14,7 +14,8 @@
 //   get_user_representations (148-159)                cdae_hip_encode
 //
 // Environment knobs (not in the reference): CDAE_BATCH_USERS (users per parameter snapshot; 1 = the
-// reference's strictly sequential schedule), CDAE_SEED (fixes the counter-stream seed; default: one draw of
+// reference's strictly sequential schedule), CDAE_FULL_OUTPUT (1: every unrated item is a negative — dense MFMA
+// decode; num_neg ignored), CDAE_SEED (fixes the counter-stream seed; default: one draw of
 // libcf::Random, i.e. time-seeded like yelp.cpp:107), CDAE_DEVICE (HIP device index).
 #ifndef CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 #define CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
@@ -90,6 +91,7 @@ class CDAE : public RecsysModelBase {
     c.using_adagrad = cfg_.using_adagrad; c.asymmetric = cfg_.asymmetric; c.user_factor = cfg_.user_factor;
     c.linear = cfg_.linear; c.scaled = cfg_.scaled; c.tanh_act = cfg_.tanh;
     c.batch_users = static_cast<uint32_t>(env_u64("CDAE_BATCH_USERS", 0));
+    c.full_output = static_cast<uint32_t>(env_u64("CDAE_FULL_OUTPUT", 0));   // north-star extension, not in CDAEConfig
     c.lambda = cfg_.lambda; c.learn_rate = cfg_.learn_rate; c.corruption_ratio = cfg_.corruption_ratio; c.beta = cfg_.beta;
     cdae_hip_t* raw = nullptr;
     CDAE_HIP_CHECK(cdae_hip_create(&c, static_cast<int>(env_u64("CDAE_DEVICE", 0)), &raw));

@@ -8,13 +8,13 @@ from oracle import binding as ob
 PARAMS = range(10)
 
 
-def make_pair(data, *, K=16, B=1, loss=cdae_amd.CROSS_ENTROPY, seed=11, **kw):
+def make_pair(data, *, K=16, B=1, loss=cdae_amd.CROSS_ENTROPY, seed=11, full_output=False, **kw):
     """A HIP model and an oracle that start from the same fp32 parameters."""
     flags = dict(using_adagrad=True, asymmetric=False, user_factor=True, linear=False, scaled=True, tanh=False)
     hyper = dict(lambda_=0.01, learn_rate=0.1, corruption_ratio=0.5, beta=1.0, num_neg=5, num_corruptions=1)
     for k, v in kw.items():
         (flags if k in flags else hyper)[k] = v
-    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=loss, batch_users=B, **flags, **hyper)
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=loss, batch_users=B, full_output=full_output, **flags, **hyper)
     model = cdae_amd.CDAE(cfg)
     model.reset(data, seed=seed)
     ocfg = orc.OracleConfig(num_dim=K, loss_type=loss, **flags, **hyper)

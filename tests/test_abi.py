@@ -32,8 +32,8 @@ def test_abi_version_and_config_layout(built):
     assert lib.cdae_hip_abi_version() == 1
     hdr = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
     assert "#define CDAE_HIP_ABI_VERSION 1" in hdr
-    # 12 uint32 + 4 double, naturally aligned
-    assert ctypes.sizeof(binding._Config) == 12 * 4 + 4 * 8
+    # 13 uint32 (+4 bytes padding) + 4 double, naturally aligned
+    assert ctypes.sizeof(binding._Config) == 14 * 4 + 4 * 8
     assert ctypes.sizeof(binding.Stats) == 8 * 11
 
 

@@ -235,3 +235,21 @@ def test_single_user_single_item_dataset(built):
     err, which = max_param_err(model, o)
     assert err < 1e-4, (err, which)
     assert model.recommend_all(10).shape == (1, 10) and 2 not in model.recommend_all(10)[0]
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(loss=cdae_amd.SQUARE, learn_rate=0.02), dict(asymmetric=True),
+                                     dict(using_adagrad=False, learn_rate=0.002)])
+@pytest.mark.parametrize("B", [1, 48, 300])
+def test_full_output_mfma_decode_matches_oracle(tiny, B, variant):
+    """BASELINE configs[1]/[4]: every unrated item is a negative; dense decode on bf16 MFMA with fp32 accumulation.
+    The oracle computes the same block-summed schedule in fp64.  Tolerance: operands (z, D) and the loss gradient
+    g are rounded to bf16 (relative 2^-9 = 2e-3 each) before the three contractions, so parameters agree to
+    2e-2 of their range after two epochs (measured 5e-4 .. 1e-2), and the loss to 1e-2 relative."""
+    model, o = make_pair(tiny, K=24, B=B, full_output=True, **variant)
+    for ep in range(2):
+        model.train_one_iteration(seed=4, epoch=ep)
+        o.train_full(4, ep, B)
+    err, which = max_param_err(model, o)
+    assert err < 2e-2, (err, which)
+    lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
+    assert abs(lg - lo) < 1e-2 * abs(lo)
