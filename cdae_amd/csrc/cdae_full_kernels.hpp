@@ -208,8 +208,6 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
   }
   float dd[NI];
   vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);
-  const bool live0 = true;
-  (void)live0;
   if (!hp.asymmetric) {
     float w[NI], a[NI];
     vload<NI>(w, W + (size_t)item * hp.Kp + lo);

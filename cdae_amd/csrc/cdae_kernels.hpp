@@ -144,8 +144,7 @@ constexpr uint32_t UNIT_POS = 128;
 
 struct UnitRef { uint32_t slot, p0, p1; };   // user slot and the positive range [p0, p1) of the unit
 
-__device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g, uint32_t n_pos_fn_unused) {
-  (void)n_pos_fn_unused;
+__device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g) {
   uint32_t lo = 0, hi = nb;                      // largest slot with uptr[slot] <= g
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
@@ -183,7 +182,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, 0);
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit);
   const uint32_t slot = ur.slot;
   const uint64_t uid = u0 + slot;
   const int64_t r0 = row_ptr[uid];
@@ -262,7 +261,7 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, 0);
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit);
   const uint64_t uid = uids ? (uint64_t)uids[ur.slot] : u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = explicit_in ? n_explicit : (uint32_t)(row_ptr[uid + 1] - r0);
@@ -524,7 +523,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, 0);
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit);
   const uint64_t uid = u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
