@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -20,6 +21,12 @@
 #include "../../include/cdae_hip.h"
 #include "cdae_kernels.hpp"
 #include "cdae_full_kernels.hpp"
+
+#ifdef CDAE_DECODE_TIMING
+#define CDAE_TOUCHED_ARG ((uint32_t*)nullptr)     // the timing build borrows `touched` for its stamps
+#else
+#define CDAE_TOUCHED_ARG h->d_touched
+#endif
 
 namespace {
 
@@ -307,7 +314,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   {
     const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
     DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
-                x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->d_touched, nb, h->P(CDAE_P_B),
+                x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), CDAE_TOUCHED_ARG, nb, h->P(CDAE_P_B),
                 h->P(CDAE_P_B_AG));
   }
   CHK(pr.end());
@@ -459,6 +466,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act;
   hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
   hp.uid_offset = 0; hp.num_items = 0; hp.K = h->K; hp.Kp = h->Kp;
+  hp.debug_rank = std::getenv("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
   *out = h;
   return 0;
 }
@@ -742,6 +750,16 @@ int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t 
   const auto t0 = std::chrono::steady_clock::now();
   CHK(enqueue_users(h, seed, epoch, u_begin, u_end));
   HIPCHK(hipStreamSynchronize(h->stream));
+#ifdef CDAE_DECODE_TIMING
+  {   // developer aid: cycle stamps of row `debug_rank` in the last decode launch (see decode_rows_kernel)
+    unsigned long long t[64];
+    HIPCHK(hipMemcpy(t, h->d_touched, sizeof t, hipMemcpyDeviceToHost));
+    const int n = (int)(t[63] & 0xffffffffu);
+    fprintf(stderr, "[decode timing] rank %u: %llu examples, %d stamps (cycles since first):", h->hp.debug_rank, t[63] >> 32, n);
+    for (int i = 1; i < n; ++i) fprintf(stderr, " %llu", t[i] - t[0]);
+    fprintf(stderr, "\n");
+  }
+#endif
   CHK(fill_stats(h, stats));
   if (stats) stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return 0;

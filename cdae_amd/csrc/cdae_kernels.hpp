@@ -38,6 +38,7 @@ struct HyperParams {
   uint64_t uid_offset;       // global id of local user 0 (data-parallel shards keep global random streams)
   uint32_t num_items;
   uint32_t K, Kp;            // num_dim and row stride (floats, = 64 * NI)
+  uint32_t debug_rank;       // -DCDAE_DECODE_TIMING builds: the row whose timeline decode_rows_kernel records
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -393,6 +394,14 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   if (beg == end) return;
   hp.loss_type = LOSS;                 // compile-time specialisation of the per-example branches
   hp.adagrad = ADAGRAD;
+#ifdef CDAE_DECODE_TIMING   // developer aid (tools/decode_timeline.py): s_memtime stamps of one row's timeline
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(touched);
+  int dbg_n = 0;
+#define CDAE_STAMP() do { if (rank == hp.debug_rank && lane == 0 && dbg_n < 60) dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CDAE_STAMP() do {} while (0)
+#endif
+  CDAE_STAMP();
   const uint32_t lo = lane * NI;
   const bool tied = !hp.asymmetric;
   float w[NI], a[NI], wref[NI];
@@ -429,6 +438,7 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
     }
   }
   uint32_t prev_slot = 0xFFFFFFFFu;
+  CDAE_STAMP();
   for (uint32_t c0 = beg; c0 < end; c0 += WAVE) {
     {
       const uint32_t q = c0 + WAVE + lane;
@@ -484,8 +494,10 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
         }
       }
     }
+    CDAE_STAMP();
     if (lane < cnt) G[cur_e] = gbuf;
-    __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    if (c0 + WAVE < end) __builtin_amdgcn_s_waitcnt(WAIT_VM0);   // (nothing follows the last chunk but the row's own stores)
+    CDAE_STAMP();
     cur_w = nxt_w; cur_e = nxt_e; cur_o = nxt_o;
   }
   if (BIAS_IN_PAD) {
@@ -500,7 +512,13 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   }
   vstore<NI>(D + (size_t)item * hp.Kp + lo, w);
   vstore<NI>(D_ag + (size_t)item * hp.Kp + lo, a);
+#ifdef CDAE_DECODE_TIMING
+  CDAE_STAMP();
+  if (rank == hp.debug_rank && lane == 0) dbg[63] = (unsigned long long)dbg_n | ((unsigned long long)(end - beg) << 32);
+#else
   if (lane == 0 && touched) touched[item] = 1u;
+#endif
+#undef CDAE_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
