@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-users", type=int, default=40000, help="users in the timed CPU-baseline sample (~20 s)")
     ap.add_argument("--seed", type=int, default=20141119)
+    ap.add_argument("--profile-every", type=int, default=8, help="HIP-event kernel timing on every n-th batch (0 = off)")
     ap.add_argument("--full-output", action="store_true", help="BASELINE configs[1]/[4]: every unrated item is a negative; "
                     "dense decode on the bf16 MFMA cores (roofline bound: mfma)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
@@ -106,7 +107,7 @@ def main():
         b = i % n_batches
         return i // n_batches, b * B, min(data.num_users, (b + 1) * B)
 
-    KEYS = ("users", "examples", "ms_sample", "ms_sort", "ms_encode", "ms_decode", "ms_hidden", "ms_input", "launches_decode")
+    KEYS = ("users", "examples", "batches", "ms_sample", "ms_sort", "ms_encode", "ms_decode", "ms_hidden", "ms_input", "launches_decode")
     acc = {k: 0 for k in KEYS}
 
     def add(st):
@@ -135,7 +136,9 @@ def main():
         step(i)
     model.collect_stats()
     acc = {k: 0 for k in KEYS}
-    model.set_profiling(True)             # HIP events on the library's own streams, around each kernel family
+    # HIP events on the library's own streams around each kernel family of every `profile_every`-th batch of the timed
+    # region (event records cost ~3 us of stream time each: 42 us per step if every batch carries its 14)
+    model.set_profiling(args.profile_every)
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
@@ -163,7 +166,7 @@ def main():
     a_user = algorithmic_bytes_per_user(K, n_u, n_in, cfg.num_neg)
     value = users_total / elapsed
     # roofline of the dominant kernel (decode_rows_kernel), rank 0's launches
-    ex_per_launch = acc["examples"] / max(1, acc["launches_decode"])
+    ex_per_launch = acc["examples"] / max(1, acc["batches"])
     ms_per_launch = acc["ms_decode"] / max(1, acc["launches_decode"])
     alg_bytes_launch = decode_bytes_per_example(K) * ex_per_launch
     achieved = alg_bytes_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
@@ -171,7 +174,7 @@ def main():
     if args.full_output:
         # dominant kernels: the three bf16 MFMA contractions, 6 K I flop per user, timed as one family
         MFMA_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-        flops_launch = 6.0 * K * data.num_items * (acc["users"] / max(1, acc["launches_decode"]))
+        flops_launch = 6.0 * K * data.num_items * (acc["users"] / max(1, acc["batches"]))
         achieved_tf = flops_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel x3 (+ bf16 operand copies, target fix-up)",
                     "achieved": achieved_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_PEAK_TFLOPS,
@@ -179,7 +182,7 @@ def main():
         workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "
                     f"FULL-OUTPUT decode (every unrated item a negative), CE loss, AdaGrad, q=0.5 scaled")
     else:
-        roofline = {"bound": "hbm", "kernel": "decode_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "decode_hybrid_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": ms_per_launch,
                     "whole_step_fraction_of_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS}
@@ -193,7 +196,8 @@ def main():
         "config": {"workload": workload, "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
                    "exchange": "all-reduce of shared-parameter deltas every step" if args.gpus > 1 else "none"},
         "roofline": roofline,
-        "kernel_ms_per_step": {k[3:]: acc[k] / args.steps for k in acc if k.startswith("ms_")},
+        "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
+        "profiled_steps": int(acc["launches_decode"]),
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(data, cfg, args)

@@ -207,8 +207,9 @@ class CDAE:
         return p.value, n.value
 
     # ---- training ----------------------------------------------------------------------------------
-    def set_profiling(self, on: bool):
-        _chk(self.lib, self.lib.cdae_hip_set_profiling(self.h, int(on)))
+    def set_profiling(self, period):
+        """0/False: off; k >= 1 (True = 1): HIP-event kernel timing on every k-th batch."""
+        _chk(self.lib, self.lib.cdae_hip_set_profiling(self.h, int(period)))
 
     def train_one_iteration(self, seed: int, epoch: int) -> Stats:
         st = Stats()

@@ -85,6 +85,8 @@ struct cdae_hip {
   int64_t* d_row_ptr = nullptr;
   uint32_t* d_col = nullptr;
   uint32_t* d_item_order = nullptr;
+  uint32_t hot_rows = 0;            // decode: rows [0, hot_rows) of item_order get a wavefront of their own
+  bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: developer switch, every row on the 64-lane path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
   uint32_t* d_unit_ptr = nullptr;
   uint32_t unit_cap = 0;                // most units in any window of batch_users users
@@ -106,9 +108,13 @@ struct cdae_hip {
     uint32_t* item = nullptr; uint64_t* val = nullptr;            // user-major example list
     uint32_t* sorted_item = nullptr; uint64_t* sorted_val = nullptr;   // the same, stably sorted by item
     uint32_t* seg = nullptr;                                      // [2*I]: first | one-past-last sorted position per item
+    uint16_t* key16 = nullptr; uint16_t* sorted_key16 = nullptr;      // 16-bit sort keys when I <= 65536 (rocPRIM then runs onesweep)
+    uint32_t* dup_of_pos = nullptr; uint32_t* dup_of_ex = nullptr;   // duplicate-negative correction rows (segment_kernel)
+    uint32_t* dup_count = nullptr;
     hipEvent_t ready = nullptr, released = nullptr;
   } ex[2];
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
+  float* d_dup_corr = nullptr; uint32_t dup_cap = 0;   // [dup_cap][Kp] hidden-gradient corrections of duplicate negatives
   float* d_HGpart = nullptr;            // [8][B][Kp] per-XCD partial hidden gradients
   // full-output decode (MFMA path): bf16 operand copies and the dense gradient, padded to 128-multiples
   uint32_t Bp = 0, Ip = 0;
@@ -130,7 +136,8 @@ struct cdae_hip {
   bool pre_valid = false;               // set (seq & 1) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
   uint64_t pre_s0 = 0, pre_seed = 0; uint32_t pre_nb = 0, pre_cidx = 0, pre_epoch = 0;
   uint64_t acc_users = 0, acc_examples = 0, acc_batches = 0;   // since the last stats collection
-  bool profiling = false;
+  int profiling = 0;                    // 0 off; k >= 1: HIP events around the kernel families of every k-th batch
+  uint64_t prof_q = 0;                  // sequence number of the batch being enqueued (sampling of the profile)
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
 
@@ -153,7 +160,7 @@ int get_event(cdae_hip* h, hipEvent_t* ev) {
 struct Prof {   // RAII-less helper: begin()/end() around one kernel family launch, on the stream it is launched on
   cdae_hip* h; Span s; bool on; hipStream_t st;
   int begin(cdae_hip* hh, int family, hipStream_t stream) {
-    h = hh; on = hh->profiling; st = stream; if (!on) return 0;
+    h = hh; on = hh->profiling > 0 && hh->prof_q % (uint64_t)hh->profiling == 0; st = stream; if (!on) return 0;
     s.family = family;
     CHK(get_event(h, &s.a)); CHK(get_event(h, &s.b));
     HIPCHK(hipEventRecord(s.a, st));
@@ -190,10 +197,10 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta};
+                  h->d_base, h->d_delta, h->d_dup_corr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
-    void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg};
+    void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
     for (void* p : q) if (p) (void)hipFree(p);
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
@@ -210,10 +217,12 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta,
-                   (void**)&h->ex[0].item, (void**)&h->ex[0].val, (void**)&h->ex[0].sorted_item, (void**)&h->ex[0].sorted_val,
-                   (void**)&h->ex[0].seg, (void**)&h->ex[1].item, (void**)&h->ex[1].val, (void**)&h->ex[1].sorted_item,
-                   (void**)&h->ex[1].sorted_val, (void**)&h->ex[1].seg};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_dup_corr};
+  for (auto& b : h->ex) {
+    void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
+                  (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
+    for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+  }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   h->rec_cap = 0;
   return 0;
@@ -240,14 +249,23 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   CHK(pr.begin(h, F_SAMPLE, st));
   const uint32_t n_units = units_of(h, bt);
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
-                     h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val);
+                     h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
+                     x.seg, 2u * I, x.dup_count, x.dup_of_ex);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st));
-  HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
-                                   (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
-  HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(segment_kernel, dim3((uint32_t)((bt.E + 255) / 256)), dim3(256), 0, st, x.sorted_item, (uint32_t)bt.E,
-                     x.seg, x.seg + I);
+  const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
+  if (x.key16) {
+    // 16-bit keys: rocPRIM picks onesweep (2 digit passes) instead of block sort + log2(tiles) merge passes
+    HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.key16, x.sorted_key16, x.val, x.sorted_val,
+                                     (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
+    hipLaunchKernelGGL(segment_kernel<uint16_t>, seg_grid, dim3(256), 0, st, x.sorted_key16, x.sorted_val, (uint32_t)bt.E,
+                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+  } else {
+    HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
+                                     (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
+    hipLaunchKernelGGL(segment_kernel<uint32_t>, seg_grid, dim3(256), 0, st, x.sorted_item, x.sorted_val, (uint32_t)bt.E,
+                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+  }
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.ready, st));
   HIPCHK(hipGetLastError());
@@ -280,8 +298,9 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
 
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   CHK(pr.begin(h, F_DECODE, st));
-#define DECODE_ARGS h->hp, h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
-                    h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_D0, h->d_touched
+#define DECODE_TAIL h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
+                    h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_D0, h->d_touched, x.dup_of_pos, h->d_dup_corr
+#define DECODE_ARGS h->hp, DECODE_TAIL
 #define DECODE_LA(NI_, L_, A_)                                                                                       \
   do {                                                                                                               \
     if (pad) hipLaunchKernelGGL((decode_rows_kernel<NI_, L_, A_, true>), grid_rows, blk, 0, st, DECODE_ARGS);        \
@@ -294,10 +313,38 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
     else if (ada) DECODE_LA(NI_, 0, true);                      \
     else DECODE_LA(NI_, 0, false);                              \
   } while (0)
+  // K <= 256: hot rows one per wavefront, all others four per wavefront (NV float4 pieces + NT tail scalars per lane)
+#define DECODE_HY(NV_, NT_)                                                                                           \
+  do {                                                                                                                \
+    if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);   \
+    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
+    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
+    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);            \
+  } while (0)
+#define DECODE_HY_NT(NV_)                                                                        \
+  do {                                                                                           \
+    if (nt == 1) DECODE_HY(NV_, 1); else if (nt == 2) DECODE_HY(NV_, 2); else DECODE_HY(NV_, 4); \
+  } while (0)
   {
     const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY, ada = h->cfg.using_adagrad != 0, pad = h->K < h->Kp;
-    switch (h->NI) { case 1: DECODE_NI(1); break; case 2: DECODE_NI(2); break; case 4: DECODE_NI(4); break; default: DECODE_NI(8); break; }
+    const uint32_t K = h->K;
+    if (K <= 256 && !h->one_row_per_wave) {
+      const uint32_t hot = std::min<uint32_t>(h->hot_rows, I);
+      const uint32_t waves = hot + (I - hot + 3) / 4;
+      const dim3 grid_hy((waves + 3) / 4);
+      const uint32_t nv = K / 64, tail = K % 64;
+      const uint32_t nt = tail == 0 ? 0u : (tail < 16 ? 1u : (tail < 32 ? 2u : 4u));   // 16 nt > tail: room for b'
+      if (nt == 0) {
+        switch (nv) { case 1: DECODE_HY(1, 0); break; case 2: DECODE_HY(2, 0); break; case 3: DECODE_HY(3, 0); break; default: DECODE_HY(4, 0); break; }
+      } else {
+        switch (nv) { case 0: DECODE_HY_NT(0); break; case 1: DECODE_HY_NT(1); break; case 2: DECODE_HY_NT(2); break; default: DECODE_HY_NT(3); break; }
+      }
+    } else {
+      switch (h->NI) { case 1: DECODE_NI(1); break; case 2: DECODE_NI(2); break; case 4: DECODE_NI(4); break; default: DECODE_NI(8); break; }
+    }
   }
+#undef DECODE_HY_NT
+#undef DECODE_HY
 #undef DECODE_LA
 #undef DECODE_NI
 #undef DECODE_ARGS
@@ -305,7 +352,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
 
   CHK(pr.begin(h, F_HIDDEN, st));
   DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
-              x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u);
+              x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
               h->d_Wu, h->d_Wu_ag, 1u);
   CHK(pr.end());
@@ -444,6 +491,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   HIPCHK(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail("device %d not available (%d HIP devices)", device_id, ndev);
   HIPCHK(hipSetDevice(device_id));
+  if (cfg->batch_users > cdae::SLOT_MASK) return fail("batch_users %u exceeds the example word's slot field (2^28 - 1)", cfg->batch_users);
   cdae_hip* h = new cdae_hip();
   h->cfg = *cfg;
   h->device = device_id;
@@ -519,6 +567,17 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pop[a] > pop[b]; });
   CHK(dev_alloc(&h->d_item_order, (size_t)I));
   HIPCHK(hipMemcpy(h->d_item_order, order.data(), I * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    // hot rows: expected positives per batch (popularity x batch share) of at least CDAE_DECODE_HOT_POS (default 48);
+    // every row also receives ~ B * mean(n_u) * num_neg / I uniformly spread negatives
+    const char* ev = std::getenv("CDAE_DECODE_HOT_POS");
+    const double hot_pos = ev ? std::atof(ev) : 48.0;
+    const double share = (double)std::min<uint64_t>(h->B, U) / (double)U;
+    uint32_t hot = 0;
+    while (hot < I && (double)pop[order[hot]] * share >= hot_pos) ++hot;
+    h->hot_rows = std::min<uint32_t>((hot + 3u) & ~3u, (uint32_t)I);
+    h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
+  }
 
   // parameters
   const size_t IK = (size_t)I * h->Kp;
@@ -578,16 +637,34 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));
     CHK(dev_alloc(&b.sorted_item, h->Ecap)); CHK(dev_alloc(&b.sorted_val, h->Ecap));
     CHK(dev_alloc(&b.seg, 2 * (size_t)I));
+    CHK(dev_alloc(&b.dup_of_pos, h->Ecap)); CHK(dev_alloc(&b.dup_of_ex, h->Ecap)); CHK(dev_alloc(&b.dup_count, 1));
+    if (I <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }
     if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b.released, hipEventDisableTiming)); }
     HIPCHK(hipEventRecord(b.released, h->stream));
   }
   CHK(dev_alloc(&h->d_D0, IK));
+  {
+    // one correction row per duplicate negative of a batch (~2 % of the examples at ML-10M shape); beyond the
+    // capacity decode falls back to atomics.  Zero-filled once: decode's 16-lane path leaves elements >= 64 NV + 16 NT
+    // of a row untouched and the gather reads whole rows.
+    const char* ev = std::getenv("CDAE_DUP_CAP");
+    const uint64_t want = ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(4096, h->Ecap / 4);
+    h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
+    CHK(dev_alloc(&h->d_dup_corr, (size_t)h->dup_cap * h->Kp));
+    HIPCHK(hipMemset(h->d_dup_corr, 0, (size_t)h->dup_cap * h->Kp * sizeof(float)));
+  }
   CHK(dev_alloc(&h->d_G, h->Ecap));
   h->sort_bits = 1;
   while ((1ull << h->sort_bits) < I) h->sort_bits++;
   h->sort_tmp_bytes = 0;
   HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->ex[0].item, h->ex[0].sorted_item, h->ex[0].val,
                                    h->ex[0].sorted_val, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
+  if (h->ex[0].key16) {
+    size_t bytes16 = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes16, h->ex[0].key16, h->ex[0].sorted_key16, h->ex[0].val, h->ex[0].sorted_val,
+                                     (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
+    h->sort_tmp_bytes = std::max(h->sort_tmp_bytes, bytes16);
+  }
   CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
@@ -681,7 +758,7 @@ int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, 
 
 int cdae_hip_set_profiling(cdae_hip_t* h, int enabled) {
   if (!h) return fail("null handle");
-  h->profiling = enabled != 0;
+  h->profiling = enabled < 0 ? 0 : enabled;
   return 0;
 }
 
@@ -718,10 +795,13 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
   std::vector<Batch> plan;
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
+  h->prof_q = h->seq;
   if (!is_prefetched(h, plan[0], seed, epoch)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
   h->pre_valid = false;
   for (size_t t = 0; t < plan.size(); ++t) {
+    h->prof_q = h->seq + 1;
     if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
+    h->prof_q = h->seq;
     if (h->cfg.full_output) CHK(compute_batch_full(h, (int)(h->seq & 1), plan[t], seed, epoch));
     else CHK(compute_batch(h, (int)(h->seq & 1), plan[t], seed, epoch));
     h->seq++;
@@ -778,6 +858,7 @@ int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
   if (is_prefetched(h, plan[0], seed, epoch)) return 0;
+  h->prof_q = h->seq;
   CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
   h->pre_valid = true;
   h->pre_s0 = plan[0].s0; h->pre_nb = plan[0].nb; h->pre_cidx = plan[0].cidx; h->pre_seed = seed; h->pre_epoch = epoch;
@@ -931,8 +1012,11 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val, E, 0u,
                                    (unsigned)h->sort_bits, h->stream));
   HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)h->I * sizeof(uint32_t), h->stream));
-  hipLaunchKernelGGL(cdae::segment_kernel, dim3((uint32_t)((E + 255) / 256)), dim3(256), 0, h->stream, x.sorted_item, (uint32_t)E,
-                     x.seg, x.seg + h->I);
+  HIPCHK(hipMemsetAsync(x.dup_count, 0, sizeof(uint32_t), h->stream));
+  HIPCHK(hipMemsetAsync(x.dup_of_ex, 0xFF, E * sizeof(uint32_t), h->stream));
+  hipLaunchKernelGGL(cdae::segment_kernel<uint32_t>, dim3((uint32_t)((E + 256 * cdae::SEG_PER_THREAD - 1) / (256 * cdae::SEG_PER_THREAD))),
+                     dim3(256), 0, h->stream, x.sorted_item, x.sorted_val,
+                     (uint32_t)E, x.seg, x.seg + h->I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
   HIPCHK(hipEventRecord(x.ready, h->stream));
   const uint32_t one_unit[2] = {0u, 1u};                         // one user, one unit
   HIPCHK(hipMemcpyAsync(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice, h->stream));
@@ -941,6 +1025,7 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   uint32_t* d_in_owned = nullptr;
   if (n_in > std::min<uint64_t>(h->B, h->U)) { CHK(dev_alloc(&d_in_owned, n_in)); d_in = d_in_owned; }
   if (n_in) HIPCHK(hipMemcpyAsync(d_in, in_sorted.data(), n_in * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  h->prof_q = h->seq;
   int rc = compute_batch(h, set, Batch{uid, 1, 0, E}, 0, 0, d_in, (uint32_t)n_in);
   h->seq++;
   hipError_t se = hipStreamSynchronize(h->stream);

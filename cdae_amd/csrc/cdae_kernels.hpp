@@ -25,7 +25,10 @@
 namespace cdae {
 
 constexpr int WAVE = 64;
-constexpr uint32_t SLOT_MASK = 0x3FFFFFFFu;   // example word: slot | target << 30 | is_input << 31
+constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   // example word: slot | dup_prev << 28 | dup_next << 29 | target << 30 | is_input << 31
+constexpr uint32_t DUP_PREV_BIT = 1u << 28;   // (set by segment_kernel) the row's previous example is the same user's
+constexpr uint32_t DUP_NEXT_BIT = 1u << 29;   // the row's next example is the same user's
+constexpr uint32_t DUP_NONE = 0xFFFFFFFFu;    // "no correction row" (dup_of_pos / dup_of_ex)
 constexpr uint32_t TARGET_BIT = 1u << 30;
 constexpr uint32_t INPUT_BIT = 1u << 31;
 
@@ -177,8 +180,14 @@ constexpr uint32_t SAMPLE_LDS_ROW = 2048;   // items of a user's row staged per 
 __global__ void __launch_bounds__(256)
 sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
               const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb, uint32_t cidx,
-              uint64_t seed, uint32_t epoch, uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val) {
+              uint64_t seed, uint32_t epoch, uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val,
+              uint16_t* __restrict__ ex_key16 /* sort key copy when num_items <= 65536, else nullptr */,
+              uint32_t* __restrict__ seg /* [seg_words] cleared here for segment_kernel */, uint32_t seg_words,
+              uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
+  // the per-batch clears ride along (no memset launches on the prep stream)
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dup_count = 0u;
   const uint32_t wid = threadIdx.x / WAVE;
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
@@ -202,6 +211,8 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
     const uint64_t e = base + p;
     ex_item[e] = row[p];
+    if (ex_key16) ex_key16[e] = (uint16_t)row[p];
+    dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
   // the wavefront's own LDS writes are visible to it once they are issued in order (no cross-wave sharing)
@@ -227,19 +238,60 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
       cand = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
     }
     ex_item[e] = cand;
+    if (ex_key16) ex_key16[e] = (uint16_t)cand;
+    dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)slot;
   }
 }
 
-// first / one-past-last sorted position of every item that has examples (others keep 0,0)
+// first / one-past-last sorted position of every item that has examples (others keep 0,0).
+// Also finds runs of one user's examples inside a row (duplicate negatives: the sampler draws with replacement like
+// recsys_model_base.hpp:46-57) and marks them in the example word.  Every second-or-later example of a run gets a row
+// `dup_idx` of the correction buffer (decode writes g * (row now - row at the user's first visit) there, the
+// hidden-gradient gather adds it): dup_of_pos[p] for decode, dup_of_ex[e] for the gather (DUP_NONE for all other
+// examples and when the buffer is full — decode then falls back to atomics).
+constexpr uint32_t SEG_PER_THREAD = 4;               // positions per thread: one global counter bump per 1024 positions
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
-segment_kernel(const uint32_t* __restrict__ sorted_item, uint32_t n_ex, uint32_t* __restrict__ seg_begin,
-               uint32_t* __restrict__ seg_end) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_ex) return;
-  const uint32_t it = sorted_item[p];
-  if (p == 0 || sorted_item[p - 1] != it) seg_begin[it] = p;
-  if (p + 1 == n_ex || sorted_item[p + 1] != it) seg_end[it] = p + 1;
+segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint32_t n_ex, uint32_t* __restrict__ seg_begin,
+               uint32_t* __restrict__ seg_end, uint32_t* __restrict__ dup_count, uint32_t dup_cap,
+               uint32_t* __restrict__ dup_of_pos, uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */) {
+  __shared__ uint32_t blk_count, blk_base;
+  if (threadIdx.x == 0) blk_count = 0u;
+  __syncthreads();
+  const uint32_t p0 = blockIdx.x * (blockDim.x * SEG_PER_THREAD) + threadIdx.x;
+  uint32_t dups = 0;                                  // bit i: position p0 + i * blockDim.x continues a run
+#pragma unroll 4
+  for (uint32_t i = 0; i < SEG_PER_THREAD; ++i) {
+    const uint32_t p = p0 + i * blockDim.x;
+    if (p >= n_ex) break;
+    const uint32_t it = sorted_item[p];
+    const bool first = p == 0 || sorted_item[p - 1] != it, last = p + 1 == n_ex || sorted_item[p + 1] != it;
+    if (first) seg_begin[it] = p;
+    if (last) seg_end[it] = p + 1;
+    const uint64_t v = sorted_val[p];
+    const uint32_t slot = (uint32_t)v & SLOT_MASK;
+    uint32_t flags = 0;                               // neighbours may be mid-update: only their slot bits are compared
+    if (!first && ((uint32_t)sorted_val[p - 1] & SLOT_MASK) == slot) flags |= DUP_PREV_BIT;
+    if (!last && ((uint32_t)sorted_val[p + 1] & SLOT_MASK) == slot) flags |= DUP_NEXT_BIT;
+    if (flags) sorted_val[p] = v | flags;
+    if (flags & DUP_PREV_BIT) dups |= 1u << i;
+  }
+  const uint32_t mine = (uint32_t)__popc(dups);
+  uint32_t off = mine ? atomicAdd(&blk_count, mine) : 0u;        // LDS
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_count) blk_base = atomicAdd(dup_count, blk_count);
+  __syncthreads();
+  off += blk_base;
+  while (dups) {
+    const uint32_t i = (uint32_t)__ffs((int)dups) - 1u;
+    dups &= dups - 1u;
+    const uint32_t p = p0 + i * blockDim.x;
+    const uint32_t idx = off < dup_cap ? off : DUP_NONE;
+    ++off;
+    dup_of_pos[p] = idx;
+    dup_of_ex[(uint32_t)(sorted_val[p] >> 32)] = idx;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -353,8 +405,8 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
 
 // ------------------------------------------------------------------------------------------------
 // K3  decode, row-major: positives loop cdae.hpp:225-260 and negatives loop cdae.hpp:262-293, for all
-// users of the batch at once.  One wavefront owns item row j: D[j], D_ag[j], b'[j], b'_ag[j] stay in
-// registers while it walks the row's examples in user order:
+// users of the batch at once.  One wavefront (or one 16-lane group of it, see below) owns item row j: D[j],
+// D_ag[j], b'[j], b'_ag[j] stay in registers while it walks the row's examples in user order:
 //   y = D[j].z_u + b'[j] (cdae.hpp:227/263, 418-426);  g = loss'(y, t) (:228/:265);
 //   b'[j] step (:230-237/:267-274);
 //   row step grad = g z_u + lambda D[j] (:241-246,:252-257/:278-283,:286-291), or, when j is one of u's
@@ -364,7 +416,8 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
 // 150 G atomics/s saturates the L2 atomic units, 3.7 ms per 4096-user batch); K4 gathers it from the
 // batch-start snapshot D0 instead, and this kernel only adds the exact correction for a user's own
 // duplicate negatives — g * (row now - row at the user's first visit) — which is what makes
-// batch_users == 1 reproduce the reference in exact arithmetic.
+// batch_users == 1 reproduce the reference in exact arithmetic.  segment_kernel marks those (rare) examples
+// in the example word, so the common path carries no bookkeeping for them.
 // D = V when asymmetric else W.  Rows are visited in `item_order` (popular rows first: their example
 // chains are the longest and bound the kernel).
 // Memory pipeline: the row's example words are fetched 64 at a time (one coalesced 512-byte load, next
@@ -374,19 +427,22 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
 // the counter and complete out of order with loads).
 constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15 = don't care), gfx9 encoding
 
+#define CDAE_DECODE_PARAMS                                                                                         \
+  const uint32_t *__restrict__ item_order, const uint32_t *__restrict__ seg_begin,                                  \
+      const uint32_t *__restrict__ seg_end, const uint64_t *__restrict__ sorted_val, const float *__restrict__ Z,  \
+      float *__restrict__ D, float *__restrict__ D_ag, float *__restrict__ bp, float *__restrict__ bp_ag,           \
+      float *__restrict__ HGcorr, float *__restrict__ G, float *__restrict__ D0, uint32_t *__restrict__ touched,    \
+      const uint32_t *__restrict__ dup_of_pos, float *__restrict__ dup_corr
+#define CDAE_DECODE_PASS \
+  item_order, seg_begin, seg_end, sorted_val, Z, D, D_ag, bp, bp_ag, HGcorr, G, D0, touched, dup_of_pos, dup_corr
+
+// One row per wavefront; lane holds NI contiguous floats of the row.
 // BIAS_IN_PAD (K < Kp, e.g. K = 200 or 50): b'[j] rides in the last pad element of the row registers with a
 // constant 1 as its "z": its AdaGrad step grad = g*1 + lambda*b' (cdae.hpp:230-237) is then the row step's own
 // arithmetic and y = D[j].z + b'[j] needs no separate add — the per-example chain loses the scalar bias
 // recurrence (two transcendentals).  Memory images of D and D0 keep their pad elements 0.
 template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
-__global__ void __launch_bounds__(256)
-decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
-                   const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
-                   const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
-                   float* __restrict__ D, float* __restrict__ D_ag, float* __restrict__ bp,
-                   float* __restrict__ bp_ag, float* __restrict__ HGcorr, float* __restrict__ G,
-                   float* __restrict__ D0, uint32_t* __restrict__ touched) {
-  const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+__device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank, CDAE_DECODE_PARAMS) {
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
@@ -437,7 +493,6 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
       vload<NI>(z[j], reinterpret_cast<const float*>(Zb + off));
     }
   }
-  uint32_t prev_slot = 0xFFFFFFFFu;
   CDAE_STAMP();
   for (uint32_t c0 = beg; c0 < end; c0 += WAVE) {
     {
@@ -453,7 +508,6 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
         const uint32_t idx = j0 + t;
         if (idx < cnt) {                                       // wave-uniform
           const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
-          const uint32_t slot = word & SLOT_MASK;
           if (BIAS_IN_PAD) z[t][NI - 1] += pad_one;            // the bias element's "z" is 1 (Z's pad elements are 0)
           float dot = 0.f;
 #pragma unroll
@@ -463,16 +517,26 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
           const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
           if (!BIAS_IN_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
           gbuf = lane == idx ? g : gbuf;
-          if (slot == prev_slot) {                             // duplicate negative of the same user (rare)
-            float* hc = HGcorr + (size_t)slot * hp.Kp + lo;
+          if (word & (DUP_PREV_BIT | DUP_NEXT_BIT)) {          // duplicate negative of the same user (rare, wave-uniform)
+            if (word & DUP_PREV_BIT) {
+              // g * (row now - row at the user's first visit): a plain row store into the correction buffer (the
+              // gather adds it to hg_u); fire-and-wait atomics here cost ~25 us per duplicate (measured)
+              const uint32_t di = dup_of_pos[c0 + idx];
+              float corr[NI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-              if (!(pad_lane && i == NI - 1)) unsafeAtomicAdd(hc + i, g * (w[i] - wref[i]));
-            __builtin_amdgcn_s_waitcnt(WAIT_VM0);              // keep the loop's VMEM stream loads-only
-          } else {
-            prev_slot = slot;
+              for (int i = 0; i < NI; ++i) corr[i] = (pad_lane && i == NI - 1) ? 0.f : g * (w[i] - wref[i]);
+              if (di != DUP_NONE) {
+                vstore<NI>(dup_corr + (size_t)di * hp.Kp + lo, corr);
+              } else {                                         // correction buffer full: slow path
+                float* hc = HGcorr + (size_t)(word & SLOT_MASK) * hp.Kp + lo;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wref[i] = w[i];
+                for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, corr[i]);
+              }
+              __builtin_amdgcn_s_waitcnt(WAIT_VM0);            // keep the loop's VMEM stream loads-only
+            } else {                                           // first of a run: remember the row at the user's first visit
+#pragma unroll
+              for (int i = 0; i < NI; ++i) wref[i] = w[i];
+            }
           }
           if (!(word & INPUT_BIT) || !tied) {
 #pragma unroll
@@ -521,6 +585,251 @@ decode_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
 #undef CDAE_STAMP
 }
 
+template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
+__global__ void __launch_bounds__(256)
+decode_rows_kernel(HyperParams hp, CDAE_DECODE_PARAMS) {
+  const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+  decode_row64<NI, LOSS, ADAGRAD, BIAS_IN_PAD>(hp, rank, CDAE_DECODE_PASS);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 (K <= 256)  FOUR item rows per wavefront, one per 16-lane group (= one DPP row).
+// Measured (profiles/r01_decode_timeline.txt): with one row per wavefront the launch is VALU-throughput bound
+// chip-wide — ~100 VALU instructions per example, a third of them (wave reduction, sigmoid, flag decoding, ring
+// bookkeeping) independent of K, and a K = 200 row fills only 50 of 64 lanes x 4 elements.  Here a row is held as
+// NV float4 pieces (lane l of the group: elements 64 v + 4 l .. + 3) plus NT tail scalars (elements 64 NV + l + 16 i),
+// so K = 200 is 3 x float4 + 1 scalar = 13 registers with 200 of 208 slots used; the reduction is four intra-row DPP
+// steps with no read-back, and every per-example instruction serves four rows.  The last tail slot (lane 15 of tail
+// register NT-1, element 64 NV + 16 NT - 1 >= K) carries b' as in BIAS_IN_PAD above; NT == 0 (K a multiple of 64)
+// keeps b' as a scalar.  Same arithmetic, same order of examples inside a row, same G / HGcorr / D0 side effects as
+// decode_row64.  Each group walks its own segment (groups of one wavefront hold neighbouring popularity ranks, i.e.
+// segments of similar length); example words are fetched 64 per group at a time (lane l holds examples l, l+16, l+32,
+// l+48) and broadcast inside the group with ds_bpermute; z rows run PF examples ahead; g is parked in four VGPRs and
+// stored once per 64 examples so the loop issues loads only (counted vmcnt, see above).
+template <int NV, int NT>
+__device__ __forceinline__ void row16_load(float (&r)[4 * NV + NT + (NV + NT == 0)], const float* __restrict__ base, uint32_t l) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const float4 q = *reinterpret_cast<const float4*>(base + 64 * v + 4 * l);
+    r[4 * v] = q.x; r[4 * v + 1] = q.y; r[4 * v + 2] = q.z; r[4 * v + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) r[4 * NV + i] = base[64 * NV + l + 16 * i];
+}
+template <int NV, int NT>
+__device__ __forceinline__ void row16_store(float* __restrict__ base, const float (&r)[4 * NV + NT + (NV + NT == 0)], uint32_t l) {
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    *reinterpret_cast<float4*>(base + 64 * v + 4 * l) = make_float4(r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) base[64 * NV + l + 16 * i] = r[4 * NV + i];
+}
+
+template <int NV, int NT, int LOSS, bool ADAGRAD>
+__device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t rank0, CDAE_DECODE_PARAMS) {
+  constexpr int GRP = 16, NE = 4 * NV + NT;
+  constexpr bool HAS_PAD = NT > 0;
+  const uint32_t lane = threadIdx.x % WAVE, l = lane & (GRP - 1), sub = lane / GRP;
+  const uint32_t rank = rank0 + sub;
+  const bool row_ok = rank < hp.num_items;
+  const uint32_t item = row_ok ? item_order[rank] : 0u;
+  const uint32_t beg = row_ok ? seg_begin[item] : 0u, end = row_ok ? seg_end[item] : 0u;
+  const uint32_t n = end - beg;
+  // longest segment of the wavefront's four groups (wave-uniform loop bound)
+  const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n, 0), (uint32_t)__builtin_amdgcn_readlane((int)n, 16)),
+                            max((uint32_t)__builtin_amdgcn_readlane((int)n, 32), (uint32_t)__builtin_amdgcn_readlane((int)n, 48)));
+  if (nmax == 0) return;
+  hp.loss_type = LOSS;
+  hp.adagrad = ADAGRAD;
+#ifdef CDAE_DECODE_TIMING   // stamps: start | loop start | every 16 steps | end   (rank0 == debug_rank)
+  unsigned long long* dbg = reinterpret_cast<unsigned long long*>(touched);
+  int dbg_n = 0;
+#define CDAE_STAMP() do { if (rank0 == hp.debug_rank && lane == 0 && dbg_n < 60) dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CDAE_STAMP() do {} while (0)
+#endif
+  CDAE_STAMP();
+  const bool tied = !hp.asymmetric;
+  const bool pad_lane = HAS_PAD && l == GRP - 1;
+  const float pad_one = pad_lane ? 1.f : 0.f;
+
+  float w[NE], a[NE], wref[NE];
+  const size_t row_off = (size_t)item * hp.Kp;
+  if (n) {
+    row16_load<NV, NT>(w, D + row_off, l);
+    row16_load<NV, NT>(a, D_ag + row_off, l);
+    row16_store<NV, NT>(D0 + row_off, w, l);                     // batch-start snapshot of the row (hidden-gradient gather)
+  } else {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { w[i] = 0.f; a[i] = 1.f; }
+  }
+  float bias = n ? bp[item] : 0.f, bias_ag = n ? bp_ag[item] : 1.f;
+  if (pad_lane) { w[NE - 1] = bias; a[NE - 1] = bias_ag; }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) wref[i] = w[i];
+
+#ifndef CDAE_DECODE16_PF
+#define CDAE_DECODE16_PF 4
+#endif
+  constexpr int PF = CDAE_DECODE16_PF;
+  const uint32_t row_bytes = hp.Kp * 4u;
+  const char* Zc = reinterpret_cast<const char*>(Z);
+  // this lane's four example words / example ids of the group's current 64-example chunk: examples l + 16 j
+  uint32_t cw[4], ce[4];
+  auto load_chunk = [&](uint32_t c0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t q = c0 + l + GRP * j;
+      const uint64_t v = q < n ? sorted_val[beg + q] : 0ull;
+      cw[j] = (uint32_t)v; ce[j] = (uint32_t)(v >> 32);
+    }
+  };
+  // word of the group's example t (t wave-uniform): lane (t & 15) of the group, register (t >> 4) & 3
+  auto word_of = [&](uint32_t t) -> uint32_t {
+    const uint32_t j = (t >> 4) & 3u;
+    const uint32_t src = j == 0 ? cw[0] : (j == 1 ? cw[1] : (j == 2 ? cw[2] : cw[3]));
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~(GRP - 1)) | (t & (GRP - 1))) << 2), (int)src);
+  };
+  load_chunk(0);
+  float z[PF][NE];
+  uint32_t zw[PF];                                               // word of the example whose z sits in ring slot
+#pragma unroll
+  for (int r = 0; r < PF; ++r) {
+    zw[r] = word_of(min((uint32_t)r, n ? n - 1u : 0u));
+    row16_load<NV, NT>(z[r], reinterpret_cast<const float*>(Zc + (size_t)(zw[r] & SLOT_MASK) * row_bytes), l);
+  }
+  float gbuf[4] = {0.f, 0.f, 0.f, 0.f};
+  CDAE_STAMP();
+  for (uint32_t t0 = 0; t0 < nmax; t0 += PF) {
+    if ((t0 & 15u) == 0u && t0) CDAE_STAMP();
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+      const uint32_t t = t0 + r;                                 // wave-uniform
+      if ((t & 63u) == 0u && t != 0u) {                          // chunk boundary: flush g, fetch the next 64 example words
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t q = t - 64u + l + GRP * j;
+          if (q < n) G[ce[j]] = gbuf[j];
+        }
+        __builtin_amdgcn_s_waitcnt(WAIT_VM0);                    // keep the loop's VMEM stream loads-only
+        load_chunk(t);
+      }
+      const uint32_t word = zw[r];
+      if (t < n) {                                               // group-uniform
+        if (HAS_PAD) z[r][NE - 1] += pad_one;
+        float d0 = 0.f, d1 = 0.f;                                // two chains: the dot is on every example's critical path
+#pragma unroll
+        for (int i = 0; i < NE; i += 2) {
+          d0 = fmaf(w[i], z[r][i], d0);
+          if (i + 1 < NE) d1 = fmaf(w[i + 1], z[r][i + 1], d1);
+        }
+        float dot = d0 + d1;
+        dot = dpp_add<0xB1>(dot);                                // quad_perm [1,0,3,2]
+        dot = dpp_add<0x4E>(dot);                                // quad_perm [2,3,0,1]
+        dot = dpp_add<0x141>(dot);                               // row_half_mirror
+        float y = dpp_add<0x140>(dot);                           // row_mirror: every lane of the group holds the row sum
+        if (!HAS_PAD) y += bias;
+        const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
+        if (!HAS_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
+        {
+          const uint32_t j = (t >> 4) & 3u;
+          const bool mine = l == (t & (GRP - 1));
+          gbuf[0] = (mine && j == 0) ? g : gbuf[0];
+          gbuf[1] = (mine && j == 1) ? g : gbuf[1];
+          gbuf[2] = (mine && j == 2) ? g : gbuf[2];
+          gbuf[3] = (mine && j == 3) ? g : gbuf[3];
+        }
+        if (word & (DUP_PREV_BIT | DUP_NEXT_BIT)) {              // duplicate negative of the same user (rare)
+          if (word & DUP_PREV_BIT) {
+            const uint32_t di = dup_of_pos[beg + t];
+            float corr[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) corr[i] = (pad_lane && i == NE - 1) ? 0.f : g * (w[i] - wref[i]);
+            if (di != DUP_NONE) {
+              row16_store<NV, NT>(dup_corr + (size_t)di * hp.Kp, corr, l);
+            } else {                                             // correction buffer full: slow path
+              float* hc = HGcorr + (size_t)(word & SLOT_MASK) * hp.Kp;
+#pragma unroll
+              for (int i = 0; i < NE; ++i) {
+                const uint32_t k = i < 4 * NV ? 64u * (i / 4) + 4u * l + (i % 4) : 64u * NV + l + 16u * (i - 4 * NV);
+                if (k < hp.K) unsafeAtomicAdd(hc + k, corr[i]);
+              }
+            }
+            __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) wref[i] = w[i];
+          }
+        }
+        if (!(word & INPUT_BIT) || !tied) {
+#pragma unroll
+          for (int i = 0; i < NE; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[r][i], hp.lambda * w[i]));
+        } else if (HAS_PAD) {                                    // deferred row step (cdae.hpp:249-250): b' still steps now
+          float bw = w[NE - 1], ba = a[NE - 1];
+          ada_step(hp, bw, ba, fmaf(hp.lambda, bw, g));
+          if (pad_lane) { w[NE - 1] = bw; a[NE - 1] = ba; }
+        }
+      }
+      // refill ring slot r with the example PF ahead (clamped; never consumed past the segment's end)
+      {
+        const uint32_t tc = min(t + PF, n ? n - 1u : 0u);
+        uint32_t nw;
+        if ((tc >> 6) == (t >> 6)) {                             // its word is in the chunk held in cw[]
+          nw = word_of(tc);
+        } else {                                                 // first PF examples of the next chunk (or a finished group)
+          nw = (uint32_t)sorted_val[beg + tc];
+        }
+        zw[r] = nw;
+        row16_load<NV, NT>(z[r], reinterpret_cast<const float*>(Zc + (size_t)(nw & SLOT_MASK) * row_bytes), l);
+      }
+    }
+  }
+  // flush g of the chunk the loop ended in (groups that finished before it were flushed at a chunk boundary)
+  {
+    const uint32_t tb = (nmax - 1u) & ~63u;                      // wave-uniform: start of the last chunk the loop entered
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t q = tb + l + GRP * j;
+      if (q < n) G[ce[j]] = gbuf[j];
+    }
+  }
+  if (n) {
+    if (HAS_PAD) {
+      if (pad_lane) { bp[item] = w[NE - 1]; bp_ag[item] = a[NE - 1]; w[NE - 1] = 0.f; a[NE - 1] = 1.f; }
+    } else if (l == 0) {
+      bp[item] = bias; bp_ag[item] = bias_ag;
+    }
+    row16_store<NV, NT>(D + row_off, w, l);
+    row16_store<NV, NT>(D_ag + row_off, a, l);
+#ifndef CDAE_DECODE_TIMING
+    if (l == 0 && touched) touched[item] = 1u;
+#endif
+  }
+#ifdef CDAE_DECODE_TIMING
+  CDAE_STAMP();
+  if (rank0 == hp.debug_rank && lane == 0) dbg[63] = (unsigned long long)dbg_n | ((unsigned long long)nmax << 32);
+#endif
+#undef CDAE_STAMP
+}
+
+// The launch for K <= 256: the `hot_rows` most popular rows (longest chains; static popularity order) take one
+// wavefront each at raised priority — their serial chain bounds the launch, and 64 lanes make its per-example latency
+// shortest — and all other rows go four to a wavefront.
+template <int NV, int NT, int LOSS, bool ADAGRAD>
+__global__ void __launch_bounds__(256)
+decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
+  constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
+  constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
+  constexpr bool PAD64 = NT > 0 || 64 * NV < 64 * NI;             // K < Kp
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+  if (wave < hot_rows) {
+    __builtin_amdgcn_s_setprio(2);
+    decode_row64<NI, LOSS, ADAGRAD, PAD64>(hp, wave, CDAE_DECODE_PASS);
+  } else {
+    decode_rows16<NV, NT, LOSS, ADAGRAD>(hp, hot_rows + (wave - hot_rows) * 4u, CDAE_DECODE_PASS);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4a  hidden gradient, XCD-partitioned gather:  hg_u = sum_e g_e D0[j_e]     cdae.hpp:240,248,277,285
 // D0 is the decoder matrix as it was at batch start (I x Kp fp32, 10.8 MB at ML-10M/K=200: larger than one
@@ -536,7 +845,8 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
                      uint32_t n_units, uint64_t u0, uint32_t nb, const uint32_t* __restrict__ ex_item,
                      const float* __restrict__ G, const float* __restrict__ D0,
                      float* __restrict__ HGpart /* [8][n_units][Kp] */,
-                     uint32_t explicit_examples /* != 0: one user, one unit, that many examples */) {
+                     uint32_t explicit_examples /* != 0: one user, one unit, that many examples */,
+                     const uint32_t* __restrict__ dup_of_ex, const float* __restrict__ dup_corr) {
   const uint32_t part = blockIdx.x & 7u;
   const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
@@ -562,7 +872,28 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
     const uint32_t e = v < n_posu ? p0 + v : neg0 + (v - n_posu);
     const uint32_t my_item = v < n_ex ? ex_item[base + e] : 0xFFFFFFFFu;
     const float my_g = v < n_ex ? G[base + e] : 0.f;
-    unsigned long long mask = __ballot(v < n_ex && (my_item & 7u) == part);
+    const bool mine = v < n_ex && (my_item & 7u) == part;
+    unsigned long long mask = __ballot(mine);
+    // duplicate negatives (rare): add decode's correction rows, in example order
+    const uint32_t my_di = v < n_ex ? dup_of_ex[base + e] : DUP_NONE;
+    unsigned long long dmask = __ballot(mine && my_di != DUP_NONE);
+    while (dmask) {
+      float cr[UN][NI];
+#pragma unroll
+      for (int t = 0; t < UN; ++t) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cr[t][i] = 0.f;
+        if (dmask) {                                           // wave-uniform
+          const int src = __ffsll((long long)dmask) - 1;
+          dmask &= dmask - 1;
+          vload<NI>(cr[t], dup_corr + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_di, src) * hp.Kp + lo);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UN; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) acc[i] += cr[t][i];
+    }
     while (mask) {
       float vv[UN][NI], gg[UN];
 #pragma unroll

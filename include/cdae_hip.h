@@ -145,7 +145,9 @@ int cdae_hip_collect_stats(cdae_hip_t* h, cdae_hip_stats* stats);
  * to feed fixed masks and negatives (duplicates allowed, processed in the given order). */
 int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32_t* input_items,
                                        size_t n_input, const uint32_t* negative_items, size_t n_negative);
-int cdae_hip_set_profiling(cdae_hip_t* h, int enabled);
+/* Developer/benchmark aid: period 0 = off; k >= 1 = HIP events (on the stream each kernel is launched on) around the
+ * kernel families of every k-th batch; cdae_hip_stats.ms_* / launches_decode then cover the sampled batches only. */
+int cdae_hip_set_profiling(cdae_hip_t* h, int period);
 int cdae_hip_synchronize(cdae_hip_t* h);
 
 /* z for `n` users (get_hidden_values, cdae.hpp:373-416).  mode 0: full train row, scale 1 (the
