@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
                     "code path on a single-GPU box together with --share-device")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
+    ap.add_argument("--exchange-every", type=int, default=2, help="N > 1: batches between exchanges of the shared-parameter "
+                    "deltas (pipelined: the all-reduce overlaps the next period; 0 = synchronous exchange after every batch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -78,7 +80,7 @@ def main():
     torch.cuda.set_device(local_rank)
     import cdae_amd
     from cdae_amd import synth
-    from cdae_amd.distributed import DeltaExchange
+    from cdae_amd.distributed import DeltaExchange, PipelinedDeltaExchange
 
     dist = None
     if world > 1:
@@ -99,7 +101,11 @@ def main():
     model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col,
                            user_id_offset=rank * data.num_users)
     model.init_params(args.seed)         # identical shared parameters on every rank; Wu differs but is private
-    exch = DeltaExchange(model, dist, world) if world > 1 else None
+    exch = pipe = None
+    if world > 1 and args.exchange_every > 0:
+        pipe = PipelinedDeltaExchange(model, dist, world, period=args.exchange_every)
+    elif world > 1:
+        exch = DeltaExchange(model, dist, world)
 
     n_batches = (data.num_users + B - 1) // B
 
@@ -125,6 +131,8 @@ def main():
         model.prefetch_users(args.seed, nep, n0, n1)
         if exch:
             exch.finish()
+        if pipe:
+            pipe.after_batch()
 
     def sync():
         if dist is not None:
@@ -143,6 +151,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    if pipe:
+        pipe.flush()                      # the last period's deltas are reduced and merged inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     add(model.collect_stats())
@@ -194,7 +204,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.full_output else "f32", "data": "synthetic",
         "config": {"workload": workload, "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
-                   "exchange": "all-reduce of shared-parameter deltas every step" if args.gpus > 1 else "none"},
+                   "exchange": ("none" if args.gpus == 1 else
+                                f"pipelined all-reduce(sum) of shared-parameter deltas every {args.exchange_every} batches, merged one period late"
+                                if args.exchange_every > 0 else "synchronous all-reduce(sum) of shared-parameter deltas every batch")},
         "roofline": roofline,
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
         "profiled_steps": int(acc["launches_decode"]),

@@ -71,6 +71,9 @@ EXPORTS = {
     "cdae_hip_delta_compute": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_delta_apply": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "cdae_hip_delta_stage": (C.c_int, [C.c_void_p]),
+    "cdae_hip_delta_recv_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "cdae_hip_delta_merge": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None
@@ -294,3 +297,14 @@ class CDAE:
 
     def delta_apply(self, world_size: int, rule: int = 0):
         _chk(self.lib, self.lib.cdae_hip_delta_apply(self.h, world_size, rule))
+
+    def delta_stage(self):
+        _chk(self.lib, self.lib.cdae_hip_delta_stage(self.h))
+
+    def delta_recv_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(self.lib, self.lib.cdae_hip_delta_recv_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def delta_merge(self):
+        _chk(self.lib, self.lib.cdae_hip_delta_merge(self.h))

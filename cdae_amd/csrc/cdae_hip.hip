@@ -130,7 +130,7 @@ struct cdae_hip {
   int sort_bits = 1;
 
   // data-parallel exchange
-  float* d_base = nullptr; float* d_delta = nullptr;
+  float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr;
 
   uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q & 1
   bool pre_valid = false;               // set (seq & 1) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
@@ -197,7 +197,7 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta, h->d_dup_corr};
+                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
@@ -217,7 +217,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_dup_corr};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
@@ -1076,6 +1076,36 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
   HIPCHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(cdae::apply_delta_kernel, dim3((uint32_t)((h->n_shared + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                      h->d_base, h->d_delta, h->d_delta + h->n_shared, h->n_matrix, h->Kp, (uint32_t)h->I, h->n_shared, world_size, rule);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// pipelined variant: see delta_stage_kernel / delta_merge_kernel
+int cdae_hip_delta_stage(cdae_hip_t* h) {
+  if (!h || !h->d_base) return fail("delta_begin must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_recv) {
+    CHK(dev_alloc(&h->d_recv, h->n_shared + 4096));            // slack: collectives may round the count up
+    HIPCHK(hipMemsetAsync(h->d_recv, 0, (h->n_shared + 4096) * sizeof(float), h->stream));
+  }
+  hipLaunchKernelGGL(cdae::delta_stage_kernel, dim3((uint32_t)((h->n_shared / 4 + 3 + 255) / 256)), dim3(256), 0, h->stream,
+                     h->d_shared, h->d_base, h->d_delta, h->d_recv, h->n_shared);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats) {
+  if (!h || !h->d_recv || !device_ptr) return fail("delta_stage must be called first");
+  *device_ptr = h->d_recv;
+  if (count_floats) *count_floats = h->n_shared;
+  return 0;
+}
+
+int cdae_hip_delta_merge(cdae_hip_t* h) {
+  if (!h || !h->d_recv) return fail("delta_stage must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(cdae::delta_merge_kernel, dim3((uint32_t)((h->n_shared / 4 + 3 + 255) / 256)), dim3(256), 0, h->stream,
+                     h->d_shared, h->d_base, h->d_delta, h->d_recv, h->n_shared);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -16,6 +16,7 @@
 // global_load_dwordx{NI} per lane = a fully coalesced 256*NI-byte wave access, with no tail predication.
 // Pad elements are 0 in every parameter / activation (accumulators: 1) and provably stay there.
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -475,14 +476,16 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
 #define CDAE_DECODE_PF 8
 #endif
   constexpr int PF = CDAE_DECODE_PF;   // z rows in flight per wavefront (must divide 64)
-  // cur / nxt: this lane's example word (slot | flags), example index and z-row byte offset of the current /
-  // next chunk.  The byte offset is computed once per chunk by all 64 lanes, so the per-example address is a
-  // v_readlane + a scalar add onto the Z base (32-bit: the batch's Z is at most 4 GiB).
+  // cur / nxt: this lane's example word (slot | flags), example index and z-row byte offset of the current / next
+  // 64-example chunk; the chunk after that is in flight (`far`).  The byte offset is computed once per chunk by all 64
+  // lanes, so the per-example address is a v_readlane + a scalar add onto the Z base (32-bit: the batch's Z is at
+  // most 4 GiB).
   const uint32_t row_bytes = hp.Kp * 4u;
   const char* Zb = reinterpret_cast<const char*>(Z) + (size_t)lo * 4u;
-  uint64_t v0 = beg + lane < end ? sorted_val[beg + lane] : 0ull;
+  const uint64_t v0 = beg + lane < end ? sorted_val[beg + lane] : 0ull;
+  const uint64_t v1 = beg + WAVE + lane < end ? sorted_val[beg + WAVE + lane] : 0ull;
   uint32_t cur_w = (uint32_t)v0, cur_e = (uint32_t)(v0 >> 32), cur_o = (cur_w & SLOT_MASK) * row_bytes;
-  uint32_t nxt_w = 0, nxt_e = 0, nxt_o = 0;
+  uint32_t nxt_w = (uint32_t)v1, nxt_e = (uint32_t)(v1 >> 32), nxt_o = (nxt_w & SLOT_MASK) * row_bytes;
   float z[PF][NI];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
@@ -493,64 +496,99 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
       vload<NI>(z[j], reinterpret_cast<const float*>(Zb + off));
     }
   }
-  CDAE_STAMP();
-  for (uint32_t c0 = beg; c0 < end; c0 += WAVE) {
-    {
-      const uint32_t q = c0 + WAVE + lane;
-      const uint64_t vn = q < end ? sorted_val[q] : 0ull;
-      nxt_w = (uint32_t)vn; nxt_e = (uint32_t)(vn >> 32); nxt_o = (nxt_w & SLOT_MASK) * row_bytes;
+  float gbuf = 0.f;
+  uint32_t c0 = beg;
+  uint32_t look = 0;                   // z offsets of the examples PF ahead: lanes >= PF this chunk's, lanes < PF the next chunk's
+
+  // One example of the row.  FAST (compile-time): the straight-line form used while the row is long — no duplicate in
+  // the group of PF, PF more examples behind it — where the deferred-input case is a 0/1 factor on the step instead of a
+  // branch and the look-ahead address is one v_readlane; the serial chain of a popular row (hundreds of examples per
+  // batch) is what bounds the launch, and each taken branch costs it an instruction-buffer refill.
+  auto example = [&](auto fast_tag, const int t, const uint32_t idx) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
+    if (BIAS_IN_PAD) z[t][NI - 1] += pad_one;                  // the bias element's "z" is 1 (Z's pad elements are 0)
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i += 2) {
+      d0 = fmaf(w[i], z[t][i], d0);
+      if (i + 1 < NI) d1 = fmaf(w[i + 1], z[t][i + 1], d1);
     }
-    const uint32_t cnt = min((uint32_t)WAVE, end - c0);
-    float gbuf = 0.f;
-    for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
+    float y = wave_sum(d0 + d1);
+    if (!BIAS_IN_PAD) y += bias;
+    const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
+    if (!BIAS_IN_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
+    gbuf = lane == idx ? g : gbuf;
+    const bool deferred = (word & INPUT_BIT) && tied;          // cdae.hpp:249-250: the row step waits for the input-row merge
+    if (FAST) {
+      const float m = deferred ? 0.f : 1.f;                    // wave-uniform
 #pragma unroll
-      for (int t = 0; t < PF; ++t) {
-        const uint32_t idx = j0 + t;
-        if (idx < cnt) {                                       // wave-uniform
-          const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
-          if (BIAS_IN_PAD) z[t][NI - 1] += pad_one;            // the bias element's "z" is 1 (Z's pad elements are 0)
-          float dot = 0.f;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) dot = fmaf(w[i], z[t][i], dot);
-          float y = wave_sum(dot);
-          if (!BIAS_IN_PAD) y += bias;
-          const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
-          if (!BIAS_IN_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
-          gbuf = lane == idx ? g : gbuf;
-          if (word & (DUP_PREV_BIT | DUP_NEXT_BIT)) {          // duplicate negative of the same user (rare, wave-uniform)
-            if (word & DUP_PREV_BIT) {
-              // g * (row now - row at the user's first visit): a plain row store into the correction buffer (the
-              // gather adds it to hg_u); fire-and-wait atomics here cost ~25 us per duplicate (measured)
-              const uint32_t di = dup_of_pos[c0 + idx];
-              float corr[NI];
-#pragma unroll
-              for (int i = 0; i < NI; ++i) corr[i] = (pad_lane && i == NI - 1) ? 0.f : g * (w[i] - wref[i]);
-              if (di != DUP_NONE) {
-                vstore<NI>(dup_corr + (size_t)di * hp.Kp + lo, corr);
-              } else {                                         // correction buffer full: slow path
-                float* hc = HGcorr + (size_t)(word & SLOT_MASK) * hp.Kp + lo;
-#pragma unroll
-                for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, corr[i]);
-              }
-              __builtin_amdgcn_s_waitcnt(WAIT_VM0);            // keep the loop's VMEM stream loads-only
-            } else {                                           // first of a run: remember the row at the user's first visit
-#pragma unroll
-              for (int i = 0; i < NI; ++i) wref[i] = w[i];
-            }
-          }
-          if (!(word & INPUT_BIT) || !tied) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
-          } else if (BIAS_IN_PAD) {                            // deferred row step (cdae.hpp:249-250): b' still steps now
-            float bw = w[NI - 1], ba = a[NI - 1];
-            ada_step(hp, bw, ba, fmaf(hp.lambda, bw, g));
-            if (pad_lane) { w[NI - 1] = bw; a[NI - 1] = ba; }
-          }
+      for (int i = 0; i < NI; ++i) {
+        const float mi = (BIAS_IN_PAD && i == NI - 1) ? fmaxf(m, pad_one) : m;   // b' (pad element) always steps
+        float grad = fmaf(g, z[t][i], hp.lambda * w[i]);
+        if (ADAGRAD) {
+          a[i] = fmaf(grad * mi, grad, a[i]);
+          grad = grad * fast_rcp(fast_sqrt(a[i]) + hp.beta);
         }
-        // refill ring slot t with the example PF ahead (clamped to the row's last example; the value is
-        // never consumed past the end).  Issued after the slot's last use so that the load lands in the
-        // same registers and the compiler can wait with a counted vmcnt instead of draining.
-        {
+        w[i] = fmaf(-hp.lr * mi, grad, w[i]);
+      }
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)look, (idx + PF) & 63u);
+      vload<NI>(z[t], reinterpret_cast<const float*>(Zb + off));
+    } else {
+      if (word & (DUP_PREV_BIT | DUP_NEXT_BIT)) {              // duplicate negative of the same user (rare, wave-uniform)
+        if (word & DUP_PREV_BIT) {
+          // g * (row now - row at the user's first visit): a plain row store into the correction buffer (the
+          // gather adds it to hg_u); fire-and-wait atomics here cost ~25 us per duplicate (measured)
+          const uint32_t di = dup_of_pos[c0 + idx];
+          float corr[NI];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) corr[i] = (pad_lane && i == NI - 1) ? 0.f : g * (w[i] - wref[i]);
+          if (di != DUP_NONE) {
+            vstore<NI>(dup_corr + (size_t)di * hp.Kp + lo, corr);
+          } else {                                             // correction buffer full: slow path
+            float* hc = HGcorr + (size_t)(word & SLOT_MASK) * hp.Kp + lo;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) unsafeAtomicAdd(hc + i, corr[i]);
+          }
+          __builtin_amdgcn_s_waitcnt(WAIT_VM0);                // keep the loop's VMEM stream loads-only
+        } else {                                               // first of a run: remember the row at the user's first visit
+#pragma unroll
+          for (int i = 0; i < NI; ++i) wref[i] = w[i];
+        }
+      }
+      if (!deferred) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
+      } else if (BIAS_IN_PAD) {                                // deferred row step: b' still steps now
+        float bw = w[NI - 1], ba = a[NI - 1];
+        ada_step(hp, bw, ba, fmaf(hp.lambda, bw, g));
+        if (pad_lane) { w[NI - 1] = bw; a[NI - 1] = ba; }
+      }
+    }
+  };
+
+  CDAE_STAMP();
+  for (; c0 < end; c0 += WAVE) {
+    // chunk after next: in flight for a whole chunk before anything reads it
+    const uint32_t qf = c0 + 2 * WAVE + lane;
+    const uint64_t far = qf < end ? sorted_val[qf] : 0ull;
+    look = lane < (uint32_t)PF ? nxt_o : cur_o;
+    const unsigned long long dupmask = __ballot((cur_w & (DUP_PREV_BIT | DUP_NEXT_BIT)) != 0u);
+    const uint32_t cnt = min((uint32_t)WAVE, end - c0);
+    gbuf = 0.f;
+    for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
+      const bool fast = c0 + j0 + 2 * PF <= end && ((dupmask >> j0) & ((1ull << PF) - 1ull)) == 0ull;
+      if (fast) {
+#pragma unroll
+        for (int t = 0; t < PF; ++t) example(std::true_type{}, t, j0 + t);
+      } else {
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+          const uint32_t idx = j0 + t;
+          if (idx < cnt) example(std::false_type{}, t, idx);   // wave-uniform
+          // refill ring slot t with the example PF ahead (clamped to the row's last example; the value is never
+          // consumed past the end).  Issued after the slot's last use so that the load lands in the same registers
+          // and the compiler can wait with a counted vmcnt instead of draining.
           const uint32_t rel = min(c0 + idx + PF, end - 1u) - c0;
           const uint32_t off = rel < (uint32_t)WAVE ? (uint32_t)__builtin_amdgcn_readlane((int)cur_o, rel & 63u)
                                                     : (uint32_t)__builtin_amdgcn_readlane((int)nxt_o, rel & 63u);
@@ -563,6 +601,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     if (c0 + WAVE < end) __builtin_amdgcn_s_waitcnt(WAIT_VM0);   // (nothing follows the last chunk but the row's own stores)
     CDAE_STAMP();
     cur_w = nxt_w; cur_e = nxt_e; cur_o = nxt_o;
+    nxt_w = (uint32_t)far; nxt_e = (uint32_t)(far >> 32); nxt_o = (nxt_w & SLOT_MASK) * row_bytes;
   }
   if (BIAS_IN_PAD) {
     if (pad_lane) {
@@ -1239,6 +1278,44 @@ apply_delta_kernel(float* __restrict__ cur, const float* __restrict__ base, cons
     else wgt = 1.f / (float)world_size;
   }
   cur[i] = fmaf(sum[i], wgt, base[i]);
+}
+
+// Pipelined exchange (cdae_hip_delta_stage / _merge): peers' contributions arrive one exchange period late.
+//   stage:  send = recv = cur - base ; base = cur          (recv is all-reduced in place while training continues)
+//   merge:  cur += recv - send ; base += recv - send       (the other ranks' part of the summed delta)
+__global__ void __launch_bounds__(256)
+delta_stage_kernel(const float* __restrict__ cur, float* __restrict__ base, float* __restrict__ send,
+                   float* __restrict__ recv, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
+  if (i < n4) {
+    const float4 c = reinterpret_cast<const float4*>(cur)[i], b = reinterpret_cast<const float4*>(base)[i];
+    const float4 d = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
+    reinterpret_cast<float4*>(send)[i] = d;
+    reinterpret_cast<float4*>(recv)[i] = d;
+    reinterpret_cast<float4*>(base)[i] = c;
+  } else if (i < n4 + n % 4) {                                   // scalar tail
+    const size_t k = 4 * n4 + (i - n4);
+    const float d = cur[k] - base[k];
+    send[k] = d; recv[k] = d; base[k] = cur[k];
+  }
+}
+__global__ void __launch_bounds__(256)
+delta_merge_kernel(float* __restrict__ cur, float* __restrict__ base, const float* __restrict__ send,
+                   const float* __restrict__ recv, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
+  if (i < n4) {
+    const float4 r = reinterpret_cast<const float4*>(recv)[i], o = reinterpret_cast<const float4*>(send)[i];
+    const float4 p = make_float4(r.x - o.x, r.y - o.y, r.z - o.z, r.w - o.w);
+    float4 c = reinterpret_cast<float4*>(cur)[i], b = reinterpret_cast<float4*>(base)[i];
+    c.x += p.x; c.y += p.y; c.z += p.z; c.w += p.w;
+    b.x += p.x; b.y += p.y; b.z += p.z; b.w += p.w;
+    reinterpret_cast<float4*>(cur)[i] = c;
+    reinterpret_cast<float4*>(base)[i] = b;
+  } else if (i < n4 + n % 4) {
+    const size_t k = 4 * n4 + (i - n4);
+    const float p = recv[k] - send[k];
+    cur[k] += p; base[k] += p;
+  }
 }
 
 }  // namespace cdae

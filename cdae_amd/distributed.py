@@ -11,6 +11,12 @@ parameters W, W_ag, (V, V_ag), b', b'_ag, b, b_ag are replicated.  One exchange 
               all-reduce(sum) of ONE contiguous fp32 buffer [delta | touch]   <- the only collective
               current = snapshot + combine(sum)                          (cdae_hip_delta_apply)
 
+`PipelinedDeltaExchange` is the overlapped form used by bench.py for N > 1: every `period` batches the rank stages
+its delta (cdae_hip_delta_stage), starts ONE asynchronous all-reduce of it and keeps training; the other ranks' part of
+the sum is merged (cdae_hip_delta_merge) at the next period boundary, i.e. one period late.  All ranks hold
+initial + sum of all staged deltas once flush() has run.  The all-reduce of the ~22 MB shared block (ML-10M, K=200)
+takes about as long over xGMI as a 512-user batch computes, so the synchronous form cannot scale past ~50 %.
+
 The delta of W is the accumulated -lr * AdaGrad-preconditioned gradient of the rank's examples and the
 delta of W_ag the accumulated squared gradient, so summing them is the data-parallel "all-reduce of the
 shared gradients"; with world_size == 1 the step is the identity.  `combine_reference` restates the
@@ -83,6 +89,90 @@ class DeltaExchange:
             with self.torch.cuda.stream(self.stream):
                 self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM)
         self.model.delta_apply(self.world, self.rule)
+
+
+class PipelinedDeltaExchange:
+    """GPU path, overlapped: stage -> async all-reduce (RCCL's own stream) -> train `period` more batches -> merge."""
+
+    def __init__(self, model, dist, world: int, period: int = 2):
+        import torch
+        self.model, self.dist, self.world, self.period = model, dist, world, max(1, int(period))
+        self.torch = torch
+        model.delta_begin()
+        model.delta_stage()                      # allocates the receive buffer (stages a zero delta)
+        ptr, count = model.delta_recv_device_ptr()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.recv = torch.as_tensor(_DeviceBuffer(ptr, count), device=dev)
+        assert self.recv.data_ptr() == ptr, "torch copied the receive buffer instead of wrapping it"
+        self.stream = torch.cuda.ExternalStream(model.stream_handle(), device=dev)
+        self.work = None
+        self.batches = 0
+
+    def after_batch(self):
+        """Call once after every enqueued batch."""
+        self.batches += 1
+        if self.batches % self.period == 0:
+            self._boundary(start_next=True)
+
+    def _boundary(self, start_next: bool):
+        with self.torch.cuda.stream(self.stream):          # "current stream" = the library's stream
+            if self.work is not None:
+                self.work.wait()                           # stream-level wait, the host does not block
+                self.work = None
+                self.model.delta_merge()
+            if start_next:
+                self.model.delta_stage()
+                if self.world > 1:
+                    self.work = self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM, async_op=True)
+                else:
+                    self.work = _Done()
+
+    def flush(self):
+        """Stage what is left, reduce it and merge: afterwards every rank holds the same shared parameters."""
+        self._boundary(start_next=True)
+        self._boundary(start_next=False)
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class HostPipelinedDeltaExchange:
+    """PipelinedDeltaExchange's protocol on host tensors (gloo): the CPU tests' stand-in for the device kernels."""
+
+    def __init__(self, get_shared, set_shared, dist, world: int, period: int = 2):
+        self.get_shared, self.set_shared, self.dist, self.world = get_shared, set_shared, dist, world
+        self.period = max(1, int(period))
+        self.base = get_shared().clone()
+        self.send = None
+        self.recv = None
+        self.work = None
+        self.batches = 0
+
+    def after_batch(self):
+        self.batches += 1
+        if self.batches % self.period == 0:
+            self._boundary(True)
+
+    def _boundary(self, start_next: bool):
+        if self.recv is not None:
+            if self.work is not None:
+                self.work.wait()
+            peers = self.recv - self.send                       # delta_merge_kernel
+            self.set_shared(self.get_shared() + peers)
+            self.base = self.base + peers
+            self.recv = self.send = self.work = None
+        if start_next:
+            cur = self.get_shared()
+            self.send = cur - self.base                         # delta_stage_kernel
+            self.recv = self.send.clone()
+            self.base = cur.clone()
+            self.work = self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+
+    def flush(self):
+        self._boundary(True)
+        self._boundary(False)
 
 
 class HostDeltaExchange:

@@ -186,6 +186,17 @@ int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_fl
 #define CDAE_DELTA_TOUCH_MEAN 1u  /* item rows / #ranks that touched them, hidden bias / world_size      */
 int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule);
 
+/* Pipelined form of the same exchange (sum rule): the all-reduce of one period's deltas overlaps the next period's
+ * training, and the other ranks' part is folded in one period late.  After cdae_hip_delta_begin():
+ *   cdae_hip_delta_stage : send = recv = current - base ; base = current
+ *   (caller all-reduces the recv buffer, cdae_hip_delta_recv_device_ptr, n floats, asynchronously)
+ *   cdae_hip_delta_merge : current += recv - send ; base += recv - send     (before the next _stage)
+ * Every rank ends at  initial + sum over periods and ranks of the staged deltas  once the last merge has run.
+ * Stream-ordered on cdae_hip_stream like the calls above. */
+int cdae_hip_delta_stage(cdae_hip_t* h);
+int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);
+int cdae_hip_delta_merge(cdae_hip_t* h);
+
 #ifdef __cplusplus
 }
 #endif

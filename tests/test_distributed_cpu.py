@@ -17,8 +17,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from cdae_amd import synth  # noqa: E402
-from cdae_amd.distributed import (HostDeltaExchange, combine_reference, shard_bounds, RULE_SUM,  # noqa: E402
-                                  RULE_TOUCH_MEAN)
+from cdae_amd.distributed import (HostDeltaExchange, HostPipelinedDeltaExchange, combine_reference,  # noqa: E402
+                                  shard_bounds, RULE_SUM, RULE_TOUCH_MEAN)
 
 SHARED = [0, 1, 8, 9, 6, 7]     # W, W_ag, bp, bp_ag, b, b_ag — the library's shared-block order (tied mode)
 K, B, STEPS = 8, 16, 3
@@ -92,6 +92,74 @@ def _emulate(world, rule):
         for o in reps:
             _set_shared(o, new)
     return _get_shared(reps[0]).numpy(), [o.get(4) for o in reps], bounds
+
+
+def _run_rank_pipelined(rank, world, port, period, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = synth.generate_shape("tiny", seed=5)
+    u0, u1 = shard_bounds(data.num_users, world, rank, data.train_ptr)
+    o = _make_oracle(data)
+    ex = HostPipelinedDeltaExchange(lambda: _get_shared(o), lambda t: _set_shared(o, t), dist, world, period=period)
+    for step in range(PIPE_STEPS):
+        s0 = u0 + step * B
+        o.train_batched(9, 0, B, s0, min(u1, s0 + B))
+        ex.after_batch()
+    ex.flush()
+    np.save(os.path.join(out_dir, f"shared_{rank}.npy"), _get_shared(o).numpy())
+    dist.destroy_process_group()
+
+
+PIPE_STEPS = 5
+
+
+def _emulate_pipelined(world, period):
+    """Single-process restatement: rank r trains from its own replica; at every boundary the previous period's peer
+    deltas are merged, then this period's own deltas are staged (they reach the peers one period later)."""
+    data = synth.generate_shape("tiny", seed=5)
+    reps = [_make_oracle(data) for _ in range(world)]
+    bounds = [shard_bounds(data.num_users, world, r, data.train_ptr) for r in range(world)]
+    base = [_get_shared(o) for o in reps]
+    in_flight = None                                  # per-rank deltas staged at the previous boundary
+
+    def boundary(start_next):
+        nonlocal in_flight
+        if in_flight is not None:
+            total = sum(in_flight)
+            for r, o in enumerate(reps):
+                peers = total - in_flight[r]
+                _set_shared(o, _get_shared(o) + peers)
+                base[r] = base[r] + peers
+            in_flight = None
+        if start_next:
+            in_flight = []
+            for r, o in enumerate(reps):
+                cur = _get_shared(o)
+                in_flight.append(cur - base[r])
+                base[r] = cur.clone()
+
+    for step in range(PIPE_STEPS):
+        for r, o in enumerate(reps):
+            u0, u1 = bounds[r]
+            s0 = u0 + step * B
+            o.train_batched(9, 0, B, s0, min(u1, s0 + B))
+        if (step + 1) % period == 0:
+            boundary(True)
+    boundary(True)
+    boundary(False)
+    return [_get_shared(o).numpy() for o in reps]
+
+
+@pytest.mark.parametrize("period", [1, 2])
+def test_two_rank_gloo_pipelined_exchange(built, tmp_path, period):
+    world = 2
+    mp.spawn(_run_rank_pipelined, args=(world, _free_port(), period, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"shared_{r}.npy") for r in range(world)]
+    ref = _emulate_pipelined(world, period)
+    np.testing.assert_allclose(got[0], got[1], rtol=1e-12, atol=1e-14)     # replicas converge after flush()
+    for r in range(world):
+        np.testing.assert_allclose(got[r], ref[r], rtol=1e-12, atol=1e-14)
 
 
 def _free_port():

@@ -159,6 +159,45 @@ def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
         np.testing.assert_allclose(model.get(w), want, rtol=0, atol=2e-6)
 
 
+def test_pipelined_exchange_kernels(tiny):
+    """cdae_hip_delta_stage / _merge with a fake peer: the "all-reduced" buffer is own delta + a known peer delta, which
+    must land on the live parameters one period late while the rank's own later steps are kept."""
+    import torch
+    from cdae_amd.distributed import PipelinedDeltaExchange
+    model, _ = make_pair(tiny, K=20, B=64)
+    shared_ids = (0, 1, 8, 9, 6, 7)
+    ex = PipelinedDeltaExchange(model, None, 1, period=1)
+    x0 = {w: model.get(w).astype(np.float64) for w in shared_ids}
+    model.train_users(seed=2, epoch=0, u_begin=0, u_end=64)
+    x1 = {w: model.get(w).astype(np.float64) for w in shared_ids}
+    model.delta_stage()                                  # send = recv = x1 - x0 ; base = x1
+    model.synchronize()
+    n = model.delta_recv_device_ptr()[1]
+    assert ex.recv.is_cuda and ex.recv.numel() == n
+    with torch.cuda.stream(ex.stream):
+        own = ex.recv.clone()
+        ex.recv.add_(0.25)                               # a peer whose delta is +0.25 everywhere
+    model.train_users(seed=2, epoch=0, u_begin=64, u_end=128)      # training goes on while the "all-reduce" runs
+    x2 = {w: model.get(w).astype(np.float64) for w in shared_ids}
+    model.delta_merge()                                  # x += recv - send
+    model.synchronize()
+    total = 0
+    for w in shared_ids:
+        got = model.get(w).astype(np.float64)
+        np.testing.assert_allclose(got, x2[w] + 0.25, rtol=0, atol=2e-6)
+        total += got.size
+    # the staged delta is exactly x1 - x0 (padded layout: compare the sums of the logical entries)
+    want_sum = sum(float((x1[w] - x0[w]).sum()) for w in shared_ids)
+    assert abs(float(own.double().sum()) - want_sum) < 1e-3 * max(1.0, abs(want_sum))
+    # next stage must not resend the peer's part: delta = own steps since the previous stage only
+    model.delta_stage()
+    model.synchronize()
+    with torch.cuda.stream(ex.stream):
+        s2 = float(ex.recv.double().sum())
+    want2 = sum(float((x2[w] - x1[w]).sum()) for w in shared_ids)
+    assert abs(s2 - want2) < 1e-3 * max(1.0, abs(want2))
+
+
 def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):
     """enqueue_users / prefetch_users only change WHEN work is queued, never the result.  (Equality up to the
     order of the few fp32 atomics that carry duplicate-negative corrections: a few fp32 ulps.)"""
