@@ -158,7 +158,8 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
                  uint32_t* __restrict__ touched) {
   const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;
   if (blockIdx.x < bias_blocks) {
-    hidden_bias_role(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
+    if (hp.adagrad) hidden_bias_role<true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
+    else hidden_bias_role<false>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
     return;
   }
   const uint32_t item = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);

@@ -1005,21 +1005,31 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
 // One thread per coordinate; the recurrence is elementwise, the delta loads run 16 users ahead of it.
 // It needs only delta, like the input rows, so it runs as the leading workgroup(s) of input_rows_kernel
 // instead of a launch of its own.
-__device__ __forceinline__ void hidden_bias_role(const HyperParams& hp, uint32_t k, uint32_t nb,
+template <bool ADAGRAD>
+__device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uint32_t nb,
                                                  const float* __restrict__ DELTA, float* __restrict__ b,
                                                  float* __restrict__ b_ag) {
-  if (k >= hp.Kp) return;
+  if (k >= hp.Kp || nb == 0) return;
+  hp.adagrad = ADAGRAD;
   float p = b[k], acc = b_ag[k];
-  constexpr int UN = 16;
-  uint32_t s = 0;
-  for (; s + UN <= nb; s += UN) {
-    float d[UN];
+  // One dependent AdaGrad chain per coordinate (7 instructions per user) bounds this role: the loop is branch-free —
+  // the next UN users' deltas are loaded (index clamped, never guarded) before the current UN steps run.
+  constexpr uint32_t UN = 16;
+  float d[UN], dn[UN];
 #pragma unroll
-    for (int j = 0; j < UN; ++j) d[j] = DELTA[(size_t)(s + j) * hp.Kp + k];
+  for (uint32_t j = 0; j < UN; ++j) d[j] = DELTA[(size_t)min(j, nb - 1u) * hp.Kp + k];
+  const uint32_t full = nb / UN;
+  for (uint32_t g = 0; g < full; ++g) {
 #pragma unroll
-    for (int j = 0; j < UN; ++j) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
+    for (uint32_t j = 0; j < UN; ++j) dn[j] = DELTA[(size_t)min((g + 1u) * UN + j, nb - 1u) * hp.Kp + k];
+#pragma unroll
+    for (uint32_t j = 0; j < UN; ++j) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
+#pragma unroll
+    for (uint32_t j = 0; j < UN; ++j) d[j] = dn[j];
   }
-  for (; s < nb; ++s) ada_step(hp, p, acc, fmaf(hp.lambda, p, DELTA[(size_t)s * hp.Kp + k]));
+#pragma unroll
+  for (uint32_t j = 0; j < UN; ++j)                            // the last nb % UN users
+    if (full * UN + j < nb) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
   b[k] = p;
   b_ag[k] = acc;
 }
@@ -1029,30 +1039,23 @@ __device__ __forceinline__ void hidden_bias_role(const HyperParams& hp, uint32_t
 //     grad = scale * delta_u + lambda W[j] + g_uj z_u   (the last term is the deferred decoder
 //     gradient input_gradient[j], cdae.hpp:249-250, 342-343; absent when asymmetric)
 // The row's example words are scanned 64 at a time; the kept inputs among them are taken in groups of UN.
-// Two groups are kept in registers: while the (elementwise, reduction-free) AdaGrad chain of group A runs,
-// the delta / z / g loads of group B are in flight (loads-only loop => counted vmcnt, see K3).
+// Three groups are kept in registers: while the (elementwise, reduction-free) AdaGrad chain of one runs, the
+// delta / z / g loads of the next two are in flight (loads-only loop => counted vmcnt, see K3).
 template <int NI, int UN>
 struct InputGroup {
   float dl[UN][NI], zz[UN][NI], gg[UN];
   bool on[UN];
 };
 
-template <int NI>
-__global__ void __launch_bounds__(256)
-input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
-                  const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
-                  const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
-                  const float* __restrict__ DELTA, const float* __restrict__ G,
-                  float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched,
-                  uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag) {
-  const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
-  if (blockIdx.x < bias_blocks) {
-    hidden_bias_role(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
-    return;
-  }
-  const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+template <int NI, bool ADAGRAD>
+__device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t rank, const uint32_t* __restrict__ item_order,
+                                               const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                                               const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
+                                               const float* __restrict__ DELTA, const float* __restrict__ G,
+                                               float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched) {
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
+  hp.adagrad = ADAGRAD;
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   if (beg == end) return;
@@ -1114,20 +1117,48 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
     }
   };
 
-  InputGroup<NI, UN> A, B;
+  // three groups in a ring: while one group's (elementwise, reduction-free) AdaGrad chain runs, the delta / z / g loads
+  // of the next two are in flight — a popular row has > 100 kept inputs per batch and one L2 round trip per group
+  // would otherwise bound the launch
+  InputGroup<NI, UN> A, B, C;
   bool hasA = fetch(A);
+  bool hasB = hasA && fetch(B);
+  bool hasC = hasB && fetch(C);
   while (hasA) {
-    const bool hasB = fetch(B);
     apply(A);
+    hasA = hasC && fetch(A);
     if (!hasB) break;
-    hasA = fetch(A);
     apply(B);
+    hasB = hasA && fetch(B);
+    if (!hasC) break;
+    apply(C);
+    hasC = hasB && fetch(C);
   }
   if (loaded) {
     vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
     vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
     if (lane == 0 && touched) touched[item] = 1u;
   }
+}
+
+template <int NI>
+__global__ void __launch_bounds__(256)
+input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
+                  const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                  const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
+                  const float* __restrict__ DELTA, const float* __restrict__ G,
+                  float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched,
+                  uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag) {
+  const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
+  if (blockIdx.x < bias_blocks) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hp.adagrad) hidden_bias_role<true>(hp, k, nb, DELTA, b, b_ag);
+    else hidden_bias_role<false>(hp, k, nb, DELTA, b, b_ag);
+    return;
+  }
+  const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
+  if (hp.adagrad) input_row_role<NI, true>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA, G, W, W_ag, touched);
+  else input_row_role<NI, false>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA, G, W, W_ag, touched);
 }
 
 // ------------------------------------------------------------------------------------------------
