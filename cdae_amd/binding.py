@@ -74,6 +74,7 @@ EXPORTS = {
     "cdae_hip_delta_stage": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_recv_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_delta_merge": (C.c_int, [C.c_void_p]),
+    "cdae_hip_delta_merge_stage": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None
@@ -308,3 +309,6 @@ class CDAE:
 
     def delta_merge(self):
         _chk(self.lib, self.lib.cdae_hip_delta_merge(self.h))
+
+    def delta_merge_stage(self):
+        _chk(self.lib, self.lib.cdae_hip_delta_merge_stage(self.h))

@@ -1110,4 +1110,13 @@ int cdae_hip_delta_merge(cdae_hip_t* h) {
   return 0;
 }
 
+int cdae_hip_delta_merge_stage(cdae_hip_t* h) {
+  if (!h || !h->d_recv) return fail("delta_stage must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(cdae::delta_merge_stage_kernel, dim3((uint32_t)((h->n_shared / 4 + 3 + 255) / 256)), dim3(256), 0, h->stream,
+                     h->d_shared, h->d_base, h->d_delta, h->d_recv, h->n_shared);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -1349,4 +1349,25 @@ delta_merge_kernel(float* __restrict__ cur, float* __restrict__ base, const floa
   }
 }
 
+// merge of the previous period and stage of this one in a single pass over the block (8 row streams instead of 11)
+__global__ void __launch_bounds__(256)
+delta_merge_stage_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ send,
+                         float* __restrict__ recv, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
+  if (i < n4) {
+    const float4 r = reinterpret_cast<const float4*>(recv)[i], o = reinterpret_cast<const float4*>(send)[i];
+    const float4 c = reinterpret_cast<const float4*>(cur)[i], b = reinterpret_cast<const float4*>(base)[i];
+    const float4 d = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);                     // own steps of this period
+    const float4 x = make_float4(c.x + (r.x - o.x), c.y + (r.y - o.y), c.z + (r.z - o.z), c.w + (r.w - o.w));
+    reinterpret_cast<float4*>(cur)[i] = x;
+    reinterpret_cast<float4*>(base)[i] = x;
+    reinterpret_cast<float4*>(send)[i] = d;
+    reinterpret_cast<float4*>(recv)[i] = d;
+  } else if (i < n4 + n % 4) {
+    const size_t k = 4 * n4 + (i - n4);
+    const float d = cur[k] - base[k], x = cur[k] + (recv[k] - send[k]);
+    cur[k] = x; base[k] = x; send[k] = d; recv[k] = d;
+  }
+}
+
 }  // namespace cdae

@@ -116,12 +116,17 @@ class PipelinedDeltaExchange:
 
     def _boundary(self, start_next: bool):
         with self.torch.cuda.stream(self.stream):          # "current stream" = the library's stream
-            if self.work is not None:
+            pending = self.work is not None
+            if pending:
                 self.work.wait()                           # stream-level wait, the host does not block
                 self.work = None
+            if pending and start_next:
+                self.model.delta_merge_stage()             # one pass over the block instead of two
+            elif pending:
                 self.model.delta_merge()
-            if start_next:
+            elif start_next:
                 self.model.delta_stage()
+            if start_next:
                 if self.world > 1:
                     self.work = self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM, async_op=True)
                 else:

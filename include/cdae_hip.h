@@ -196,6 +196,7 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule);
 int cdae_hip_delta_stage(cdae_hip_t* h);
 int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);
 int cdae_hip_delta_merge(cdae_hip_t* h);
+int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous period then _stage of this one, in one pass */
 
 #ifdef __cplusplus
 }

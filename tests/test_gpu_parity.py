@@ -160,42 +160,52 @@ def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
 
 
 def test_pipelined_exchange_kernels(tiny):
-    """cdae_hip_delta_stage / _merge with a fake peer: the "all-reduced" buffer is own delta + a known peer delta, which
-    must land on the live parameters one period late while the rank's own later steps are kept."""
+    """cdae_hip_delta_stage / _merge / _merge_stage with a fake peer: the "all-reduced" buffer is a multiple of the rank's
+    own staged delta (so the row pads stay zero, as with real peers); the peer part must land on the live parameters one
+    period late while the rank's own later steps are kept, and must never be re-sent."""
     import torch
     from cdae_amd.distributed import PipelinedDeltaExchange
     model, _ = make_pair(tiny, K=20, B=64)
     shared_ids = (0, 1, 8, 9, 6, 7)
     ex = PipelinedDeltaExchange(model, None, 1, period=1)
-    x0 = {w: model.get(w).astype(np.float64) for w in shared_ids}
+
+    def snap():
+        return {w: model.get(w).astype(np.float64) for w in shared_ids}
+
+    def staged_sum():
+        model.synchronize()
+        with torch.cuda.stream(ex.stream):
+            return float(ex.recv.double().sum())
+
+    def close(a, b):
+        return abs(a - b) < 1e-3 * max(1.0, abs(b))
+
+    x0 = snap()
     model.train_users(seed=2, epoch=0, u_begin=0, u_end=64)
-    x1 = {w: model.get(w).astype(np.float64) for w in shared_ids}
-    model.delta_stage()                                  # send = recv = x1 - x0 ; base = x1
-    model.synchronize()
-    n = model.delta_recv_device_ptr()[1]
-    assert ex.recv.is_cuda and ex.recv.numel() == n
+    x1 = snap()
+    model.delta_stage()                                  # send = recv = d1 = x1 - x0 ; base = x1
+    assert ex.recv.is_cuda and ex.recv.numel() == model.delta_recv_device_ptr()[1]
+    assert close(staged_sum(), sum(float((x1[w] - x0[w]).sum()) for w in shared_ids))
     with torch.cuda.stream(ex.stream):
-        own = ex.recv.clone()
-        ex.recv.add_(0.25)                               # a peer whose delta is +0.25 everywhere
+        ex.recv.mul_(3.0)                                # "all-reduce": two peers with the same delta -> their part is 2 d1
     model.train_users(seed=2, epoch=0, u_begin=64, u_end=128)      # training goes on while the "all-reduce" runs
-    x2 = {w: model.get(w).astype(np.float64) for w in shared_ids}
+    x2 = snap()
     model.delta_merge()                                  # x += recv - send
     model.synchronize()
-    total = 0
+    x3 = snap()
     for w in shared_ids:
-        got = model.get(w).astype(np.float64)
-        np.testing.assert_allclose(got, x2[w] + 0.25, rtol=0, atol=2e-6)
-        total += got.size
-    # the staged delta is exactly x1 - x0 (padded layout: compare the sums of the logical entries)
-    want_sum = sum(float((x1[w] - x0[w]).sum()) for w in shared_ids)
-    assert abs(float(own.double().sum()) - want_sum) < 1e-3 * max(1.0, abs(want_sum))
-    # next stage must not resend the peer's part: delta = own steps since the previous stage only
-    model.delta_stage()
-    model.synchronize()
+        np.testing.assert_allclose(x3[w], x2[w] + 2.0 * (x1[w] - x0[w]), rtol=1e-6, atol=5e-6)
+    model.delta_stage()                                  # stages d2 = x2 - x1 only: the peers' part is not re-sent
+    assert close(staged_sum(), sum(float((x2[w] - x1[w]).sum()) for w in shared_ids))
     with torch.cuda.stream(ex.stream):
-        s2 = float(ex.recv.double().sum())
-    want2 = sum(float((x2[w] - x1[w]).sum()) for w in shared_ids)
-    assert abs(s2 - want2) < 1e-3 * max(1.0, abs(want2))
+        ex.recv.mul_(0.5)                                # peers' part of this period: -0.5 d2
+    model.train_users(seed=2, epoch=0, u_begin=128, u_end=192)
+    x4 = snap()
+    model.delta_merge_stage()                            # fused boundary: merge the above, stage d3 = x4 - x3
+    model.synchronize()
+    for w in shared_ids:
+        np.testing.assert_allclose(model.get(w).astype(np.float64), x4[w] - 0.5 * (x2[w] - x1[w]), rtol=1e-6, atol=5e-6)
+    assert close(staged_sum(), sum(float((x4[w] - x3[w]).sum()) for w in shared_ids))
 
 
 def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):
