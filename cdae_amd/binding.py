@@ -21,7 +21,7 @@ SQUARE, LOGISTIC, LOG, HINGE, SQUARED_HINGE, CROSS_ENTROPY, LOGM = range(7)
 
 P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG = range(10)
 
-DEFAULT_BATCH_USERS = 1024
+DEFAULT_BATCH_USERS = 0        # 0 = the library's default (num_users / 160, within [32, 512])
 
 
 class _Config(C.Structure):

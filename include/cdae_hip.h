@@ -75,6 +75,7 @@ typedef struct cdae_hip_config {
   uint32_t tanh_act;         /* cdae.hpp:30                                                */
   uint32_t batch_users;      /* users whose encode sees the same parameter snapshot; 1 ==  */
                              /* the reference's strictly sequential schedule; 0 -> default */
+                             /* (num_users/160 rounded to 32, within [32, 512])            */
   uint32_t full_output;      /* 1: every unrated item is a negative with target 0 (north-star */
                              /* extension; num_neg is ignored): dense decode on the MFMA cores, */
                              /* per-block summed decoder gradient            */
