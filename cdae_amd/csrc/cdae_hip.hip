@@ -88,6 +88,7 @@ struct cdae_hip {
   uint32_t hot_rows = 0;            // decode: rows [0, hot_rows) of item_order get a wavefront of their own
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: developer switch, every row on the 64-lane path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
+  uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
   uint32_t* d_unit_ptr = nullptr;
   uint32_t unit_cap = 0;                // most units in any window of batch_users users
   float* d_Hpart = nullptr;             // [unit_cap][Kp] encode partial sums
@@ -197,7 +198,7 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr};
+                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
@@ -217,7 +218,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
@@ -250,7 +251,7 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   const uint32_t n_units = units_of(h, bt);
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
-                     x.seg, 2u * I, x.dup_count, x.dup_of_ex);
+                     x.seg, 2u * I, x.dup_count, x.dup_of_ex, h->d_unit_user);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st));
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
@@ -291,7 +292,8 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
   const dim3 grid_units((n_units + 3) / 4);
   DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
-              (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit);
+              (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
+              explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
               (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG);
   CHK(pr.end());
@@ -352,7 +354,8 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
 
   CHK(pr.begin(h, F_HIDDEN, st));
   DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
-              x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr);
+              x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr,
+              explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
               h->d_Wu, h->d_Wu_ag, 1u);
   CHK(pr.end());
@@ -386,7 +389,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   CHK(pr.begin(h, F_ENCODE, st));
   DISPATCH_NI(h->NI, encode_partial_kernel, dim3((n_units + 3) / 4), blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr,
               n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart,
-              (const uint32_t*)nullptr, 0u);
+              (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
               (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG);
   CHK(pr.end());
@@ -447,7 +450,7 @@ int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, 
   if (n_units > h->unit_cap) return fail("%u work units exceed the capacity %u", n_units, h->unit_cap);
   DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
               h->P(CDAE_P_W), uptr, n_units, d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Hpart,
-              (const uint32_t*)nullptr, 0u);
+              (const uint32_t*)nullptr, 0u, d_uids ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, h->d_Wu,
               h->P(CDAE_P_B), d_uids, u0, nb, mode, h->d_Z, (float*)nullptr, (float*)nullptr);
   HIPCHK(hipGetLastError());
@@ -631,6 +634,13 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   }
   CHK(dev_alloc(&h->d_unit_ptr, U + 1));
   HIPCHK(hipMemcpy(h->d_unit_ptr, h->h_unit_ptr.data(), (U + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> unit_user(h->h_unit_ptr[U]);
+    for (uint64_t u = 0; u < U; ++u)
+      for (uint32_t g = h->h_unit_ptr[u]; g < h->h_unit_ptr[u + 1]; ++g) unit_user[g] = (uint32_t)u;
+    CHK(dev_alloc(&h->d_unit_user, std::max<size_t>(unit_user.size(), 1)));
+    HIPCHK(hipMemcpy(h->d_unit_user, unit_user.data(), unit_user.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   CHK(dev_alloc(&h->d_Hpart, (size_t)h->unit_cap * h->Kp));
   CHK(dev_alloc(&h->d_uptr_tmp, (size_t)B + 1));
   {

@@ -149,11 +149,16 @@ constexpr uint32_t UNIT_POS = 128;
 
 struct UnitRef { uint32_t slot, p0, p1; };   // user slot and the positive range [p0, p1) of the unit
 
-__device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g) {
+__device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g,
+                                               const uint32_t* __restrict__ unit_user = nullptr, uint64_t u0 = 0) {
   uint32_t lo = 0, hi = nb;                      // largest slot with uptr[slot] <= g
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (uptr[mid] <= g) lo = mid; else hi = mid;
+  if (unit_user) {                               // `uptr` is a window of the data set's own prefix: one table look-up
+    lo = unit_user[g] - (uint32_t)u0;            // instead of log2(nb) dependent loads at the head of every wavefront
+  } else {
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (uptr[mid] <= g) lo = mid; else hi = mid;
+    }
   }
   UnitRef r;
   r.slot = lo;
@@ -184,7 +189,8 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               uint64_t seed, uint32_t epoch, uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val,
               uint16_t* __restrict__ ex_key16 /* sort key copy when num_items <= 65536, else nullptr */,
               uint32_t* __restrict__ seg /* [seg_words] cleared here for segment_kernel */, uint32_t seg_words,
-              uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex) {
+              uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
+              const uint32_t* __restrict__ unit_user /* global unit -> user id */) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
@@ -193,7 +199,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit);
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint32_t slot = ur.slot;
   const uint64_t uid = u0 + slot;
   const int64_t r0 = row_ptr[uid];
@@ -311,11 +317,12 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
                       const float* __restrict__ W, const uint32_t* __restrict__ uptr, uint32_t n_units,
                       const uint32_t* __restrict__ uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream,
                       uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Hpart,
-                      const uint32_t* __restrict__ explicit_in, uint32_t n_explicit) {
+                      const uint32_t* __restrict__ explicit_in, uint32_t n_explicit,
+                      const uint32_t* __restrict__ unit_user /* nullptr unless uptr is a window of the data set's prefix */) {
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit);
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = uids ? (uint64_t)uids[ur.slot] : u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = explicit_in ? n_explicit : (uint32_t)(row_ptr[uid + 1] - r0);
@@ -499,6 +506,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
   float gbuf = 0.f;
   uint32_t c0 = beg;
   uint32_t look = 0;                   // z offsets of the examples PF ahead: lanes >= PF this chunk's, lanes < PF the next chunk's
+  float cur_t = 0.f;                   // this lane's example target (1 positive / 0 negative) of the current chunk
 
   // One example of the row.  FAST (compile-time): the straight-line form used while the row is long — no duplicate in
   // the group of PF, PF more examples behind it — where the deferred-input case is a 0/1 factor on the step instead of a
@@ -516,21 +524,21 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     }
     float y = wave_sum(d0 + d1);
     if (!BIAS_IN_PAD) y += bias;
-    const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
+    const float tgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_t), idx));
+    const float g = loss_grad(hp.loss_type, y, tgt);
     if (!BIAS_IN_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
     gbuf = lane == idx ? g : gbuf;
     const bool deferred = (word & INPUT_BIT) && tied;          // cdae.hpp:249-250: the row step waits for the input-row merge
     if (FAST) {
-      const float m = deferred ? 0.f : 1.f;                    // wave-uniform
+      // two straight-line bodies behind one wave-uniform branch: a deferred example (a kept input of its user, ~40 % of a
+      // popular row's examples) only steps b'
+      if (!deferred) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const float mi = (BIAS_IN_PAD && i == NI - 1) ? fmaxf(m, pad_one) : m;   // b' (pad element) always steps
-        float grad = fmaf(g, z[t][i], hp.lambda * w[i]);
-        if (ADAGRAD) {
-          a[i] = fmaf(grad * mi, grad, a[i]);
-          grad = grad * fast_rcp(fast_sqrt(a[i]) + hp.beta);
-        }
-        w[i] = fmaf(-hp.lr * mi, grad, w[i]);
+        for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
+      } else if (BIAS_IN_PAD) {
+        float bw = w[NI - 1], ba = a[NI - 1];
+        ada_step(hp, bw, ba, fmaf(hp.lambda, bw, g));
+        if (pad_lane) { w[NI - 1] = bw; a[NI - 1] = ba; }
       }
       const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)look, (idx + PF) & 63u);
       vload<NI>(z[t], reinterpret_cast<const float*>(Zb + off));
@@ -573,6 +581,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     const uint32_t qf = c0 + 2 * WAVE + lane;
     const uint64_t far = qf < end ? sorted_val[qf] : 0ull;
     look = lane < (uint32_t)PF ? nxt_o : cur_o;
+    cur_t = (cur_w & TARGET_BIT) ? 1.f : 0.f;
     const unsigned long long dupmask = __ballot((cur_w & (DUP_PREV_BIT | DUP_NEXT_BIT)) != 0u);
     const uint32_t cnt = min((uint32_t)WAVE, end - c0);
     gbuf = 0.f;
@@ -885,12 +894,13 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
                      const float* __restrict__ G, const float* __restrict__ D0,
                      float* __restrict__ HGpart /* [8][n_units][Kp] */,
                      uint32_t explicit_examples /* != 0: one user, one unit, that many examples */,
-                     const uint32_t* __restrict__ dup_of_ex, const float* __restrict__ dup_corr) {
+                     const uint32_t* __restrict__ dup_of_ex, const float* __restrict__ dup_corr,
+                     const uint32_t* __restrict__ unit_user) {
   const uint32_t part = blockIdx.x & 7u;
   const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit);
+  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
@@ -902,19 +912,31 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   const uint32_t neg0 = n + p0 * hp.num_neg;
   const uint32_t n_ex = n_posu + n_negu;
   const uint32_t lo = lane * NI;
+  // pad lanes (lo >= K, e.g. 14 of 64 at K = 200) re-read lane 0's bytes instead of the row's zero padding: same cache
+  // line, no extra L2 traffic (-22 % at K = 200); their sums are discarded at the end
+  const uint32_t lo_ld = lo < hp.K ? lo : 0u;
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   constexpr int UN = 8;
-  for (uint32_t c0 = 0; c0 < n_ex; c0 += WAVE) {
-    const uint32_t v = c0 + lane;
+  // this lane's (item, g, correction row) of a 64-example chunk; the next chunk is loaded before the current one's rows
+  // are gathered, so a wavefront pays one L2 round trip per chunk, not two
+  auto load_chunk = [&](uint32_t c, uint32_t& item, float& g, uint32_t& di) {
+    const uint32_t v = c + lane;
     const uint32_t e = v < n_posu ? p0 + v : neg0 + (v - n_posu);
-    const uint32_t my_item = v < n_ex ? ex_item[base + e] : 0xFFFFFFFFu;
-    const float my_g = v < n_ex ? G[base + e] : 0.f;
-    const bool mine = v < n_ex && (my_item & 7u) == part;
+    const bool in = v < n_ex;
+    item = in ? ex_item[base + e] : 0xFFFFFFFFu;
+    g = in ? G[base + e] : 0.f;
+    di = in ? dup_of_ex[base + e] : DUP_NONE;
+  };
+  uint32_t my_item, my_di, nx_item = 0xFFFFFFFFu, nx_di = DUP_NONE;
+  float my_g, nx_g = 0.f;
+  load_chunk(0, my_item, my_g, my_di);
+  for (uint32_t c0 = 0; c0 < n_ex; c0 += WAVE) {
+    if (c0 + WAVE < n_ex) load_chunk(c0 + WAVE, nx_item, nx_g, nx_di);
+    const bool mine = my_item != 0xFFFFFFFFu && (my_item & 7u) == part;
     unsigned long long mask = __ballot(mine);
     // duplicate negatives (rare): add decode's correction rows, in example order
-    const uint32_t my_di = v < n_ex ? dup_of_ex[base + e] : DUP_NONE;
     unsigned long long dmask = __ballot(mine && my_di != DUP_NONE);
     while (dmask) {
       float cr[UN][NI];
@@ -925,7 +947,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
         if (dmask) {                                           // wave-uniform
           const int src = __ffsll((long long)dmask) - 1;
           dmask &= dmask - 1;
-          vload<NI>(cr[t], dup_corr + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_di, src) * hp.Kp + lo);
+          vload<NI>(cr[t], dup_corr + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_di, src) * hp.Kp + lo_ld);
         }
       }
 #pragma unroll
@@ -942,7 +964,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
           mask &= mask - 1;
           const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)my_item, src);
           gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), src));
-          vload<NI>(vv[t], D0 + (size_t)it * hp.Kp + lo);
+          vload<NI>(vv[t], D0 + (size_t)it * hp.Kp + lo_ld);
         } else {
           gg[t] = 0.f;
 #pragma unroll
@@ -954,6 +976,12 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[i] = fmaf(gg[t], vv[t][i], acc[i]);
     }
+    my_item = nx_item; my_g = nx_g; my_di = nx_di;
+    nx_item = 0xFFFFFFFFu; nx_g = 0.f; nx_di = DUP_NONE;
+  }
+  if (lo >= hp.K) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   }
   vstore<NI>(HGpart + ((size_t)part * n_units + unit) * hp.Kp + lo, acc);
 }
