@@ -127,7 +127,7 @@ class PipelinedDeltaExchange:
             elif start_next:
                 self.model.delta_stage()
             if start_next:
-                if self.world > 1:
+                if self.dist is not None:                  # also with one rank: same stream semantics, RCCL no-op
                     self.work = self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM, async_op=True)
                 else:
                     self.work = _Done()

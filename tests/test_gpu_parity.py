@@ -208,6 +208,34 @@ def test_pipelined_exchange_kernels(tiny):
     assert close(staged_sum(), sum(float((x4[w] - x3[w]).sum()) for w in shared_ids))
 
 
+def test_pipelined_exchange_over_rccl_single_rank(tiny):
+    """The real collective path with a one-rank RCCL group: async all_reduce on the wrapped library stream, stream-level
+    wait, merge.  With one rank the sum is the rank's own delta, so training must be unaffected by the exchange."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if not dist.is_nccl_available():
+        pytest.skip("no RCCL in this torch build")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        from cdae_amd.distributed import PipelinedDeltaExchange
+        a, _ = make_pair(tiny, K=24, B=32)
+        b, _ = make_pair(tiny, K=24, B=32)
+        ex = PipelinedDeltaExchange(a, dist, 1, period=2)
+        for i in range(5):
+            a.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
+            ex.after_batch()
+            b.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
+        ex.flush()
+        a.synchronize(); b.synchronize()
+        torch.cuda.synchronize()
+        for which in (0, 1, 6, 7, 8, 9):
+            np.testing.assert_allclose(a.get(which), b.get(which), rtol=2e-6, atol=2e-6)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):
     """enqueue_users / prefetch_users only change WHEN work is queued, never the result.  (Equality up to the
     order of the few fp32 atomics that carry duplicate-negative corrections: a few fp32 ulps.)"""
