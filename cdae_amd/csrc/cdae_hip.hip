@@ -21,6 +21,7 @@
 #include "../../include/cdae_hip.h"
 #include "cdae_kernels.hpp"
 #include "cdae_full_kernels.hpp"
+#include "cdae_recommend_kernels.hpp"
 
 #ifdef CDAE_DECODE_TIMING
 #define CDAE_TOUCHED_ARG ((uint32_t*)nullptr)     // the timing build borrows `touched` for its stamps
@@ -128,6 +129,8 @@ struct cdae_hip {
   double* d_scalar = nullptr;
   uint32_t* d_uids = nullptr;
   uint32_t* d_rec = nullptr; size_t rec_cap = 0;
+  float* d_zeval = nullptr; float* d_hpart_eval = nullptr; uint32_t eval_cap = 0, eval_unit_cap = 0;   // evaluation workspace
+  uint32_t* d_bits = nullptr; size_t bits_cap = 0;                                                     // recommend: rated-item bitmap
   int sort_bits = 1;
 
   // data-parallel exchange
@@ -198,7 +201,7 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user};
+                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
@@ -218,7 +221,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
@@ -226,6 +229,7 @@ int free_interaction_state(cdae_hip* h) {
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   h->rec_cap = 0;
+  h->eval_cap = 0; h->eval_unit_cap = 0; h->bits_cap = 0;
   return 0;
 }
 
@@ -444,16 +448,37 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 
 // z for nb users: a contiguous range [u0, u0+nb) (d_uids == nullptr) or the list d_uids (prefix in d_uptr_tmp)
 int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream_id,
-                 uint32_t cidx, uint64_t seed, uint32_t epoch, uint32_t n_units_list = 0) {
+                 uint32_t cidx, uint64_t seed, uint32_t epoch, uint32_t n_units_list = 0, float* z_out = nullptr,
+                 float* hpart = nullptr, uint32_t hpart_cap = 0) {
   const uint32_t n_units = d_uids ? n_units_list : h->h_unit_ptr[u0 + nb] - h->h_unit_ptr[u0];
   const uint32_t* uptr = d_uids ? h->d_uptr_tmp : h->d_unit_ptr + u0;
-  if (n_units > h->unit_cap) return fail("%u work units exceed the capacity %u", n_units, h->unit_cap);
+  if (!hpart) { hpart = h->d_Hpart; hpart_cap = h->unit_cap; }
+  if (n_units > hpart_cap) return fail("%u work units exceed the capacity %u", n_units, hpart_cap);
   DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
-              h->P(CDAE_P_W), uptr, n_units, d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, h->d_Hpart,
+              h->P(CDAE_P_W), uptr, n_units, d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, hpart,
               (const uint32_t*)nullptr, 0u, d_uids ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
-  DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, h->d_Wu,
-              h->P(CDAE_P_B), d_uids, u0, nb, mode, h->d_Z, (float*)nullptr, (float*)nullptr);
+  DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, hpart, uptr, h->d_Wu,
+              h->P(CDAE_P_B), d_uids, u0, nb, mode, z_out ? z_out : h->d_Z, (float*)nullptr, (float*)nullptr);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Evaluation workspace (data_loss, recommend): z rows and encode partial sums for up to EVAL_CHUNK users per launch — the
+// training workspace holds only batch_users of them, far too few wavefronts to fill the chip.
+constexpr uint32_t EVAL_CHUNK = 32768;
+int ensure_eval_ws(cdae_hip* h, uint32_t users, uint32_t units) {
+  if (h->eval_cap < users) {
+    if (h->d_zeval) HIPCHK(hipFree(h->d_zeval));
+    h->d_zeval = nullptr; h->eval_cap = 0;
+    CHK(dev_alloc(&h->d_zeval, (size_t)users * h->Kp));
+    h->eval_cap = users;
+  }
+  if (h->eval_unit_cap < units) {
+    if (h->d_hpart_eval) HIPCHK(hipFree(h->d_hpart_eval));
+    h->d_hpart_eval = nullptr; h->eval_unit_cap = 0;
+    CHK(dev_alloc(&h->d_hpart_eval, (size_t)units * h->Kp));
+    h->eval_unit_cap = units;
+  }
   return 0;
 }
 
@@ -918,13 +943,14 @@ int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out
   if (!h || !h->d_shared || !out) return fail("bad argument");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
-  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
-  for (uint64_t s0 = 0; s0 < h->U; s0 += B) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, h->U - s0);
+  for (uint64_t s0 = 0; s0 < h->U; s0 += EVAL_CHUNK) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(EVAL_CHUNK, h->U - s0);
+    const uint32_t n_units = h->h_unit_ptr[s0 + nb] - h->h_unit_ptr[s0];
+    CHK(ensure_eval_ws(h, nb, n_units));
     for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) {       // cdae.hpp:86
-      CHK(encode_chunk(h, nullptr, s0, nb, 1, CDAE_STREAM_LOSS_CORRUPT, c, seed, epoch));
-      DISPATCH_NI(h->NI, cdae::data_loss_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
-                  s0, nb, h->d_Z, h->dec(), h->P(CDAE_P_BP), h->d_scalar);
+      CHK(encode_chunk(h, nullptr, s0, nb, 1, CDAE_STREAM_LOSS_CORRUPT, c, seed, epoch, 0, h->d_zeval, h->d_hpart_eval, h->eval_unit_cap));
+      DISPATCH_NI(h->NI, cdae::data_loss_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+                  h->d_unit_ptr + s0, n_units, (const uint32_t*)h->d_unit_user, s0, nb, h->d_zeval, h->dec(), h->P(CDAE_P_BP), h->d_scalar);
     }
   }
   HIPCHK(hipGetLastError());
@@ -962,6 +988,46 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
   if (u_begin > u_end || u_end > h->U) return fail("bad user range");
   if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
   HIPCHK(hipSetDevice(h->device));
+  if (topk <= (uint32_t)cdae::REC_TOPK_MAX && h->K <= 256 && !std::getenv("CDAE_RECOMMEND_PER_USER")) {
+    // matrix-core path: all users of a chunk in one launch (cdae_recommend_kernels.hpp)
+    const uint32_t nch = h->K <= 32 ? 4 : (h->K <= 64 ? 8 : (h->K <= 128 ? 16 : (h->K <= 200 ? 25 : 32)));
+    const uint32_t words = (uint32_t)((h->I + 31) / 32);
+    const uint64_t n_all = u_end - u_begin;
+    const uint32_t UC = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_all, 1), EVAL_CHUNK);
+    if (h->bits_cap < (size_t)UC * words) {
+      if (h->d_bits) HIPCHK(hipFree(h->d_bits));
+      h->d_bits = nullptr; h->bits_cap = 0;
+      CHK(dev_alloc(&h->d_bits, (size_t)UC * words));
+      h->bits_cap = (size_t)UC * words;
+    }
+    if (h->rec_cap < (size_t)UC * topk) {
+      if (h->d_rec) HIPCHK(hipFree(h->d_rec));
+      h->d_rec = nullptr; h->rec_cap = 0;
+      CHK(dev_alloc(&h->d_rec, (size_t)UC * topk));
+      h->rec_cap = (size_t)UC * topk;
+    }
+    const size_t lds = cdae::recommend_mfma_lds_bytes((int)nch);
+    for (uint64_t c0 = u_begin; c0 < u_end; c0 += UC) {
+      const uint32_t nu = (uint32_t)std::min<uint64_t>(UC, u_end - c0);
+      CHK(ensure_eval_ws(h, nu, h->h_unit_ptr[c0 + nu] - h->h_unit_ptr[c0]));
+      HIPCHK(hipMemsetAsync(h->d_bits, 0, (size_t)nu * words * sizeof(uint32_t), h->stream));
+      hipLaunchKernelGGL(cdae::rated_bits_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->d_row_ptr, h->d_col, c0, nu, words, h->d_bits);
+      CHK(encode_chunk(h, nullptr, c0, nu, 0, CDAE_STREAM_CORRUPT, 0, 0, 0, 0, h->d_zeval, h->d_hpart_eval, h->eval_unit_cap));   // cdae.hpp:167-172, full rows
+      const dim3 grid((nu + cdae::REC_USERS_PER_BLOCK - 1) / cdae::REC_USERS_PER_BLOCK);
+#define REC_LAUNCH(NCH_)                                                                                                              \
+  do {                                                                                                                                \
+    HIPCHK(hipFuncSetAttribute((const void*)cdae::recommend_mfma_kernel<NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(cdae::recommend_mfma_kernel<NCH_>, grid, dim3(256), lds, h->stream, h->hp, h->d_zeval, nu, h->dec(),           \
+                       h->P(CDAE_P_BP), h->d_bits, words, topk, h->d_rec);                                                           \
+  } while (0)
+      switch (nch) { case 4: REC_LAUNCH(4); break; case 8: REC_LAUNCH(8); break; case 16: REC_LAUNCH(16); break; case 25: REC_LAUNCH(25); break; default: REC_LAUNCH(32); break; }
+#undef REC_LAUNCH
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(out + (c0 - u_begin) * topk, h->d_rec, (size_t)nu * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+  }
   const size_t shmem = (size_t)h->I * sizeof(float) + 64;
   if (shmem > 160 * 1024) return fail("recommend: %llu items exceed the 160 KiB LDS score buffer", (unsigned long long)h->I);
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);

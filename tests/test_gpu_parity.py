@@ -291,6 +291,39 @@ def test_ragged_rows_multi_unit_users_and_long_rows(ragged, B, K):
     np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
 
 
+def _assert_valid_topk(model, data, rec, topk, K):
+    """rec[u] must be a correct top-k of the unrated items under fp64 scores z_u . D[j] + b'[j], up to fp32 noise."""
+    uids = np.arange(data.num_users, dtype=np.uint32)
+    Z = model.get_hidden_values(uids, seed=0, epoch=0, mode=0).astype(np.float64)
+    D = model.get(0).astype(np.float64).reshape(data.num_items, -1)[:, :K]
+    bp = model.get(8).astype(np.float64)
+    S = Z[:, :K] @ D.T + bp
+    eps = 2e-5 * (1.0 + np.abs(S).max())
+    for u in range(data.num_users):
+        rated = data.train_col[data.train_ptr[u]:data.train_ptr[u + 1]]
+        ids = rec[u]
+        assert len(set(ids.tolist())) == topk and not np.intersect1d(ids, rated).size
+        sc = S[u, ids]
+        assert np.all(np.diff(sc) <= eps), (u, sc)                       # descending
+        s = S[u].copy()
+        s[rated] = -np.inf
+        kth = np.sort(s)[::-1][topk - 1]
+        assert sc.min() >= kth - eps, (u, sc.min(), kth)                  # nothing better was left out
+
+
+@pytest.mark.parametrize("K,topk", [(8, 1), (40, 10), (100, 16), (200, 10), (256, 5), (64, 20), (300, 10)])
+def test_recommend_matrix_core_path(ragged, K, topk):
+    """K7 on MFMA (K <= 256, topk <= 16) and the per-user fallback (topk 20, K 300): ragged user/item counts that are no
+    multiples of the 128-user / 32-item tiles."""
+    model, _ = make_pair(ragged, K=K, B=32, num_neg=2)
+    model.train_one_iteration(seed=5, epoch=0)
+    rec = model.recommend_all(topk)
+    assert rec.shape == (ragged.num_users, topk)
+    _assert_valid_topk(model, ragged, rec, topk, K)
+    part = model.recommend_all(topk, 3, ragged.num_users - 2)            # a sub-range of users
+    np.testing.assert_array_equal(part, rec[3:ragged.num_users - 2])
+
+
 @pytest.mark.parametrize("K", [100, 256, 300, 512])
 def test_wide_rows(tiny, K):
     """NI = 2, 4 (no pad element: separate bias path), 8."""
