@@ -159,6 +159,23 @@ def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
         np.testing.assert_allclose(model.get(w), want, rtol=0, atol=2e-6)
 
 
+def test_duplicate_correction_overflow_falls_back_to_atomics(tiny, monkeypatch):
+    """CDAE_DUP_CAP bounds the duplicate-negative correction buffer; examples beyond it take the atomic path and the
+    result is the same trajectory (up to the order of a few fp32 additions)."""
+    monkeypatch.setenv("CDAE_DUP_CAP", "2")
+    small_cap, o = make_pair(tiny, K=24, B=64, num_neg=20)          # many negatives per user -> many duplicates
+    monkeypatch.delenv("CDAE_DUP_CAP")
+    roomy, _ = make_pair(tiny, K=24, B=64, num_neg=20)
+    for ep in range(2):
+        small_cap.train_one_iteration(seed=8, epoch=ep)
+        roomy.train_one_iteration(seed=8, epoch=ep)
+        o.train_batched(8, ep, 64)
+    err, which = max_param_err(small_cap, o)
+    assert err < 2e-4, (err, which)
+    for which in (0, 1, 4, 5, 6, 7, 8, 9):
+        np.testing.assert_allclose(small_cap.get(which), roomy.get(which), rtol=2e-5, atol=2e-6)
+
+
 def test_pipelined_exchange_kernels(tiny):
     """cdae_hip_delta_stage / _merge / _merge_stage with a fake peer: the "all-reduced" buffer is a multiple of the rank's
     own staged delta (so the row pads stay zero, as with real peers); the peer part must land on the live parameters one
