@@ -186,7 +186,7 @@ def main():
         MFMA_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
         flops_launch = 6.0 * K * data.num_items * (acc["users"] / max(1, acc["batches"]))
         achieved_tf = flops_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel x3 (+ bf16 operand copies, target fix-up)",
+        roofline = {"bound": "mfma", "kernel": "full_decode_fused_kernel + gemm_nt_bf16_kernel (+ bf16 operand copies, rated-items bitmap)",
                     "achieved": achieved_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_PEAK_TFLOPS,
                     "traffic": None, "algorithmic_flops_per_launch": flops_launch, "avg_launch_ms": ms_per_launch}
         workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "

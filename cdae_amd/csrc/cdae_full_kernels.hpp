@@ -129,6 +129,155 @@ gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused forward + loss' + hidden gradient (replaces GEMM 1, the positive fix-up and GEMM 2 when Kp <= 256):
+// a workgroup owns 128 users (wavefront w: 32 of them) and one slice of the item dimension, and walks the slice in tiles
+// of 32 items.  Per tile and wavefront:
+//   C1[item][user] = D_tile Z^T                      Kp/16 MFMAs; A = D tile from LDS (row-major, ds_read_b128),
+//                                                    B = the wave's z rows, held in registers for the whole launch
+//   g = loss'(C1 + b'[item], target)                 target = bit of the user's rated-items word of this tile
+//                                                    (rated_bits_kernel), so positives need no second pass
+//   G^T[item][user] = bf16(g)                        the only image of G that reaches memory (GEMM 3 and the row step
+//                                                    read it); lanes of one item hold 32 consecutive users
+//   hg[user][k] += sum_items g D[item][k]            2 * Kp/32 MFMAs; A = the 8 g values a lane already holds per
+//                                                    16-item step (C1 puts 4 consecutive items of ONE user in a lane,
+//                                                    and the contraction order is free as long as A and B agree),
+//                                                    B = D^T tile from LDS (two 8-byte reads)
+// so G never takes the [users x items] detour through HBM on its way into the second product.  The per-slice partial
+// hg is stored to HGpart[slice][user] and summed in fixed order by hidden_finish_kernel.
+constexpr int FUSED_TILE = 32;
+constexpr size_t full_fused_lds_bytes(uint32_t Kp) {
+  return 2 * ((size_t)FUSED_TILE * (Kp + 8) + (size_t)Kp * (FUSED_TILE + 4)) * sizeof(__bf16);
+}
+
+template <int NKS /* Kp / 16 */>
+__global__ void __launch_bounds__(256)
+full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x Kp] */, const __bf16* __restrict__ Db /* [Ip x Kp] */,
+                         const __bf16* __restrict__ DTb /* [Kp x Ip] */, uint32_t Ip, const float* __restrict__ bp,
+                         const uint32_t* __restrict__ bits /* [nb x words] */, uint32_t words, uint32_t nb,
+                         uint32_t tiles_per_slice, __bf16* __restrict__ GT /* [Ip x ldgt] */, uint32_t ldgt,
+                         float* __restrict__ HGpart /* [slices][nb][Kp] */) {
+  constexpr int Kp = 16 * NKS, NT = Kp / 32;
+  constexpr int DROW = Kp + 8;                       // D tile row stride (bf16): 16-byte reads of 16 rows hit distinct banks
+  constexpr int TROW = FUSED_TILE + 4;               // D^T tile row stride
+  extern __shared__ __attribute__((aligned(16))) char fused_smem[];
+  __bf16* dt = reinterpret_cast<__bf16*>(fused_smem);                          // [2][32][DROW]
+  __bf16* dtt = dt + 2 * FUSED_TILE * DROW;                                    // [2][Kp][TROW]
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+  const uint32_t col = lane & 31u, half = lane >> 5;
+  const uint32_t user = blockIdx.y * 128u + wave * 32u + col;                  // batch slot
+  const bool user_ok = user < nb;
+  const uint32_t n_tiles = Ip / FUSED_TILE;
+  const uint32_t t_begin = blockIdx.x * tiles_per_slice, t_end = min(n_tiles, t_begin + tiles_per_slice);
+  if (t_begin >= t_end) return;
+
+  bf16x8 zf[NKS];                                    // B operand of product 1: Z[user][16 s + 8 half .. + 7]
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) zf[s] = *reinterpret_cast<const bf16x8*>(Zb + (size_t)user * Kp + 16 * s + 8 * half);
+
+  f32x16 hg[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hg[nt][r] = 0.f;
+
+  // staging: D tile = 32 rows x Kp bf16 (2 Kp / 16 sixteen-byte pieces per row), D^T tile = Kp rows x 32 items (4 pieces)
+  constexpr int D_PIECES = FUSED_TILE * Kp / 8, T_PIECES = Kp * FUSED_TILE / 8;
+  constexpr int D_PER = (D_PIECES + 255) / 256, T_PER = (T_PIECES + 255) / 256;
+  bf16x8 sd[D_PER], stt[T_PER];
+  auto fetch = [&](uint32_t t) {
+    const uint32_t i0 = t * FUSED_TILE;
+#pragma unroll
+    for (int q = 0; q < D_PER; ++q) {
+      const uint32_t f = threadIdx.x + 256u * q;
+      if (f < (uint32_t)D_PIECES) sd[q] = *reinterpret_cast<const bf16x8*>(Db + (size_t)(i0 + f / (Kp / 8)) * Kp + 8 * (f % (Kp / 8)));
+    }
+#pragma unroll
+    for (int q = 0; q < T_PER; ++q) {
+      const uint32_t f = threadIdx.x + 256u * q;
+      if (f < (uint32_t)T_PIECES) stt[q] = *reinterpret_cast<const bf16x8*>(DTb + (size_t)(f / 4) * Ip + i0 + 8 * (f % 4));
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < D_PER; ++q) {
+      const uint32_t f = threadIdx.x + 256u * q;
+      if (f < (uint32_t)D_PIECES) *reinterpret_cast<bf16x8*>(dt + (size_t)buf * FUSED_TILE * DROW + (f / (Kp / 8)) * DROW + 8 * (f % (Kp / 8))) = sd[q];
+    }
+#pragma unroll
+    for (int q = 0; q < T_PER; ++q) {
+      const uint32_t f = threadIdx.x + 256u * q;
+      if (f < (uint32_t)T_PIECES) {
+        // rows are 72 bytes apart: two 8-byte stores (a 16-byte one would straddle the alignment)
+        __bf16* dst = dtt + (size_t)buf * Kp * TROW + (f / 4) * TROW + 8 * (f % 4);
+        const bf16x4 lo = {stt[q][0], stt[q][1], stt[q][2], stt[q][3]}, hi = {stt[q][4], stt[q][5], stt[q][6], stt[q][7]};
+        *reinterpret_cast<bf16x4*>(dst) = lo;
+        *reinterpret_cast<bf16x4*>(dst + 4) = hi;
+      }
+    }
+  };
+  fetch(t_begin);
+  commit(0);
+  __syncthreads();
+
+  for (uint32_t t = t_begin; t < t_end; ++t) {
+    const int buf = (int)((t - t_begin) & 1u);
+    if (t + 1 < t_end) fetch(t + 1);
+    const uint32_t word = user_ok && t < words ? bits[(size_t)user * words + t] : 0u;   // the user's training items in the tile
+    // product 1: C1[item][user]
+    f32x16 c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c1[r] = 0.f;
+    const __bf16* arow = dt + (size_t)buf * FUSED_TILE * DROW + col * DROW + 8 * half;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zf[s], c1, 0, 0, 0);
+    }
+    // loss gradient of the lane's 16 (item, user) pairs: items 8 q + 4 half + e of the tile
+    bf16x8 ga[2];                                                             // A operands of product 2 (16-item steps)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t i0 = t * FUSED_TILE + 8u * q + 4u * half;
+      const float4 b4 = *reinterpret_cast<const float4*>(bp + i0);            // bp is padded to Ip by the caller
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t item = i0 + (uint32_t)e;
+        const float tgt = (word >> (8u * q + 4u * half + (uint32_t)e)) & 1u ? 1.f : 0.f;
+        float g = 0.f;
+        if (user_ok && item < hp.num_items) g = loss_grad(hp.loss_type, c1[4 * q + e] + bb[e], tgt);
+        const __bf16 gb = (__bf16)g;
+        ga[q >> 1][4 * (q & 1) + e] = gb;
+        GT[(size_t)item * ldgt + user] = gb;
+      }
+    }
+    // product 2: hg[user][k] += sum over the tile's items; step ks covers tile items {16 ks + 4 half + 0..3, 16 ks + 8 + 4 half + 0..3}
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const __bf16* brow = dtt + (size_t)buf * Kp * TROW + (size_t)(32 * nt + col) * TROW + 4 * half;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x4 b_lo = *reinterpret_cast<const bf16x4*>(brow + 16 * ks);
+        const bf16x4 b_hi = *reinterpret_cast<const bf16x4*>(brow + 16 * ks + 8);
+        const bf16x8 bfrag = {b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+        hg[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], bfrag, hg[nt], 0, 0, 0);
+      }
+    }
+    if (t + 1 < t_end) commit(buf ^ 1);
+    __syncthreads();
+  }
+  // C layout: column n = lane & 31 (hidden index 32 nt + n), rows = users 8 (r / 4) + 4 half + (r % 4) of the wave's 32
+  float* out = HGpart + ((size_t)blockIdx.x * nb) * Kp;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const uint32_t u = blockIdx.y * 128u + wave * 32u + 8u * (r >> 2) + 4u * half + (r & 3);
+      if (u < nb) out[(size_t)u * Kp + 32 * nt + col] = hg[nt][r];
+    }
+}
+
 // Targets: GEMM 1 computed every g against target 0.  For a positive, loss'(y, 1) = loss'(y, 0) - c with
 // c = 1 (cross-entropy: sigmoid(y) - t) or 2 (square: -2 (t - y)), so the batch's positives are patched in place.
 __global__ void __launch_bounds__(256)
@@ -141,6 +290,15 @@ full_positive_fixup_kernel(const uint32_t* __restrict__ ex_item, const uint64_t*
   const float g = (float)G[(size_t)slot * ldg + item] - c;
   G[(size_t)slot * ldg + item] = (__bf16)g;
   GT[(size_t)item * ldgt + slot] = (__bf16)g;
+}
+
+// K4b as a launch of its own: the full-output path runs it on a second stream beside GEMM 3 (2048 users x 58 ns of
+// strictly sequential chain would otherwise sit on the critical path).
+__global__ void __launch_bounds__(256)
+hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA, float* __restrict__ b, float* __restrict__ b_ag) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hp.adagrad) hidden_bias_role<true>(hp, k, nb, DELTA, b, b_ag);
+  else hidden_bias_role<false>(hp, k, nb, DELTA, b, b_ag);
 }
 
 // Row steps of the full-output schedule (+ the hidden-bias recurrence as the leading workgroups, like K5):
@@ -156,7 +314,7 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
                  float* __restrict__ W, float* __restrict__ W_ag, float* __restrict__ V, float* __restrict__ V_ag,
                  float* __restrict__ bp, float* __restrict__ bp_ag, float* __restrict__ b, float* __restrict__ b_ag,
                  uint32_t* __restrict__ touched) {
-  const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;
+  const uint32_t bias_blocks = b ? (hp.Kp + blockDim.x - 1) / blockDim.x : 0u;   // b == nullptr: the recurrence runs in hidden_bias_kernel
   if (blockIdx.x < bias_blocks) {
     if (hp.adagrad) hidden_bias_role<true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
     else hidden_bias_role<false>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);

@@ -122,6 +122,11 @@ struct cdae_hip {
   uint32_t Bp = 0, Ip = 0;
   __bf16 *d_Zb = nullptr, *d_ZTb = nullptr, *d_Db = nullptr, *d_DTb = nullptr, *d_Gb = nullptr, *d_GTb = nullptr;
   float* d_dD = nullptr;
+  uint32_t* d_iota = nullptr;           // 0..B: identity unit prefix (fused full-output path: one hg partial row per user)
+  uint32_t* d_bits_train = nullptr;     // [B x ceil(I/32)] rated-item bitmap of the batch (targets of the fused full-output decode)
+  uint32_t full_slices = 1;
+  hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
   hipStream_t prep = nullptr;           // sampling + sorting of the next batch
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
@@ -201,7 +206,7 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval};
+                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
@@ -210,6 +215,10 @@ void free_all(cdae_hip* h) {
     if (b.released) (void)hipEventDestroy(b.released);
   }
   if (h->prep) (void)hipStreamDestroy(h->prep);
+  if (h->aux) (void)hipStreamDestroy(h->aux);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_delta) (void)hipEventDestroy(h->ev_delta);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (Span& s : h->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -221,7 +230,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
@@ -361,7 +370,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
               x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr,
               explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
-              h->d_Wu, h->d_Wu_ag, 1u);
+              h->d_Wu, h->d_Wu_ag, 8u);
   CHK(pr.end());
   // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
   CHK(pr.begin(h, F_INPUT, st));
@@ -402,6 +411,27 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // bf16 operand copies of this batch: Z, Z^T (rows >= nb zero) and D, D^T (rows >= I zero)
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  const bool fused = Kp <= 256 && !std::getenv("CDAE_FULL_UNFUSED");
+  uint32_t hg_parts = 0;                         // slabs of HGpart holding hg (0: accumulated into HG by atomics)
+  if (fused) {
+    // targets: one bit per (batch user, item); then forward + loss' + hidden gradient in one launch (cdae_full_kernels.hpp)
+    const uint32_t words = (I + 31) / 32, slices = h->full_slices, tiles = Ip / 32;
+    HIPCHK(hipMemsetAsync(h->d_bits_train, 0, (size_t)nb * words * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(rated_bits_kernel, dim3((nb + 3) / 4), blk, 0, st, h->d_row_ptr, h->d_col, s0, nb, words, h->d_bits_train);
+    const uint32_t tps = (tiles + slices - 1) / slices;
+    const dim3 grid(slices, Bp / 128);
+    const size_t lds = full_fused_lds_bytes(Kp);
+#define FUSED_LAUNCH(NKS_)                                                                                                          \
+  do {                                                                                                                              \
+    HIPCHK(hipFuncSetAttribute((const void*)full_decode_fused_kernel<NKS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL(full_decode_fused_kernel<NKS_>, grid, blk, lds, st, h->hp, h->d_Zb, h->d_Db, h->d_DTb, Ip, h->P(CDAE_P_BP),   \
+                       h->d_bits_train, words, nb, tps, h->d_GTb, Bp, h->d_HGpart);                                                 \
+  } while (0)
+    switch (Kp) { case 64: FUSED_LAUNCH(4); break; case 128: FUSED_LAUNCH(8); break; default: FUSED_LAUNCH(16); break; }
+#undef FUSED_LAUNCH
+    hg_parts = slices;
+    HIPCHK(hipStreamWaitEvent(st, x.ready, 0));   // the row step below reads the sorted positives list
+  } else {
   GemmEpilogue ep{};
   ep.bp = h->P(CDAE_P_BP); ep.G = h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
   ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
@@ -419,6 +449,21 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
                        h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
   }
+  }
+  // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
+  // hg only; they run beside GEMM 3, and the row steps join them.
+  HIPCHK(hipEventRecord(h->ev_fork, st));
+  HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+  {
+    Prof pa;
+    CHK(pa.begin(h, F_HIDDEN, h->aux));
+    DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, hg_parts ? (const uint32_t*)h->d_iota : uptr,
+                hg_parts ? nb : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts);
+    CHK(pa.end());
+  }
+  HIPCHK(hipEventRecord(h->ev_delta, h->aux));
+  hipLaunchKernelGGL(hidden_bias_kernel, dim3((Kp + 255u) / 256u), blk, 0, h->aux, h->hp, nb, h->d_HG, h->P(CDAE_P_B), h->P(CDAE_P_B_AG));
+  HIPCHK(hipEventRecord(h->ev_join, h->aux));
   // GEMM 3: dD = G^T Z  (contraction over the batch's users)
   {
     GemmEpilogue e3{};
@@ -428,18 +473,12 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   }
   CHK(pr.end());
 
-  CHK(pr.begin(h, F_HIDDEN, st));
-  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
-              h->d_Wu, h->d_Wu_ag, 0u);
-  CHK(pr.end());
-
+  HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
   CHK(pr.begin(h, F_INPUT, st));
-  {
-    const uint32_t bias_blocks = (Kp + 255u) / 256u;
-    DISPATCH_NI(h->NI, full_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->d_HG,
-                h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
-                h->P(CDAE_P_BP_AG), h->P(CDAE_P_B), h->P(CDAE_P_B_AG), h->d_touched);
-  }
+  DISPATCH_NI(h->NI, full_rows_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->d_HG,
+              h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
+              h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
+  HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
   HIPCHK(hipGetLastError());
@@ -530,6 +569,10 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming);
   if (e != hipSuccess) { free_all(h); delete h; return fail("stream/event setup failed: %s", hipGetErrorString(e)); }
   e = hipMalloc((void**)&h->d_scalar, 8 * sizeof(double));
   if (e != hipSuccess) { free_all(h); delete h; return fail("hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -708,7 +751,6 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
-  CHK(dev_alloc(&h->d_HGpart, 8 * (size_t)h->unit_cap * h->Kp));
   if (h->cfg.full_output) {
     h->Bp = (B + 127u) & ~127u;
     h->Ip = ((uint32_t)I + 127u) & ~127u;
@@ -716,7 +758,20 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
     CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
     CHK(dev_alloc(&h->d_dD, (size_t)h->Ip * h->Kp));
+    {
+      std::vector<uint32_t> iota((size_t)B + 1);
+      std::iota(iota.begin(), iota.end(), 0u);
+      CHK(dev_alloc(&h->d_iota, iota.size()));
+      HIPCHK(hipMemcpy(h->d_iota, iota.data(), iota.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      CHK(dev_alloc(&h->d_bits_train, (size_t)B * ((I + 31) / 32)));
+      // item slices of the fused decode: slices x Bp/128 workgroups ~ one per CU (measured best at B = 2048: 16 slices; every
+      // slice adds a [B x Kp] partial of hg)
+      const uint32_t tiles = h->Ip / 32, ublocks = h->Bp / 128;
+      h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>({32u, tiles, (256u + ublocks - 1) / ublocks}));
+      if (const char* ev = std::getenv("CDAE_FULL_SLICES")) h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)std::atoi(ev)));
+    }
   }
+  CHK(dev_alloc(&h->d_HGpart, std::max<size_t>(8 * (size_t)h->unit_cap, h->cfg.full_output ? (size_t)h->full_slices * B : 0) * h->Kp));
   CHK(dev_alloc(&h->d_touched, (size_t)I));
   HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
   CHK(dev_alloc(&h->d_uids, (size_t)B));

@@ -994,7 +994,7 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
                      const float* __restrict__ HGpart, const float* __restrict__ Dz,
                      float* __restrict__ HG /* in: corrections (or the whole hg), out: delta */,
                      float* __restrict__ Wu, float* __restrict__ Wu_ag,
-                     uint32_t use_parts /* 0: HG already holds hg (full-output path) */) {
+                     uint32_t n_parts /* slabs of HGpart [n_parts][n_units][Kp] to add to HG (0: HG already holds hg) */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -1003,10 +1003,10 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
   vload<NI>(hg, HG + o);
-  const uint32_t ub = use_parts ? uptr[slot] - uptr[0] : 0u, ue = use_parts ? uptr[slot + 1] - uptr[0] : 0u;
+  const uint32_t ub = n_parts ? uptr[slot] - uptr[0] : 0u, ue = n_parts ? uptr[slot + 1] - uptr[0] : 0u;
   for (uint32_t u = ub; u < ue; ++u) {                          // fixed order: deterministic
-#pragma unroll
-    for (int x = 0; x < 8; ++x) {
+#pragma unroll 8
+    for (uint32_t x = 0; x < n_parts; ++x) {
       float part[NI];
       vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
 #pragma unroll
