@@ -917,6 +917,28 @@ int fill_stats(cdae_hip* h, cdae_hip_stats* stats) {
 
 }  // namespace
 
+// geometry and launch of the pipelined-exchange kernels (delta_pipe_kernel)
+namespace {
+struct PipeGeom { uint32_t Kc; size_t n_tail, n_compact, threads; };
+PipeGeom pipe_geom(const cdae_hip* h) {
+  PipeGeom g;
+  g.Kc = (h->K + 3u) & ~3u;
+  g.n_tail = h->n_shared - h->n_matrix;
+  const size_t n_rows = h->n_matrix / h->Kp;
+  g.n_compact = n_rows * g.Kc + g.n_tail;
+  g.threads = n_rows * (g.Kc / 4) + g.n_tail / 4 + g.n_tail % 4;
+  return g;
+}
+template <int MODE>
+int launch_pipe(cdae_hip* h) {
+  const PipeGeom g = pipe_geom(h);
+  hipLaunchKernelGGL(cdae::delta_pipe_kernel<MODE>, dim3((uint32_t)((g.threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
+                     h->d_base, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, g.n_tail);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end, cdae_hip_stats* stats) {
@@ -1216,7 +1238,7 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
   return 0;
 }
 
-// pipelined variant: see delta_stage_kernel / delta_merge_kernel
+// pipelined variant: see delta_pipe_kernel.  The staged / received buffers are compact (no pad columns).
 int cdae_hip_delta_stage(cdae_hip_t* h) {
   if (!h || !h->d_base) return fail("delta_begin must be called first");
   HIPCHK(hipSetDevice(h->device));
@@ -1224,35 +1246,26 @@ int cdae_hip_delta_stage(cdae_hip_t* h) {
     CHK(dev_alloc(&h->d_recv, h->n_shared + 4096));            // slack: collectives may round the count up
     HIPCHK(hipMemsetAsync(h->d_recv, 0, (h->n_shared + 4096) * sizeof(float), h->stream));
   }
-  hipLaunchKernelGGL(cdae::delta_stage_kernel, dim3((uint32_t)((h->n_shared / 4 + 3 + 255) / 256)), dim3(256), 0, h->stream,
-                     h->d_shared, h->d_base, h->d_delta, h->d_recv, h->n_shared);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return launch_pipe<cdae::DELTA_STAGE>(h);
 }
 
 int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats) {
   if (!h || !h->d_recv || !device_ptr) return fail("delta_stage must be called first");
   *device_ptr = h->d_recv;
-  if (count_floats) *count_floats = h->n_shared;
+  if (count_floats) *count_floats = pipe_geom(h).n_compact;
   return 0;
 }
 
 int cdae_hip_delta_merge(cdae_hip_t* h) {
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(cdae::delta_merge_kernel, dim3((uint32_t)((h->n_shared / 4 + 3 + 255) / 256)), dim3(256), 0, h->stream,
-                     h->d_shared, h->d_base, h->d_delta, h->d_recv, h->n_shared);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return launch_pipe<cdae::DELTA_MERGE>(h);
 }
 
 int cdae_hip_delta_merge_stage(cdae_hip_t* h) {
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(cdae::delta_merge_stage_kernel, dim3((uint32_t)((h->n_shared / 4 + 3 + 255) / 256)), dim3(256), 0, h->stream,
-                     h->d_shared, h->d_base, h->d_delta, h->d_recv, h->n_shared);
-  HIPCHK(hipGetLastError());
-  return 0;
+  return launch_pipe<cdae::DELTA_MERGE_STAGE>(h);
 }
 
 }  // extern "C"

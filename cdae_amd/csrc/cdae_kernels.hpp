@@ -1359,62 +1359,66 @@ apply_delta_kernel(float* __restrict__ cur, const float* __restrict__ base, cons
   cur[i] = fmaf(sum[i], wgt, base[i]);
 }
 
-// Pipelined exchange (cdae_hip_delta_stage / _merge): peers' contributions arrive one exchange period late.
-//   stage:  send = recv = cur - base ; base = cur          (recv is all-reduced in place while training continues)
-//   merge:  cur += recv - send ; base += recv - send       (the other ranks' part of the summed delta)
-__global__ void __launch_bounds__(256)
-delta_stage_kernel(const float* __restrict__ cur, float* __restrict__ base, float* __restrict__ send,
-                   float* __restrict__ recv, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
-  if (i < n4) {
-    const float4 c = reinterpret_cast<const float4*>(cur)[i], b = reinterpret_cast<const float4*>(base)[i];
-    const float4 d = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);
-    reinterpret_cast<float4*>(send)[i] = d;
-    reinterpret_cast<float4*>(recv)[i] = d;
-    reinterpret_cast<float4*>(base)[i] = c;
-  } else if (i < n4 + n % 4) {                                   // scalar tail
-    const size_t k = 4 * n4 + (i - n4);
-    const float d = cur[k] - base[k];
-    send[k] = d; recv[k] = d; base[k] = cur[k];
-  }
-}
-__global__ void __launch_bounds__(256)
-delta_merge_kernel(float* __restrict__ cur, float* __restrict__ base, const float* __restrict__ send,
-                   const float* __restrict__ recv, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
-  if (i < n4) {
-    const float4 r = reinterpret_cast<const float4*>(recv)[i], o = reinterpret_cast<const float4*>(send)[i];
-    const float4 p = make_float4(r.x - o.x, r.y - o.y, r.z - o.z, r.w - o.w);
-    float4 c = reinterpret_cast<float4*>(cur)[i], b = reinterpret_cast<float4*>(base)[i];
-    c.x += p.x; c.y += p.y; c.z += p.z; c.w += p.w;
-    b.x += p.x; b.y += p.y; b.z += p.z; b.w += p.w;
-    reinterpret_cast<float4*>(cur)[i] = c;
-    reinterpret_cast<float4*>(base)[i] = b;
-  } else if (i < n4 + n % 4) {
-    const size_t k = 4 * n4 + (i - n4);
-    const float p = recv[k] - send[k];
-    cur[k] += p; base[k] += p;
+// Pipelined exchange (cdae_hip_delta_stage / _merge / _merge_stage): peers' contributions arrive one exchange period late.
+//   STAGE:        send = recv = cur - base ; base = cur         (recv is all-reduced in place while training continues)
+//   MERGE:        cur += recv - send ; base += recv - send      (the other ranks' part of the summed delta)
+//   MERGE_STAGE:  both at one boundary in a single pass: p = recv - send; d = cur - base; cur = base = cur + p; send = recv = d
+// send / recv are COMPACT: the matrices' pad columns (56 of 256 at K = 200) are neither staged nor all-reduced — row r of a
+// matrix occupies Kc = round_up(K, 4) floats there — followed by the block's tail [b' | b'_ag | b | b_ag] as it is.
+enum { DELTA_STAGE = 0, DELTA_MERGE = 1, DELTA_MERGE_STAGE = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void delta_pipe_elem(float& c, float& b, float& s, float& r) {
+  if (MODE == DELTA_STAGE) {
+    const float d = c - b;
+    s = d; r = d; b = c;
+  } else if (MODE == DELTA_MERGE) {
+    const float p = r - s;
+    c += p; b += p;
+  } else {
+    const float p = r - s, d = c - b, x = c + p;
+    c = x; b = x; s = d; r = d;
   }
 }
 
-// merge of the previous period and stage of this one in a single pass over the block (8 row streams instead of 11)
+template <int MODE>
 __global__ void __launch_bounds__(256)
-delta_merge_stage_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ send,
-                         float* __restrict__ recv, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n4 = n / 4;
-  if (i < n4) {
-    const float4 r = reinterpret_cast<const float4*>(recv)[i], o = reinterpret_cast<const float4*>(send)[i];
-    const float4 c = reinterpret_cast<const float4*>(cur)[i], b = reinterpret_cast<const float4*>(base)[i];
-    const float4 d = make_float4(c.x - b.x, c.y - b.y, c.z - b.z, c.w - b.w);                     // own steps of this period
-    const float4 x = make_float4(c.x + (r.x - o.x), c.y + (r.y - o.y), c.z + (r.z - o.z), c.w + (r.w - o.w));
-    reinterpret_cast<float4*>(cur)[i] = x;
-    reinterpret_cast<float4*>(base)[i] = x;
-    reinterpret_cast<float4*>(send)[i] = d;
-    reinterpret_cast<float4*>(recv)[i] = d;
-  } else if (i < n4 + n % 4) {
-    const size_t k = 4 * n4 + (i - n4);
-    const float d = cur[k] - base[k], x = cur[k] + (recv[k] - send[k]);
-    cur[k] = x; base[k] = x; send[k] = d; recv[k] = d;
+delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ send, float* __restrict__ recv,
+                  size_t n_matrix /* padded floats of all matrices */, uint32_t Kp, uint32_t Kc, size_t n_tail) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q_per_row = Kc / 4;
+  const size_t n_rows = n_matrix / Kp, n_mat4 = n_rows * q_per_row, n_tail4 = n_tail / 4;
+  size_t pad_off, cmp_off;                                        // float offsets of this thread's element(s)
+  int width;
+  if (i < n_mat4) {
+    const size_t row = i / q_per_row;
+    const uint32_t q = (uint32_t)(i - row * q_per_row);
+    pad_off = row * Kp + 4u * q; cmp_off = row * Kc + 4u * q; width = 4;
+  } else if (i - n_mat4 < n_tail4) {
+    const size_t j = i - n_mat4;
+    pad_off = n_matrix + 4 * j; cmp_off = n_rows * Kc + 4 * j; width = 4;
+  } else if (i - n_mat4 - n_tail4 < n_tail % 4) {
+    const size_t j = 4 * n_tail4 + (i - n_mat4 - n_tail4);
+    pad_off = n_matrix + j; cmp_off = n_rows * Kc + j; width = 1;
+  } else {
+    return;
+  }
+  if (width == 4) {
+    float4 c = *reinterpret_cast<float4*>(cur + pad_off), b = *reinterpret_cast<float4*>(base + pad_off);
+    float4 s = MODE == DELTA_STAGE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(send + cmp_off);
+    float4 r = MODE == DELTA_STAGE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(recv + cmp_off);
+    delta_pipe_elem<MODE>(c.x, b.x, s.x, r.x); delta_pipe_elem<MODE>(c.y, b.y, s.y, r.y);
+    delta_pipe_elem<MODE>(c.z, b.z, s.z, r.z); delta_pipe_elem<MODE>(c.w, b.w, s.w, r.w);
+    if (MODE != DELTA_STAGE) *reinterpret_cast<float4*>(cur + pad_off) = c;
+    *reinterpret_cast<float4*>(base + pad_off) = b;
+    if (MODE != DELTA_MERGE) { *reinterpret_cast<float4*>(send + cmp_off) = s; *reinterpret_cast<float4*>(recv + cmp_off) = r; }
+  } else {
+    float c = cur[pad_off], b = base[pad_off];
+    float s = MODE == DELTA_STAGE ? 0.f : send[cmp_off], r = MODE == DELTA_STAGE ? 0.f : recv[cmp_off];
+    delta_pipe_elem<MODE>(c, b, s, r);
+    if (MODE != DELTA_STAGE) cur[pad_off] = c;
+    base[pad_off] = b;
+    if (MODE != DELTA_MERGE) { send[cmp_off] = s; recv[cmp_off] = r; }
   }
 }
 

@@ -190,7 +190,8 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule);
 /* Pipelined form of the same exchange (sum rule): the all-reduce of one period's deltas overlaps the next period's
  * training, and the other ranks' part is folded in one period late.  After cdae_hip_delta_begin():
  *   cdae_hip_delta_stage : send = recv = current - base ; base = current
- *   (caller all-reduces the recv buffer, cdae_hip_delta_recv_device_ptr, n floats, asynchronously)
+ *   (caller all-reduces the recv buffer, cdae_hip_delta_recv_device_ptr, n floats, asynchronously; the buffer is
+ *    compact: the matrices' pad columns are not exchanged)
  *   cdae_hip_delta_merge : current += recv - send ; base += recv - send     (before the next _stage)
  * Every rank ends at  initial + sum over periods and ranks of the staged deltas  once the last merge has run.
  * Stream-ordered on cdae_hip_stream like the calls above. */
