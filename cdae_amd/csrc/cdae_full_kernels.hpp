@@ -145,9 +145,10 @@ gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm,
 //                                                    B = D^T tile from LDS (two 8-byte reads)
 // so G never takes the [users x items] detour through HBM on its way into the second product.  The per-slice partial
 // hg is stored to HGpart[slice][user] and summed in fixed order by hidden_finish_kernel.
-constexpr int FUSED_TILE = 32;
+constexpr int FUSED_TILE = 32;                       // items per MFMA tile
+constexpr int FUSED_SUB = 2;                         // tiles staged through LDS per step (64 items: loads get two tiles of work to land)
 constexpr size_t full_fused_lds_bytes(uint32_t Kp) {
-  return 2 * ((size_t)FUSED_TILE * (Kp + 8) + (size_t)Kp * (FUSED_TILE + 4)) * sizeof(__bf16);
+  return 2 * ((size_t)FUSED_SUB * FUSED_TILE * (Kp + 8) + (size_t)Kp * (FUSED_SUB * FUSED_TILE + 4)) * sizeof(__bf16);
 }
 
 template <int NKS /* Kp / 16 */>
@@ -155,21 +156,22 @@ __global__ void __launch_bounds__(256)
 full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x Kp] */, const __bf16* __restrict__ Db /* [Ip x Kp] */,
                          const __bf16* __restrict__ DTb /* [Kp x Ip] */, uint32_t Ip, const float* __restrict__ bp,
                          const uint32_t* __restrict__ bits /* [nb x words] */, uint32_t words, uint32_t nb,
-                         uint32_t tiles_per_slice, __bf16* __restrict__ GT /* [Ip x ldgt] */, uint32_t ldgt,
+                         uint32_t steps_per_slice, __bf16* __restrict__ GT /* [Ip x ldgt] */, uint32_t ldgt,
                          float* __restrict__ HGpart /* [slices][nb][Kp] */) {
   constexpr int Kp = 16 * NKS, NT = Kp / 32;
+  constexpr int STEP = FUSED_SUB * FUSED_TILE;       // items per staged step
   constexpr int DROW = Kp + 8;                       // D tile row stride (bf16): 16-byte reads of 16 rows hit distinct banks
-  constexpr int TROW = FUSED_TILE + 4;               // D^T tile row stride
+  constexpr int TROW = STEP + 4;                     // D^T tile row stride: 8-byte reads of 32 rows hit distinct banks
   extern __shared__ __attribute__((aligned(16))) char fused_smem[];
-  __bf16* dt = reinterpret_cast<__bf16*>(fused_smem);                          // [2][32][DROW]
-  __bf16* dtt = dt + 2 * FUSED_TILE * DROW;                                    // [2][Kp][TROW]
+  __bf16* dt = reinterpret_cast<__bf16*>(fused_smem);                          // [2][STEP][DROW]
+  __bf16* dtt = dt + 2 * STEP * DROW;                                          // [2][Kp][TROW]
   const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
   const uint32_t col = lane & 31u, half = lane >> 5;
   const uint32_t user = blockIdx.y * 128u + wave * 32u + col;                  // batch slot
   const bool user_ok = user < nb;
-  const uint32_t n_tiles = Ip / FUSED_TILE;
-  const uint32_t t_begin = blockIdx.x * tiles_per_slice, t_end = min(n_tiles, t_begin + tiles_per_slice);
-  if (t_begin >= t_end) return;
+  const uint32_t n_steps = Ip / STEP;                                          // Ip is a multiple of 128
+  const uint32_t s_begin = blockIdx.x * steps_per_slice, s_end = min(n_steps, s_begin + steps_per_slice);
+  if (s_begin >= s_end) return;
 
   bf16x8 zf[NKS];                                    // B operand of product 1: Z[user][16 s + 8 half .. + 7]
 #pragma unroll
@@ -181,12 +183,12 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
     for (int r = 0; r < 16; ++r) hg[nt][r] = 0.f;
 
-  // staging: D tile = 32 rows x Kp bf16 (2 Kp / 16 sixteen-byte pieces per row), D^T tile = Kp rows x 32 items (4 pieces)
-  constexpr int D_PIECES = FUSED_TILE * Kp / 8, T_PIECES = Kp * FUSED_TILE / 8;
+  // staging: D rows = STEP rows x Kp bf16 (Kp / 8 sixteen-byte pieces per row), D^T = Kp rows x STEP items (STEP / 8 pieces)
+  constexpr int D_PIECES = STEP * Kp / 8, T_PIECES = Kp * STEP / 8, T_PER_ROW = STEP / 8;
   constexpr int D_PER = (D_PIECES + 255) / 256, T_PER = (T_PIECES + 255) / 256;
   bf16x8 sd[D_PER], stt[T_PER];
-  auto fetch = [&](uint32_t t) {
-    const uint32_t i0 = t * FUSED_TILE;
+  auto fetch = [&](uint32_t st) {
+    const uint32_t i0 = st * STEP;
 #pragma unroll
     for (int q = 0; q < D_PER; ++q) {
       const uint32_t f = threadIdx.x + 256u * q;
@@ -195,76 +197,91 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
     for (int q = 0; q < T_PER; ++q) {
       const uint32_t f = threadIdx.x + 256u * q;
-      if (f < (uint32_t)T_PIECES) stt[q] = *reinterpret_cast<const bf16x8*>(DTb + (size_t)(f / 4) * Ip + i0 + 8 * (f % 4));
+      if (f < (uint32_t)T_PIECES) stt[q] = *reinterpret_cast<const bf16x8*>(DTb + (size_t)(f / T_PER_ROW) * Ip + i0 + 8 * (f % T_PER_ROW));
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < D_PER; ++q) {
       const uint32_t f = threadIdx.x + 256u * q;
-      if (f < (uint32_t)D_PIECES) *reinterpret_cast<bf16x8*>(dt + (size_t)buf * FUSED_TILE * DROW + (f / (Kp / 8)) * DROW + 8 * (f % (Kp / 8))) = sd[q];
+      if (f < (uint32_t)D_PIECES) *reinterpret_cast<bf16x8*>(dt + (size_t)buf * STEP * DROW + (f / (Kp / 8)) * DROW + 8 * (f % (Kp / 8))) = sd[q];
     }
 #pragma unroll
     for (int q = 0; q < T_PER; ++q) {
       const uint32_t f = threadIdx.x + 256u * q;
       if (f < (uint32_t)T_PIECES) {
-        // rows are 72 bytes apart: two 8-byte stores (a 16-byte one would straddle the alignment)
-        __bf16* dst = dtt + (size_t)buf * Kp * TROW + (f / 4) * TROW + 8 * (f % 4);
+        // rows are 8 (mod 16) bytes apart: two 8-byte stores
+        __bf16* dst = dtt + (size_t)buf * Kp * TROW + (f / T_PER_ROW) * TROW + 8 * (f % T_PER_ROW);
         const bf16x4 lo = {stt[q][0], stt[q][1], stt[q][2], stt[q][3]}, hi = {stt[q][4], stt[q][5], stt[q][6], stt[q][7]};
         *reinterpret_cast<bf16x4*>(dst) = lo;
         *reinterpret_cast<bf16x4*>(dst + 4) = hi;
       }
     }
   };
-  fetch(t_begin);
+  fetch(s_begin);
   commit(0);
   __syncthreads();
 
-  for (uint32_t t = t_begin; t < t_end; ++t) {
-    const int buf = (int)((t - t_begin) & 1u);
-    if (t + 1 < t_end) fetch(t + 1);
-    const uint32_t word = user_ok && t < words ? bits[(size_t)user * words + t] : 0u;   // the user's training items in the tile
-    // product 1: C1[item][user]
-    f32x16 c1;
+  for (uint32_t st = s_begin; st < s_end; ++st) {
+    const int buf = (int)((st - s_begin) & 1u);
+    if (st + 1 < s_end) fetch(st + 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c1[r] = 0.f;
-    const __bf16* arow = dt + (size_t)buf * FUSED_TILE * DROW + col * DROW + 8 * half;
+    for (int sub = 0; sub < FUSED_SUB; ++sub) {
+      const uint32_t t = st * FUSED_SUB + sub;                                 // global 32-item tile index
+      const uint32_t word = user_ok && t < words ? bits[(size_t)user * words + t] : 0u;   // the user's training items in the tile
+      // product 1: C1[item][user]
+      // (all fragments are read from LDS first, then the MFMAs issue back to back on two alternating accumulators: with one
+      // wavefront per SIMD nothing else hides a dependent MFMA's latency or an LDS wait between two of them)
+      f32x16 c1, c1b;
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zf[s], c1, 0, 0, 0);
-    }
-    // loss gradient of the lane's 16 (item, user) pairs: items 8 q + 4 half + e of the tile
-    bf16x8 ga[2];                                                             // A operands of product 2 (16-item steps)
+      for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c1b[r] = 0.f; }
+      const __bf16* arow = dt + (size_t)buf * STEP * DROW + (sub * FUSED_TILE + col) * DROW + 8 * half;
+      bf16x8 af[NKS];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t i0 = t * FUSED_TILE + 8u * q + 4u * half;
-      const float4 b4 = *reinterpret_cast<const float4*>(bp + i0);            // bp is padded to Ip by the caller
-      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      for (int s = 0; s < NKS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t item = i0 + (uint32_t)e;
-        const float tgt = (word >> (8u * q + 4u * half + (uint32_t)e)) & 1u ? 1.f : 0.f;
-        float g = 0.f;
-        if (user_ok && item < hp.num_items) g = loss_grad(hp.loss_type, c1[4 * q + e] + bb[e], tgt);
-        const __bf16 gb = (__bf16)g;
-        ga[q >> 1][4 * (q & 1) + e] = gb;
-        GT[(size_t)item * ldgt + user] = gb;
+      for (int s = 0; s < NKS; s += 2) {
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], zf[s], c1, 0, 0, 0);
+        if (s + 1 < NKS) c1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s + 1], zf[s + 1], c1b, 0, 0, 0);
       }
-    }
-    // product 2: hg[user][k] += sum over the tile's items; step ks covers tile items {16 ks + 4 half + 0..3, 16 ks + 8 + 4 half + 0..3}
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const __bf16* brow = dtt + (size_t)buf * Kp * TROW + (size_t)(32 * nt + col) * TROW + 4 * half;
+      for (int r = 0; r < 16; ++r) c1[r] += c1b[r];
+      // loss gradient of the lane's 16 (item, user) pairs: items 8 q + 4 half + e of the tile
+      bf16x8 ga[2];                                                            // A operands of product 2 (16-item steps)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x4 b_lo = *reinterpret_cast<const bf16x4*>(brow + 16 * ks);
-        const bf16x4 b_hi = *reinterpret_cast<const bf16x4*>(brow + 16 * ks + 8);
-        const bf16x8 bfrag = {b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
-        hg[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], bfrag, hg[nt], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t i0 = t * FUSED_TILE + 8u * q + 4u * half;
+        const float4 b4 = *reinterpret_cast<const float4*>(bp + i0);           // in bounds up to Ip: b'_ag, b, b_ag follow b'
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t item = i0 + (uint32_t)e;
+          const float tgt = (word >> (8u * q + 4u * half + (uint32_t)e)) & 1u ? 1.f : 0.f;
+          float g = 0.f;
+          if (user_ok && item < hp.num_items) g = loss_grad(hp.loss_type, c1[4 * q + e] + bb[e], tgt);
+          const __bf16 gb = (__bf16)g;
+          ga[q >> 1][4 * (q & 1) + e] = gb;
+          GT[(size_t)item * ldgt + user] = gb;
+        }
       }
+      // product 2: hg[user][k] += sum over the tile's items; step ks covers tile items {16 ks + 4 half + 0..3, 16 ks + 8 + 4 half + 0..3}
+      bf16x8 bf[2][NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const __bf16* brow = dtt + (size_t)buf * Kp * TROW + (size_t)(32 * nt + col) * TROW + sub * FUSED_TILE + 4 * half;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x4 b_lo = *reinterpret_cast<const bf16x4*>(brow + 16 * ks);
+          const bf16x4 b_hi = *reinterpret_cast<const bf16x4*>(brow + 16 * ks + 8);
+          bf[ks][nt] = bf16x8{b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)                                           // consecutive MFMAs write different accumulators
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) hg[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], bf[ks][nt], hg[nt], 0, 0, 0);
     }
-    if (t + 1 < t_end) commit(buf ^ 1);
+    if (st + 1 < s_end) commit(buf ^ 1);
     __syncthreads();
   }
   // C layout: column n = lane & 31 (hidden index 32 nt + n), rows = users 8 (r / 4) + 4 half + (r % 4) of the wave's 32
@@ -305,7 +322,7 @@ hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA,
 //   b'[j]: grad = sum_u G[u][j] + lambda b'[j]                                 cdae.hpp:230-237, summed over the block
 //   tied : W[j]: grad = dD[j] + scale * sum_{u: j kept} delta_u + lambda W[j]     cdae.hpp:252-257 + 337-348 merged
 //   asym : V[j]: grad = dD[j] + lambda V[j];  W[j] (only if some user kept j): scale * sum delta_u + lambda W[j]
-// One wavefront per item row; the kept inputs of the row come from the item-sorted positives list.
+// One workgroup per item row; the kept inputs of the row come from the item-sorted positives list.
 template <int NI>
 __global__ void __launch_bounds__(256)
 full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
@@ -320,8 +337,11 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
     else hidden_bias_role<false>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
     return;
   }
-  const uint32_t item = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
-  const uint32_t lane = threadIdx.x % WAVE;
+  // One workgroup per item row: its four wavefronts split the row's kept inputs (a popular row has ~500 of them per
+  // 2048-user block, one L2 round trip per 8 would otherwise be a 60 us chain) and the G^T row, and meet in LDS.
+  __shared__ float part[4][WAVE * NI + 1];
+  const uint32_t item = blockIdx.x - bias_blocks;
+  const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
   if (item >= hp.num_items) return;
   const uint32_t lo = lane * NI;
   // summed input gradient of the row
@@ -331,7 +351,7 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
   bool has_in = false;
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   constexpr int UN = 8;
-  for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
+  for (uint32_t p0 = beg + wave * WAVE; p0 < end; p0 += 4 * WAVE) {
     const uint32_t p = p0 + lane;
     const uint32_t word = p < end ? (uint32_t)sorted_val[p] : 0u;
     unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
@@ -353,13 +373,25 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
 #pragma unroll
       for (int t = 0; t < UN; ++t)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) din[i] += v[t][i];        // user order: deterministic
+        for (int i = 0; i < NI; ++i) din[i] += v[t][i];        // fixed order per wavefront: deterministic
     }
   }
-  // b'[j]
+  // b'[j] gradient: sum of the row of G^T, also split over the four wavefronts
   float gsum = 0.f;
-  for (uint32_t u = lane; u < nb; u += WAVE) gsum += (float)GT[(size_t)item * ldgt + u];
+  for (uint32_t u = threadIdx.x; u < nb; u += blockDim.x) gsum += (float)GT[(size_t)item * ldgt + u];
   gsum = wave_sum(gsum);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) part[wave][lo + i] = din[i];
+  if (lane == 0) part[wave][WAVE * NI] = has_in ? 1.f : 0.f;
+  __shared__ float gpart[4];
+  if (lane == 0) gpart[wave] = gsum;
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) din[i] = ((part[0][lo + i] + part[1][lo + i]) + part[2][lo + i]) + part[3][lo + i];
+  has_in = part[0][WAVE * NI] + part[1][WAVE * NI] + part[2][WAVE * NI] + part[3][WAVE * NI] > 0.f;
+  gsum = ((gpart[0] + gpart[1]) + gpart[2]) + gpart[3];
+  // b'[j]
   {
     float p = bp[item], pa = bp_ag[item];
     ada_step(hp, p, pa, fmaf(hp.lambda, p, gsum));

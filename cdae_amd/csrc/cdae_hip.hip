@@ -415,7 +415,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   uint32_t hg_parts = 0;                         // slabs of HGpart holding hg (0: accumulated into HG by atomics)
   if (fused) {
     // targets: one bit per (batch user, item); then forward + loss' + hidden gradient in one launch (cdae_full_kernels.hpp)
-    const uint32_t words = (I + 31) / 32, slices = h->full_slices, tiles = Ip / 32;
+    const uint32_t words = (I + 31) / 32, slices = h->full_slices, tiles = Ip / (32 * FUSED_SUB);   // staged steps of 64 items
     HIPCHK(hipMemsetAsync(h->d_bits_train, 0, (size_t)nb * words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(rated_bits_kernel, dim3((nb + 3) / 4), blk, 0, st, h->d_row_ptr, h->d_col, s0, nb, words, h->d_bits_train);
     const uint32_t tps = (tiles + slices - 1) / slices;
@@ -475,7 +475,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
   CHK(pr.begin(h, F_INPUT, st));
-  DISPATCH_NI(h->NI, full_rows_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->d_HG,
+  DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->d_HG,
               h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
               h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
   HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -766,7 +766,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       CHK(dev_alloc(&h->d_bits_train, (size_t)B * ((I + 31) / 32)));
       // item slices of the fused decode: slices x Bp/128 workgroups ~ one per CU (measured best at B = 2048: 16 slices; every
       // slice adds a [B x Kp] partial of hg)
-      const uint32_t tiles = h->Ip / 32, ublocks = h->Bp / 128;
+      const uint32_t tiles = h->Ip / (32 * cdae::FUSED_SUB), ublocks = h->Bp / 128;
       h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>({32u, tiles, (256u + ublocks - 1) / ublocks}));
       if (const char* ev = std::getenv("CDAE_FULL_SLICES")) h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)std::atoi(ev)));
     }
