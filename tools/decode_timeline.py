@@ -6,10 +6,11 @@ every 64-example chunk's G store, row end).
           cdae_amd/csrc/cdae_hip.hip -o /tmp/libcdae_hip_timing.so
     CDAE_DEBUG_RANK=<popularity rank> python tools/decode_timeline.py /tmp/libcdae_hip_timing.so [batch_users]
 
-Round-1 finding (profiles/r01_decode_timeline.txt): at batch_users=512 a typical row (32-43 examples) spends
-2000-5000 cycles per example while 8 wavefronts share each SIMD, the rank-0 row (257 examples) 750-1150, and the
-same rank-0 row 620 once the rest of the chip has drained (batch_users=4096 tail): the kernel is VALU-issue bound
-chip-wide (~55 VALU + ~22 SALU instructions per example), not bandwidth or latency bound.
+Round-1 history (profiles/r01_decode_timeline.txt, then profiles/r01_decode_bisect.txt): the first timelines (2000-5000
+cycles per example on every row while the launch ran) were read as chip-wide VALU-issue pressure; stripping the loop body
+showed the time was in the duplicate-negative path instead (an fp32 atomic + s_waitcnt vmcnt(0) stalled a wavefront ~25 us,
+and almost every row has a duplicate per batch).  With that fixed a popular row walks ~500 cycles per example and the
+others ~1400 cycles per step of four rows.
 """
 import os
 import sys
