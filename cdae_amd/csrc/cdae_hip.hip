@@ -87,7 +87,10 @@ struct cdae_hip {
   uint32_t* d_col = nullptr;
   uint32_t* d_item_order = nullptr;
   uint32_t hot_rows = 0;            // decode: rows [0, hot_rows) of item_order get a wavefront of their own
-  bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: developer switch, every row on the 64-lane path
+  // developer switches, read once in cdae_hip_create (DESIGN.md lists them)
+  bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
+  bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
+  bool recommend_per_user = false;  // CDAE_RECOMMEND_PER_USER: recommend_kernel instead of the MFMA path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
   uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
   uint32_t* d_unit_ptr = nullptr;
@@ -411,7 +414,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // bf16 operand copies of this batch: Z, Z^T (rows >= nb zero) and D, D^T (rows >= I zero)
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
-  const bool fused = Kp <= 256 && !std::getenv("CDAE_FULL_UNFUSED");
+  const bool fused = Kp <= 256 && !h->full_unfused;
   uint32_t hg_parts = 0;                         // slabs of HGpart holding hg (0: accumulated into HG by atomics)
   if (fused) {
     // targets: one bit per (batch user, item); then forward + loss' + hidden gradient in one launch (cdae_full_kernels.hpp)
@@ -566,6 +569,9 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->NI = cfg->num_dim <= 64 ? 1 : (cfg->num_dim <= 128 ? 2 : (cfg->num_dim <= 256 ? 4 : 8));
   h->Kp = 64u * h->NI;
   h->B = cfg->batch_users ? cfg->batch_users : 1024u;
+  h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
+  h->full_unfused = std::getenv("CDAE_FULL_UNFUSED") != nullptr;
+  h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
@@ -652,7 +658,6 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     uint32_t hot = 0;
     while (hot < I && (double)pop[order[hot]] * share >= hot_pos) ++hot;
     h->hot_rows = std::min<uint32_t>((hot + 3u) & ~3u, (uint32_t)I);
-    h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
   }
 
   // parameters
@@ -1065,7 +1070,7 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
   if (u_begin > u_end || u_end > h->U) return fail("bad user range");
   if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
   HIPCHK(hipSetDevice(h->device));
-  if (topk <= (uint32_t)cdae::REC_TOPK_MAX && h->K <= 256 && !std::getenv("CDAE_RECOMMEND_PER_USER")) {
+  if (topk <= (uint32_t)cdae::REC_TOPK_MAX && h->K <= 256 && !h->recommend_per_user) {
     // matrix-core path: all users of a chunk in one launch (cdae_recommend_kernels.hpp)
     const uint32_t nch = h->K <= 32 ? 4 : (h->K <= 64 ? 8 : (h->K <= 128 ? 16 : (h->K <= 200 ? 25 : 32)));
     const uint32_t words = (uint32_t)((h->I + 31) / 32);
