@@ -736,7 +736,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     // capacity decode falls back to atomics.  Zero-filled once: decode's 16-lane path leaves elements >= 64 NV + 16 NT
     // of a row untouched and the gather reads whole rows.
     const char* ev = std::getenv("CDAE_DUP_CAP");
-    const uint64_t want = ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(4096, h->Ecap / 4);
+    const uint64_t want = ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4);   // small problems: every example
     h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
     CHK(dev_alloc(&h->d_dup_corr, (size_t)h->dup_cap * h->Kp));
     HIPCHK(hipMemset(h->d_dup_corr, 0, (size_t)h->dup_cap * h->Kp * sizeof(float)));

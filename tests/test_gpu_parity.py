@@ -159,6 +159,26 @@ def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
         np.testing.assert_allclose(model.get(w), want, rtol=0, atol=2e-6)
 
 
+def test_training_is_bit_deterministic_and_handles_reload(tiny, small):
+    """Two fresh handles, and a handle that held another data set before, produce bit-identical parameters: no atomics are
+    left on the default path (duplicate corrections are summed in example order)."""
+    cfg = cdae_amd.CDAEConfig(num_dim=40, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=96)
+
+    def run(model, data):
+        model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col)
+        model.init_params(3)
+        model.train_one_iteration(1, 0)
+        return {w: model.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+
+    first = run(cdae_amd.CDAE(cfg), tiny)
+    second = run(cdae_amd.CDAE(cfg), tiny)
+    reused = cdae_amd.CDAE(cfg)
+    run(reused, small)
+    third = run(reused, tiny)
+    for w in first:
+        assert np.array_equal(first[w], second[w]) and np.array_equal(first[w], third[w]), w
+
+
 def test_duplicate_correction_overflow_falls_back_to_atomics(tiny, monkeypatch):
     """CDAE_DUP_CAP bounds the duplicate-negative correction buffer; examples beyond it take the atomic path and the
     result is the same trajectory (up to the order of a few fp32 additions)."""
