@@ -148,7 +148,8 @@ gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm,
 constexpr int FUSED_TILE = 32;                       // items per MFMA tile
 constexpr int FUSED_SUB = 2;                         // tiles staged through LDS per step (64 items: loads get two tiles of work to land)
 constexpr size_t full_fused_lds_bytes(uint32_t Kp) {
-  return 2 * ((size_t)FUSED_SUB * FUSED_TILE * (Kp + 8) + (size_t)Kp * (FUSED_SUB * FUSED_TILE + 4)) * sizeof(__bf16);
+  return 2 * ((size_t)FUSED_SUB * FUSED_TILE * (Kp + 8) + (size_t)Kp * (FUSED_SUB * FUSED_TILE + 4)) * sizeof(__bf16) +
+         2 * ((size_t)FUSED_SUB * FUSED_TILE * sizeof(float) + (size_t)FUSED_SUB * 128 * sizeof(uint32_t));   // + b' and target words
 }
 
 template <int NKS /* Kp / 16 */>
@@ -165,6 +166,11 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
   extern __shared__ __attribute__((aligned(16))) char fused_smem[];
   __bf16* dt = reinterpret_cast<__bf16*>(fused_smem);                          // [2][STEP][DROW]
   __bf16* dtt = dt + 2 * STEP * DROW;                                          // [2][Kp][TROW]
+  // b' of the step's items and the users' rated-items words also come through LDS: a global load inside the epilogue makes
+  // the compiler drain vmcnt to 0 (loads and stores share the counter and complete out of order), i.e. wait for the G^T
+  // stores just issued — eight HBM write round trips per step
+  float* bpt = reinterpret_cast<float*>(dtt + 2 * Kp * TROW);                  // [2][STEP]
+  uint32_t* wt = reinterpret_cast<uint32_t*>(bpt + 2 * STEP);                   // [2][FUSED_SUB][128]
   const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
   const uint32_t col = lane & 31u, half = lane >> 5;
   const uint32_t user = blockIdx.y * 128u + wave * 32u + col;                  // batch slot
@@ -187,8 +193,15 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
   constexpr int D_PIECES = STEP * Kp / 8, T_PIECES = Kp * STEP / 8, T_PER_ROW = STEP / 8;
   constexpr int D_PER = (D_PIECES + 255) / 256, T_PER = (T_PIECES + 255) / 256;
   bf16x8 sd[D_PER], stt[T_PER];
+  float sb = 0.f;
+  uint32_t sw = 0u;
   auto fetch = [&](uint32_t st) {
     const uint32_t i0 = st * STEP;
+    if (threadIdx.x < (uint32_t)STEP) sb = bp[i0 + threadIdx.x];               // in bounds up to Ip: b'_ag, b, b_ag follow b'
+    {
+      const uint32_t u = blockIdx.y * 128u + (threadIdx.x & 127u), t = st * FUSED_SUB + (threadIdx.x >> 7);
+      sw = (u < nb && t < words) ? bits[(size_t)u * words + t] : 0u;           // 256 threads = FUSED_SUB x 128 users
+    }
 #pragma unroll
     for (int q = 0; q < D_PER; ++q) {
       const uint32_t f = threadIdx.x + 256u * q;
@@ -201,6 +214,8 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
     }
   };
   auto commit = [&](int buf) {
+    if (threadIdx.x < (uint32_t)STEP) bpt[buf * STEP + threadIdx.x] = sb;
+    wt[buf * FUSED_SUB * 128 + threadIdx.x] = sw;
 #pragma unroll
     for (int q = 0; q < D_PER; ++q) {
       const uint32_t f = threadIdx.x + 256u * q;
@@ -228,7 +243,7 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
     for (int sub = 0; sub < FUSED_SUB; ++sub) {
       const uint32_t t = st * FUSED_SUB + sub;                                 // global 32-item tile index
-      const uint32_t word = user_ok && t < words ? bits[(size_t)user * words + t] : 0u;   // the user's training items in the tile
+      const uint32_t word = wt[(buf * FUSED_SUB + sub) * 128 + wave * 32u + col];          // the user's training items in the tile
       // product 1: C1[item][user]
       // (all fragments are read from LDS first, then the MFMAs issue back to back on two alternating accumulators: with one
       // wavefront per SIMD nothing else hides a dependent MFMA's latency or an LDS wait between two of them)
@@ -251,7 +266,7 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t i0 = t * FUSED_TILE + 8u * q + 4u * half;
-        const float4 b4 = *reinterpret_cast<const float4*>(bp + i0);           // in bounds up to Ip: b'_ag, b, b_ag follow b'
+        const float4 b4 = *reinterpret_cast<const float4*>(bpt + buf * STEP + sub * FUSED_TILE + 8 * q + 4 * half);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
