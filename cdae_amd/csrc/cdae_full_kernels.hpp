@@ -152,7 +152,7 @@ constexpr size_t full_fused_lds_bytes(uint32_t Kp) {
          2 * ((size_t)FUSED_SUB * FUSED_TILE * sizeof(float) + (size_t)FUSED_SUB * 128 * sizeof(uint32_t));   // + b' and target words
 }
 
-template <int NKS /* Kp / 16 */>
+template <int NKS /* Kp / 16 */, int LOSS>
 __global__ void __launch_bounds__(256)
 full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x Kp] */, const __bf16* __restrict__ Db /* [Ip x Kp] */,
                          const __bf16* __restrict__ DTb /* [Kp x Ip] */, uint32_t Ip, const float* __restrict__ bp,
@@ -174,7 +174,6 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
   const uint32_t lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
   const uint32_t col = lane & 31u, half = lane >> 5;
   const uint32_t user = blockIdx.y * 128u + wave * 32u + col;                  // batch slot
-  const bool user_ok = user < nb;
   const uint32_t n_steps = Ip / STEP;                                          // Ip is a multiple of 128
   const uint32_t s_begin = blockIdx.x * steps_per_slice, s_end = min(n_steps, s_begin + steps_per_slice);
   if (s_begin >= s_end) return;
@@ -195,43 +194,51 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
   bf16x8 sd[D_PER], stt[T_PER];
   float sb = 0.f;
   uint32_t sw = 0u;
+  // per-thread piece addresses are fixed up to the step's offset: computed once, advanced by a constant per step
+  uint32_t d_src[D_PER], d_dst[D_PER], t_src[T_PER], t_dst[T_PER];                 // element offsets (bf16)
+#pragma unroll
+  for (int q = 0; q < D_PER; ++q) {
+    const uint32_t f = threadIdx.x + 256u * q, r = f / (Kp / 8), c = f % (Kp / 8);
+    d_src[q] = r * Kp + 8 * c; d_dst[q] = r * DROW + 8 * c;
+  }
+#pragma unroll
+  for (int q = 0; q < T_PER; ++q) {
+    const uint32_t f = threadIdx.x + 256u * q, r = f / T_PER_ROW, c = f % T_PER_ROW;
+    t_src[q] = r * Ip + 8 * c; t_dst[q] = r * TROW + 8 * c;
+  }
+  const uint32_t w_user = blockIdx.y * 128u + (threadIdx.x & 127u), w_sub = threadIdx.x >> 7;   // 256 threads = FUSED_SUB x 128 users
   auto fetch = [&](uint32_t st) {
     const uint32_t i0 = st * STEP;
+    const __bf16* dsrc = Db + (size_t)i0 * Kp;
+    const __bf16* tsrc = DTb + i0;
     if (threadIdx.x < (uint32_t)STEP) sb = bp[i0 + threadIdx.x];               // in bounds up to Ip: b'_ag, b, b_ag follow b'
     {
-      const uint32_t u = blockIdx.y * 128u + (threadIdx.x & 127u), t = st * FUSED_SUB + (threadIdx.x >> 7);
-      sw = (u < nb && t < words) ? bits[(size_t)u * words + t] : 0u;           // 256 threads = FUSED_SUB x 128 users
+      const uint32_t t = st * FUSED_SUB + w_sub;
+      sw = (w_user < nb && t < words) ? bits[(size_t)w_user * words + t] : 0u;
     }
 #pragma unroll
-    for (int q = 0; q < D_PER; ++q) {
-      const uint32_t f = threadIdx.x + 256u * q;
-      if (f < (uint32_t)D_PIECES) sd[q] = *reinterpret_cast<const bf16x8*>(Db + (size_t)(i0 + f / (Kp / 8)) * Kp + 8 * (f % (Kp / 8)));
-    }
+    for (int q = 0; q < D_PER; ++q)
+      if (threadIdx.x + 256u * q < (uint32_t)D_PIECES) sd[q] = *reinterpret_cast<const bf16x8*>(dsrc + d_src[q]);
 #pragma unroll
-    for (int q = 0; q < T_PER; ++q) {
-      const uint32_t f = threadIdx.x + 256u * q;
-      if (f < (uint32_t)T_PIECES) stt[q] = *reinterpret_cast<const bf16x8*>(DTb + (size_t)(f / T_PER_ROW) * Ip + i0 + 8 * (f % T_PER_ROW));
-    }
+    for (int q = 0; q < T_PER; ++q)
+      if (threadIdx.x + 256u * q < (uint32_t)T_PIECES) stt[q] = *reinterpret_cast<const bf16x8*>(tsrc + t_src[q]);
   };
   auto commit = [&](int buf) {
     if (threadIdx.x < (uint32_t)STEP) bpt[buf * STEP + threadIdx.x] = sb;
     wt[buf * FUSED_SUB * 128 + threadIdx.x] = sw;
+    __bf16* ddst = dt + (size_t)buf * STEP * DROW;
+    __bf16* tdst = dtt + (size_t)buf * Kp * TROW;
 #pragma unroll
-    for (int q = 0; q < D_PER; ++q) {
-      const uint32_t f = threadIdx.x + 256u * q;
-      if (f < (uint32_t)D_PIECES) *reinterpret_cast<bf16x8*>(dt + (size_t)buf * STEP * DROW + (f / (Kp / 8)) * DROW + 8 * (f % (Kp / 8))) = sd[q];
-    }
+    for (int q = 0; q < D_PER; ++q)
+      if (threadIdx.x + 256u * q < (uint32_t)D_PIECES) *reinterpret_cast<bf16x8*>(ddst + d_dst[q]) = sd[q];
 #pragma unroll
-    for (int q = 0; q < T_PER; ++q) {
-      const uint32_t f = threadIdx.x + 256u * q;
-      if (f < (uint32_t)T_PIECES) {
+    for (int q = 0; q < T_PER; ++q)
+      if (threadIdx.x + 256u * q < (uint32_t)T_PIECES) {
         // rows are 8 (mod 16) bytes apart: two 8-byte stores
-        __bf16* dst = dtt + (size_t)buf * Kp * TROW + (f / T_PER_ROW) * TROW + 8 * (f % T_PER_ROW);
         const bf16x4 lo = {stt[q][0], stt[q][1], stt[q][2], stt[q][3]}, hi = {stt[q][4], stt[q][5], stt[q][6], stt[q][7]};
-        *reinterpret_cast<bf16x4*>(dst) = lo;
-        *reinterpret_cast<bf16x4*>(dst + 4) = hi;
+        *reinterpret_cast<bf16x4*>(tdst + t_dst[q]) = lo;
+        *reinterpret_cast<bf16x4*>(tdst + t_dst[q] + 4) = hi;
       }
-    }
   };
   fetch(s_begin);
   commit(0);
@@ -261,22 +268,24 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) c1[r] += c1b[r];
-      // loss gradient of the lane's 16 (item, user) pairs: items 8 q + 4 half + e of the tile
+      // loss gradient of the lane's 16 (item, user) pairs: items 8 q + 4 half + e of the tile.  Straight-line: rows of padding
+      // users (z = 0) and their G^T columns are never read back, so only items beyond num_items (last tile; their b' slot
+      // holds other parameters) are forced to g = 0, and the store address is a 32-bit offset from a uniform base.
       bf16x8 ga[2];                                                            // A operands of product 2 (16-item steps)
+      const bool tail_tile = (t + 1u) * FUSED_TILE > hp.num_items;             // wave-uniform
+      const uint32_t gt_off = (t * FUSED_TILE + 4u * half) * ldgt + user;      // G^T is < 2^32 elements (checked by the host)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t i0 = t * FUSED_TILE + 8u * q + 4u * half;
         const float4 b4 = *reinterpret_cast<const float4*>(bpt + buf * STEP + sub * FUSED_TILE + 8 * q + 4 * half);
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t item = i0 + (uint32_t)e;
-          const float tgt = (word >> (8u * q + 4u * half + (uint32_t)e)) & 1u ? 1.f : 0.f;
-          float g = 0.f;
-          if (user_ok && item < hp.num_items) g = loss_grad(hp.loss_type, c1[4 * q + e] + bb[e], tgt);
+          const float tgt = (float)((word >> (8u * q + 4u * half + (uint32_t)e)) & 1u);
+          float g = loss_grad(LOSS, c1[4 * q + e] + bb[e], tgt);
+          if (tail_tile && t * FUSED_TILE + 8u * q + 4u * half + (uint32_t)e >= hp.num_items) g = 0.f;
           const __bf16 gb = (__bf16)g;
           ga[q >> 1][4 * (q & 1) + e] = gb;
-          GT[(size_t)item * ldgt + user] = gb;
+          GT[gt_off + (8u * q + (uint32_t)e) * ldgt] = gb;
         }
       }
       // product 2: hg[user][k] += sum over the tile's items; step ks covers tile items {16 ks + 4 half + 0..3, 16 ks + 8 + 4 half + 0..3}

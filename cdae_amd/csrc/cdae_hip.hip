@@ -424,13 +424,19 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     const uint32_t tps = (tiles + slices - 1) / slices;
     const dim3 grid(slices, Bp / 128);
     const size_t lds = full_fused_lds_bytes(Kp);
-#define FUSED_LAUNCH(NKS_)                                                                                                          \
-  do {                                                                                                                              \
-    HIPCHK(hipFuncSetAttribute((const void*)full_decode_fused_kernel<NKS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-    hipLaunchKernelGGL(full_decode_fused_kernel<NKS_>, grid, blk, lds, st, h->hp, h->d_Zb, h->d_Db, h->d_DTb, Ip, h->P(CDAE_P_BP),   \
-                       h->d_bits_train, words, nb, tps, h->d_GTb, Bp, h->d_HGpart);                                                 \
+#define FUSED_LAUNCH2(NKS_, L_)                                                                                                         \
+  do {                                                                                                                                  \
+    HIPCHK(hipFuncSetAttribute((const void*)full_decode_fused_kernel<NKS_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL((full_decode_fused_kernel<NKS_, L_>), grid, blk, lds, st, h->hp, h->d_Zb, h->d_Db, h->d_DTb, Ip, h->P(CDAE_P_BP), \
+                       h->d_bits_train, words, nb, tps, h->d_GTb, Bp, h->d_HGpart);                                                     \
   } while (0)
+#define FUSED_LAUNCH(NKS_)                                                                       \
+  do {                                                                                           \
+    if (h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY) FUSED_LAUNCH2(NKS_, 5); else FUSED_LAUNCH2(NKS_, 0); \
+  } while (0)
+    if ((uint64_t)Ip * Bp > 0xFFFFFFFFull) return fail("full-output decode: G^T of %u x %u exceeds 2^32 elements; lower batch_users", Ip, Bp);
     switch (Kp) { case 64: FUSED_LAUNCH(4); break; case 128: FUSED_LAUNCH(8); break; default: FUSED_LAUNCH(16); break; }
+#undef FUSED_LAUNCH2
 #undef FUSED_LAUNCH
     hg_parts = slices;
     HIPCHK(hipStreamWaitEvent(st, x.ready, 0));   // the row step below reads the sorted positives list
