@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256)
 gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
                     uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep) {
   const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;
-  const uint32_t m_base = blockIdx.y * 128 + (wid >> 1) * 64;
+  const uint32_t m_base = blockIdx.y * (blockDim.x / 2) + (wid >> 1) * 64;   // 256 threads: 128 rows per workgroup; 128 threads: 64
   const uint32_t n_base = blockIdx.x * 128 + (wid & 1) * 64;
   if (m_base >= M || n_base >= N) return;
   const uint32_t k_begin = blockIdx.z * k_per_split;

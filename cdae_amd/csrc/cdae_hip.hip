@@ -477,7 +477,8 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   {
     GemmEpilogue e3{};
     e3.Cout = h->d_dD; e3.ldc = Kp;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 128, 1), blk, 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
+    // 64-row workgroups (two wavefronts): 2 x Ip/64 of them spread over all CUs, 128-row ones would occupy only 166 at ML-10M shape
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
                        Bp, Bp, Bp, Bp, e3);
   }
   CHK(pr.end());
