@@ -211,7 +211,7 @@ def main():
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
         "profiled_steps": int(acc["launches_decode"]),
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.gpus == 1:          # reported at N = 1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(data, cfg, args)
     print(json.dumps(out), flush=True)
     if dist is not None:
