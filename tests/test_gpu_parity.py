@@ -196,13 +196,14 @@ def test_duplicate_correction_overflow_falls_back_to_atomics(tiny, monkeypatch):
         np.testing.assert_allclose(small_cap.get(which), roomy.get(which), rtol=2e-5, atol=2e-6)
 
 
-def test_pipelined_exchange_kernels(tiny):
+@pytest.mark.parametrize("K", [1, 20, 50, 200])
+def test_pipelined_exchange_kernels(tiny, K):
     """cdae_hip_delta_stage / _merge / _merge_stage with a fake peer: the "all-reduced" buffer is a multiple of the rank's
     own staged delta (so the row pads stay zero, as with real peers); the peer part must land on the live parameters one
     period late while the rank's own later steps are kept, and must never be re-sent."""
     import torch
     from cdae_amd.distributed import PipelinedDeltaExchange
-    model, _ = make_pair(tiny, K=20, B=64)
+    model, _ = make_pair(tiny, K=K, B=64)
     shared_ids = (0, 1, 8, 9, 6, 7)
     ex = PipelinedDeltaExchange(model, None, 1, period=1)
 
