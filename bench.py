@@ -60,8 +60,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
                     "code path on a single-GPU box together with --share-device")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
-    ap.add_argument("--exchange-every", type=int, default=2, help="N > 1: batches between exchanges of the shared-parameter "
-                    "deltas (pipelined: the all-reduce overlaps the next period; 0 = synchronous exchange after every batch)")
+    ap.add_argument("--exchange-every", type=int, default=-1, help="N > 1: batches between exchanges of the shared-parameter "
+                    "deltas (pipelined: the all-reduce overlaps the next period).  -1 (default): chosen at start-up so that one "
+                    "period of training covers a measured all-reduce; 0: synchronous exchange after every batch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -102,8 +103,8 @@ def main():
                            user_id_offset=rank * data.num_users)
     model.init_params(args.seed)         # identical shared parameters on every rank; Wu differs but is private
     exch = pipe = None
-    if world > 1 and args.exchange_every > 0:
-        pipe = PipelinedDeltaExchange(model, dist, world, period=args.exchange_every)
+    if world > 1 and args.exchange_every != 0:
+        pipe = PipelinedDeltaExchange(model, dist, world, period=max(1, args.exchange_every))
     elif world > 1:
         exch = DeltaExchange(model, dist, world)
 
@@ -140,6 +141,20 @@ def main():
         model.synchronize()
         torch.cuda.synchronize()
 
+    exchange_note = None
+    if pipe and args.exchange_every < 0:
+        # auto period: time a few batches without exchange and a few idle all-reduces of the real buffer, before anything
+        # that counts has been staged
+        pipe.period = 1 << 30
+        sync()
+        tw = time.perf_counter()
+        for i in range(min(args.warmup, 10)):
+            step(i)
+        sync()
+        t_step = (time.perf_counter() - tw) / max(1, min(args.warmup, 10))
+        pipe.flush()                      # exchange what those batches did, so the replicas agree again
+        args.exchange_every, t_ar = pipe.choose_period(t_step)
+        exchange_note = f"period chosen at start-up: all-reduce {t_ar * 1e6:.0f} us vs {t_step * 1e6:.0f} us per batch"
     for i in range(args.warmup):
         step(i)
     model.collect_stats()
@@ -206,6 +221,7 @@ def main():
         "config": {"workload": workload, "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
                    "exchange": ("none" if args.gpus == 1 else
                                 f"pipelined all-reduce(sum) of shared-parameter deltas every {args.exchange_every} batches, merged one period late"
+                                + (f" ({exchange_note})" if exchange_note else "")
                                 if args.exchange_every > 0 else "synchronous all-reduce(sum) of shared-parameter deltas every batch")},
         "roofline": roofline,
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},

@@ -137,6 +137,45 @@ class PipelinedDeltaExchange:
         self._boundary(start_next=True)
         self._boundary(start_next=False)
 
+    def time_all_reduce(self, repeats: int = 5) -> float:
+        """Seconds per all-reduce of the exchange buffer, measured with the device otherwise idle (call between
+        boundaries: the buffer's contents are summed `repeats` + 2 times, so only use it before the first stage that
+        matters, e.g. during warm-up)."""
+        torch = self.torch
+        if self.dist is None:
+            return 0.0
+        with torch.cuda.stream(self.stream):
+            if self.work is not None:
+                self.work.wait()
+            for _ in range(2):
+                self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+            for _ in range(repeats):
+                self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM)
+            b.record(self.stream)
+            b.synchronize()
+            return a.elapsed_time(b) * 1e-3 / repeats
+
+    def choose_period(self, step_seconds: float, lo: int = 1, hi: int = 8, slack: float = 1.5):
+        """Smallest period whose training time covers one all-reduce (x slack: the collective shares the chip with the
+        kernels it overlaps); agreed across ranks (MAX).  Call it right after flush(): it restages a zero delta.  Returns
+        (period, seconds per all-reduce)."""
+        torch = self.torch
+        t_ar = self.time_all_reduce()
+        want = int(min(hi, max(lo, -(-slack * t_ar // max(step_seconds, 1e-9)))))
+        if self.dist is not None and self.world > 1:
+            t = torch.tensor([want], dtype=torch.int32, device=self.recv.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            want = int(t.item())
+        self.period = want
+        self.batches = 0
+        self.work = None
+        with torch.cuda.stream(self.stream):
+            self.model.delta_begin()                       # fresh base; the timing runs left garbage in the receive buffer
+            self.model.delta_stage()
+        return want, t_ar
+
 
 class _Done:
     def wait(self):

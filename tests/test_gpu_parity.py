@@ -260,8 +260,16 @@ def test_pipelined_exchange_over_rccl_single_rank(tiny):
         from cdae_amd.distributed import PipelinedDeltaExchange
         a, _ = make_pair(tiny, K=24, B=32)
         b, _ = make_pair(tiny, K=24, B=32)
-        ex = PipelinedDeltaExchange(a, dist, 1, period=2)
-        for i in range(5):
+        ex = PipelinedDeltaExchange(a, dist, 1, period=1 << 30)
+        for i in range(2):                                 # bench.py's start-up: a few batches without exchange, flush,
+            a.enqueue_users(3, 0, 32 * i, 32 * (i + 1))    # then the period is chosen from a timed all-reduce
+            ex.after_batch()
+            b.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
+        ex.flush()
+        period, t_ar = ex.choose_period(step_seconds=1e-4)
+        assert 1 <= period <= 8 and t_ar > 0 and ex.period == period
+        ex.period = 2
+        for i in range(2, 7):
             a.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
             ex.after_batch()
             b.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
