@@ -642,9 +642,10 @@ decode_rows_kernel(HyperParams hp, CDAE_DECODE_PARAMS) {
 
 // ------------------------------------------------------------------------------------------------
 // K3 (K <= 256)  FOUR item rows per wavefront, one per 16-lane group (= one DPP row).
-// Measured (profiles/r01_decode_timeline.txt): with one row per wavefront the launch is VALU-throughput bound
-// chip-wide — ~100 VALU instructions per example, a third of them (wave reduction, sigmoid, flag decoding, ring
-// bookkeeping) independent of K, and a K = 200 row fills only 50 of 64 lanes x 4 elements.  Here a row is held as
+// The rows below the popular ones carry 98 % of the examples; what they cost is instruction issue (PMC: ~34 M
+// instructions per launch with one row per wavefront, ~22 M here, at 5-6 cycles per instruction per SIMD;
+// profiles/r01_decode_bisect.txt), a third of it (wave reduction, sigmoid, flag decoding, ring bookkeeping) independent of
+// K, and a K = 200 row fills only 50 of 64 lanes x 4 elements in the one-row layout.  Here a row is held as
 // NV float4 pieces (lane l of the group: elements 64 v + 4 l .. + 3) plus NT tail scalars (elements 64 NV + l + 16 i),
 // so K = 200 is 3 x float4 + 1 scalar = 13 registers with 200 of 208 slots used; the reduction is four intra-row DPP
 // steps with no read-back, and every per-example instruction serves four rows.  The last tail slot (lane 15 of tail
