@@ -656,7 +656,7 @@ decode_rows_kernel(HyperParams hp, CDAE_DECODE_PARAMS) {
 // l+48) and broadcast inside the group with ds_bpermute; z rows run PF examples ahead; g is parked in four VGPRs and
 // stored once per 64 examples so the loop issues loads only (counted vmcnt, see above).
 template <int NV, int NT>
-__device__ __forceinline__ void row16_load(float (&r)[4 * NV + NT + (NV + NT == 0)], const float* __restrict__ base, uint32_t l) {
+__device__ __forceinline__ void row16_load(float (&r)[4 * NV + NT], const float* __restrict__ base, uint32_t l) {
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const float4 q = *reinterpret_cast<const float4*>(base + 64 * v + 4 * l);
@@ -666,7 +666,7 @@ __device__ __forceinline__ void row16_load(float (&r)[4 * NV + NT + (NV + NT == 
   for (int i = 0; i < NT; ++i) r[4 * NV + i] = base[64 * NV + l + 16 * i];
 }
 template <int NV, int NT>
-__device__ __forceinline__ void row16_store(float* __restrict__ base, const float (&r)[4 * NV + NT + (NV + NT == 0)], uint32_t l) {
+__device__ __forceinline__ void row16_store(float* __restrict__ base, const float (&r)[4 * NV + NT], uint32_t l) {
 #pragma unroll
   for (int v = 0; v < NV; ++v)
     *reinterpret_cast<float4*>(base + 64 * v + 4 * l) = make_float4(r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]);
