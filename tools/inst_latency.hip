@@ -54,12 +54,43 @@ __global__ void k_rcp4(float* out, unsigned long long* cyc, float x0, float c) {
   out[threadIdx.x] = a + b + d + e;
   if (threadIdx.x == 0) *cyc = t1 - t0;
 }
+// cross-row sum + broadcast after four in-row DPP stages: (a) two row_bcast stages + v_readlane + first use,
+// (b) one v_mfma_f32_16x16x4_f32 with A = 1 (sums the four 16-lane rows into every lane) + first use
+__global__ void k_tail_dpp(float* out, unsigned long long* cyc, float x0, float c) {
+  float x = x0 + threadIdx.x * 1e-6f, y = c;
+  unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll
+  for (int i = 0; i < REP; ++i)
+    asm volatile("s_nop 1\n v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 1\n"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xf bank_mask:0xf bound_ctrl:1\n s_nop 0\n"
+                 "v_readlane_b32 s20, %0, 63\n s_nop 3\n v_mul_f32 %0, s20, %1" : "+v"(x) : "v"(y) : "s20");
+  unsigned long long t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = x;
+  if (threadIdx.x == 0) *cyc = t1 - t0;
+}
+__global__ void k_tail_mfma(float* out, unsigned long long* cyc, float x0, float c) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  float x = x0 + threadIdx.x * 1e-6f, y = c;
+  asm volatile("" : "+v"(x));
+  unsigned long long t0 = __builtin_readcyclecounter();
+  asm volatile("" : "+v"(x));
+#pragma unroll
+  for (int i = 0; i < REP; ++i) {
+    v4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, x, acc, 0, 0, 0);
+    x = acc[0] * y;
+    asm volatile("" : "+v"(x));
+  }
+  unsigned long long t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = x;
+  if (threadIdx.x == 0) *cyc = t1 - t0;
+}
 #define RUN(NAME, N) do { k_##NAME<<<1, 64>>>(out, cyc, 1.0001f, 0.999f); hipDeviceSynchronize(); k_##NAME<<<1, 64>>>(out, cyc, 1.0001f, 0.999f); hipDeviceSynchronize(); \
   unsigned long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost); printf("%-14s %7.1f cycles per step (%d instr/step)\n", #NAME, (double)h / REP, N); } while (0)
 int main() {
   float* out; unsigned long long* cyc;
   hipMalloc(&out, 256); hipMalloc(&cyc, 8);
   RUN(fma, 1); RUN(mul, 1); RUN(pkfma, 1); RUN(exp, 1); RUN(rcp, 1); RUN(sqrt, 1); RUN(rsq, 1); RUN(dpp_quad, 1); RUN(dpp_bcast, 1);
-  RUN(readlane, 2); RUN(fma_then_exp, 2); RUN(sqrt_add_rcp, 3); RUN(fma4, 4); RUN(rcp4, 4);
+  RUN(readlane, 2); RUN(fma_then_exp, 2); RUN(sqrt_add_rcp, 3); RUN(fma4, 4); RUN(rcp4, 4); RUN(tail_dpp, 4); RUN(tail_mfma, 2);
   return 0;
 }
