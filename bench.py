@@ -14,6 +14,12 @@ torch.cuda.synchronize() on both sides of exactly K steps, max over ranks; rank 
 """
 from __future__ import annotations
 
+import os as _os
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The library runs three streams (main, prep, aux);
+# with RCCL's own streams on top two of them end up sharing a queue and the prep / main overlap is lost (measured: 158 ->
+# 254 us per step as soon as an RCCL communicator exists before the handle is created).  Must be set before HIP initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import argparse
 import json
 import os
@@ -83,15 +89,6 @@ def main():
     from cdae_amd import synth
     from cdae_amd.distributed import DeltaExchange, PipelinedDeltaExchange
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
-
     # every rank owns one ML-10M-shaped shard of users over the same item space
     data = synth.generate_shape(args.shape, seed=args.seed + 7919 * rank)
     K, B = args.num_dim, min(args.batch_users, data.num_users)
@@ -102,10 +99,22 @@ def main():
     model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col,
                            user_id_offset=rank * data.num_users)
     model.init_params(args.seed)         # identical shared parameters on every rank; Wu differs but is private
+    # The process group is created AFTER the library handle: with an RCCL communicator (and its streams) in place first, the
+    # handle's streams are assigned hardware queues that make the overlapped exchange several times slower (measured with
+    # a one-rank group: 0.42 vs 0.18 ms per step).
+    dist = None
+    force_dist = bool(os.environ.get("CDAE_BENCH_FORCE_DIST"))   # developer aid: exercise the RCCL path with one rank
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     exch = pipe = None
-    if world > 1 and args.exchange_every != 0:
+    if (world > 1 or force_dist) and args.exchange_every != 0:
         pipe = PipelinedDeltaExchange(model, dist, world, period=max(1, args.exchange_every))
-    elif world > 1:
+    elif world > 1 or force_dist:
         exch = DeltaExchange(model, dist, world)
 
     n_batches = (data.num_users + B - 1) // B
@@ -153,7 +162,7 @@ def main():
         sync()
         t_step = (time.perf_counter() - tw) / max(1, min(args.warmup, 10))
         pipe.flush()                      # exchange what those batches did, so the replicas agree again
-        args.exchange_every, t_ar = pipe.choose_period(t_step)
+        args.exchange_every, t_ar = pipe.choose_period(t_step, lo=2)       # a boundary costs ~40 us of stream time: never every batch
         exchange_note = f"period chosen at start-up: all-reduce {t_ar * 1e6:.0f} us vs {t_step * 1e6:.0f} us per batch"
     for i in range(args.warmup):
         step(i)
@@ -181,6 +190,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, users_total = float(tmax[0]), float(t[1])
 
+    if dist is not None:
+        # RCCL writes a version banner to the C stdout buffer of every rank: push it out now, on all ranks, so that
+        # rank 0's JSON line is the last thing the job prints
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -229,9 +244,11 @@ def main():
     }
     if not args.no_cpu_baseline and args.gpus == 1:          # reported at N = 1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(data, cfg, args)
-    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 def measured_traffic(shape, K, B):

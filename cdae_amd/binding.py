@@ -93,6 +93,9 @@ def load_library(path: str = LIB_PATH):
     # to the system's (7.2).  If this library pulled the system copies in first, a later `import torch` (needed
     # only for torch.distributed) finds a foreign runtime already loaded and reports "No HIP GPUs are available".
     # Loading torch first makes both share torch's copy, which the kernels run on unchanged.
+    # three library streams + the caller's (torch, RCCL) need more than HIP's default four hardware queues to stay
+    # concurrent (bench.py has the measurement); only effective if HIP has not been initialised yet
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         import torch  # noqa: F401
     except ImportError:

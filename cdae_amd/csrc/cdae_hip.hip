@@ -550,6 +550,11 @@ int copy_param_out(cdae_hip* h, uint32_t which, float* host, size_t count) {
 
 }  // namespace
 
+// The library keeps three HIP streams busy (main, prep, aux) next to the host application's own (e.g. RCCL's): more than
+// HIP's default of four hardware queues, beyond which streams share a queue and serialise.  Runs at load time, i.e. before
+// this process's first HIP call when the library is loaded first; a no-op if the variable is already set.
+__attribute__((constructor)) static void cdae_hip_raise_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" {
 
 const char* cdae_hip_last_error(void) { return g_err.c_str(); }
