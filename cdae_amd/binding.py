@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcdae_hip.so")
 # libcf::LossType values (/root/reference/src/model/loss.hpp:10-18)
 SQUARE, LOGISTIC, LOG, HINGE, SQUARED_HINGE, CROSS_ENTROPY, LOGM = range(7)
 
-P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG = range(10)
+P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG, P_UU, P_UU_AG = range(12)
+P_COUNT = 12
 
 DEFAULT_BATCH_USERS = 0        # 0 = the library's default (num_users / 160, within [32, 512])
 
@@ -27,7 +28,7 @@ DEFAULT_BATCH_USERS = 0        # 0 = the library's default (num_users / 160, wit
 class _Config(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "struct_size", "num_dim", "num_neg", "num_corruptions", "loss_type", "using_adagrad",
-        "asymmetric", "user_factor", "linear", "scaled", "tanh_act", "batch_users", "full_output")] + [
+        "asymmetric", "user_factor", "linear", "scaled", "tanh_act", "batch_users", "full_output", "linear_function")] + [
             (n, C.c_double) for n in ("lambda_", "learn_rate", "corruption_ratio", "beta")]
 
 
@@ -150,13 +151,12 @@ class CDAE:
     """
 
     def __init__(self, mcfg: CDAEConfig, device: int = 0):
-        if mcfg.linear_function:
-            raise CDAEError("linear_function (Uu) is not supported (cdae.sh:23 only ever passes false)")
         self.lib = load_library()
         self.cfg = mcfg
         c = _Config(C.sizeof(_Config), mcfg.num_dim, mcfg.num_neg, mcfg.num_corruptions, mcfg.lt,
                     int(mcfg.using_adagrad), int(mcfg.asymmetric), int(mcfg.user_factor), int(mcfg.linear),
-                    int(mcfg.scaled), int(mcfg.tanh), mcfg.batch_users, int(mcfg.full_output), mcfg.lambda_, mcfg.learn_rate,
+                    int(mcfg.scaled), int(mcfg.tanh), mcfg.batch_users, int(mcfg.full_output), int(mcfg.linear_function),
+                    mcfg.lambda_, mcfg.learn_rate,
                     mcfg.corruption_ratio, mcfg.beta)
         self.h = C.c_void_p()
         _chk(self.lib, self.lib.cdae_hip_create(C.byref(c), device, C.byref(self.h)))
@@ -195,7 +195,7 @@ class CDAE:
             return (self.num_items,)
         if which in (P_B, P_B_AG):
             return (K,)
-        if which in (P_WU, P_WU_AG):
+        if which in (P_WU, P_WU_AG, P_UU, P_UU_AG):
             return (self.num_users, K)
         return (self.num_items, K)
 

@@ -105,6 +105,10 @@ struct cdae_hip {
   size_t cnt[CDAE_P_COUNT] = {0};   // padded element counts
   float* d_Wu = nullptr;
   float* d_Wu_ag = nullptr;
+  float* d_Uu = nullptr;                // linear_function only: [U][Kp] per-user gate (cdae.hpp:437-438)
+  float* d_Uu_ag = nullptr;
+  float* d_Ssum = nullptr;              // linear_function only: [B][Kp] unscaled input sums of the batch (Uu step)
+  float* d_delta_rows = nullptr;        // linear_function only: [B][Kp] Uu[u] (.) delta_u (what the input rows receive)
 
   // batch workspace
   uint64_t Ecap = 0;
@@ -156,10 +160,13 @@ struct cdae_hip {
   float* P(uint32_t which) {
     if (which == CDAE_P_WU) return d_Wu;
     if (which == CDAE_P_WU_AG) return d_Wu_ag;
+    if (which == CDAE_P_UU) return d_Uu;
+    if (which == CDAE_P_UU_AG) return d_Uu_ag;
     return cnt[which] ? d_shared + off[which] : nullptr;
   }
   float* dec() { return cfg.asymmetric ? P(CDAE_P_V) : P(CDAE_P_W); }
   float* dec_ag() { return cfg.asymmetric ? P(CDAE_P_V_AG) : P(CDAE_P_W_AG); }
+  float* delta_rows() { return cfg.linear_function ? d_delta_rows : d_HG; }
 };
 
 namespace {
@@ -209,7 +216,8 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train};
+                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
+                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
@@ -233,7 +241,8 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train};
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
+                   (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
@@ -311,7 +320,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
               (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
               explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG);
+              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
   CHK(pr.end());
 
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
@@ -373,7 +382,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
               x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr,
               explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
-              h->d_Wu, h->d_Wu_ag, 8u);
+              h->d_Wu, h->d_Wu_ag, 8u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
   CHK(pr.end());
   // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
   CHK(pr.begin(h, F_INPUT, st));
@@ -381,7 +390,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
     const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
     DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
                 x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), CDAE_TOUCHED_ARG, nb, h->P(CDAE_P_B),
-                h->P(CDAE_P_B_AG));
+                h->P(CDAE_P_B_AG), h->delta_rows());
   }
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
@@ -407,7 +416,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
               n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart,
               (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG);
+              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
   CHK(pr.end());
 
   CHK(pr.begin(h, F_DECODE, st));
@@ -467,7 +476,8 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     Prof pa;
     CHK(pa.begin(h, F_HIDDEN, h->aux));
     DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, hg_parts ? (const uint32_t*)h->d_iota : uptr,
-                hg_parts ? nb : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts);
+                hg_parts ? nb : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts,
+                h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
     CHK(pa.end());
   }
   HIPCHK(hipEventRecord(h->ev_delta, h->aux));
@@ -485,7 +495,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
   CHK(pr.begin(h, F_INPUT, st));
-  DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->d_HG,
+  DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
               h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
               h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
   HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -507,7 +517,7 @@ int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, 
               h->P(CDAE_P_W), uptr, n_units, d_uids, u0, nb, mode, stream_id, cidx, seed, epoch, hpart,
               (const uint32_t*)nullptr, 0u, d_uids ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
   DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, hpart, uptr, h->d_Wu,
-              h->P(CDAE_P_B), d_uids, u0, nb, mode, z_out ? z_out : h->d_Z, (float*)nullptr, (float*)nullptr);
+              h->P(CDAE_P_B), d_uids, u0, nb, mode, z_out ? z_out : h->d_Z, (float*)nullptr, (float*)nullptr, h->d_Uu, (float*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -535,7 +545,7 @@ int copy_param_out(cdae_hip* h, uint32_t which, float* host, size_t count) {
   float* d = h->P(which);
   if (!d) return count == 0 ? 0 : fail("parameter %u is not allocated in this configuration", which);
   const bool vec = (which == CDAE_P_BP || which == CDAE_P_BP_AG);
-  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
+  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
   if (vec) {
     if (count != h->I) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)h->I, count);
     HIPCHK(hipMemcpyAsync(host, d, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -600,7 +610,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hp.num_neg = cfg->full_output ? 0u : cfg->num_neg;     // full output: the example list holds the positives only
   hp.loss_type = cfg->loss_type;
   hp.adagrad = cfg->using_adagrad; hp.asymmetric = cfg->asymmetric; hp.user_factor = cfg->user_factor;
-  hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act;
+  hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act; hp.linear_function = cfg->linear_function;
   hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
   hp.uid_offset = 0; hp.num_items = 0; hp.K = h->K; hp.Kp = h->Kp;
   hp.debug_rank = std::getenv("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
@@ -690,6 +700,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(dev_alloc(&h->d_Wu_ag, (size_t)U * h->Kp));
   HIPCHK(hipMemset(h->d_Wu, 0, (size_t)U * h->Kp * sizeof(float)));
   HIPCHK(hipMemset(h->d_Wu_ag, 0, (size_t)U * h->Kp * sizeof(float)));
+  if (h->cfg.linear_function) {
+    h->cnt[CDAE_P_UU] = h->cnt[CDAE_P_UU_AG] = (size_t)U * h->Kp;
+    CHK(dev_alloc(&h->d_Uu, (size_t)U * h->Kp));
+    CHK(dev_alloc(&h->d_Uu_ag, (size_t)U * h->Kp));
+  }
 
   // batch workspace sized for the largest batch of B consecutive users
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, U);
@@ -768,6 +783,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
+  if (h->cfg.linear_function) { CHK(dev_alloc(&h->d_Ssum, BK)); CHK(dev_alloc(&h->d_delta_rows, BK)); }
   if (h->cfg.full_output) {
     h->Bp = (B + 127u) & ~127u;
     h->Ip = ((uint32_t)I + 127u) & ~127u;
@@ -801,6 +817,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   fillm(h->P(CDAE_P_W_AG), I, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_V_AG), I, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->d_Wu_ag, U, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->d_Uu, U, h->K, h->Kp, 1.f, 0.f);                 // cdae.hpp:131-132
+  fillm(h->d_Uu_ag, U, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_BP_AG), I, 1, 1, 1e-4f, 1.f);
   HIPCHK(hipGetLastError());
@@ -827,6 +845,10 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   else { fill(h->d_Wu, h->U, h->K, h->Kp, 0.f); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }
   fill(h->P(CDAE_P_B), 1, h->K, h->Kp, 0.f); fill(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f);    // :123-124
   fill(h->P(CDAE_P_BP), h->I, 1, 1, 0.f); fill(h->P(CDAE_P_BP_AG), h->I, 1, 1, 1e-4f);          // :125-126
+  if (h->cfg.linear_function) {                                                                 // :130-133
+    hipLaunchKernelGGL(fill_matrix_kernel, blocks(h->U * h->Kp), dim3(256), 0, h->stream, h->d_Uu, h->U, h->K, h->Kp, 1.f, 0.f);
+    fill(h->d_Uu_ag, h->U, h->K, h->Kp, 1e-4f);
+  }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -843,7 +865,7 @@ int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t 
     HIPCHK(hipMemcpy(d, host, count * sizeof(float), hipMemcpyHostToDevice));
     return 0;
   }
-  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
+  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
   if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
   const bool is_acc = (which & 1u) != 0u;                 // odd ids are the *_AG accumulators: pad lanes stay 1
   hipLaunchKernelGGL(cdae::fill_matrix_kernel, dim3((uint32_t)((rows * h->Kp + 255) / 256)), dim3(256), 0, h->stream, d, rows,

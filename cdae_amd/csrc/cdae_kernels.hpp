@@ -38,6 +38,7 @@ struct HyperParams {
   uint32_t num_neg;
   uint32_t loss_type;        // 0 SQUARE, 5 CROSS_ENTROPY (loss.hpp:10-18)
   uint32_t adagrad, asymmetric, user_factor, linear, tanh_act;
+  uint32_t linear_function;  // per-user elementwise gate Uu on the input sum (cdae.hpp:382-384)
   uint64_t keep_thr;         // cdae_keep_threshold(q)
   uint64_t uid_offset;       // global id of local user 0 (data-parallel shards keep global random streams)
   uint32_t num_items;
@@ -373,7 +374,9 @@ __global__ void __launch_bounds__(256)
 encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t* __restrict__ uptr,
                      const float* __restrict__ Wu, const float* __restrict__ b, const uint32_t* __restrict__ uids,
                      uint64_t u0, uint32_t nb, int mode, float* __restrict__ Z, float* __restrict__ Dz,
-                     float* __restrict__ HGzero /* training: the batch's duplicate-correction rows start at 0 */) {
+                     float* __restrict__ HGzero /* training: the batch's duplicate-correction rows start at 0 */,
+                     const float* __restrict__ Uu /* linear_function only */,
+                     float* __restrict__ Ssum /* linear_function training: the unscaled input sums, for the Uu step */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -393,6 +396,13 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
   float bb[NI], wu[NI], z[NI], dz[NI];
   vload<NI>(bb, b + lo);
   if (hp.user_factor) vload<NI>(wu, Wu + (size_t)uid * hp.Kp + lo);
+  if (hp.linear_function) {                                  // h1 = Uu[u] (.) h1   cdae.hpp:382-384
+    float uu[NI];
+    vload<NI>(uu, Uu + (size_t)uid * hp.Kp + lo);
+    if (Ssum) vstore<NI>(Ssum + (size_t)slot * hp.Kp + lo, acc);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] *= uu[i];
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     float h = fmaf(acc[i], sc, bb[i]);
@@ -995,7 +1005,9 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
                      const float* __restrict__ HGpart, const float* __restrict__ Dz,
                      float* __restrict__ HG /* in: corrections (or the whole hg), out: delta */,
                      float* __restrict__ Wu, float* __restrict__ Wu_ag,
-                     uint32_t n_parts /* slabs of HGpart [n_parts][n_units][Kp] to add to HG (0: HG already holds hg) */) {
+                     uint32_t n_parts /* slabs of HGpart [n_parts][n_units][Kp] to add to HG (0: HG already holds hg) */,
+                     float* __restrict__ Uu, float* __restrict__ Uu_ag, const float* __restrict__ Ssum,
+                     float* __restrict__ DELTA_ROWS /* linear_function only: Uu[u] (.) delta_u for the input rows */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -1027,6 +1039,24 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
     for (int i = 0; i < NI; ++i) ada_step(hp, p[i], pa[i], fmaf(hp.lambda, p[i], delta[i]));
     vstore<NI>(Wu + ou, p);
     vstore<NI>(Wu_ag + ou, pa);
+  }
+  if (hp.linear_function) {
+    // The input rows take Uu[u] (.) delta (cdae.hpp:339) with Uu[u] from BEFORE its own step (:351-357 comes last).
+    // Uu_grad = lambda Uu[u] + sum_k delta (.) W[k] (cdae.hpp:295-299, 340 — no input scale there): the kept rows have
+    // not moved since the encode inside one user's step, so the sum is delta (.) Ssum with the encode's own row sum.
+    const size_t ou = (size_t)uid * hp.Kp + lo;
+    float p[NI], pa[NI], ss[NI], dr[NI];
+    vload<NI>(p, Uu + ou);
+    vload<NI>(pa, Uu_ag + ou);
+    vload<NI>(ss, Ssum + o);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      dr[i] = p[i] * delta[i];
+      ada_step(hp, p[i], pa[i], fmaf(hp.lambda, p[i], delta[i] * ss[i]));
+    }
+    vstore<NI>(DELTA_ROWS + o, dr);
+    vstore<NI>(Uu + ou, p);
+    vstore<NI>(Uu_ag + ou, pa);
   }
 }
 
@@ -1177,7 +1207,8 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                   const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
                   const float* __restrict__ DELTA, const float* __restrict__ G,
                   float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched,
-                  uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag) {
+                  uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag,
+                  const float* __restrict__ DELTA_ROWS /* == DELTA unless linear_function (then Uu[u] (.) delta_u) */) {
   const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
   if (blockIdx.x < bias_blocks) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1186,8 +1217,8 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
     return;
   }
   const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
-  if (hp.adagrad) input_row_role<NI, true>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA, G, W, W_ag, touched);
-  else input_row_role<NI, false>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA, G, W, W_ag, touched);
+  if (hp.adagrad) input_row_role<NI, true>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+  else input_row_role<NI, false>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,7 +59,9 @@ extern "C" {
 #define CDAE_P_B_AG 7u
 #define CDAE_P_BP 8u     /* items      : output bias b_prime                                  */
 #define CDAE_P_BP_AG 9u
-#define CDAE_P_COUNT 10u
+#define CDAE_P_UU 10u     /* users x K  : per-user gate on the input sum, linear_function only, cdae.hpp:437 */
+#define CDAE_P_UU_AG 11u
+#define CDAE_P_COUNT 12u
 
 typedef struct cdae_hip_config {
   uint32_t struct_size;      /* sizeof(cdae_hip_config), for ABI checking                  */
@@ -79,6 +81,8 @@ typedef struct cdae_hip_config {
   uint32_t full_output;      /* 1: every unrated item is a negative with target 0 (north-star */
                              /* extension; num_neg is ignored): dense decode on the MFMA cores, */
                              /* per-block summed decoder gradient            */
+  uint32_t linear_function;  /* cdae.hpp:29: h = Uu[u] (.) (scale * sum W[k]) + b + Wu[u], Uu trained */
+                             /* (fills what used to be alignment padding: struct_size is unchanged)   */
   double lambda;             /* cdae.hpp:15 */
   double learn_rate;         /* cdae.hpp:16 */
   double corruption_ratio;   /* cdae.hpp:21 */

@@ -13,7 +13,8 @@ _SO = os.path.join(_HERE, "libcdae_oracle.so")
 
 LOSS_SQUARE = 0
 LOSS_CE = 5
-P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG = range(10)
+P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG, P_UU, P_UU_AG = range(12)
+P_COUNT = 12
 
 
 def build(force: bool = False) -> str:
@@ -29,7 +30,7 @@ def build(force: bool = False) -> str:
 class _Cfg(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "num_dim", "num_neg", "num_corruptions", "loss_type", "using_adagrad", "asymmetric",
-        "user_factor", "linear", "scaled", "tanh_act")] + [(n, C.c_double) for n in (
+        "user_factor", "linear", "scaled", "tanh_act", "linear_function")] + [(n, C.c_double) for n in (
             "lambda_", "learn_rate", "corruption_ratio", "beta")]
 
 
@@ -46,6 +47,7 @@ class OracleConfig:
     linear: bool = False
     scaled: bool = True
     tanh: bool = False
+    linear_function: bool = False
     lambda_: float = 0.01
     learn_rate: float = 0.1
     corruption_ratio: float = 0.5
@@ -54,7 +56,7 @@ class OracleConfig:
     def _c(self) -> _Cfg:
         return _Cfg(self.num_dim, self.num_neg, self.num_corruptions, self.loss_type,
                     int(self.using_adagrad), int(self.asymmetric), int(self.user_factor),
-                    int(self.linear), int(self.scaled), int(self.tanh), self.lambda_,
+                    int(self.linear), int(self.scaled), int(self.tanh), int(self.linear_function), self.lambda_,
                     self.learn_rate, self.corruption_ratio, self.beta)
 
 

@@ -42,7 +42,7 @@ enum { LOSS_SQUARE = 0, LOSS_CE = 5 };  // loss.hpp:10-18
 
 struct Cfg {
   uint32_t num_dim, num_neg, num_corruptions, loss_type;
-  uint32_t using_adagrad, asymmetric, user_factor, linear, scaled, tanh_act;
+  uint32_t using_adagrad, asymmetric, user_factor, linear, scaled, tanh_act, linear_function;
   double lambda, learn_rate, corruption_ratio, beta;
 };
 
@@ -53,6 +53,7 @@ struct Oracle {
   std::vector<uint32_t> col;
   // cdae.hpp:430-439
   std::vector<double> W, W_ag, V, V_ag, Wu, Wu_ag, b, b_ag, bp, bp_ag;
+  std::vector<double> Uu, Uu_ag;   // cdae.hpp:437-438, linear_function only
 
   // ---- loss.hpp:48-55 (SQUARE), loss.hpp:132-147 (CROSS_ENTROPY) ----
   double loss_eval(double pred, double truth) const {
@@ -78,6 +79,7 @@ struct Oracle {
       const double* w = &W[(size_t)items[t] * K];
       for (size_t k = 0; k < K; ++k) h[k] += w[k] * sc;
     }
+    if (c.linear_function) for (size_t k = 0; k < K; ++k) h[k] = Uu[uid * K + k] * h[k];   // :382-384
     for (size_t k = 0; k < K; ++k) h[k] += b[k];                            // :386
     if (c.user_factor) for (size_t k = 0; k < K; ++k) h[k] += Wu[uid * K + k];   // :387-389
     if (!c.linear) {
@@ -145,7 +147,7 @@ struct Oracle {
       neg[i] = cdae_sample_negative(key, (uint64_t)cidx * m + i, row, (uint32_t)n, (uint32_t)I);
   }
 
-  // ---- train_one_user_corruption, cdae.hpp:198-358 (linear_function == false) ----
+  // ---- train_one_user_corruption, cdae.hpp:198-358 ----
   // Optional taps (z, y per output, g per output, hg) for the known-answer fixtures.
   void train_user_literal(size_t uid, const uint32_t* in, size_t n_in, const uint32_t* neg,
                           size_t n_neg, double* tap_z, double* tap_y, double* tap_g, double* tap_hg) {
@@ -197,17 +199,28 @@ struct Oracle {
       for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * wu[k];
       ada_row(wu, &Wu_ag[uid * K], grad.data());
     }
+    std::vector<double> uu_grad;
+    if (c.linear_function) {                                                 // :295-299
+      uu_grad.resize(K);
+      for (size_t k = 0; k < K; ++k) uu_grad[k] = Uu[uid * K + k] * c.lambda;
+    }
     for (size_t p = 0; p < n_pos; ++p) {                                     // :333-349 (input rows, CSR order)
       if (!is_in[p]) continue;
       size_t jid = pos[p];
       double* row = &W[jid * K];
       for (size_t k = 0; k < K; ++k) {
-        double g = delta[k] * sc + c.lambda * row[k];                        // :337
+        double g;
+        if (!c.linear_function) g = delta[k] * sc + c.lambda * row[k];       // :337
+        else {
+          g = Uu[uid * K + k] * delta[k] * sc + c.lambda * row[k];           // :339
+          uu_grad[k] += delta[k] * row[k];                                   // :340 (row before its step)
+        }
         if (!c.asymmetric) g += defer_g[p] * z[k];                           // :342-343 (input_gradient = g*z, :250)
         grad[k] = g;
       }
       ada_row(row, &W_ag[jid * K], grad.data());                             // :344-348
     }
+    if (c.linear_function) ada_row(&Uu[uid * K], &Uu_ag[uid * K], uu_grad.data());   // :351-357
   }
 
   // ---- train_one_iteration, cdae.hpp:136-146 ----
@@ -235,6 +248,7 @@ struct Oracle {
       for (uint32_t ci = 0; ci < c.num_corruptions; ++ci) {
         // phase A: sample + encode with block-start parameters
         std::vector<double> Z(nb * K), Dv(nb * K), HG(nb * K, 0.);
+        std::vector<double> SSUM(c.linear_function ? nb * K : 0, 0.);   // unscaled input sums (block-start rows)
         std::vector<Ex> ex;
         std::vector<double> G;     // per example loss gradient (for deferred rows)
         for (size_t s = 0; s < nb; ++s) {
@@ -245,6 +259,7 @@ struct Oracle {
           draw_negatives(seed, epoch, uid, ci, neg);
           hidden(uid, in.data(), in.size(), sc, &Z[s * K]);
           act_deriv(&Z[s * K], &Dv[s * K]);
+          if (c.linear_function) input_sum(in.data(), in.size(), &SSUM[s * K]);
           size_t t = 0;
           for (size_t p = 0; p < n_pos; ++p) {
             while (t < in.size() && in[t] < pos[p]) ++t;
@@ -287,7 +302,7 @@ struct Oracle {
           const double* row0 = &D0[(size_t)e.item * K];
           for (size_t k = 0; k < K; ++k) hg[k] += G[e.order] * row0[k];
         }
-        // phase C: hidden bias + user node, user order
+        // phase C: hidden bias + user node(s), user order
         std::vector<double> DELTA(nb * K);
         for (size_t s = 0; s < nb; ++s) {
           size_t uid = s0 + s;
@@ -300,6 +315,7 @@ struct Oracle {
             for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * wu[k];
             ada_row(wu, &Wu_ag[uid * K], grad.data());
           }
+          if (c.linear_function) uu_step(uid, delta, &SSUM[s * K], grad.data());
         }
         // phase D: input rows, row-major, user order inside a row
         for (const Ex& e : sorted) {
@@ -309,7 +325,7 @@ struct Oracle {
           const double* delta = &DELTA[(size_t)e.slot * K];
           const double* z = &Z[(size_t)e.slot * K];
           for (size_t k = 0; k < K; ++k) {
-            double g = delta[k] * sc + c.lambda * row[k];
+            double g = delta[k] * sc + c.lambda * row[k];          // delta already carries Uu[u] (uu_step)
             if (!c.asymmetric) g += G[e.order] * z[k];
             grad[k] = g;
           }
@@ -317,6 +333,27 @@ struct Oracle {
         }
       }
     }
+  }
+
+  // linear_function in the block schedules.  The reference accumulates Uu_grad += delta (.) W[k] over the kept inputs
+  // with each row read just before its own step (cdae.hpp:340); inside one user's step those rows have not moved since
+  // the encode (tied mode defers them, cdae.hpp:249-250; asymmetric mode's decode never touches W), so the sum is
+  // delta (.) sum_k W[k] with the rows of the encode — the block schedules use the block-start rows, which is the same
+  // thing at batch_users == 1.  The input rows see Uu[u] from before its step (cdae.hpp:339 precedes :351-357).
+  void input_sum(const uint32_t* items, size_t n, double* out) const {
+    for (size_t k = 0; k < K; ++k) out[k] = 0.;
+    for (size_t t = 0; t < n; ++t) {
+      const double* w = &W[(size_t)items[t] * K];
+      for (size_t k = 0; k < K; ++k) out[k] += w[k];
+    }
+  }
+  void uu_step(size_t uid, double* delta /* in: delta, out: Uu_old (.) delta */, const double* ssum, double* grad) {
+    double* uu = &Uu[uid * K];
+    for (size_t k = 0; k < K; ++k) {
+      grad[k] = c.lambda * uu[k] + delta[k] * ssum[k];
+      delta[k] *= uu[k];
+    }
+    ada_row(uu, &Uu_ag[uid * K], grad);
   }
 
   // ---- full-output decode (north-star extension) ----
@@ -341,6 +378,7 @@ struct Oracle {
       const size_t s1 = std::min(u1, s0 + B), nb = s1 - s0;
       for (uint32_t ci = 0; ci < c.num_corruptions; ++ci) {
         std::vector<double> Z(nb * K), Dv(nb * K), HG(nb * K, 0.), DELTA(nb * K);
+        std::vector<double> SSUM(c.linear_function ? nb * K : 0, 0.);
         std::vector<double> dD(I * K, 0.), dbp(I, 0.), dIn(I * K, 0.);
         std::vector<char> has_in(I, 0);
         std::vector<std::vector<uint32_t>> kept(nb);
@@ -350,6 +388,7 @@ struct Oracle {
           kept[s] = in;
           hidden(uid, in.data(), in.size(), sc, &Z[s * K]);
           act_deriv(&Z[s * K], &Dv[s * K]);
+          if (c.linear_function) input_sum(in.data(), in.size(), &SSUM[s * K]);
         }
         for (size_t s = 0; s < nb; ++s) {                      // dense decode against the block-start rows
           const size_t uid = s0 + s;
@@ -377,6 +416,7 @@ struct Oracle {
             for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * wu[k];
             ada_row(wu, &Wu_ag[uid * K], grad.data());
           }
+          if (c.linear_function) uu_step(uid, delta, &SSUM[s * K], grad.data());
           for (uint32_t j : kept[s]) { has_in[j] = 1; for (size_t k = 0; k < K; ++k) dIn[(size_t)j * K + k] += sc * delta[k]; }
         }
         for (size_t j = 0; j < I; ++j) {                       // one step per row with the block's summed gradient
@@ -476,6 +516,7 @@ std::vector<double>* param(Oracle* o, uint32_t which) {
     case 0: return &o->W; case 1: return &o->W_ag; case 2: return &o->V; case 3: return &o->V_ag;
     case 4: return &o->Wu; case 5: return &o->Wu_ag; case 6: return &o->b; case 7: return &o->b_ag;
     case 8: return &o->bp; case 9: return &o->bp_ag;
+    case 10: return &o->Uu; case 11: return &o->Uu_ag;
   }
   return nullptr;
 }
@@ -486,7 +527,7 @@ extern "C" {
 
 struct oracle_config {   // mirrors cdae_hip_config minus struct_size / batch_users
   uint32_t num_dim, num_neg, num_corruptions, loss_type;
-  uint32_t using_adagrad, asymmetric, user_factor, linear, scaled, tanh_act;
+  uint32_t using_adagrad, asymmetric, user_factor, linear, scaled, tanh_act, linear_function;
   double lambda, learn_rate, corruption_ratio, beta;
 };
 
@@ -517,6 +558,8 @@ void oracle_init_params(void* h, uint64_t seed) {
   else { o->Wu.clear(); o->Wu_ag.clear(); }
   o->b.assign(K, 0.); o->b_ag.assign(K, 0.0001);                             // :123-124
   o->bp.assign(o->I, 0.); o->bp_ag.assign(o->I, 0.0001);                     // :125-126
+  if (o->c.linear_function) { o->Uu.assign(o->U * K, 1.); o->Uu_ag.assign(o->U * K, 0.0001); }   // :130-133
+  else { o->Uu.clear(); o->Uu_ag.clear(); }
 }
 
 size_t oracle_param_size(void* h, uint32_t which) { auto* p = param((Oracle*)h, which); return p ? p->size() : 0; }

@@ -80,7 +80,6 @@ class CDAE : public RecsysModelBase {
     ModelBase::reset(data_set);
     num_users_ = data_->feature_group_total_dimension(0);
     num_items_ = data_->feature_group_total_dimension(1);
-    CHECK(!cfg_.linear_function) << "linear_function (Uu) is not provided by the HIP path (cdae.sh only ever passes false)";
     CHECK(cfg_.pt == L2) << "CDAE's gradient hard-codes the L2 term (cdae.hpp:231)";
     cdae_hip_config c;
     c.struct_size = sizeof(c);
@@ -92,6 +91,7 @@ class CDAE : public RecsysModelBase {
     c.linear = cfg_.linear; c.scaled = cfg_.scaled; c.tanh_act = cfg_.tanh;
     c.batch_users = static_cast<uint32_t>(env_u64("CDAE_BATCH_USERS", 0));
     c.full_output = static_cast<uint32_t>(env_u64("CDAE_FULL_OUTPUT", 0));   // north-star extension, not in CDAEConfig
+    c.linear_function = cfg_.linear_function;
     c.lambda = cfg_.lambda; c.learn_rate = cfg_.learn_rate; c.corruption_ratio = cfg_.corruption_ratio; c.beta = cfg_.beta;
     cdae_hip_t* raw = nullptr;
     CDAE_HIP_CHECK(cdae_hip_create(&c, static_cast<int>(env_u64("CDAE_DEVICE", 0)), &raw));

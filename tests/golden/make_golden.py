@@ -31,6 +31,8 @@ VARIANTS = {
     "sq_asym_sgd": dict(loss_type=ob.LOSS_SQUARE, asymmetric=True, using_adagrad=False, learn_rate=0.02),
     "ce_tied_sgd_unscaled": dict(loss_type=ob.LOSS_CE, using_adagrad=False, learn_rate=0.02, scaled=False),
     "ce_tanh_nouser": dict(loss_type=ob.LOSS_CE, tanh=True, user_factor=False),
+    "ce_tied_ada_gate": dict(loss_type=ob.LOSS_CE, linear_function=True),
+    "sq_asym_ada_gate": dict(loss_type=ob.LOSS_SQUARE, asymmetric=True, linear_function=True),
 }
 
 
@@ -47,6 +49,8 @@ def step_kat():
          ob.P_BP: rng.uniform(-0.2, 0.2, I), ob.P_W_AG: rng.uniform(0.01, 0.5, (I, K)),
          ob.P_V_AG: rng.uniform(0.01, 0.5, (I, K)), ob.P_WU_AG: rng.uniform(0.01, 0.5, (U, K)),
          ob.P_B_AG: rng.uniform(0.01, 0.5, K), ob.P_BP_AG: rng.uniform(0.01, 0.5, I)}
+    # drawn after everything else so that the older entries of the file keep their values
+    P[ob.P_UU] = rng.uniform(0.5, 1.5, (U, K)); P[ob.P_UU_AG] = rng.uniform(0.01, 0.5, (U, K))
     P = {k: v.astype(np.float32).astype(np.float64) for k, v in P.items()}
     for k, v in P.items():
         out[f"init_{k}"] = v

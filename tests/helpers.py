@@ -5,12 +5,13 @@ import cdae_amd
 import oracle as orc
 from oracle import binding as ob
 
-PARAMS = range(10)
+PARAMS = range(12)
 
 
 def make_pair(data, *, K=16, B=1, loss=cdae_amd.CROSS_ENTROPY, seed=11, full_output=False, **kw):
     """A HIP model and an oracle that start from the same fp32 parameters."""
-    flags = dict(using_adagrad=True, asymmetric=False, user_factor=True, linear=False, scaled=True, tanh=False)
+    flags = dict(using_adagrad=True, asymmetric=False, user_factor=True, linear=False, scaled=True, tanh=False,
+                 linear_function=False)
     hyper = dict(lambda_=0.01, learn_rate=0.1, corruption_ratio=0.5, beta=1.0, num_neg=5, num_corruptions=1)
     for k, v in kw.items():
         (flags if k in flags else hyper)[k] = v

@@ -22,6 +22,8 @@ VARIANTS = {
     "sq_asym_sgd": dict(loss=ob.LOSS_SQUARE, asymmetric=True, using_adagrad=False, learn_rate=0.02),
     "ce_tied_sgd_unscaled": dict(loss=ob.LOSS_CE, using_adagrad=False, learn_rate=0.02, scaled=False),
     "ce_tanh_nouser": dict(loss=ob.LOSS_CE, tanh=True, user_factor=False),
+    "ce_tied_ada_gate": dict(loss=ob.LOSS_CE, linear_function=True),
+    "sq_asym_ada_gate": dict(loss=ob.LOSS_SQUARE, asymmetric=True, linear_function=True),
 }
 
 
@@ -39,13 +41,13 @@ def test_oracle_reproduces_step_kat(built, name):
     cfg = orc.OracleConfig(num_dim=int(g["K"]), loss_type=loss, learn_rate=lr, lambda_=0.01, corruption_ratio=0.5, beta=1.0, **kw)
     o = orc.Oracle(cfg, int(g["U"]), int(g["I"]), g["ptr"], g["col"])
     o.init_params(0)
-    for k in range(10):
+    for k in range(12):
         if o.get(k).size:
             o.set(k, g[f"init_{k}"])
     z, y, gr, hg = o.step_user(int(g["uid"]), g["kept"], g["neg"])
     for got, key in ((z, "z"), (y, "y"), (gr, "g"), (hg, "hg")):
         np.testing.assert_allclose(got, g[f"{name}_{key}"], rtol=1e-13, atol=1e-15)
-    for k in range(10):
+    for k in range(12):
         if o.get(k).size:
             np.testing.assert_allclose(o.get(k), g[f"{name}_after_{k}"].ravel(), rtol=1e-13, atol=1e-15)
 
@@ -94,7 +96,7 @@ def test_hip_reproduces_step_kat(built, name):
                               batch_users=1, **kw)
     m = cdae_amd.CDAE(cfg)
     m.set_interactions(U, I, g["ptr"], g["col"])
-    present = [k for k in range(10) if f"{name}_after_{k}" in g]
+    present = [k for k in range(12) if f"{name}_after_{k}" in g]
     for k in present:
         m.set(k, g[f"init_{k}"])
     z = m.get_hidden_values([int(g["uid"])], mode=0)     # sanity: full-row encode is finite

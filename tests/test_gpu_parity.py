@@ -10,6 +10,7 @@ import pytest
 import cdae_amd
 from cdae_amd import synth
 import oracle as orc
+from oracle import binding as ob
 from helpers import make_pair, max_param_err
 
 pytestmark = pytest.mark.gpu
@@ -71,6 +72,44 @@ def test_batched_schedule_matches_oracle(tiny, B, variant):
         o.train_batched(1, ep, B)
     err, which = max_param_err(model, o)
     assert err < 2e-4, (err, which)
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(asymmetric=True, loss=cdae_amd.SQUARE), dict(using_adagrad=False, learn_rate=0.01),
+                                     dict(user_factor=False, tanh=True)])
+@pytest.mark.parametrize("B,K", [(1, 24), (64, 40), (300, 200)])
+def test_linear_function_gate_matches_oracle(tiny, B, K, variant):
+    """linear_function (cdae.hpp:29, 382-384, 295-299, 339-340, 351-357): the per-user gate Uu on the input sum, its own
+    AdaGrad step, and Uu[u] (.) delta in the input rows.  B = 1 against the LITERAL restatement, B > 1 against the block
+    schedule; encode, loss and top-k go through the gate as well."""
+    model, o = make_pair(tiny, K=K, B=B, linear_function=True, **variant)
+    assert (model.get(cdae_amd.P_UU) == 1).all() and (model.get(cdae_amd.P_UU_AG) == np.float32(1e-4)).all()   # cdae.hpp:131-132
+    for ep in range(2):
+        model.train_one_iteration(seed=7, epoch=ep)
+        if B == 1:
+            o.train_literal(7, ep)
+        else:
+            o.train_batched(7, ep, B)
+    assert np.abs(o.get(ob.P_UU) - 1.).max() > 1e-2          # the gate trained
+    err, which = max_param_err(model, o)
+    assert err < 2e-4, (err, which)
+    uids = np.arange(tiny.num_users, dtype=np.uint32)
+    for mode in (0, 1):      # activations in [-1, 1] from parameters that themselves agree to 2e-4 of their range
+        assert np.abs(model.get_hidden_values(uids, seed=3, epoch=2, mode=mode) - o.encode(3, 2, mode, uids)).max() < 3e-4
+    lg, lo = model.data_loss(5, 0), o.data_loss(5, 0)
+    assert abs(lg - lo) < 3e-4 * abs(lo)
+    rec_g = model.recommend_all(10)
+    rec_o, sc_o = o.recommend(10, with_scores=True)
+    clear = np.abs(np.diff(sc_o, axis=1)).min(axis=1) > 1e-3
+    np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
+
+
+def test_linear_function_full_output(tiny):
+    model, o = make_pair(tiny, K=24, B=48, full_output=True, linear_function=True)
+    for ep in range(2):
+        model.train_one_iteration(seed=4, epoch=ep)
+        o.train_full(4, ep, 48)
+    err, which = max_param_err(model, o)
+    assert err < 2e-2, (err, which)                            # bf16 operands, see test_full_output_mfma_decode_matches_oracle
 
 
 def test_loss_and_recommend_match_oracle(small):
