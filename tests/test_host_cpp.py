@@ -107,3 +107,23 @@ def test_reference_yelp_app_trains_cdae_on_gpu(host_bins, tmp_path):
     pop_r10 = float(rows[1].split("|")[8])
     best = max(float(r.split("|")[8]) for r in rows[2:])
     assert best > pop_r10, (best, pop_r10)
+
+
+@pytest.mark.gpu
+def test_reference_yelp_app_trains_cdae_with_linear_function_gate(host_bins, tmp_path):
+    """--linear_function=true (the one CDAE flag cdae.sh never switches on): the gate Uu runs on the GPU too."""
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=20", "--loss_type=SQUARE", "--cratio=0.5", "--scaled=true",
+                   "--beta=1", "--linear_function=true"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "32"})
+    assert rc == 0, out[-3000:]
+    assert "LinearFunction: 1" in out
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+    assert len(rows) == 2 + 51
+    losses = [float(r.split("|")[2]) for r in rows[3:]]
+    assert all(np.isfinite(losses))
+    assert max(float(r.split("|")[8]) for r in rows[2:]) > float(rows[2].split("|")[8])      # improves over the untrained model
