@@ -42,7 +42,9 @@
 extern "C" {
 #endif
 
-#define CDAE_HIP_ABI_VERSION 1
+/* 2: cdae_hip_config.linear_function (in what was tail padding of the uint32 block: zero the struct before filling it),
+ *    parameters CDAE_P_UU / CDAE_P_UU_AG; pipelined delta exchange entry points */
+#define CDAE_HIP_ABI_VERSION 2
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u

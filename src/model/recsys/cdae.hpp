@@ -81,7 +81,7 @@ class CDAE : public RecsysModelBase {
     num_users_ = data_->feature_group_total_dimension(0);
     num_items_ = data_->feature_group_total_dimension(1);
     CHECK(cfg_.pt == L2) << "CDAE's gradient hard-codes the L2 term (cdae.hpp:231)";
-    cdae_hip_config c;
+    cdae_hip_config c = cdae_hip_config();
     c.struct_size = sizeof(c);
     c.num_dim = static_cast<uint32_t>(cfg_.num_dim);
     c.num_neg = static_cast<uint32_t>(cfg_.num_neg);
