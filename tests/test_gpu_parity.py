@@ -448,3 +448,28 @@ def test_full_output_mfma_decode_matches_oracle(tiny, B, variant):
     assert err < 2e-2, (err, which)
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
+
+
+def test_more_than_65536_items(built):
+    """I > 65536 leaves the 16-bit sort keys (rocPRIM onesweep) for the 32-bit ones and widens every item-indexed table;
+    BASELINE configs[4] (1 M items) lives there.  Sampled schedule, loss, top-k and the full-output decode vs the oracle."""
+    data = synth.generate(160, 70_000, 6_400, seed=21, min_items=12)
+    assert data.num_items > 65536
+    model, o = make_pair(data, K=8, B=64)
+    for ep in range(2):
+        model.train_one_iteration(seed=3, epoch=ep)
+        o.train_batched(3, ep, 64)
+    err, which = max_param_err(model, o)
+    assert err < 2e-4, (err, which)
+    lg, lo = model.data_loss(5, 0), o.data_loss(5, 0)
+    assert abs(lg - lo) < 2e-4 * abs(lo)
+    rec_g = model.recommend_all(10)
+    rec_o, sc_o = o.recommend(10, with_scores=True)
+    clear = np.abs(np.diff(sc_o, axis=1)).min(axis=1) > 1e-4
+    assert clear.mean() > 0.5
+    np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
+    full, of = make_pair(data, K=8, B=32, full_output=True)
+    full.train_one_iteration(seed=3, epoch=0)
+    of.train_full(3, 0, 32)
+    err, which = max_param_err(full, of)
+    assert err < 2e-2, (err, which)
