@@ -26,6 +26,8 @@ SHAPES = {
     "ml10m": (70_000, 10_600, 10_000_000),
     "netflix": (480_000, 17_700, 100_000_000),
     "yelp": (10_000, 7_000, 312_500),
+    # BASELINE configs[4] item space (1 M items, ~100 interactions per user) with as many users as a single-GPU bench needs
+    "cfg5_items": (20_000, 1_000_000, 2_000_000),
     "tiny": (300, 120, 9_000),
     "small": (4_000, 1_500, 240_000),
 }
