@@ -90,6 +90,8 @@ struct cdae_hip {
   // developer switches, read once in cdae_hip_create (DESIGN.md lists them)
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
   bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
+  bool gemm_direct = false;         // CDAE_GEMM_DIRECT: the fragment-from-L1 GEMM kernel instead of the LDS-staged one (A/B switch)
+  bool gemm3_lds = false;           // CDAE_GEMM3_LDS: LDS-staged GEMM 3 also beside the fused kernel (K <= 256)
   bool recommend_per_user = false;  // CDAE_RECOMMEND_PER_USER: recommend_kernel instead of the MFMA path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
   uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
@@ -462,8 +464,12 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   ep.bp = h->P(CDAE_P_BP); ep.G = h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
   ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
   // GEMM 1: Y = Z D^T (+ b'), g = loss'(y, 0) -> G [Bp x Ip], G^T [Ip x Bp]
-  hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
-                     Kp, ep);
+  if (h->gemm_direct)
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
+                       Kp, ep);
+  else
+    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
+                       Kp, ep);
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
                      h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
@@ -472,8 +478,12 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     const uint32_t kps = 2048;
     GemmEpilogue e2{};
     e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
-                       h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
+    if (h->gemm_direct)
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
+                         h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
+    else
+      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
+                         h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
   }
   }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
@@ -496,8 +506,13 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     GemmEpilogue e3{};
     e3.Cout = h->d_dD; e3.ldc = Kp;
     // 64-row workgroups (two wavefronts): 2 x Ip/64 of them spread over all CUs, 128-row ones would occupy only 166 at ML-10M shape
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
-                       Bp, Bp, Bp, Bp, e3);
+    // (the LDS-staged kernel, 128-row workgroups, where there are enough row tiles to fill the chip: the K > 256 shapes)
+    if (h->gemm_direct || (fused && !h->gemm3_lds))
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
+                         Bp, Bp, Bp, Bp, e3);
+    else
+      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 128, 1), blk, 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
+                         Bp, Bp, Bp, Bp, e3);
   }
   CHK(pr.end());
 
@@ -601,6 +616,8 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->B = cfg->batch_users ? cfg->batch_users : 1024u;
   h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
   h->full_unfused = std::getenv("CDAE_FULL_UNFUSED") != nullptr;
+  h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
+  h->gemm3_lds = std::getenv("CDAE_GEMM3_LDS") != nullptr;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
