@@ -607,4 +607,89 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
   if (lane == 0 && touched) touched[item] = 1u;
 }
 
+// The same row step with one wavefront per row (four rows per workgroup, no LDS hand-off): for item spaces so large that
+// rows are plentiful and nearly all of them have no kept input at all (1 M items: one workgroup per row was a million
+// three-round-trip chains, 3.2 ms per 1024-user block).  Every load that does not depend on the row's example list is issued up front.
+template <int NI>
+__global__ void __launch_bounds__(256)
+full_rows_wave_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                      const uint64_t* __restrict__ sorted_val, const float* __restrict__ DELTA,
+                      const float* __restrict__ dD, const __bf16* __restrict__ GT, uint32_t ldgt, uint32_t nb,
+                      float* __restrict__ W, float* __restrict__ W_ag, float* __restrict__ V, float* __restrict__ V_ag,
+                      float* __restrict__ bp, float* __restrict__ bp_ag, uint32_t* __restrict__ touched) {
+  const uint32_t item = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (item >= hp.num_items) return;
+  const uint32_t lo = lane * NI;
+  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  float* const P0 = hp.asymmetric ? V : W;
+  float* const P0a = hp.asymmetric ? V_ag : W_ag;
+  float dd[NI], w[NI], a[NI];
+  vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);
+  vload<NI>(w, P0 + (size_t)item * hp.Kp + lo);
+  vload<NI>(a, P0a + (size_t)item * hp.Kp + lo);
+  float p = bp[item], pa = bp_ag[item];
+  // b'[j] gradient: the row of G^T (columns >= nb belong to padding users and are not defined)
+  float gsum = 0.f;
+  const __bf16* grow = GT + (size_t)item * ldgt;
+  for (uint32_t u0 = lane * 8u; u0 < nb; u0 += WAVE * 8u) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(grow + u0);          // ldgt is a multiple of 128: in bounds
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gsum += (u0 + (uint32_t)e < nb) ? (float)v[e] : 0.f;
+  }
+  float din[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) din[i] = 0.f;
+  bool has_in = false;
+  constexpr int UN = 8;
+  for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
+    const uint32_t q = p0 + lane;
+    const uint32_t word = q < end ? (uint32_t)sorted_val[q] : 0u;
+    unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
+    has_in = has_in || mask != 0ull;
+    while (mask) {
+      float v[UN][NI];
+#pragma unroll
+      for (int t = 0; t < UN; ++t) {
+        if (mask) {
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, src) & SLOT_MASK;
+          vload<NI>(v[t], DELTA + (size_t)slot * hp.Kp + lo);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) v[t][i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UN; ++t)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) din[i] += v[t][i];
+    }
+  }
+  gsum = wave_sum(gsum);
+  ada_step(hp, p, pa, fmaf(hp.lambda, p, gsum));
+  if (lane == 0) { bp[item] = p; bp_ag[item] = pa; }
+  if (!hp.asymmetric) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
+    vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
+    vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.lambda, w[i], dd[i]));
+    vstore<NI>(V + (size_t)item * hp.Kp + lo, w);
+    vstore<NI>(V_ag + (size_t)item * hp.Kp + lo, a);
+    if (has_in) {
+      vload<NI>(w, W + (size_t)item * hp.Kp + lo);
+      vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], hp.lambda * w[i]));
+      vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
+      vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+    }
+  }
+  if (lane == 0 && touched) touched[item] = 1u;
+}
+
 }  // namespace cdae
