@@ -149,15 +149,37 @@ gemm_nt_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm,
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_SLICE_BYTES = 128 * GEMM_BK * 2;      // one operand slice: 128 rows x 64 bf16
 
+// Workgroup -> tile mapping, XCD-aware: workgroup ids go round-robin over the 8 XCDs (id & 7), each with its own 4 MiB L2.
+// The tiles that share the big streamed operand — GEMM 1: the M-tiles of one D tile; GEMM 3: the N-tiles of one G^T tile;
+// GEMM 2: all (m, n) tiles of one contraction split — are given consecutive slots of ONE XCD, so that operand comes from
+// HBM once and from that L2 afterwards (with the natural x-fastest order the 8 user-tiles of a D tile ran 8192 workgroups
+// apart: 8 GB of D traffic per 1024-user block at 1 M items instead of 1 GB).
+struct GemmGrid {
+  uint32_t Mt, Nt, Zt;      // tiles along M, N and contraction splits
+  uint32_t mode;            // 0: inner = M-tiles, outer = N-tiles; 1: inner = N-tiles, outer = M-tiles; 2: inner = (m, n), outer = split
+  __host__ __device__ uint32_t inner() const { return mode == 0 ? Mt : (mode == 1 ? Nt : Mt * Nt); }
+  __host__ __device__ uint32_t outer() const { return mode == 0 ? Nt : (mode == 1 ? Mt : Zt); }
+  __host__ uint32_t workgroups() const { return 8u * inner() * ((outer() + 7u) / 8u); }
+};
+
 template <int EPI>
 __global__ void __launch_bounds__(256)
 gemm_nt_bf16_lds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
-                        uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep) {
+                        uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep, GemmGrid gg) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * GEMM_SLICE_BYTES];     // [buffer][A | B][128 rows][128 B]
   const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;
-  const uint32_t m_tile = blockIdx.y * 128u, n_tile = blockIdx.x * 128u;
+  uint32_t mt, nt, zt;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, in = gg.inner();
+    const uint32_t t = j % in, o = (j / in) * 8u + xcd;
+    if (o >= gg.outer()) return;                                           // (whole workgroup)
+    if (gg.mode == 0) { mt = t; nt = o; zt = 0; }
+    else if (gg.mode == 1) { nt = t; mt = o; zt = 0; }
+    else { mt = t / gg.Nt; nt = t % gg.Nt; zt = o; }
+  }
+  const uint32_t m_tile = mt * 128u, n_tile = nt * 128u;
   const uint32_t m_base = m_tile + (wid >> 1) * 64u, n_base = n_tile + (wid & 1u) * 64u;
-  const uint32_t k_begin = blockIdx.z * k_per_split;
+  const uint32_t k_begin = zt * k_per_split;
   const uint32_t k_end = min(Kd, k_begin + k_per_split);
   f32x16 acc[2][2];
 #pragma unroll

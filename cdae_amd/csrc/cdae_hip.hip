@@ -468,22 +468,32 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
                        Kp, ep);
   else
-    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
-                       Kp, ep);
+  {
+    const GemmGrid gg{Bp / 128, Ip / 128, 1, 0};
+    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_LOSS>), dim3(gg.workgroups()), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
+                       Kp, ep, gg);
+  }
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
                      h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
   // GEMM 2: hg = G D  (contraction over items, split; fp32 atomics into the zeroed HG)
   {
-    const uint32_t kps = 2048;
+    // contraction splits: about 2048 workgroups in all (every split ends in 128 x 128 fp32 atomics per tile: with the 2048-item
+    // splits of the first version, 1 M items meant 256 M atomics per block, 1.7 ms)
+    const uint32_t tiles2 = ((Kp + 127) / 128) * (Bp / 128);
+    const uint32_t want = std::max<uint32_t>(1, std::min<uint32_t>(Ip / 64, (2048 + tiles2 - 1) / tiles2));
+    const uint32_t kps = h->gemm_direct ? 2048 : (((Ip + want - 1) / want + 63) / 64) * 64;
     GemmEpilogue e2{};
     e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
     if (h->gemm_direct)
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
                          h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
     else
-      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
-                         h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
+    {
+      const GemmGrid gg{Bp / 128, (Kp + 127) / 128, (Ip + kps - 1) / kps, 2};
+      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_ATOMIC>), dim3(gg.workgroups()), blk, 0, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip,
+                         kps, e2, gg);
+    }
   }
   }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
@@ -511,8 +521,11 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
                          Bp, Bp, Bp, Bp, e3);
     else
-      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 128, 1), blk, 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
-                         Bp, Bp, Bp, Bp, e3);
+    {
+      const GemmGrid gg{Ip / 128, (Kp + 127) / 128, 1, 1};
+      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_STORE>), dim3(gg.workgroups()), blk, 0, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp,
+                         Bp, e3, gg);
+    }
   }
   CHK(pr.end());
 
