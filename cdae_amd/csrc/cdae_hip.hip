@@ -91,7 +91,6 @@ struct cdae_hip {
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
   bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
   bool gemm_direct = false;         // CDAE_GEMM_DIRECT: the fragment-from-L1 GEMM kernel instead of the LDS-staged one (A/B switch)
-  bool gemm3_lds = false;           // CDAE_GEMM3_LDS: LDS-staged GEMM 3 also beside the fused kernel (K <= 256)
   bool recommend_per_user = false;  // CDAE_RECOMMEND_PER_USER: recommend_kernel instead of the MFMA path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
   uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
@@ -516,8 +515,8 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     GemmEpilogue e3{};
     e3.Cout = h->d_dD; e3.ldc = Kp;
     // 64-row workgroups (two wavefronts): 2 x Ip/64 of them spread over all CUs, 128-row ones would occupy only 166 at ML-10M shape
-    // (the LDS-staged kernel, 128-row workgroups, where there are enough row tiles to fill the chip: the K > 256 shapes)
-    if (h->gemm_direct || (fused && !h->gemm3_lds))
+    // (developer switch CDAE_GEMM_DIRECT; the default is the LDS-staged kernel: 73 -> 31 us at ML-10M shape, 2048 users)
+    if (h->gemm_direct)
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
                          Bp, Bp, Bp, Bp, e3);
     else
@@ -635,7 +634,6 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
   h->full_unfused = std::getenv("CDAE_FULL_UNFUSED") != nullptr;
   h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
-  h->gemm3_lds = std::getenv("CDAE_GEMM3_LDS") != nullptr;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
