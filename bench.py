@@ -229,7 +229,9 @@ def main():
         workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "
                     f"num_neg=5, CE loss, AdaGrad, q=0.5 scaled")
     out = {
-        "metric": "users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity",
+        # BASELINE.json's metric on its own workload; other shapes / K (developer runs) are named as what they are
+        "metric": ("users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity" if (args.shape == "ml10m" and args.num_dim == 200)
+                   else f"users/sec (whole node) K={args.num_dim} {args.shape}-shape"),
         "value": value, "unit": "users/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.full_output else "f32", "data": "synthetic",
