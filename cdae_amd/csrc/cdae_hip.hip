@@ -136,6 +136,7 @@ struct cdae_hip {
   uint32_t full_slices = 1;
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
+  bool join_pending = false;            // full-output path: the aux stream's b recurrence of the last batch has not been joined yet
   hipStream_t prep = nullptr;           // sampling + sorting of the next batch
   void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
@@ -172,6 +173,18 @@ struct cdae_hip {
 };
 
 namespace {
+
+// Full-output path: the hidden-bias recurrence of a batch runs on the aux stream and is joined as LATE as possible — right
+// before the next batch's encode_finish (the first consumer of b and of the delta buffer), so that the next batch's input
+// gather and the bf16 copies of D overlap its tail.  Every other entry point that touches parameters or the main stream
+// joins first.
+int join_aux(cdae_hip* h) {
+  if (h->join_pending) {
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    h->join_pending = false;
+  }
+  return 0;
+}
 
 int get_event(cdae_hip* h, hipEvent_t* ev) {
   if (!h->pool.empty()) { *ev = h->pool.back(); h->pool.pop_back(); return 0; }
@@ -425,14 +438,17 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   DISPATCH_NI(h->NI, encode_partial_kernel, dim3((n_units + 3) / 4), blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr,
               n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart,
               (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user);
+  // bf16 copies D, D^T (rows >= I zero) of this batch: like the input gather above they need the previous batch's row steps
+  // but not its b recurrence, which may still be running on the aux stream — joined here, in front of its first consumer
+  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  CHK(join_aux(h));
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
               (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
   CHK(pr.end());
 
   CHK(pr.begin(h, F_DECODE, st));
-  // bf16 operand copies of this batch: Z, Z^T (rows >= nb zero) and D, D^T (rows >= I zero)
+  // bf16 operand copies Z, Z^T (rows >= nb zero)
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
-  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
   const bool fused = Kp <= 256 && !h->full_unfused;
   uint32_t hg_parts = 0;                         // slabs of HGpart holding hg (0: accumulated into HG by atomics)
   if (fused) {
@@ -538,7 +554,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
-  HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+  h->join_pending = true;                                      // the aux stream (b recurrence) is joined by its next consumer: join_aux
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
   HIPCHK(hipGetLastError());
@@ -682,6 +698,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   if (I >= (1ull << 30) || U >= (1ull << 30)) return fail("at most 2^30 users and items");
   if (row_ptr[0] != 0) return fail("row_ptr[0] must be 0");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   std::vector<uint64_t> pop(I, 0);
   for (uint64_t u = 0; u < U; ++u) {
     const int64_t a = row_ptr[u], b = row_ptr[u + 1];
@@ -871,6 +888,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
 int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   using namespace cdae;
   const double init_scale = 4. * std::sqrt(6. / (double)(h->I + h->K));          // cdae.hpp:112
   auto blocks = [](size_t n) { return dim3((uint32_t)((n + 255) / 256)); };
@@ -900,6 +918,7 @@ int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t 
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (which >= CDAE_P_COUNT || !host) return fail("bad argument");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   float* d = h->P(which);
   if (!d) return fail("parameter %u is not allocated in this configuration", which);
   if (which == CDAE_P_BP || which == CDAE_P_BP_AG) {
@@ -922,6 +941,7 @@ int cdae_hip_get_param(cdae_hip_t* h, uint32_t which, float* host, size_t count)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (which >= CDAE_P_COUNT || !host) return fail("bad argument");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   return copy_param_out(h, which, host, count);
 }
 
@@ -941,6 +961,7 @@ int cdae_hip_set_profiling(cdae_hip_t* h, int enabled) {
 int cdae_hip_synchronize(cdae_hip_t* h) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1027,6 +1048,7 @@ int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t 
   HIPCHK(hipSetDevice(h->device));
   const auto t0 = std::chrono::steady_clock::now();
   CHK(enqueue_users(h, seed, epoch, u_begin, u_end));
+  CHK(join_aux(h));
   HIPCHK(hipStreamSynchronize(h->stream));
 #ifdef CDAE_DECODE_TIMING
   {   // developer aid: cycle stamps of row `debug_rank` in the last decode launch (see decode_rows_kernel)
@@ -1066,6 +1088,7 @@ int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64
 int cdae_hip_collect_stats(cdae_hip_t* h, cdae_hip_stats* stats) {
   if (!h) return fail("null handle");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   return fill_stats(h, stats);
 }
@@ -1080,6 +1103,7 @@ int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, cons
   if ((!uids || !Z) && n) return fail("null argument");
   if (mode != 0 && mode != 1) return fail("mode must be 0 or 1");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
   for (size_t i = 0; i < n; ++i) if (uids[i] >= h->U) return fail("user id %u out of range", uids[i]);
   for (size_t c0 = 0; c0 < n; c0 += B) {
@@ -1100,6 +1124,7 @@ int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, cons
 int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out) {
   if (!h || !h->d_shared || !out) return fail("bad argument");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
   for (uint64_t s0 = 0; s0 < h->U; s0 += EVAL_CHUNK) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(EVAL_CHUNK, h->U - s0);
@@ -1122,6 +1147,7 @@ int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out
 int cdae_hip_penalty_loss(cdae_hip_t* h, double* out) {
   if (!h || !h->d_shared || !out) return fail("bad argument");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
   auto add = [&](const float* p, size_t n) {
     if (p && n) hipLaunchKernelGGL(cdae::sqnorm_kernel, dim3((uint32_t)std::min<size_t>(2048, (n + 255) / 256)), dim3(256), 0,
@@ -1146,6 +1172,7 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
   if (u_begin > u_end || u_end > h->U) return fail("bad user range");
   if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   if (topk <= (uint32_t)cdae::REC_TOPK_MAX && h->K <= 256 && !h->recommend_per_user) {
     // matrix-core path: all users of a chunk in one launch (cdae_recommend_kernels.hpp)
     const uint32_t nch = h->K <= 32 ? 4 : (h->K <= 64 ? 8 : (h->K <= 128 ? 16 : (h->K <= 200 ? 25 : 32)));
@@ -1218,6 +1245,7 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   if (h->cfg.full_output) return fail("train_one_user_corruption takes an explicit negative list; it is not available in full_output mode");
   if ((n_in && !input_items) || (n_neg && !negative_items)) return fail("null argument");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   const int64_t r0 = h->h_row_ptr[uid];
   const size_t n_pos = (size_t)(h->h_row_ptr[uid + 1] - r0);
   const size_t E = n_pos + n_neg;
@@ -1278,6 +1306,7 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
 int cdae_hip_delta_begin(cdae_hip_t* h) {
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   if (!h->d_base) { CHK(dev_alloc(&h->d_base, h->n_shared)); CHK(dev_alloc(&h->d_delta, h->n_shared + h->I)); }
   HIPCHK(hipMemcpyAsync(h->d_base, h->d_shared, h->n_shared * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(hipMemsetAsync(h->d_touched, 0, h->I * sizeof(uint32_t), h->stream));
@@ -1293,6 +1322,7 @@ int cdae_hip_stream(cdae_hip_t* h, void** hip_stream) {
 int cdae_hip_delta_compute(cdae_hip_t* h) {
   if (!h || !h->d_base) return fail("delta_begin must be called first");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   hipLaunchKernelGGL(cdae::delta_kernel, dim3((uint32_t)((h->n_shared + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                      h->d_base, h->d_delta, h->n_shared);
   hipLaunchKernelGGL(cdae::touch_to_float_kernel, dim3((uint32_t)((h->I + 255) / 256)), dim3(256), 0, h->stream, h->d_touched,
@@ -1313,6 +1343,7 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
   if (world_size == 0) return fail("world_size must be >= 1");
   if (rule > CDAE_DELTA_TOUCH_MEAN) return fail("unknown delta rule %u", rule);
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   hipLaunchKernelGGL(cdae::apply_delta_kernel, dim3((uint32_t)((h->n_shared + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                      h->d_base, h->d_delta, h->d_delta + h->n_shared, h->n_matrix, h->Kp, (uint32_t)h->I, h->n_shared, world_size, rule);
   HIPCHK(hipGetLastError());
@@ -1323,6 +1354,7 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
 int cdae_hip_delta_stage(cdae_hip_t* h) {
   if (!h || !h->d_base) return fail("delta_begin must be called first");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   if (!h->d_recv) {
     CHK(dev_alloc(&h->d_recv, h->n_shared + 4096));            // slack: collectives may round the count up
     HIPCHK(hipMemsetAsync(h->d_recv, 0, (h->n_shared + 4096) * sizeof(float), h->stream));
@@ -1340,12 +1372,14 @@ int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* cou
 int cdae_hip_delta_merge(cdae_hip_t* h) {
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   return launch_pipe<cdae::DELTA_MERGE>(h);
 }
 
 int cdae_hip_delta_merge_stage(cdae_hip_t* h) {
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
   return launch_pipe<cdae::DELTA_MERGE_STAGE>(h);
 }
 
