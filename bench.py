@@ -236,7 +236,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if args.full_output else "f32", "data": "synthetic",
         "config": {"workload": workload, "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
-                   "exchange": ("none" if args.gpus == 1 else
+                   "exchange": ("none" if (pipe is None and exch is None) else
                                 f"pipelined all-reduce(sum) of shared-parameter deltas every {args.exchange_every} batches, merged one period late"
                                 + (f" ({exchange_note})" if exchange_note else "")
                                 if args.exchange_every > 0 else "synchronous all-reduce(sum) of shared-parameter deltas every batch")},
