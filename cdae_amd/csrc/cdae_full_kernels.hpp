@@ -307,6 +307,167 @@ gemm_nt_bf16_lds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__
   }
 }
 
+// Deeper form for the big shapes (M % 256 == 0): 512 threads own a 256 x 128 tile (eight wavefronts, 4 x 2, 64 x 64 each:
+// 85 flop per staged byte instead of 64) and keep TWO slices in flight across each barrier — three LDS stages of 48 KiB, counted
+// `s_waitcnt vmcnt(6)` (a wavefront issues 6 DMA instructions per slice) and raw `s_barrier`; `__syncthreads()` would carry a
+// `vmcnt(0)` and drain the pipeline (cdna_hip_programming.md §5).  Order per step k: wait for this wavefront's slice-k DMAs ->
+// barrier (everyone's slice k has landed, everyone is done reading slice k-1) -> issue slice k+2 into the stage slice k-1
+// occupied -> MFMAs on slice k.
+constexpr int GEMM3S_STAGE_BYTES = (256 + 128) * GEMM_BK * 2;     // 48 KiB: A slice 256 x 64 bf16, then B slice 128 x 64
+constexpr size_t gemm3s_lds_bytes() { return 3 * (size_t)GEMM3S_STAGE_BYTES; }
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm_nt_bf16_lds3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
+                         uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep, GemmGrid gg) {
+  extern __shared__ __attribute__((aligned(1024))) char smem3[];
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;      // wid 0..7
+  uint32_t mt, nt, zt;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, in = gg.inner();
+    const uint32_t t = j % in, o = (j / in) * 8u + xcd;
+    if (o >= gg.outer()) return;
+    if (gg.mode == 0) { mt = t; nt = o; zt = 0; }
+    else if (gg.mode == 1) { nt = t; mt = o; zt = 0; }
+    else { mt = t / gg.Nt; nt = t % gg.Nt; zt = o; }
+  }
+  const uint32_t m_tile = mt * 256u, n_tile = nt * 128u;
+  const uint32_t wm = (wid >> 1) * 64u, wn = (wid & 1u) * 64u;
+  const uint32_t m_base = m_tile + wm, n_base = n_tile + wn;
+  const uint32_t k_begin = zt * k_per_split;
+  const uint32_t k_end = min(Kd, k_begin + k_per_split);
+  const uint32_t n_steps = (k_end - k_begin) / GEMM_BK;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: a stage is 48 DMA instructions of 1 KiB (8 rows each): 32 of A then 16 of B; wavefront w issues 4w..4w+3 of A and
+  // 2w, 2w+1 of B
+  const uint32_t st_row = lane >> 3, st_slot = lane & 7u;
+  const __bf16* a_src[4];
+  const __bf16* b_src[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t r = (wid * 4u + q) * 8u + st_row;
+    a_src[q] = A + (size_t)(m_tile + r) * lda + 8u * (st_slot ^ ((r >> 1) & 7u));
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t r = (wid * 2u + q) * 8u + st_row;
+    b_src[q] = Bm + (size_t)min(n_tile + r, N - 1u) * ldb + 8u * (st_slot ^ ((r >> 1) & 7u));
+  }
+  auto stage = [&](uint32_t step, uint32_t slot) {
+    char* base = smem3 + slot * GEMM3S_STAGE_BYTES;
+    const uint32_t k = k_begin + step * GEMM_BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + k),
+                                       (__attribute__((address_space(3))) void*)(base + (wid * 4u + q) * 1024u), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + k),
+                                       (__attribute__((address_space(3))) void*)(base + 256 * 128 + (wid * 2u + q) * 1024u), 16, 0, 0);
+  };
+  const uint32_t f_row = lane & 31u, f_half = lane >> 5;
+  uint32_t a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint32_t ra = wm + i * 32u + f_row, rb = wn + i * 32u + f_row;
+    a_off[i] = ra * 128u; a_sw[i] = (ra >> 1) & 7u;
+    b_off[i] = 256u * 128u + rb * 128u; b_sw[i] = (rb >> 1) & 7u;
+  }
+
+  // prologue: slices 0 and 1 in flight
+  stage(0, 0);
+  if (n_steps > 1) stage(1, 1);
+  uint32_t slot = 0;
+  for (uint32_t step = 0; step < n_steps; ++step) {
+    // this wavefront's DMAs of slice `step` have landed: all but the 6 of slice step+1 (none behind the last slice)
+    if (step + 1 < n_steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; slice step-1 is free
+    const uint32_t nslot = slot == 0 ? 2u : slot - 1u;                     // (slot + 2) % 3: the stage slice step-1 occupied
+    if (step + 2 < n_steps) stage(step + 2u, nslot);
+    const char* base = smem3 + slot * GEMM3S_STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 16; ++s) {
+      const uint32_t c = 2u * s + f_half;
+      const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(base + a_off[0] + ((c ^ a_sw[0]) << 4));
+      const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(base + a_off[1] + ((c ^ a_sw[1]) << 4));
+      const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(base + b_off[0] + ((c ^ b_sw[0]) << 4));
+      const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(base + b_off[1] + ((c ^ b_sw[1]) << 4));
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0u : slot + 1u;
+  }
+  __syncthreads();                                                         // every wavefront is done with the stages
+  if constexpr (EPI == EPI_LOSS) {
+    // as in the 128 x 128 kernel: the tile leaves through LDS, once per orientation, as 16-byte pieces of whole rows
+    const uint32_t half = lane >> 5, col = lane & 31u;
+    __bf16 gb[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t n = n_base + j * 32 + col;
+        const float bias = n < ep.cols_live ? ep.bp[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float g = 0.f;
+          if (m < ep.rows_live && n < ep.cols_live) g = loss_grad(ep.loss_type, acc[i][j][r] + bias, 0.f);
+          gb[i][j][r] = (__bf16)g;
+        }
+      }
+    constexpr uint32_t TS1 = 272;                                           // [256 m][128 n] image, row stride 272 B
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t ml = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, nl = wn + j * 32 + col;
+          *reinterpret_cast<__bf16*>(smem3 + ml * TS1 + nl * 2u) = gb[i][j][r];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 4, c16 = pc & 15u;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem3 + row * TS1 + c16 * 16u);
+      *reinterpret_cast<bf16x8*>(ep.G + (size_t)(m_tile + row) * ep.ldg + n_tile + c16 * 8u) = v;
+    }
+    __syncthreads();
+    constexpr uint32_t TS2 = 528;                                           // [128 n][256 m] image, row stride 528 B
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t nl = wn + j * 32 + col, m0 = wm + i * 32 + 8 * q + 4 * half;
+          const bf16x4 v = {gb[i][j][4 * q], gb[i][j][4 * q + 1], gb[i][j][4 * q + 2], gb[i][j][4 * q + 3]};
+          *reinterpret_cast<bf16x4*>(smem3 + nl * TS2 + m0 * 2u) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem3 + row * TS2 + c16 * 16u);
+      if (n_tile + row < N) *reinterpret_cast<bf16x8*>(ep.GT + (size_t)(n_tile + row) * ep.ldgt + m_tile + c16 * 8u) = v;
+    }
+  } else {
+    if (m_base >= M || n_base >= N) return;
+    gemm_tile_epilogue<EPI>(acc, m_base, n_base, lane, ep);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused forward + loss' + hidden gradient (replaces GEMM 1, the positive fix-up and GEMM 2 when Kp <= 256):
 // a workgroup owns 128 users (wavefront w: 32 of them) and one slice of the item dimension, and walks the slice in tiles

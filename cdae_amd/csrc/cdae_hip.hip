@@ -91,6 +91,7 @@ struct cdae_hip {
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
   bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
   bool gemm_direct = false;         // CDAE_GEMM_DIRECT: the fragment-from-L1 GEMM kernel instead of the LDS-staged one (A/B switch)
+  bool gemm_two_stage = false;      // CDAE_GEMM_TWO_STAGE: always the 128 x 128 two-stage LDS kernel (A/B switch)
   bool recommend_per_user = false;  // CDAE_RECOMMEND_PER_USER: recommend_kernel instead of the MFMA path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
   uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
@@ -421,6 +422,28 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   return 0;
 }
 
+// LDS-staged NT GEMM: the 256 x 128 three-stage kernel where the rows allow it (M % 256 == 0), else the 128 x 128 one.
+template <int EPI>
+int launch_gemm_lds(cdae_hip* h, hipStream_t st, const __bf16* A, const __bf16* Bm, uint32_t M, uint32_t N, uint32_t Kd, uint32_t lda,
+                    uint32_t ldb, uint32_t kps, const cdae::GemmEpilogue& ep, uint32_t splits, uint32_t mode) {
+  using namespace cdae;
+  const uint32_t Nt = (N + 127) / 128;
+  if (M % 256 == 0 && !h->gemm_two_stage) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_bf16_lds3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm3s_lds_bytes()));
+      attr_set = true;
+    }
+    const GemmGrid gg{M / 256, Nt, splits, mode};
+    hipLaunchKernelGGL((gemm_nt_bf16_lds3_kernel<EPI>), dim3(gg.workgroups()), dim3(512), gemm3s_lds_bytes(), st, A, Bm, M, N, Kd, lda, ldb,
+                       kps, ep, gg);
+  } else {
+    const GemmGrid gg{M / 128, Nt, splits, mode};
+    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI>), dim3(gg.workgroups()), dim3(256), 0, st, A, Bm, M, N, Kd, lda, ldb, kps, ep, gg);
+  }
+  return 0;
+}
+
 // Full-output decode of one batch (MFMA path, cdae_full_kernels.hpp).  The example list holds the positives only.
 int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
   using namespace cdae;
@@ -483,11 +506,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
                        Kp, ep);
   else
-  {
-    const GemmGrid gg{Bp / 128, Ip / 128, 1, 0};
-    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_LOSS>), dim3(gg.workgroups()), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
-                       Kp, ep, gg);
-  }
+    CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
                      h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
@@ -504,11 +523,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
                          h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
     else
-    {
-      const GemmGrid gg{Bp / 128, (Kp + 127) / 128, (Ip + kps - 1) / kps, 2};
-      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_ATOMIC>), dim3(gg.workgroups()), blk, 0, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip,
-                         kps, e2, gg);
-    }
+      CHK(launch_gemm_lds<EPI_ATOMIC>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, (Ip + kps - 1) / kps, 2));
   }
   }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
@@ -536,11 +551,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
                          Bp, Bp, Bp, Bp, e3);
     else
-    {
-      const GemmGrid gg{Ip / 128, (Kp + 127) / 128, 1, 1};
-      hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI_STORE>), dim3(gg.workgroups()), blk, 0, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp,
-                         Bp, e3, gg);
-    }
+      CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp, Bp, e3, 1, 1));
   }
   CHK(pr.end());
 
@@ -650,6 +661,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
   h->full_unfused = std::getenv("CDAE_FULL_UNFUSED") != nullptr;
   h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
+  h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -844,7 +856,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   if (h->cfg.linear_function) { CHK(dev_alloc(&h->d_Ssum, BK)); CHK(dev_alloc(&h->d_delta_rows, BK)); }
   if (h->cfg.full_output) {
     h->Bp = (B + 127u) & ~127u;
-    h->Ip = ((uint32_t)I + 127u) & ~127u;
+    h->Ip = I >= 32768 ? (((uint32_t)I + 255u) & ~255u) : (((uint32_t)I + 127u) & ~127u);   // big item spaces: 256-row GEMM tiles
     CHK(dev_alloc(&h->d_Zb, (size_t)h->Bp * h->Kp)); CHK(dev_alloc(&h->d_ZTb, (size_t)h->Kp * h->Bp));
     CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
     CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));

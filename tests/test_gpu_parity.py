@@ -475,16 +475,18 @@ def test_more_than_65536_items(built):
     assert err < 2e-2, (err, which)
 
 
-@pytest.mark.parametrize("K,B,unfused_env", [(300, 48, False), (512, 130, False), (24, 48, True), (200, 64, True)])
-def test_full_output_three_gemm_path(tiny, monkeypatch, K, B, unfused_env):
+@pytest.mark.parametrize("K,B,unfused_env", [(300, 48, False), (512, 130, False), (24, 48, True), (200, 64, True), (300, 256, False)])
+def test_full_output_three_gemm_path(tiny, small, monkeypatch, K, B, unfused_env):
     """K > 256 (BASELINE configs[4]: K = 512) keeps the three separate matrix-core products — GEMM 1 with the loss epilogue,
     split-K GEMM 2, GEMM 3 — instead of the fused kernel; CDAE_FULL_UNFUSED selects them for any K.  Same oracle as
     test_full_output_mfma_decode_matches_oracle; the bf16 rounding of z and D enters y = D z through K products, so the
     tolerance on the parameters is 3e-2 of their range here (measured 2.1e-2 .. 2.5e-2 on b', the smallest-valued
-    parameter, at K = 200 .. 512; the fused kernel measures the same at K = 200) against 2e-2 at K = 24."""
+    parameter, at K = 200 .. 512; the fused kernel measures the same at K = 200) against 2e-2 at K = 24.  B = 256 rows
+    take the 256 x 128 three-stage kernel (counted vmcnt) for GEMM 1 and 2, the others the 128 x 128 one."""
     if unfused_env:
         monkeypatch.setenv("CDAE_FULL_UNFUSED", "1")
-    model, o = make_pair(tiny, K=K, B=B, full_output=True)
+    data = small if B >= 256 else tiny      # (with 256 of tiny's 300 users per block there are two AdaGrad steps per epoch: b' alone is 3.8e-2 off)
+    model, o = make_pair(data, K=K, B=B, full_output=True)
     for ep in range(2):
         model.train_one_iteration(seed=4, epoch=ep)
         o.train_full(4, ep, B)
