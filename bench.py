@@ -156,11 +156,14 @@ def main():
         # that counts has been staged
         pipe.period = 1 << 30
         sync()
+        n_cal = max(3, min(args.warmup, 10))        # calibration batches (set-up, before the W warm-up steps)
+        step(0)                                      # first batch: cold pipeline, not timed
+        sync()
         tw = time.perf_counter()
-        for i in range(min(args.warmup, 10)):
+        for i in range(1, 1 + n_cal):
             step(i)
         sync()
-        t_step = (time.perf_counter() - tw) / max(1, min(args.warmup, 10))
+        t_step = (time.perf_counter() - tw) / n_cal
         pipe.flush()                      # exchange what those batches did, so the replicas agree again
         args.exchange_every, t_ar = pipe.choose_period(t_step, lo=2)       # a boundary costs ~40 us of stream time: never every batch
         exchange_note = f"period chosen at start-up: all-reduce {t_ar * 1e6:.0f} us vs {t_step * 1e6:.0f} us per batch"
