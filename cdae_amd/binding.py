@@ -63,10 +63,13 @@ EXPORTS = {
     "cdae_hip_train_one_user_corruption": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "cdae_hip_synchronize": (C.c_int, [C.c_void_p]),
+    "cdae_hip_debug_sample_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8
+                                    + [C.POINTER(C.c_uint64)]),
     "cdae_hip_encode": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cdae_hip_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "cdae_hip_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "cdae_hip_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "cdae_hip_recommend_user": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "cdae_hip_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cdae_hip_delta_begin": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_compute": (C.c_int, [C.c_void_p]),
@@ -179,6 +182,7 @@ class CDAE:
         _chk(self.lib, self.lib.cdae_hip_set_interactions(self.h, num_users, num_items, rp.ctypes.data, ci.ctypes.data))
         _chk(self.lib, self.lib.cdae_hip_set_user_id_offset(self.h, user_id_offset))
         self.num_users, self.num_items = int(num_users), int(num_items)
+        self._row_ptr = rp
 
     def reset(self, train, seed: int = 0):
         """train: object with num_users, num_items, train_ptr, train_col (cdae_amd.synth.Interactions)."""
@@ -242,6 +246,21 @@ class CDAE:
     def synchronize(self):
         _chk(self.lib, self.lib.cdae_hip_synchronize(self.h))
 
+    def debug_sample_batch(self, seed: int, epoch: int, u_begin: int, n_users: int, cidx: int = 0) -> dict:
+        """Integer work of one batch (masks, negatives, item sort, segments, duplicate numbering) copied back from the
+        device (cdae_hip_debug_sample_batch) — the bit-exact parity tests compare it with the oracle's draws."""
+        nnz = int(self._row_ptr[u_begin + n_users] - self._row_ptr[u_begin])
+        E = nnz * (1 if self.cfg.full_output else 1 + self.cfg.num_neg)
+        out = {"ex_item": np.empty(E, np.uint32), "ex_val": np.empty(E, np.uint64), "sorted_item": np.empty(E, np.uint32),
+               "sorted_val": np.empty(E, np.uint64), "seg_begin": np.empty(self.num_items, np.uint32),
+               "seg_end": np.empty(self.num_items, np.uint32), "dup_of_pos": np.empty(E, np.uint32),
+               "dup_of_ex": np.empty(E, np.uint32)}
+        n = C.c_uint64(E)
+        _chk(self.lib, self.lib.cdae_hip_debug_sample_batch(
+            self.h, seed, epoch, u_begin, n_users, cidx, *[a.ctypes.data for a in out.values()], C.byref(n)))
+        assert n.value == E
+        return out
+
     def train_one_user_corruption(self, uid: int, input_items, negative_items):
         """cdae.hpp:198-200 with explicit input set; negatives as the reference would have drawn them."""
         i = np.ascontiguousarray(input_items, dtype=np.uint32)
@@ -272,6 +291,13 @@ class CDAE:
         u_end = self.num_users if u_end is None else u_end
         out = np.empty((u_end - u_begin, topk), dtype=np.uint32)
         _chk(self.lib, self.lib.cdae_hip_recommend_all(self.h, u_begin, u_end, topk, out.ctypes.data))
+        return out
+
+    def recommend_user(self, uid: int, rated_items, topk: int = 10) -> np.ndarray:
+        """recommend(uid, topk, rated_item_set) for a set that is not the train row (cdae.hpp:162-196)."""
+        r = np.ascontiguousarray(rated_items, dtype=np.uint32)
+        out = np.empty(topk, dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_recommend_user(self.h, uid, r.ctypes.data, r.size, topk, out.ctypes.data))
         return out
 
     def pre_recommend(self, topk: int = 10):

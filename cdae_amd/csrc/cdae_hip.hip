@@ -145,9 +145,11 @@ struct cdae_hip {
   double* d_scalar = nullptr;
   uint32_t* d_uids = nullptr;
   uint32_t* d_rec = nullptr; size_t rec_cap = 0;
+  float* d_score = nullptr; size_t score_cap = 0;      // recommend, general path: score rows when num_items * 4 B exceed the LDS
   float* d_zeval = nullptr; float* d_hpart_eval = nullptr; uint32_t eval_cap = 0, eval_unit_cap = 0;   // evaluation workspace
   uint32_t* d_bits = nullptr; size_t bits_cap = 0;                                                     // recommend: rated-item bitmap
   int sort_bits = 1;
+  bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
 
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr;
@@ -233,7 +235,7 @@ void free_all(cdae_hip* h) {
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
-                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows};
+                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
@@ -258,14 +260,14 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
-                   (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows};
+                   (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
     for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
-  h->rec_cap = 0;
+  h->rec_cap = 0; h->score_cap = 0;
   h->eval_cap = 0; h->eval_unit_cap = 0; h->bits_cap = 0;
   return 0;
 }
@@ -429,10 +431,9 @@ int launch_gemm_lds(cdae_hip* h, hipStream_t st, const __bf16* A, const __bf16* 
   using namespace cdae;
   const uint32_t Nt = (N + 127) / 128;
   if (M % 256 == 0 && !h->gemm_two_stage) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!h->gemm3_attr_set[EPI]) {     // per handle: the attribute belongs to the (function, device) pair
       HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_bf16_lds3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm3s_lds_bytes()));
-      attr_set = true;
+      h->gemm3_attr_set[EPI] = true;
     }
     const GemmGrid gg{M / 256, Nt, splits, mode};
     hipLaunchKernelGGL((gemm_nt_bf16_lds3_kernel<EPI>), dim3(gg.workgroups()), dim3(512), gemm3s_lds_bytes(), st, A, Bm, M, N, Kd, lda, ldb,
@@ -817,6 +818,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint32_t one_unit[2] = {0u, 1u};          // explicit-input step: one user, one unit
     HIPCHK(hipMemcpy(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice));
   }
+  if ((uint64_t)B * h->Kp * sizeof(float) > 0xFFFFFFFFull)      // decode addresses z rows with 32-bit byte offsets (cdae_kernels.hpp)
+    return fail("batch_users %u x row stride %u floats exceeds the 4 GiB the batch's Z may occupy; lower batch_users", B, h->Kp);
   if (h->Ecap > 0xFFFFFFF0ull) return fail("batch of %u users holds %llu examples (> 2^32); lower batch_users", B, (unsigned long long)h->Ecap);
   for (auto& b : h->ex) {
     CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));
@@ -904,16 +907,16 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   using namespace cdae;
   const double init_scale = 4. * std::sqrt(6. / (double)(h->I + h->K));          // cdae.hpp:112
   auto blocks = [](size_t n) { return dim3((uint32_t)((n + 255) / 256)); };
-  auto init = [&](float* M, size_t rows, uint32_t id) {
+  auto init = [&](float* M, size_t rows, uint32_t id, uint64_t row0 = 0) {
     hipLaunchKernelGGL(init_matrix_kernel, blocks(rows * h->Kp), dim3(256), 0, h->stream, M, rows, h->K, h->Kp,
-                       cdae_rng_key(seed, 0, id, CDAE_STREAM_INIT), init_scale);
+                       cdae_rng_key(seed, 0, id, CDAE_STREAM_INIT), init_scale, row0);
   };
   auto fill = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v) {     // accumulator pads are 1, others 0
     hipLaunchKernelGGL(fill_matrix_kernel, blocks(rows * Kp), dim3(256), 0, h->stream, M, rows, K, Kp, v, v == 0.f ? 0.f : 1.f);
   };
   init(h->P(CDAE_P_W), h->I, CDAE_P_W); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
   if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
-  if (h->cfg.user_factor) { init(h->d_Wu, h->U, CDAE_P_WU); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }   // :119-122
+  if (h->cfg.user_factor) { init(h->d_Wu, h->U, CDAE_P_WU, h->uid_offset); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }   // :119-122
   else { fill(h->d_Wu, h->U, h->K, h->Kp, 0.f); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }
   fill(h->P(CDAE_P_B), 1, h->K, h->Kp, 0.f); fill(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f);    // :123-124
   fill(h->P(CDAE_P_BP), h->I, 1, 1, 0.f); fill(h->P(CDAE_P_BP_AG), h->I, 1, 1, 1e-4f);          // :125-126
@@ -1031,6 +1034,67 @@ int fill_stats(cdae_hip* h, cdae_hip_stats* stats) {
 
 }  // namespace
 
+// recommend(), general path (cdae_kernels.hpp recommend_kernel): any num_dim / topk / item count; one workgroup per user.
+// rated != nullptr: ONE user whose input set and mask are the caller's list (sorted, unique) instead of the train row.
+namespace {
+int recommend_general(cdae_hip* h, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out, const uint32_t* rated, uint32_t n_rated) {
+  const size_t lds_scores = (size_t)h->I * sizeof(float) + 64;
+  const bool in_lds = lds_scores <= 160 * 1024;
+  const size_t shmem = in_lds ? lds_scores : 64;
+  uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
+  if (!in_lds) {     // scores of a launch in a global workspace of <= 256 MiB
+    B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, (256ull << 20) / ((uint64_t)h->I * sizeof(float))));
+    if (h->score_cap < (size_t)B * h->I) {
+      if (h->d_score) HIPCHK(hipFree(h->d_score));
+      h->d_score = nullptr; h->score_cap = 0;
+      CHK(dev_alloc(&h->d_score, (size_t)B * h->I));
+      h->score_cap = (size_t)B * h->I;
+    }
+  }
+  if (h->rec_cap < (size_t)B * topk) {
+    if (h->d_rec) HIPCHK(hipFree(h->d_rec));
+    h->d_rec = nullptr; h->rec_cap = 0;
+    CHK(dev_alloc(&h->d_rec, (size_t)B * topk));
+    h->rec_cap = (size_t)B * topk;
+  }
+#define SET_SHMEM(NI_) HIPCHK(hipFuncSetAttribute((const void*)cdae::recommend_kernel<NI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+  switch (h->NI) { case 1: SET_SHMEM(1); break; case 2: SET_SHMEM(2); break; case 4: SET_SHMEM(4); break; default: SET_SHMEM(8); break; }
+#undef SET_SHMEM
+  uint32_t* d_rated = nullptr;
+  if (rated) {
+    CHK(dev_alloc(&d_rated, std::max<uint32_t>(n_rated, 1)));
+    if (n_rated) HIPCHK(hipMemcpyAsync(d_rated, rated, n_rated * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    const uint32_t one_unit[2] = {0u, 1u};
+    HIPCHK(hipMemcpyAsync(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  int rc = 0;
+  for (uint64_t s0 = u_begin; s0 < u_end && !rc; s0 += B) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
+    if (rated) {
+      // get_hidden_values(uid, rated_items) with the default scale 1 (cdae.hpp:169; q == 1 -> empty input, :168-172)
+      const bool none = h->hp.keep_thr == 0x100000000ull;
+      DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3(1), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W),
+                  (const uint32_t*)h->d_uptr_tmp, 1u, (const uint32_t*)nullptr, s0, 1u, 0, CDAE_STREAM_CORRUPT, 0u, (uint64_t)0, 0u, h->d_Hpart,
+                  (const uint32_t*)d_rated, none ? 0u : n_rated, (const uint32_t*)nullptr);
+      DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->hp, h->d_Hpart, (const uint32_t*)h->d_uptr_tmp, h->d_Wu,
+                  h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, 1u, 0, h->d_Z, (float*)nullptr, (float*)nullptr, h->d_Uu, (float*)nullptr);
+    } else {
+      rc = encode_chunk(h, nullptr, s0, nb, 0, CDAE_STREAM_CORRUPT, 0, 0, 0);      // cdae.hpp:167-172
+      if (rc) break;
+    }
+    DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, s0,
+                h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score, (const uint32_t*)d_rated, n_rated);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail("recommend: %s", hipGetErrorString(e));
+  }
+  if (d_rated) (void)hipFree(d_rated);
+  return rc;
+}
+}  // namespace
+
 // geometry and launch of the pipelined-exchange kernels (delta_pipe_kernel)
 namespace {
 struct PipeGeom { uint32_t Kc; size_t n_tail, n_compact, threads; };
@@ -1103,6 +1167,67 @@ int cdae_hip_collect_stats(cdae_hip_t* h, cdae_hip_stats* stats) {
   CHK(join_aux(h));
   HIPCHK(hipStreamSynchronize(h->stream));
   return fill_stats(h, stats);
+}
+
+int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint32_t n_users,
+                                uint32_t cidx, uint32_t* ex_item, uint64_t* ex_val, uint32_t* sorted_item,
+                                uint64_t* sorted_val, uint32_t* seg_begin, uint32_t* seg_end, uint32_t* dup_of_pos,
+                                uint32_t* dup_of_ex, uint64_t* n_examples) {
+  if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if (!n_examples) return fail("null argument");
+  if (n_users == 0 || u_begin + n_users > h->U) return fail("bad user range [%llu, +%u)", (unsigned long long)u_begin, n_users);
+  if (n_users > std::min<uint64_t>(h->B, h->U)) return fail("%u users exceed batch_users %u", n_users, h->B);
+  if (cidx >= h->cfg.num_corruptions) return fail("corruption index %u out of range", cidx);
+  HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
+  const uint64_t E = (uint64_t)(h->h_row_ptr[u_begin + n_users] - h->h_row_ptr[u_begin]) * (1u + h->hp.num_neg);
+  if (E > h->Ecap) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
+  if (E > *n_examples) return fail("batch has %llu examples, the caller's arrays hold %llu", (unsigned long long)E, (unsigned long long)*n_examples);
+  *n_examples = E;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->prep));
+  h->pre_valid = false;                                   // the set is overwritten: a prefetched batch is gone
+  const int set = (int)(h->seq & 1);
+  const int prof = h->profiling;
+  h->profiling = 0;
+  const int rc = prep_batch(h, set, Batch{u_begin, n_users, cidx, E}, seed, epoch);
+  h->profiling = prof;
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->prep));
+  cdae_hip::ExBuf& x = h->ex[set];
+  const size_t I = (size_t)h->I;
+  auto out = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (dst && bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+  };
+  CHK(out(ex_item, x.item, E * sizeof(uint32_t)));
+  CHK(out(ex_val, x.val, E * sizeof(uint64_t)));
+  CHK(out(sorted_val, x.sorted_val, E * sizeof(uint64_t)));
+  CHK(out(seg_begin, x.seg, I * sizeof(uint32_t)));
+  CHK(out(seg_end, x.seg + I, I * sizeof(uint32_t)));
+  CHK(out(dup_of_pos, x.dup_of_pos, E * sizeof(uint32_t)));
+  CHK(out(dup_of_ex, x.dup_of_ex, E * sizeof(uint32_t)));
+  if (sorted_item && E) {
+    if (x.key16) {                                        // I <= 65536: the sort ran on 16-bit copies of the item ids
+      std::vector<uint16_t> k16(E);
+      HIPCHK(hipMemcpy(k16.data(), x.sorted_key16, E * sizeof(uint16_t), hipMemcpyDeviceToHost));
+      for (uint64_t i = 0; i < E; ++i) sorted_item[i] = k16[i];
+    } else {
+      CHK(out(sorted_item, x.sorted_item, E * sizeof(uint32_t)));
+    }
+  }
+  // dup_of_pos is only written at the positions segment_kernel numbered: report DUP_NONE everywhere else
+  if (dup_of_pos && sorted_val) {
+    for (uint64_t p = 0; p < E; ++p)
+      if (!((uint32_t)sorted_val[p] & cdae::DUP_PREV_BIT)) dup_of_pos[p] = cdae::DUP_NONE;
+  } else if (dup_of_pos) {
+    std::vector<uint64_t> sv(E);
+    if (E) HIPCHK(hipMemcpy(sv.data(), x.sorted_val, E * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (uint64_t p = 0; p < E; ++p)
+      if (!((uint32_t)sv[p] & cdae::DUP_PREV_BIT)) dup_of_pos[p] = cdae::DUP_NONE;
+  }
+  HIPCHK(hipEventRecord(x.released, h->stream));          // nothing trains on this set: hand it back
+  return 0;
 }
 
 int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats) {
@@ -1225,29 +1350,24 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
     }
     return 0;
   }
-  const size_t shmem = (size_t)h->I * sizeof(float) + 64;
-  if (shmem > 160 * 1024) return fail("recommend: %llu items exceed the 160 KiB LDS score buffer", (unsigned long long)h->I);
-  const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
-  if (h->rec_cap < (size_t)B * topk) {
-    if (h->d_rec) HIPCHK(hipFree(h->d_rec));
-    h->d_rec = nullptr;
-    CHK(dev_alloc(&h->d_rec, (size_t)B * topk));
-    h->rec_cap = (size_t)B * topk;
+  return recommend_general(h, u_begin, u_end, topk, out, nullptr, 0);
+}
+
+int cdae_hip_recommend_user(cdae_hip_t* h, uint64_t uid, const uint32_t* rated_items, size_t n_rated, uint32_t topk, uint32_t* out) {
+  if (!h || !h->d_shared || !out) return fail("bad argument");
+  if (uid >= h->U) return fail("user id %llu out of range", (unsigned long long)uid);
+  if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
+  if (n_rated && !rated_items) return fail("null argument");
+  if (n_rated + topk > h->I) return fail("%zu rated items leave fewer than topk = %u candidates", n_rated, topk);
+  HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
+  std::vector<uint32_t> rated(rated_items, rated_items + n_rated);
+  std::sort(rated.begin(), rated.end());                         // encode sums in ascending item order like the train row
+  for (size_t i = 0; i < n_rated; ++i) {
+    if (rated[i] >= h->I) return fail("rated item %u out of range", rated[i]);
+    if (i && rated[i] == rated[i - 1]) return fail("duplicate rated item %u", rated[i]);
   }
-#define SET_SHMEM(NI_) HIPCHK(hipFuncSetAttribute((const void*)cdae::recommend_kernel<NI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
-  switch (h->NI) { case 1: SET_SHMEM(1); break; case 2: SET_SHMEM(2); break; case 3: SET_SHMEM(3); break; case 4: SET_SHMEM(4); break;
-                   case 5: SET_SHMEM(5); break; case 6: SET_SHMEM(6); break; case 7: SET_SHMEM(7); break; default: SET_SHMEM(8); break; }
-#undef SET_SHMEM
-  for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
-    CHK(encode_chunk(h, nullptr, s0, nb, 0, CDAE_STREAM_CORRUPT, 0, 0, 0));      // cdae.hpp:167-172
-    DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, s0,
-                h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-  }
-  return 0;
+  return recommend_general(h, uid, uid + 1, topk, out, rated.data(), (uint32_t)n_rated);
 }
 
 int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32_t* input_items, size_t n_in,

@@ -1288,19 +1288,27 @@ sqnorm_kernel(const float* __restrict__ x, size_t n, double* __restrict__ out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7  recommend (cdae.hpp:162-196): scores of all items for one user per block, rated items masked,
+// K7  recommend (cdae.hpp:162-196), general path: scores of all items for one user per block, rated items masked,
 // top-k by repeated block arg-max (k = 10, evaluation.hpp:145).  Ties resolve to the lower item id.
-// One block (256 threads) per user: each wavefront scores items wave-strided; scores go to LDS.
+// One block (256 threads) per user: each wavefront scores items wave-strided.  The scores live in LDS when
+// num_items * 4 bytes fit (score_ws == nullptr), else in a global workspace row of the user (1 M items = 4 MB, L2
+// resident) — any num_dim <= 512, any topk, any item count.  Each thread caches the best of the items it owns
+// (item % 256 == thread); after a winner is taken only its owner rescans, so a user costs one pass over the scores plus
+// topk * num_items / 256 reads instead of topk passes.
+// rated_override != nullptr (one user per launch): the caller's rated set replaces the train row as the mask
+// (recommend(uid, topk, rated_item_set) with a set that is not the train row).
 template <int NI>
 __global__ void __launch_bounds__(256)
 recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                  uint64_t u0, const float* __restrict__ Z, const float* __restrict__ D,
-                 const float* __restrict__ bp, uint32_t topk, uint32_t* __restrict__ out) {
+                 const float* __restrict__ bp, uint32_t topk, uint32_t* __restrict__ out,
+                 float* __restrict__ score_ws /* [gridDim.x][num_items] or nullptr */,
+                 const uint32_t* __restrict__ rated_override, uint32_t n_override) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* score = reinterpret_cast<float*>(smem_raw);                         // [num_items]
-  float* red_v = score + hp.num_items;                                       // [4]
-  uint32_t* red_i = reinterpret_cast<uint32_t*>(red_v + 4);                  // [4]
+  float* red_v = reinterpret_cast<float*>(smem_raw);                         // [4]
+  uint32_t* red_i = reinterpret_cast<uint32_t*>(red_v + 4);                  // [4] + winner at [4]
   const uint32_t slot = blockIdx.x;
+  float* score = score_ws ? score_ws + (size_t)slot * hp.num_items : reinterpret_cast<float*>(smem_raw + 64);
   const uint64_t uid = u0 + slot;
   const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
   const uint32_t lo = lane * NI;
@@ -1316,24 +1324,34 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
     if (lane == 0) score[item] = y;
   }
   __syncthreads();
-  const int64_t r0 = row_ptr[uid];
-  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
-  for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) score[col[r0 + p]] = -INFINITY;   // cdae.hpp:177-179
+  if (rated_override) {
+    for (uint32_t p = threadIdx.x; p < n_override; p += blockDim.x) score[rated_override[p]] = -INFINITY;
+  } else {
+    const int64_t r0 = row_ptr[uid];
+    const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+    for (uint32_t p = threadIdx.x; p < n; p += blockDim.x) score[col[r0 + p]] = -INFINITY;   // cdae.hpp:177-179
+  }
   __syncthreads();
-  for (uint32_t t = 0; t < topk; ++t) {
-    float best = -INFINITY;
-    uint32_t best_i = 0xFFFFFFFFu;
+  float best = -INFINITY;
+  uint32_t best_i = 0xFFFFFFFFu;
+  auto rescan = [&]() {
+    best = -INFINITY; best_i = 0xFFFFFFFFu;
     for (uint32_t item = threadIdx.x; item < hp.num_items; item += blockDim.x) {
       const float v = score[item];
       if (v > best || (v == best && item < best_i)) { best = v; best_i = item; }
     }
+  };
+  rescan();
+  for (uint32_t t = 0; t < topk; ++t) {
+    float wv = best;
+    uint32_t wi = best_i;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(best, off, WAVE);
-      const uint32_t oi = __shfl_xor(best_i, off, WAVE);
-      if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+      const float ov = __shfl_xor(wv, off, WAVE);
+      const uint32_t oi = __shfl_xor(wi, off, WAVE);
+      if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
     }
-    if (lane == 0) { red_v[wid] = best; red_i[wid] = best_i; }
+    if (lane == 0) { red_v[wid] = wv; red_i[wid] = wi; }
     __syncthreads();
     if (threadIdx.x == 0) {
       float bv = red_v[0];
@@ -1341,7 +1359,13 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
       for (uint32_t w2 = 1; w2 < nw; ++w2)
         if (red_v[w2] > bv || (red_v[w2] == bv && red_i[w2] < bi)) { bv = red_v[w2]; bi = red_i[w2]; }
       out[(size_t)slot * topk + t] = bi;
-      if (bi != 0xFFFFFFFFu) score[bi] = -INFINITY;
+      red_i[4] = bi;
+    }
+    __syncthreads();
+    const uint32_t win = red_i[4];
+    if (win != 0xFFFFFFFFu && win % blockDim.x == threadIdx.x) {             // the owner retires the winner and rescans
+      score[win] = -INFINITY;
+      rescan();
     }
     __syncthreads();
   }
@@ -1350,12 +1374,13 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
 // ------------------------------------------------------------------------------------------------
 // parameter init (cdae.hpp:109-134) from the CDAE_STREAM_INIT counter stream; pad elements get `pad`
 __global__ void __launch_bounds__(256)
-init_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, uint64_t key, double init_scale) {
+init_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, uint64_t key, double init_scale,
+                   uint64_t row0 /* global index of local row 0: a data-parallel shard's Wu rows draw what the whole matrix would */) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * Kp) return;
   const size_t r = idx / Kp;
   const uint32_t k = (uint32_t)(idx % Kp);
-  M[idx] = k < K ? (float)(cdae_init_uniform(key, r * K + k) * init_scale) : 0.f;
+  M[idx] = k < K ? (float)(cdae_init_uniform(key, (row0 + r) * K + k) * init_scale) : 0.f;
 }
 __global__ void __launch_bounds__(256)
 fill_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, float value, float pad) {

@@ -28,6 +28,8 @@ SHAPES = {
     "yelp": (10_000, 7_000, 312_500),
     # BASELINE configs[4] item space (1 M items, ~100 interactions per user) with as many users as a single-GPU bench needs
     "cfg5_items": (20_000, 1_000_000, 2_000_000),
+    # reduced configs[4] for the parity fixture: > 65 536 items (32-bit sort keys, 256-row GEMM tiles) at K = 512
+    "cfg5_small": (256, 131_072, 25_600),
     "tiny": (300, 120, 9_000),
     "small": (4_000, 1_500, 240_000),
 }

@@ -44,7 +44,8 @@ extern "C" {
 
 /* 2: cdae_hip_config.linear_function (in what was tail padding of the uint32 block: zero the struct before filling it),
  *    parameters CDAE_P_UU / CDAE_P_UU_AG; pipelined delta exchange entry points */
-#define CDAE_HIP_ABI_VERSION 2
+/* 3: cdae_hip_debug_sample_batch (integer-parity test hook) */
+#define CDAE_HIP_ABI_VERSION 3
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -123,7 +124,8 @@ uint32_t cdae_hip_row_stride(const cdae_hip_t* h);
 int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t global_id_of_local_user_0);
 
 /* reset(): W, V, Wu ~ U(-1,1) * 4*sqrt(6/(I+K)), accumulators 1e-4, biases 0 (cdae.hpp:109-134),
- * drawn from the CDAE_STREAM_INIT counter stream of include/cdae_rng.h. */
+ * drawn from the CDAE_STREAM_INIT counter stream of include/cdae_rng.h.  Wu rows are keyed by GLOBAL user id
+ * (cdae_hip_set_user_id_offset): a shard initialises its rows to what a single-GPU run would. */
 int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed);
 
 /* dense [rows x num_dim] (or [n]) fp32 host arrays, unpadded */
@@ -157,6 +159,24 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
 int cdae_hip_set_profiling(cdae_hip_t* h, int period);
 int cdae_hip_synchronize(cdae_hip_t* h);
 
+/* Test hook for the INTEGER work of the path (bit-exact parity, tests/test_gpu_integer.py): runs the sampling, the
+ * item sort and the segmentation of ONE batch — users [u_begin, u_begin + n_users) (n_users <= batch_users),
+ * corruption `cidx` — exactly as cdae_hip_train_users would (get_corrputed_input cdae.hpp:361-371, sample_negative_item
+ * recsys_model_base.hpp:46-57 / cdae.hpp:217-220) and copies the example lists back instead of training on them:
+ *   ex_item / ex_val [E]          user-major: per user its n_u train items, then its n_u * num_neg negatives;
+ *                                 val = example index << 32 | slot | target << 30 | is_input << 31
+ *   sorted_item / sorted_val [E]  the same list stably sorted by item (user order inside an item); sorted_val also
+ *                                 carries dup_prev << 28 | dup_next << 29 (neighbour in the row is the same user's)
+ *   seg_begin / seg_end [num_items]   sorted range of every item (0, 0 for items without examples)
+ *   dup_of_pos / dup_of_ex [E]    correction-row number of every second-or-later duplicate negative, by sorted
+ *                                 position / by example (0xFFFFFFFF elsewhere); the numbering itself is arbitrary
+ * E = (1 + num_neg) * (train items of the batch's users) (full_output: the positives only); *n_examples is the
+ * capacity of the arrays on entry and E on return.  Any output pointer may be NULL. */
+int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint32_t n_users,
+                                uint32_t cidx, uint32_t* ex_item, uint64_t* ex_val, uint32_t* sorted_item,
+                                uint64_t* sorted_val, uint32_t* seg_begin, uint32_t* seg_end, uint32_t* dup_of_pos,
+                                uint32_t* dup_of_ex, uint64_t* n_examples);
+
 /* z for `n` users (get_hidden_values, cdae.hpp:373-416).  mode 0: full train row, scale 1 (the
  * inference form, cdae.hpp:169); mode 1: training corruption of (seed, epoch, corruption 0) with the
  * configured scale.  Z is [n x num_dim] fp32 on the host. */
@@ -168,10 +188,18 @@ int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out
 int cdae_hip_penalty_loss(cdae_hip_t* h, double* out);
 
 /* recommend() for users [u_begin, u_end): top-k unrated items by W'[i].z + b'[i], descending score,
- * ties -> lower item id first (heap.hpp:44-52 + utils.hpp:16-19 with ascending scan order).
+ * ties -> lower item id first (heap.hpp:44-52 + utils.hpp:16-19 with ascending scan order).  num_dim <= 256 and topk <= 16
+ * run on the matrix cores (all users of a chunk per launch); any other combination — and any item count — takes the
+ * general one-workgroup-per-user path.
  * out is [(u_end-u_begin) x topk] uint32 on the host. */
 int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint32_t topk,
                            uint32_t* out);
+
+/* recommend(uid, topk, rated_item_set) (cdae.hpp:162-196) for a rated set that is NOT the user's train row: the hidden
+ * layer is encoded from `rated_items` (scale 1, cdae.hpp:169) and exactly those items are excluded (cdae.hpp:177-179).
+ * Items need not be sorted; duplicates are an error.  out is [topk] uint32 on the host. */
+int cdae_hip_recommend_user(cdae_hip_t* h, uint64_t uid, const uint32_t* rated_items, size_t n_rated, uint32_t topk,
+                            uint32_t* out);
 
 /* ---- data-parallel exchange (north star: RCCL all-reduce of the shared W / W' / bias gradients;
  * Wu never leaves its GPU).  Each rank trains its own users from a common snapshot, then

@@ -71,6 +71,20 @@ int main(int argc, char* argv[]) {
     CDAE model(cfg);
     Solver<CDAE> solver(model, FLAGS_iters);
     solver.train(train, test, {TOPN});
+    // recommend() with the train row is the precomputed table; with any other rated set the hidden layer is encoded from
+    // THAT set and exactly it is excluded (cdae.hpp:167-179)
+    std::shared_ptr<CDAE> trained = solver.get_model();
+    auto train_sets = train.get_feature_pair_label_hashtable(0, 1);
+    const std::unordered_map<size_t, double>& row = train_sets.begin()->second;
+    const size_t uid = train_sets.begin()->first;
+    CHECK(trained->recommend(uid, 10, row) == trained->recommend_train_row(uid, 10));
+    std::unordered_map<size_t, double> fewer(row);
+    const size_t dropped = fewer.begin()->first;
+    fewer.erase(fewer.begin());
+    const std::vector<size_t> rec = trained->recommend(uid, 10, fewer);
+    CHECK_EQ(rec.size(), size_t(10));
+    for (size_t iid : rec) CHECK(!fewer.count(iid)) << "a rated item was recommended";
+    LOG(INFO) << "explicit rated set OK (dropped item " << dropped << ")";
   }
   LOG(INFO) << "host layer OK";
   return 0;

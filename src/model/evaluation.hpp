@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
+#include <utility>
 #include <iomanip>
 #include <memory>
 #include <sstream>
@@ -62,8 +64,9 @@ class TOPN_Evaluation : public Evaluation<Model> {
     return ss.str();
   }
 
-  // evaluation.hpp:183-219
-  static std::vector<double> evaluate_rec_list(const std::vector<size_t>& list, const std::unordered_map<size_t, double>& truth) {
+  // evaluation.hpp:183-219; `truth` only needs count() and size()
+  template <class Truth>
+  static std::vector<double> evaluate_rec_list(const std::vector<size_t>& list, const Truth& truth) {
     std::vector<double> r(8, 0.);
     const size_t top = std::min<size_t>(20, list.size());
     double hit = 0., map5 = 0., map10 = 0.;
@@ -82,35 +85,74 @@ class TOPN_Evaluation : public Evaluation<Model> {
     return r;
   }
 
+  // The reference rebuilds two uid -> {iid -> label} hashtables (validation and train) on EVERY call
+  // (evaluation.hpp:118-123) — U + nnz node allocations per epoch.  Here the validation rows are one CSR, built once per
+  // Data object and kept across epochs, and a model that can answer "top-k for the user's own train row" without being
+  // handed the set (recommend_train_row: libcf::CDAE holds the rows it was reset with) is never given one; other models
+  // (Popularity, ...) get the train hashtable as before, also built once.
   std::string evaluate(Model& model, const Data& validation, const Data& train = Data()) const {
     CHECK_GT(validation.size(), size_t(0));
-    auto val_sets = validation.get_feature_pair_label_hashtable(0, 1);
-    std::unordered_map<size_t, std::unordered_map<size_t, double>> train_sets;
-    if (train.size()) train_sets = train.get_feature_pair_label_hashtable(0, 1);
     const size_t num_users = train.feature_group_total_dimension(0);
     const size_t num_items = train.feature_group_total_dimension(1);
-    CHECK_EQ(num_users, train_sets.size());
+    const Rows& val = rows_of(validation, val_cache_);
+    size_t n_test_users = 0;
+    for (size_t u = 0; u + 1 < val.row_ptr.size(); ++u) n_test_users += val.row_ptr[u + 1] > val.row_ptr[u];
+    const bool self_rows = has_train_row_recommend<Model>::value;
+    if (!self_rows) {
+      if (train_sets_src_ != train.data() || train_sets_n_ != train.size()) {
+        train_sets_ = train.get_feature_pair_label_hashtable(0, 1);
+        train_sets_src_ = train.data(); train_sets_n_ = train.size();
+      }
+      CHECK_EQ(num_users, train_sets_.size());
+    }
     Timer t;
     std::vector<std::vector<double>> per_user(num_users, std::vector<double>(8, 0.));
     model.pre_recommend();                                         // evaluation.hpp:135
     dynamic_parallel_for(0, num_users, [&](size_t uid) {           // recommend() is called concurrently
-      auto vit = val_sets.find(uid);
-      if (vit == val_sets.end()) return;
-      auto tit = train_sets.find(uid);
-      CHECK(tit != train_sets.end());
-      const std::vector<size_t> rec = model.recommend(uid, 10, tit->second);
+      if (uid + 1 >= val.row_ptr.size() || val.row_ptr[uid + 1] == val.row_ptr[uid]) return;
+      const std::vector<size_t> rec = recommend_for(model, uid, std::integral_constant<bool, has_train_row_recommend<Model>::value>());
       for (size_t iid : rec) CHECK_LT(iid, num_items);
-      per_user[uid] = evaluate_rec_list(rec, vit->second);
+      per_user[uid] = evaluate_rec_list(rec, RowView{val.col.data() + val.row_ptr[uid], static_cast<size_t>(val.row_ptr[uid + 1] - val.row_ptr[uid])});
     });
-    const double n_test_users = static_cast<double>(val_sets.size());
     std::vector<double> mean(8, 0.);
     for (size_t u = 0; u < num_users; ++u)
-      for (size_t c = 0; c < 8; ++c) mean[c] += per_user[u][c] / n_test_users;
+      for (size_t c = 0; c < 8; ++c) mean[c] += per_user[u][c] / static_cast<double>(n_test_users);
     std::stringstream ss;
     for (size_t c = 0; c < 8; ++c) ss << std::setw(8) << std::setprecision(5) << mean[c] << "|";
     ss << std::setw(8) << std::setprecision(3) << t.elapsed();
     return ss.str();
   }
+
+ private:
+  struct Rows { const void* src = nullptr; size_t n = 0; std::vector<int64_t> row_ptr; std::vector<uint32_t> col; };
+  struct RowView {                                             // a sorted CSR row seen as the `truth` set
+    const uint32_t* p; size_t n;
+    size_t size() const { return n; }
+    size_t count(size_t item) const { return std::binary_search(p, p + n, static_cast<uint32_t>(item)) ? 1 : 0; }
+  };
+  template <class M>
+  struct has_train_row_recommend {
+    template <class T> static auto test(int) -> decltype(std::declval<const T&>().recommend_train_row(size_t(0), size_t(0)), std::true_type());
+    template <class> static std::false_type test(...);
+    static const bool value = decltype(test<M>(0))::value;
+  };
+  std::vector<size_t> recommend_for(Model& model, size_t uid, std::true_type) const { return model.recommend_train_row(uid, 10); }
+  std::vector<size_t> recommend_for(Model& model, size_t uid, std::false_type) const {
+    auto tit = train_sets_.find(uid);
+    CHECK(tit != train_sets_.end());
+    return model.recommend(uid, 10, tit->second);
+  }
+  static const Rows& rows_of(const Data& d, Rows& cache) {
+    if (cache.src != d.data() || cache.n != d.size()) {
+      d.to_csr(0, 1, cache.row_ptr, cache.col);
+      cache.src = d.data(); cache.n = d.size();
+    }
+    return cache;
+  }
+  mutable Rows val_cache_;
+  mutable std::unordered_map<size_t, std::unordered_map<size_t, double>> train_sets_;
+  mutable const void* train_sets_src_ = nullptr;
+  mutable size_t train_sets_n_ = 0;
 };
 
 template <class Model>

@@ -96,10 +96,10 @@ class CDAE : public RecsysModelBase {
     cdae_hip_t* raw = nullptr;
     CDAE_HIP_CHECK(cdae_hip_create(&c, static_cast<int>(env_u64("CDAE_DEVICE", 0)), &raw));
     dev_.reset(raw, [](cdae_hip_t* h) { cdae_hip_destroy(h); });
-    std::vector<int64_t> row_ptr;
-    std::vector<uint32_t> col;
-    data_->to_csr(0, 1, row_ptr, col);                     // uid -> sorted {iid}; labels are all 1 (yelp.cpp:66)
-    CDAE_HIP_CHECK(cdae_hip_set_interactions(dev_.get(), num_users_, num_items_, row_ptr.data(), col.data()));
+    std::shared_ptr<Csr> csr = std::make_shared<Csr>();
+    data_->to_csr(0, 1, csr->row_ptr, csr->col);           // uid -> sorted {iid}; labels are all 1 (yelp.cpp:66)
+    CDAE_HIP_CHECK(cdae_hip_set_interactions(dev_.get(), num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
+    train_csr_ = csr;
     seed_ = std::getenv("CDAE_SEED") ? env_u64("CDAE_SEED", 0) : Random::next_u64();
     CDAE_HIP_CHECK(cdae_hip_init_params(dev_.get(), seed_));
     epoch_ = 0;
@@ -120,6 +120,8 @@ class CDAE : public RecsysModelBase {
   void train_one_user_corruption(size_t uid, const std::unordered_map<size_t, double>& input_set,
                                  const std::unordered_map<size_t, double>& output_set) {
     CHECK(dev_ != nullptr) << "reset() must be called first";
+    // the device decodes the user's TRAIN row as the positives (that is what train_one_iteration passes, cdae.hpp:143)
+    CHECK(is_train_row(uid, output_set)) << "train_one_user_corruption: output_set must be the user's train row";
     std::vector<uint32_t> in, neg(output_set.size() * cfg_.num_neg);
     for (auto& p : input_set) in.push_back(static_cast<uint32_t>(p.first));
     for (auto& n : neg) n = static_cast<uint32_t>(sample_negative_item(output_set));
@@ -156,16 +158,48 @@ class CDAE : public RecsysModelBase {
   // starts); recommend() is then a read of an immutable table and safe to call concurrently (evaluation.hpp:137).
   void pre_recommend() { ensure_table(10); }
 
-  std::vector<size_t> recommend(size_t uid, size_t topk, const std::unordered_map<size_t, double>& /*rated_item_set*/) const {
+  // The reference encodes the hidden layer FROM rated_item_set and excludes exactly that set (cdae.hpp:167-179).
+  // Evaluation passes the user's train row, which is what the precomputed table holds; any other set takes the
+  // explicit device path (cdae_hip_recommend_user), serialised on the handle's mutex.
+  std::vector<size_t> recommend(size_t uid, size_t topk, const std::unordered_map<size_t, double>& rated_item_set) const {
+    CHECK_LT(uid, num_users_);
+    if (is_train_row(uid, rated_item_set)) return recommend_train_row(uid, topk);
+    std::vector<uint32_t> rated;
+    rated.reserve(rated_item_set.size());
+    for (auto& p : rated_item_set) { CHECK_LT(p.first, num_items_); rated.push_back(static_cast<uint32_t>(p.first)); }
+    std::vector<uint32_t> ids(topk);
+    {
+      std::lock_guard<std::mutex> lk(*mu_);
+      CHECK(dev_ != nullptr) << "reset() must be called first";
+      CDAE_HIP_CHECK(cdae_hip_recommend_user(dev_.get(), uid, rated.data(), rated.size(), static_cast<uint32_t>(topk), ids.data()));
+    }
+    return std::vector<size_t>(ids.begin(), ids.end());
+  }
+
+  // recommend() for the user's own train row — what Evaluation asks for — without the caller building a hashtable
+  // per user per epoch (evaluation.hpp:118-123): TOPN_Evaluation detects this method and uses it.
+  std::vector<size_t> recommend_train_row(size_t uid, size_t topk) const {
     CHECK_LT(uid, num_users_);
     std::shared_ptr<const Table> t = ensure_table(topk);
     std::vector<size_t> out(topk);
     for (size_t i = 0; i < topk; ++i) out[i] = t->ids[uid * topk + i];
     return out;
   }
+  // the train rows the model was reset with, as CSR (sorted item ids per user)
+  const std::vector<int64_t>& train_row_ptr() const { CHECK(train_csr_ != nullptr); return train_csr_->row_ptr; }
+  const std::vector<uint32_t>& train_col_idx() const { CHECK(train_csr_ != nullptr); return train_csr_->col; }
 
  private:
   struct Table { size_t topk; std::vector<uint32_t> ids; };
+  struct Csr { std::vector<int64_t> row_ptr; std::vector<uint32_t> col; };
+
+  bool is_train_row(size_t uid, const std::unordered_map<size_t, double>& rated) const {
+    CHECK(train_csr_ != nullptr) << "reset() must be called first";
+    const int64_t a = train_csr_->row_ptr[uid], b = train_csr_->row_ptr[uid + 1];
+    if (static_cast<size_t>(b - a) != rated.size()) return false;
+    for (int64_t p = a; p < b; ++p) if (!rated.count(train_csr_->col[p])) return false;
+    return true;
+  }
 
   std::shared_ptr<const Table> ensure_table(size_t topk) const {
     std::lock_guard<std::mutex> lk(*mu_);
@@ -188,6 +222,7 @@ class CDAE : public RecsysModelBase {
   std::shared_ptr<cdae_hip_t> dev_;                  // shared by copies: Solver copies the model (solver.hpp:17)
   std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
   mutable std::shared_ptr<const Table> rec_;
+  std::shared_ptr<const Csr> train_csr_;             // host copy of the train rows (recommend: is the caller's set the train row?)
   uint64_t seed_ = 0;
   uint32_t epoch_ = 0;
 };

@@ -1,0 +1,88 @@
+#!/usr/bin/env python
+"""Accuracy fixtures at the BASELINE.json shapes, from the CPU oracle's LITERAL schedule (tests/golden/*_literal_*.npz).
+
+    python tests/golden/make_literal_curves.py --shape ml10m --seed 20141119 --epochs 5
+
+What the fixture pins: the table the reference prints per epoch — "Train Loss" = data_loss + penalty_loss
+(/root/reference/src/solver/solver-inl.hpp:55) and the TOPN row, of which Recall@10 is rets[5]
+(/root/reference/src/model/evaluation.hpp:183-219) — when `train_one_iteration` (cdae.hpp:136-146) runs strictly
+user by user in fp64, on the synthetic data set `cdae_amd.synth.generate_shape(shape, seed)` with the counter-based
+random streams of include/cdae_rng.h keyed by the same seed.  `tests/test_gpu_accuracy.py` trains the HIP path at
+bench.py's default `batch_users` on the same data / init / streams and asserts |dRecall@10| <= 0.002 per epoch
+(the north star's tolerance) and the loss-curve tolerance stated there.
+
+The reference itself cannot be built in this image (Eigen / Boost / glog / gflags absent), so this is the oracle's
+restatement, not the reference binary: "parity unpinned"  applies to these files too.
+
+One ML-10M-shape epoch costs ~90 s of one core for training plus ~100 s for the fp64 top-10 of 70 000 users.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from cdae_amd import synth  # noqa: E402
+import oracle as orc  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# benchmark hyper-parameters — tests/test_gpu_accuracy.py and bench.py use the same
+HYPER = dict(num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="ml10m")
+    ap.add_argument("--seed", type=int, default=20141119)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--num-dim", type=int, default=200)
+    ap.add_argument("--loss", default="CE", choices=["CE", "SQUARE"])
+    ap.add_argument("--full-output-batch", type=int, default=0,
+                    help="> 0: the full-output block schedule (Oracle.train_full) with this many users per block instead of the literal one")
+    args = ap.parse_args()
+
+    d = synth.generate_shape(args.shape, seed=args.seed)
+    lt = ob.LOSS_CE if args.loss == "CE" else ob.LOSS_SQUARE
+    o = orc.Oracle(orc.OracleConfig(num_dim=args.num_dim, loss_type=lt, **HYPER), d.num_users, d.num_items, d.train_ptr, d.train_col)
+    o.init_params(args.seed)
+    rec10, loss, data_loss, metrics, secs = [], [], [], [], []
+    for ep in range(args.epochs):
+        t0 = time.time()
+        if args.full_output_batch:
+            o.train_full(args.seed, ep, args.full_output_batch)
+        else:
+            o.train_literal(args.seed, ep)
+        secs.append(time.time() - t0)
+        dl = o.data_loss(args.seed, ep)
+        data_loss.append(dl)
+        loss.append(dl + o.penalty_loss())
+        m = orc.eval_topn(o.recommend(10), d.test_ptr, d.test_col)
+        metrics.append(m)
+        rec10.append(m[5])
+        print(f"[{args.shape} seed {args.seed}] epoch {ep + 1}: loss {loss[-1]:.1f} recall@10 {rec10[-1]:.5f} ({secs[-1]:.0f} s train)", flush=True)
+    # parameter probes (full-output fixtures compare parameters too: Recall is uninformative on a few hundred users)
+    rng = np.random.default_rng(args.seed)
+    pop = np.bincount(d.train_col, minlength=d.num_items)
+    probe_items = np.unique(np.concatenate([np.argsort(-pop)[:32], rng.choice(d.num_items, 32, replace=False)])).astype(np.int64)
+    probe_users = np.sort(rng.choice(d.num_users, min(16, d.num_users), replace=False)).astype(np.int64)
+    K = args.num_dim
+    probes = dict(probe_items=probe_items, probe_users=probe_users,
+                  W_rows=o.get(ob.P_W).reshape(d.num_items, K)[probe_items], bp_rows=o.get(ob.P_BP)[probe_items],
+                  Wu_rows=o.get(ob.P_WU).reshape(d.num_users, K)[probe_users], b=o.get(ob.P_B),
+                  W_absmax=np.abs(o.get(ob.P_W)).max(), Wu_absmax=np.abs(o.get(ob.P_WU)).max(), bp_absmax=np.abs(o.get(ob.P_BP)).max())
+    tag = f"full{args.full_output_batch}" if args.full_output_batch else "literal"
+    name = f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_{tag}_seed{args.seed}.npz"
+    np.savez(os.path.join(OUT, name), shape=args.shape, seed=args.seed, num_dim=args.num_dim, loss=args.loss,
+             full_output_batch=args.full_output_batch, hyper=np.array(sorted(HYPER.items()), dtype=object).astype(str),
+             recall10=np.array(rec10), train_loss=np.array(loss), data_loss=np.array(data_loss), topn=np.array(metrics),
+             train_seconds=np.array(secs), nnz_train=d.nnz_train, **probes)
+    print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

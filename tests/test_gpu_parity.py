@@ -494,3 +494,58 @@ def test_full_output_three_gemm_path(tiny, small, monkeypatch, K, B, unfused_env
     assert err < (3e-2 if K > 64 else 2e-2), (err, which)
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
+
+
+def _clear_rows(sc, tol=1e-4):
+    return np.abs(np.diff(sc, axis=1)).min(axis=1) > tol
+
+
+def test_recommend_general_path_large_item_space_and_k_above_256(built):
+    """num_dim in (256, 512] and topk > 16 do not fit the matrix-core top-k kernel, and 50 000 items x 4 B do not fit the
+    160 KiB LDS: the general recommend path keeps its scores in a global workspace (this combination used to
+    CHECK-abort the first TOPN row of Solver::train)."""
+    d = synth.generate(200, 50_000, 8_000, seed=12, min_items=20)
+    model, o = make_pair(d, K=300, B=64)
+    model.train_one_iteration(seed=2, epoch=0)
+    o.train_batched(2, 0, 64)
+    for topk in (10, 20):
+        rec_g = model.recommend_all(topk)
+        rec_o, sc_o = o.recommend(topk, with_scores=True)
+        clear = _clear_rows(sc_o)
+        assert clear.mean() > 0.8
+        np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
+    # K <= 256 with topk > 16 on the same item space: general path as well
+    model2, o2 = make_pair(d, K=40, B=64)
+    rec_g = model2.recommend_all(24)
+    rec_o, sc_o = o2.recommend(24, with_scores=True)
+    clear = _clear_rows(sc_o, 1e-5)
+    np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
+
+
+def test_recommend_with_a_rated_set_that_is_not_the_train_row(small):
+    """recommend(uid, topk, rated_item_set) encodes FROM the given set and masks exactly it (cdae.hpp:167-179): compare with
+    an oracle whose row of that user IS the foreign set."""
+    model, o = make_pair(small, K=50, B=128)
+    model.train_one_iteration(seed=2, epoch=0)
+    rng = np.random.default_rng(0)
+    for uid in (0, 17, small.num_users - 1):
+        row = small.train_col[small.train_ptr[uid]:small.train_ptr[uid + 1]]
+        other = np.setdiff1d(np.arange(small.num_items, dtype=np.uint32), row)
+        foreign = np.sort(np.concatenate([row[::2], rng.choice(other, 7, replace=False)])).astype(np.uint32)
+        ptr, col = small.train_ptr.copy(), small.train_col
+        col2 = np.concatenate([col[:ptr[uid]], foreign, col[ptr[uid + 1]:]])
+        ptr2 = ptr.copy()
+        ptr2[uid + 1:] += foreign.size - row.size
+        o2 = orc.Oracle(o.cfg, small.num_users, small.num_items, ptr2, col2)
+        for which in range(12):
+            if o.get(which).size:
+                o2.set(which, model.get(which).astype(np.float64))
+        ref, sc = o2.recommend(10, uid, uid + 1, with_scores=True)
+        got = model.recommend_user(uid, rng.permutation(foreign), 10)          # any order
+        assert not np.intersect1d(got, foreign).size
+        if _clear_rows(sc)[0]:
+            np.testing.assert_array_equal(got, ref[0])
+        # the train row itself through the explicit path == the table
+        np.testing.assert_array_equal(model.recommend_user(uid, row, 10), model.recommend_all(10, uid, uid + 1)[0])
+    with pytest.raises(cdae_amd.CDAEError):
+        model.recommend_user(0, [1, 1, 2], 10)

@@ -127,3 +127,24 @@ def test_reference_yelp_app_trains_cdae_with_linear_function_gate(host_bins, tmp
     losses = [float(r.split("|")[2]) for r in rows[3:]]
     assert all(np.isfinite(losses))
     assert max(float(r.split("|")[8]) for r in rows[2:]) > float(rows[2].split("|")[8])      # improves over the untrained model
+
+
+@pytest.mark.gpu
+def test_reference_yelp_app_trains_cdae_full_output_k50(host_bins, tmp_path):
+    """BASELINE configs[1] through the drop-in boundary: the unmodified yelp app, K=50 sigmoid + CE, with the full-output
+    (bf16 MFMA) decode switched on by CDAE_FULL_OUTPUT=1 — every unrated item is a negative, --num_neg is ignored."""
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.5", "--scaled=true",
+                   "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "64", "CDAE_FULL_OUTPUT": "1"})
+    assert rc == 0, out[-3000:]
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+    assert len(rows) == 2 + 51
+    losses = [float(r.split("|")[2]) for r in rows[3:]]
+    assert all(np.isfinite(losses))
+    pop_r10 = float(rows[1].split("|")[8])
+    assert max(float(r.split("|")[8]) for r in rows[2:]) > pop_r10

@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Accuracy envelope of the HIP path against the committed literal-schedule fixtures (tests/golden/*_literal_seed*.npz).
+
+    python tools/accuracy_envelope.py --batch-users 128 256 384 512 [--seeds 7 1234] [--shards 8 --period 2]
+
+Single handle (default): trains the HIP path at each `batch_users` on the fixture's data / init / random streams and
+prints, per epoch, Recall@10 and the reported train loss next to the fixture's, plus users/s of the training calls.
+--shards N > 1: the data-parallel schedule on ONE GPU — the data set is split into N user shards (balanced by nnz like
+cdae_amd.distributed.shard_bounds), N logical ranks train `batch_users` users each per step from replicated shared
+parameters and exchange their accumulated deltas (cdae_hip_delta_stage / _merge on every shard, a sum over the staged buffers in between: synchronous when
+--period 0, one period late otherwise).  One JSON line per run; DESIGN.md §2 / §7 tables are made from these lines.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import cdae_amd  # noqa: E402
+from cdae_amd import synth  # noqa: E402
+import oracle as orc  # noqa: E402  (test infrastructure: only its metric function eval_topn is used here)
+
+HYPER = dict(num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01)
+
+
+def fixtures(shape, K, loss, seeds):
+    out = []
+    for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", f"{shape}_k{K}_{loss.lower()}_literal_seed*.npz"))):
+        f = np.load(p, allow_pickle=True)
+        if seeds and int(f["seed"]) not in seeds:
+            continue
+        out.append(f)
+    return out
+
+
+def run_single(d, seed, K, lt, B, epochs):
+    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER))
+    m.reset(d, seed=seed)
+    rec, loss, secs = [], [], 0.0
+    for ep in range(epochs):
+        st = m.train_one_iteration(seed, ep)
+        secs += st.wall_seconds
+        loss.append(m.current_loss(seed, ep))
+        rec.append(float(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5]))
+    m.close()
+    return rec, loss, d.num_users * epochs / secs
+
+
+def shard_cuts(row_ptr, num_users, shards):
+    from cdae_amd.distributed import shard_bounds
+    return [shard_bounds(num_users, shards, r, row_ptr) for r in range(shards)]
+
+
+def run_sharded(d, seed, K, lt, B, epochs, shards, period):
+    """`shards` single-GPU handles on cuda:0 driven through the same C-ABI calls (cdae_hip_delta_stage / _merge) as the
+    data-parallel ranks; the all-reduce(sum) between them is a torch sum over the staged buffers.  period 0 = synchronous."""
+    import torch
+    from cdae_amd.distributed import _DeviceBuffer
+    dev = torch.device("cuda", 0)
+    cuts = shard_cuts(d.train_ptr, d.num_users, shards)
+    ms, sends, recvs = [], [], []
+    for r, (u0, u1) in enumerate(cuts):
+        sd = d.user_range(u0, u1)
+        m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER))
+        m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
+        m.init_params(seed)                      # shared block identical on every shard; Wu rows keyed by GLOBAL user id
+        m.delta_begin(); m.delta_stage(); m.synchronize()
+        ps, _ = m.delta_device_ptr()
+        pr, n = m.delta_recv_device_ptr()
+        sends.append(torch.as_tensor(_DeviceBuffer(ps, n), device=dev))
+        recvs.append(torch.as_tensor(_DeviceBuffer(pr, n), device=dev))
+        ms.append(m)
+    sizes = [u1 - u0 for u0, u1 in cuts]
+    steps = -(-max(sizes) // B)
+    per = [-(-n // steps) for n in sizes]        # users per step of every shard: all shards finish an epoch together
+
+    def reduce_all():
+        for m in ms:
+            m.synchronize()
+        total = sends[0].clone()
+        for t in sends[1:]:
+            total += t
+        for t in recvs:
+            t.copy_(total)
+        torch.cuda.synchronize()
+
+    def boundary(pending, start_next):
+        for m in ms:
+            if pending and start_next:
+                m.delta_merge_stage()
+            elif pending:
+                m.delta_merge()
+            elif start_next:
+                m.delta_stage()
+        if start_next:
+            reduce_all()
+
+    rec, loss, secs = [], [], 0.0
+    for ep in range(epochs):
+        t0 = time.perf_counter()
+        pending, batches = False, 0
+        for t in range(steps):
+            for r, m in enumerate(ms):
+                a, b = min(sizes[r], t * per[r]), min(sizes[r], (t + 1) * per[r])
+                if b > a:
+                    m.enqueue_users(seed, ep, a, b)
+            batches += 1
+            if period == 0:
+                boundary(False, True); boundary(True, False)
+            elif batches % period == 0:
+                boundary(pending, True); pending = True
+        if period:                                # flush: every shard ends the epoch with the same shared parameters
+            boundary(pending, True); boundary(True, False)
+        for m in ms:
+            m.synchronize()
+        secs += time.perf_counter() - t0
+        # evaluation: the reported loss and the top-10 of every user, each from the shard that owns the user
+        dl = sum(m.data_loss(seed, ep) for m in ms)
+        pen = ms[0].penalty_loss() + sum(0.5 * HYPER["lambda_"] * float((m.get(cdae_amd.P_WU).astype(np.float64) ** 2).sum()) for m in ms[1:])
+        loss.append(dl + pen)
+        top = np.concatenate([m.recommend_all(10) for m in ms])
+        rec.append(float(orc.eval_topn(top, d.test_ptr, d.test_col)[5]))
+    for m in ms:
+        m.close()
+    return rec, loss, d.num_users * epochs / secs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="ml10m")
+    ap.add_argument("--num-dim", type=int, default=200)
+    ap.add_argument("--loss", default="CE")
+    ap.add_argument("--batch-users", type=int, nargs="+", default=[512])
+    ap.add_argument("--seeds", type=int, nargs="*", default=[])
+    ap.add_argument("--epochs", type=int, default=0, help="0 = as many as the fixture holds")
+    ap.add_argument("--shards", type=int, nargs="+", default=[1])
+    ap.add_argument("--period", type=int, nargs="+", default=[0], help="exchange period of the sharded runs (0 = synchronous)")
+    args = ap.parse_args()
+    lt = cdae_amd.CROSS_ENTROPY if args.loss == "CE" else cdae_amd.SQUARE
+    fx = fixtures(args.shape, args.num_dim, args.loss, args.seeds)
+    if not fx:
+        raise SystemExit("no fixture found (tests/golden/make_literal_curves.py makes them)")
+    for f in fx:
+        seed = int(f["seed"])
+        d = synth.generate_shape(args.shape, seed=seed)
+        ep = args.epochs or len(f["recall10"])
+        ref_r, ref_l = f["recall10"][:ep], f["train_loss"][:ep]
+        print(json.dumps({"run": "fixture literal", "seed": seed, "recall10": [round(float(x), 5) for x in ref_r],
+                          "loss": [round(float(x), 1) for x in ref_l]}), flush=True)
+        for shards in args.shards:
+            for period in (args.period if shards > 1 else [0]):
+                for B in args.batch_users:
+                    if shards == 1:
+                        rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep)
+                    else:
+                        rec, loss, ups = run_sharded(d, seed, args.num_dim, lt, B, ep, shards, period)
+                    dr = np.abs(np.array(rec) - ref_r)
+                    dl = np.array(loss) / ref_l - 1.0
+                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "batch_users": B,
+                                      "recall10": [round(x, 5) for x in rec], "abs_d_recall": [round(float(x), 5) for x in dr],
+                                      "max_abs_d_recall": round(float(dr.max()), 5), "rel_d_loss": [round(float(x), 4) for x in dl],
+                                      "users_per_s": round(ups)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
