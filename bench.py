@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 # users per parameter snapshot of the default line.  Chosen from the accuracy envelope, not for speed:
 # tests/test_gpu_accuracy.py trains at THIS value and asserts |dRecall@10| <= 0.002 against the literal-schedule fixtures
 # at every epoch for every seed (DESIGN.md §2 has the sweep)
-DEFAULT_BATCH_USERS = 512
+DEFAULT_BATCH_USERS = 256
 
 
 def algorithmic_bytes_per_user(K, n_u, n_in, num_neg):

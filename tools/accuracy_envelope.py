@@ -56,7 +56,7 @@ def shard_cuts(row_ptr, num_users, shards):
     return [shard_bounds(num_users, shards, r, row_ptr) for r in range(shards)]
 
 
-def run_sharded(d, seed, K, lt, B, epochs, shards, period):
+def run_sharded(d, seed, K, lt, B, epochs, shards, period, rule=0):
     """`shards` single-GPU handles on cuda:0 driven through the same C-ABI calls (cdae_hip_delta_stage / _merge) as the
     data-parallel ranks; the all-reduce(sum) between them is a torch sum over the staged buffers.  period 0 = synchronous."""
     import torch
@@ -70,10 +70,13 @@ def run_sharded(d, seed, K, lt, B, epochs, shards, period):
         m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
         m.init_params(seed)                      # shared block identical on every shard; Wu rows keyed by GLOBAL user id
         m.delta_begin(); m.delta_stage(); m.synchronize()
-        ps, _ = m.delta_device_ptr()
+        ps, nfull = m.delta_device_ptr()
         pr, n = m.delta_recv_device_ptr()
-        sends.append(torch.as_tensor(_DeviceBuffer(ps, n), device=dev))
-        recvs.append(torch.as_tensor(_DeviceBuffer(pr, n), device=dev))
+        if rule:                                 # touch-mean: the synchronous API's [delta | touch] buffer, reduced in place
+            sends.append(torch.as_tensor(_DeviceBuffer(ps, nfull), device=dev))
+        else:
+            sends.append(torch.as_tensor(_DeviceBuffer(ps, n), device=dev))
+            recvs.append(torch.as_tensor(_DeviceBuffer(pr, n), device=dev))
         ms.append(m)
     sizes = [u1 - u0 for u0, u1 in cuts]
     steps = -(-max(sizes) // B)
@@ -110,11 +113,22 @@ def run_sharded(d, seed, K, lt, B, epochs, shards, period):
                 if b > a:
                     m.enqueue_users(seed, ep, a, b)
             batches += 1
-            if period == 0:
+            if rule:                              # synchronous, CDAE_DELTA_TOUCH_MEAN (rows / #ranks that touched them)
+                for m in ms:
+                    m.delta_compute(); m.synchronize()
+                total = sends[0].clone()
+                for t in sends[1:]:
+                    total += t
+                for t in sends:
+                    t.copy_(total)
+                torch.cuda.synchronize()
+                for m in ms:
+                    m.delta_apply(shards, rule); m.delta_begin()
+            elif period == 0:
                 boundary(False, True); boundary(True, False)
             elif batches % period == 0:
                 boundary(pending, True); pending = True
-        if period:                                # flush: every shard ends the epoch with the same shared parameters
+        if period and not rule:                   # flush: every shard ends the epoch with the same shared parameters
             boundary(pending, True); boundary(True, False)
         for m in ms:
             m.synchronize()
@@ -140,6 +154,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=0, help="0 = as many as the fixture holds")
     ap.add_argument("--shards", type=int, nargs="+", default=[1])
     ap.add_argument("--period", type=int, nargs="+", default=[0], help="exchange period of the sharded runs (0 = synchronous)")
+    ap.add_argument("--rule", type=int, default=0, help="0 sum, 1 touch-mean (synchronous only)")
     args = ap.parse_args()
     lt = cdae_amd.CROSS_ENTROPY if args.loss == "CE" else cdae_amd.SQUARE
     fx = fixtures(args.shape, args.num_dim, args.loss, args.seeds)
@@ -158,10 +173,10 @@ def main():
                     if shards == 1:
                         rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep)
                     else:
-                        rec, loss, ups = run_sharded(d, seed, args.num_dim, lt, B, ep, shards, period)
+                        rec, loss, ups = run_sharded(d, seed, args.num_dim, lt, B, ep, shards, period, args.rule)
                     dr = np.abs(np.array(rec) - ref_r)
                     dl = np.array(loss) / ref_l - 1.0
-                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "batch_users": B,
+                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "rule": args.rule, "batch_users": B,
                                       "recall10": [round(x, 5) for x in rec], "abs_d_recall": [round(float(x), 5) for x in dr],
                                       "max_abs_d_recall": round(float(dr.max()), 5), "rel_d_loss": [round(float(x), 4) for x in dl],
                                       "users_per_s": round(ups)}), flush=True)
