@@ -22,6 +22,7 @@
 #include "cdae_kernels.hpp"
 #include "cdae_full_kernels.hpp"
 #include "cdae_recommend_kernels.hpp"
+#include "cdae_sort_kernels.hpp"
 
 #ifdef CDAE_DECODE_TIMING
 #define CDAE_TOUCHED_ARG ((uint32_t*)nullptr)     // the timing build borrows `touched` for its stamps
@@ -93,7 +94,7 @@ struct cdae_hip {
   bool gemm_direct = false;         // CDAE_GEMM_DIRECT: the fragment-from-L1 GEMM kernel instead of the LDS-staged one (A/B switch)
   bool gemm_two_stage = false;      // CDAE_GEMM_TWO_STAGE: always the 128 x 128 two-stage LDS kernel (A/B switch)
   bool recommend_per_user = false;  // CDAE_RECOMMEND_PER_USER: recommend_kernel instead of the MFMA path
-  std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= UNIT_POS positives each) per user
+  std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= hp.unit_pos positives each) per user
   uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
   uint32_t* d_unit_ptr = nullptr;
   uint32_t unit_cap = 0;                // most units in any window of batch_users users
@@ -122,6 +123,8 @@ struct cdae_hip {
     uint16_t* key16 = nullptr; uint16_t* sorted_key16 = nullptr;      // 16-bit sort keys when I <= 65536 (rocPRIM then runs onesweep)
     uint32_t* dup_of_pos = nullptr; uint32_t* dup_of_ex = nullptr;   // duplicate-negative correction rows (segment_kernel)
     uint32_t* dup_count = nullptr;
+    // counting sort (cdae_sort_kernels.hpp; num_items <= 65536): per-item counts / prefix / scatter cursor (`rank`), item-bucketed values
+    uint32_t* item_count = nullptr; uint32_t* prefix = nullptr; uint32_t* rank = nullptr; uint64_t* bucketed = nullptr;
     hipEvent_t ready = nullptr, released = nullptr;
   } ex[2];
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
@@ -149,6 +152,7 @@ struct cdae_hip {
   float* d_zeval = nullptr; float* d_hpart_eval = nullptr; uint32_t eval_cap = 0, eval_unit_cap = 0;   // evaluation workspace
   uint32_t* d_bits = nullptr; size_t bits_cap = 0;                                                     // recommend: rated-item bitmap
   int sort_bits = 1;
+  bool counting_sort = false;           // hand-written counting sort on the prep stream instead of rocPRIM (num_items <= 65536)
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
 
   // data-parallel exchange
@@ -238,7 +242,8 @@ void free_all(cdae_hip* h) {
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
-    void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16};
+    void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
+                 b.item_count, b.prefix, b.rank, b.bucketed};
     for (void* p : q) if (p) (void)hipFree(p);
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
@@ -263,7 +268,8 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
-                  (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16};
+                  (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
+                  (void**)&b.item_count, (void**)&b.prefix, (void**)&b.rank, (void**)&b.bucketed};
     for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
@@ -294,11 +300,19 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   const uint32_t n_units = units_of(h, bt);
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
-                     x.seg, 2u * I, x.dup_count, x.dup_of_ex, h->d_unit_user);
+                     x.seg, h->counting_sort ? 0u : 2u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
+                     h->counting_sort ? x.item_count : (uint32_t*)nullptr);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st));
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
-  if (x.key16) {
+  if (h->counting_sort) {
+    // item-major order by counting (cdae_sort_kernels.hpp): tickets were taken by sample_kernel
+    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, x.item_count, I, x.prefix, x.rank, x.seg, x.seg + I, x.dup_count);
+    if (bt.E) hipLaunchKernelGGL(scatter_kernel, dim3((uint32_t)((bt.E + 255) / 256)), dim3(256), 0, st, x.item, x.val, (uint32_t)bt.E,
+                                 x.rank, x.sorted_item, x.bucketed);
+    hipLaunchKernelGGL(segment_sort_kernel, dim3((I + SEGSORT_ITEMS - 1) / SEGSORT_ITEMS), dim3(SEGSORT_THREADS), 0, st, I, x.prefix, x.bucketed,
+                       x.sorted_val, x.item_count, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+  } else if (x.key16) {
     // 16-bit keys: rocPRIM picks onesweep (2 digit passes) instead of block sort + log2(tiles) merge passes
     HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.key16, x.sorted_key16, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
@@ -730,6 +744,15 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     h->B = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(32, (U / 160) & ~(uint64_t)31));
   }
   h->U = U; h->I = I; h->hp.num_items = (uint32_t)I;
+  {
+    // Work-unit size of the user-parallel kernels (sample, encode, hidden gather, data_loss: one wavefront per unit).  Those
+    // launches are latency-bound per wavefront — a unit's rows are gathered a few at a time — so a batch should offer the chip
+    // (256 CUs x 4 SIMDs) several thousand wavefronts: small batches take small units.
+    const uint64_t Bu = std::min<uint64_t>(h->B, U);
+    uint32_t up = Bu <= 1024 ? 64u : cdae::UNIT_POS_MAX;          // measured at ML-10M shape, batch_users 256 / 512: 64 best (profiles/r02_unit_size.txt)
+    if (const char* ev = std::getenv("CDAE_UNIT_POS")) up = (uint32_t)std::atoi(ev);
+    h->hp.unit_pos = std::max<uint32_t>(1u, std::min<uint32_t>(up, cdae::UNIT_POS_MAX));
+  }
   h->h_row_ptr.assign(row_ptr, row_ptr + U + 1);
   const size_t nnz = (size_t)row_ptr[U];
   CHK(dev_alloc(&h->d_row_ptr, U + 1));
@@ -786,9 +809,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   }
   h->Ecap = emax * (1u + h->hp.num_neg);
   h->seq = 0; h->pre_valid = false;
+  // opt-in (CDAE_SORT_COUNTING=1): measured slower than rocPRIM's onesweep beside the training kernels (profiles/r02_*)
+  h->counting_sort = I <= cdae::COUNTING_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_COUNTING") != nullptr;
   h->h_unit_ptr.assign(U + 1, 0u);
   for (uint64_t u = 0; u < U; ++u)
-    h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + cdae::UNIT_POS - 1) / cdae::UNIT_POS);
+    h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + h->hp.unit_pos - 1) / h->hp.unit_pos);
   h->unit_cap = 0;
   for (uint64_t s0 = 0; s0 < U; ++s0) {
     const uint64_t s1 = std::min<uint64_t>(U, s0 + B);
@@ -826,7 +851,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&b.sorted_item, h->Ecap)); CHK(dev_alloc(&b.sorted_val, h->Ecap));
     CHK(dev_alloc(&b.seg, 2 * (size_t)I));
     CHK(dev_alloc(&b.dup_of_pos, h->Ecap)); CHK(dev_alloc(&b.dup_of_ex, h->Ecap)); CHK(dev_alloc(&b.dup_count, 1));
-    if (I <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }
+    if (h->counting_sort) {
+      CHK(dev_alloc(&b.item_count, (size_t)I)); CHK(dev_alloc(&b.prefix, (size_t)I + 1));
+      CHK(dev_alloc(&b.rank, (size_t)I)); CHK(dev_alloc(&b.bucketed, h->Ecap));      // rank: scatter cursor per item
+      HIPCHK(hipMemset(b.item_count, 0, (size_t)I * sizeof(uint32_t)));      // segment_sort_kernel leaves it zero after every batch
+    } else if (I <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }
     if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b.released, hipEventDisableTiming)); }
     HIPCHK(hipEventRecord(b.released, h->stream));
   }

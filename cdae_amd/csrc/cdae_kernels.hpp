@@ -43,6 +43,7 @@ struct HyperParams {
   uint64_t uid_offset;       // global id of local user 0 (data-parallel shards keep global random streams)
   uint32_t num_items;
   uint32_t K, Kp;            // num_dim and row stride (floats, = 64 * NI)
+  uint32_t unit_pos;         // positives per work unit (<= UNIT_POS_MAX), see "Work units" below
   uint32_t debug_rank;       // -DCDAE_DECODE_TIMING builds: the row whose timeline decode_rows_kernel records
 };
 
@@ -146,14 +147,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // Work units.  User activity is heavy-tailed (n_u from 16 to 1468 at ML-10M shape), and a kernel that gives
 // every user one wavefront takes as long as its longest user.  The user-parallel kernels therefore run on
-// UNITS of at most UNIT_POS positives of one user: unit k of a user covers positives [k*UNIT_POS, ...) and the
+// UNITS of at most unit_pos positives of one user: unit k of a user covers positives [k*unit_pos, ...) and the
 // num_neg x as many negatives that belong to them.  `uptr` is the batch's prefix array (nb + 1 entries, any
 // base): user slot s owns units uptr[s] .. uptr[s+1]-1.
-constexpr uint32_t UNIT_POS = 128;
+constexpr uint32_t UNIT_POS_MAX = 128;     // HyperParams::unit_pos (set per data set / batch size by the host) never exceeds it
 
 struct UnitRef { uint32_t slot, p0, p1; };   // user slot and the positive range [p0, p1) of the unit
 
-__device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g,
+__device__ __forceinline__ UnitRef locate_unit(const uint32_t unit_pos, const uint32_t* __restrict__ uptr, uint32_t nb, uint32_t g,
                                                const uint32_t* __restrict__ unit_user = nullptr, uint64_t u0 = 0) {
   uint32_t lo = 0, hi = nb;                      // largest slot with uptr[slot] <= g
   if (unit_user) {                               // `uptr` is a window of the data set's own prefix: one table look-up
@@ -166,8 +167,8 @@ __device__ __forceinline__ UnitRef locate_unit(const uint32_t* __restrict__ uptr
   }
   UnitRef r;
   r.slot = lo;
-  r.p0 = (g - uptr[lo]) * UNIT_POS;
-  r.p1 = r.p0 + UNIT_POS;
+  r.p0 = (g - uptr[lo]) * unit_pos;
+  r.p1 = r.p0 + unit_pos;
   return r;
 }
 
@@ -194,7 +195,8 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               uint16_t* __restrict__ ex_key16 /* sort key copy when num_items <= 65536, else nullptr */,
               uint32_t* __restrict__ seg /* [seg_words] cleared here for segment_kernel */, uint32_t seg_words,
               uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
-              const uint32_t* __restrict__ unit_user /* global unit -> user id */) {
+              const uint32_t* __restrict__ unit_user /* global unit -> user id */,
+              uint32_t* __restrict__ item_count /* counting sort (cdae_sort_kernels.hpp): per-item example counts, zero on entry; or nullptr */) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
@@ -203,7 +205,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
+  const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint32_t slot = ur.slot;
   const uint64_t uid = u0 + slot;
   const int64_t r0 = row_ptr[uid];
@@ -223,6 +225,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     const uint64_t e = base + p;
     ex_item[e] = row[p];
     if (ex_key16) ex_key16[e] = (uint16_t)row[p];
+    if (item_count) atomicAdd(item_count + row[p], 1u);          // no return value used: fire-and-forget
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
@@ -250,6 +253,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     }
     ex_item[e] = cand;
     if (ex_key16) ex_key16[e] = (uint16_t)cand;
+    if (item_count) atomicAdd(item_count + cand, 1u);
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)slot;
   }
@@ -326,7 +330,7 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
+  const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = uids ? (uint64_t)uids[ur.slot] : u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = explicit_in ? n_explicit : (uint32_t)(row_ptr[uid + 1] - r0);
@@ -588,6 +592,50 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     }
   };
 
+  // Speculative software pipeline of the straight-line body (rows whose b' is a scalar, i.e. !BIAS_IN_PAD — the popular rows of
+  // decode_hybrid_kernel).  The chain of a popular row is what bounds the launch, and ~47 % of its examples are DEFERRED
+  // (positives that are kept inputs of their user, cdae.hpp:249-250): they step b' but leave the row alone.  So the dot
+  // product + wave reduction of example i+1 is issued against the row as it stands while example i's scalar chain
+  // (y -> loss' -> b' step) is still in flight; if example i turns out to step the row, the dot is simply redone after the
+  // step (the wasted instructions fill stall slots of the dependent chain).  A deferred example then costs the scalar chain
+  // only (~11 dependent instructions instead of ~23).  Same arithmetic, same order: results are bit-identical.
+  float s_carry = 0.f;                 // reduced dot of the NEXT example with the current row, valid when s_valid
+  bool s_valid = false;                // wave-uniform
+  auto row_dot = [&](const float (&zz)[NI]) -> float {
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i += 2) {
+      d0 = fmaf(w[i], zz[i], d0);
+      if (i + 1 < NI) d1 = fmaf(w[i + 1], zz[i + 1], d1);
+    }
+    return wave_sum(d0 + d1);
+  };
+  auto fast_group_spec = [&](const uint32_t j0) {
+    float sdot = s_valid ? s_carry : row_dot(z[0]);
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      const uint32_t idx = j0 + t;
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
+      const float tgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_t), idx));
+      const float y = sdot + bias;
+      const float g = loss_grad(hp.loss_type, y, tgt);
+      gbuf = lane == idx ? g : gbuf;
+      const float spec = row_dot(z[(t + 1) % PF]);             // next example against the row as it is now
+      ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
+      if ((word & INPUT_BIT) && tied) {                        // deferred: the row did not move, the speculation holds
+        sdot = spec;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
+        sdot = row_dot(z[(t + 1) % PF]);
+      }
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)look, (idx + PF) & 63u);
+      vload<NI>(z[t], reinterpret_cast<const float*>(Zb + off));
+    }
+    s_carry = sdot;
+    s_valid = true;
+  };
+
   CDAE_STAMP();
   for (; c0 < end; c0 += WAVE) {
     // chunk after next: in flight for a whole chunk before anything reads it
@@ -601,9 +649,14 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
       const bool fast = c0 + j0 + 2 * PF <= end && ((dupmask >> j0) & ((1ull << PF) - 1ull)) == 0ull;
       if (fast) {
+        if constexpr (!BIAS_IN_PAD) {
+          fast_group_spec(j0);
+        } else {
 #pragma unroll
-        for (int t = 0; t < PF; ++t) example(std::true_type{}, t, j0 + t);
+          for (int t = 0; t < PF; ++t) example(std::true_type{}, t, j0 + t);
+        }
       } else {
+        s_valid = false;
 #pragma unroll
         for (int t = 0; t < PF; ++t) {
           const uint32_t idx = j0 + t;
@@ -882,11 +935,10 @@ __global__ void __launch_bounds__(256)
 decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
   constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
   constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
-  constexpr bool PAD64 = NT > 0 || 64 * NV < 64 * NI;             // K < Kp
   const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   if (wave < hot_rows) {
     __builtin_amdgcn_s_setprio(2);
-    decode_row64<NI, LOSS, ADAGRAD, PAD64>(hp, wave, CDAE_DECODE_PASS);
+    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
   } else {
     decode_rows16<NV, NT, LOSS, ADAGRAD>(hp, hot_rows + (wave - hot_rows) * 4u, CDAE_DECODE_PASS);
   }
@@ -914,7 +966,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
+  const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
@@ -1237,7 +1289,7 @@ data_loss_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
-  const UnitRef ur = locate_unit(uptr, nb, uptr[0] + unit, unit_user, u0);
+  const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
   const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);

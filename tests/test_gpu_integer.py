@@ -154,3 +154,19 @@ def test_user_id_offset_shifts_the_streams_like_a_global_run(built):
     b = m2.debug_sample_batch(4, 1, 0, 60)
     for k in ("ex_item", "ex_val", "sorted_item", "sorted_val", "seg_begin", "seg_end"):
         np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_counting_sort_path_gives_the_same_bit_exact_order(built, monkeypatch):
+    """cdae_sort_kernels.hpp (opt-in, CDAE_SORT_COUNTING=1): counting sort + per-item ordering instead of the library sort"""
+    monkeypatch.setenv("CDAE_SORT_COUNTING", "1")
+    d = synth.generate(1200, 500, 60_000, seed=9)
+    model, o = make(d, B=96)
+    dups = sum(check_batch(model, o, d, 20141119, ep, u0, 96) for ep, u0 in ((0, 0), (3, 96), (1, 1200 - 96)))
+    assert dups > 0
+    # a hot item longer than the LDS window of segment_sort_kernel (3072 examples): every user rated item 0
+    rng = np.random.default_rng(1)
+    rows = [np.unique(np.r_[0, rng.choice(np.arange(1, 400), 30, replace=False)]).astype(np.uint32) for _ in range(3500)]
+    ptr = np.r_[0, np.cumsum([r.size for r in rows])].astype(np.int64)
+    d2 = synth.Interactions(len(rows), 400, ptr, np.concatenate(rows), np.zeros(len(rows) + 1, np.int64), np.empty(0, np.uint32))
+    m2, o2 = make(d2, B=3500, num_neg=1)
+    check_batch(m2, o2, d2, 2, 0, 0, 3500, num_neg=1)

@@ -1,0 +1,13 @@
+mkdir -p gpurun_out/r02
+python -m pytest tests/test_gpu_integer.py tests/test_gpu_parity.py tests/test_gpu_edge.py tests/test_golden.py -m gpu -q -x 2>&1 | tail -n 15 > gpurun_out/r02/gputest4.log
+tail -n 4 gpurun_out/r02/gputest4.log
+for up in 16 32 64 128; do for b in 256 512; do
+  CDAE_UNIT_POS=$up python bench.py --no-cpu-baseline --batch-users $b 2>/dev/null | tail -n 1 > gpurun_out/r02/bench_b${b}_u${up}.json
+done; done
+CDAE_SORT_ROCPRIM=1 python bench.py --no-cpu-baseline --batch-users 256 2>/dev/null | tail -n 1 > gpurun_out/r02/bench_b256_rocprim.json
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/r02/bench_b*_u*.json'))+['gpurun_out/r02/bench_b256_rocprim.json']:
+    d=json.load(open(f))
+    print(f.split('/')[-1], round(d['value']), round(d['ms_per_step'],4), {k:round(v,4) for k,v in d['kernel_ms_per_step'].items()})
+PY
