@@ -7,8 +7,9 @@ Workload (config.workload): BASELINE.json configs[2] — ML-10M-shape synthetic 
 ~10M interactions, 80/20 per-user split), K=200, num_neg=5, sigmoid hidden, cross-entropy loss, AdaGrad.
 A step = one pass of the hot path (sample -> sort -> encode -> row-major decode -> hidden -> input rows)
 over one batch of `batch_users` users, cycling through the shard; with N > 1 every rank (one process per
-GPU, launched by torch.distributed.run) trains its OWN ML-10M-shaped shard (weak scaling: per-GPU work
-is fixed) and each step ends with one RCCL all-reduce of the shared-parameter deltas.
+GPU, launched by torch.distributed.run) trains its OWN ML-10M-shaped data set (weak scaling: per-GPU work
+is fixed; --scaling strong shards ONE data set instead) and the ranks exchange the accumulated deltas of the
+shared parameters with one RCCL all-reduce per period on a communicator the library owns (cdae_multi.hip).
 Inputs (CSR, parameters) are resident in HBM before the timed region.  Timing: barrier +
 torch.cuda.synchronize() on both sides of exactly K steps, max over ranks; rank 0 prints ONE JSON line.
 """
@@ -51,11 +52,21 @@ def decode_bytes_per_example(K):
     return 4.0 * K * 4.0 + 4.0 + 16.0
 
 
+def compulsory_decode_bytes(K, Kp, num_items, examples, batch_users):
+    """HBM bytes ONE decode launch must move under the transposed schedule: every item row that has an example
+    is read once (D, D_ag), written once (D, D_ag) and copied once to the batch-start snapshot D0 — 5 row streams of 4 Kp bytes,
+    b' / b'_ag r+w — the batch's z rows are read once from HBM (every later read is an L2 hit), the sorted example words are
+    read (8 B) and one g is written (4 B) per example.  The reference's formulation (4 row streams per
+    EXAMPLE, 3220 B each at K=200) is what this schedule avoids; it is reported separately as `reference_algorithmic_bytes`."""
+    rows = num_items * (1.0 - np.exp(-examples / num_items))      # rows with at least one of the batch's examples
+    return rows * (5.0 * 4.0 * Kp + 16.0) + batch_users * 4.0 * Kp + examples * 12.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=274)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=548)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch-users", type=int, default=int(os.environ.get("CDAE_BATCH_USERS", DEFAULT_BATCH_USERS)),
                     help="users per parameter snapshot; the default is the largest value whose Recall@10 stays within +-0.002 of "
                          "the sequential reference at every epoch for every fixture seed (tests/test_gpu_accuracy.py)")
@@ -67,9 +78,13 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="HIP-event kernel timing on every n-th batch (0 = off)")
     ap.add_argument("--full-output", action="store_true", help="BASELINE configs[1]/[4]: every unrated item is a negative; "
                     "dense decode on the bf16 MFMA cores (roofline bound: mfma)")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only to smoke-test the N>1 "
-                    "code path on a single-GPU box together with --share-device")
-    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test only)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1.  weak (default): every rank trains its OWN data set of the named shape (per-GPU work fixed).  strong: "
+                         "ONE data set of the named shape, users sharded over the ranks by interactions (BASELINE configs[3]: "
+                         "--shape netflix --scaling strong).  Either way the ranks exchange shared-parameter deltas, which is "
+                         "OUTSIDE the single-GPU accuracy envelope (DESIGN.md §7): the N > 1 value is a throughput figure")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test of the N > 1 path on one GPU; "
+                    "RCCL refuses two ranks on one device, so the exchange runs as one-rank groups)")
     ap.add_argument("--exchange-every", type=int, default=-1, help="N > 1: batches between exchanges of the shared-parameter "
                     "deltas (pipelined: the all-reduce overlaps the next period).  -1 (default): chosen at start-up so that one "
                     "period of training covers a measured all-reduce; 0: synchronous exchange after every batch")
@@ -91,35 +106,46 @@ def main():
     torch.cuda.set_device(local_rank)
     import cdae_amd
     from cdae_amd import synth
-    from cdae_amd.distributed import DeltaExchange, PipelinedDeltaExchange
+    from cdae_amd.distributed import shard_bounds
 
-    # every rank owns one ML-10M-shaped shard of users over the same item space
-    data = synth.generate_shape(args.shape, seed=args.seed + 7919 * rank)
+    if args.scaling == "strong" and world > 1:
+        whole = synth.generate_shape(args.shape, seed=args.seed)          # the same data set on every rank ...
+        u0, u1 = shard_bounds(whole.num_users, world, rank, whole.train_ptr)
+        data, uid_offset = whole.user_range(u0, u1), u0                   # ... of which this rank trains its users
+        shape_note = f"{args.shape}-shape synthetic {whole.num_users}x{whole.num_items} sharded over {world} GPUs by interactions"
+        del whole
+    else:
+        # every rank owns one data set of the named shape over the same item space
+        data, uid_offset = synth.generate_shape(args.shape, seed=args.seed + 7919 * rank), rank * synth.SHAPES[args.shape][0]
+        shape_note = f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU"
     K, B = args.num_dim, min(args.batch_users, data.num_users)
     cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, num_corruptions=1,
                               corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01,
                               using_adagrad=True, user_factor=True, batch_users=B, full_output=args.full_output)
     model = cdae_amd.CDAE(cfg, device=local_rank)
-    model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col,
-                           user_id_offset=rank * data.num_users)
-    model.init_params(args.seed)         # identical shared parameters on every rank; Wu differs but is private
-    # The process group is created AFTER the library handle: with an RCCL communicator (and its streams) in place first, the
-    # handle's streams are assigned hardware queues that make the overlapped exchange several times slower (measured with
-    # a one-rank group: 0.42 vs 0.18 ms per step).
+    model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col, user_id_offset=uid_offset)
+    model.init_params(args.seed)         # identical shared parameters on every rank; Wu is private (keyed by global user id)
+    # Rendezvous over gloo (CPU): torch.distributed only carries the 128-byte RCCL id, the barriers and the timing reductions.
+    # The data path — one all-reduce of the staged deltas per period — runs inside the library on its own RCCL communicator
+    # and stream (cdae_multi.hip), created AFTER the handle's streams: with a communicator in place first the handle's
+    # streams share hardware queues with RCCL's and the overlapped exchange is several times slower (r01 measurement).
     dist = None
     force_dist = bool(os.environ.get("CDAE_BENCH_FORCE_DIST"))   # developer aid: exercise the RCCL path with one rank
-    if world > 1 or force_dist:
+    exchanging = world > 1 or force_dist
+    if exchanging:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ids = [cdae_amd.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        if os.environ.get("CDAE_BENCH_NO_COMM"):
+            pass                                                        # developer aid: the exchange schedule without any RCCL object
+        elif args.share_device and world > 1:
+            model.comm_init_rank(1, 0, cdae_amd.comm_unique_id())      # functional smoke test: RCCL refuses duplicate devices
         else:
-            dist.init_process_group(args.dist_backend)
-    exch = pipe = None
-    if (world > 1 or force_dist) and args.exchange_every != 0:
-        pipe = PipelinedDeltaExchange(model, dist, world, period=max(1, args.exchange_every))
-    elif world > 1 or force_dist:
-        exch = DeltaExchange(model, dist, world)
+            model.comm_init_rank(world, rank, ids[0])
+        model.exchange_configure(max(0, args.exchange_every) if args.exchange_every >= 0 else 1 << 30)
 
     n_batches = (data.num_users + B - 1) // B
 
@@ -136,29 +162,31 @@ def main():
 
     def step(i):
         ep, u0, u1 = batch_of(i)
-        if exch:
-            exch.begin()
         # steps queue asynchronously on the library's stream; the next batch is sampled and sorted on the side
-        # stream while this one trains (and, with N > 1, while its deltas are all-reduced)
+        # stream while this one trains (and, with N > 1, while the previous period's deltas are all-reduced)
         model.enqueue_users(args.seed, ep, u0, u1)
         nep, n0, n1 = batch_of(i + 1)
         model.prefetch_users(args.seed, nep, n0, n1)
-        if exch:
-            exch.finish()
-        if pipe:
-            pipe.after_batch()
+        if exchanging:
+            model.exchange_step()
+
+    def host_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     def sync():
         if dist is not None:
             dist.barrier()
         model.synchronize()
         torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
 
     exchange_note = None
-    if pipe and args.exchange_every < 0:
+    if exchanging and args.exchange_every < 0:
         # auto period: time a few batches without exchange and a few idle all-reduces of the real buffer, before anything
-        # that counts has been staged
-        pipe.period = 1 << 30
+        # that counts has been staged (the period is 2^30 here: no boundary is reached)
         sync()
         n_cal = max(3, min(args.warmup, 10))        # calibration batches (set-up, before the W warm-up steps)
         step(0)                                      # first batch: cold pipeline, not timed
@@ -168,8 +196,10 @@ def main():
             step(i)
         sync()
         t_step = (time.perf_counter() - tw) / n_cal
-        pipe.flush()                      # exchange what those batches did, so the replicas agree again
-        args.exchange_every, t_ar = pipe.choose_period(t_step, lo=2)       # a boundary costs ~40 us of stream time: never every batch
+        t_ar = model.exchange_time_all_reduce(5)     # flushes what the calibration batches did, then restarts the exchange
+        want = int(min(8, max(2, -(-1.5 * t_ar // max(t_step, 1e-9)))))       # a boundary costs ~40 us of stream time: never every batch
+        args.exchange_every = int(host_max(want))
+        model.exchange_configure(args.exchange_every)
         exchange_note = f"period chosen at start-up: all-reduce {t_ar * 1e6:.0f} us vs {t_step * 1e6:.0f} us per batch"
     for i in range(args.warmup):
         step(i)
@@ -182,8 +212,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
-    if pipe:
-        pipe.flush()                      # the last period's deltas are reduced and merged inside the timed region
+    if exchanging:
+        model.exchange_flush()            # the last period's deltas are reduced and merged inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     add(model.collect_stats())
@@ -191,19 +221,16 @@ def main():
 
     users_total = float(acc["users"])
     if dist is not None:
-        t = torch.tensor([elapsed, users_total], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        t = torch.tensor([users_total], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, users_total = float(tmax[0]), float(t[1])
-
-    if dist is not None:
+        elapsed, users_total = host_max(elapsed), float(t[0])
         # RCCL writes a version banner to the C stdout buffer of every rank: push it out now, on all ranks, so that
         # rank 0's JSON line is the last thing the job prints
         import ctypes
         ctypes.CDLL(None).fflush(None)
         dist.barrier()
     if rank != 0:
+        model.close()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -212,47 +239,67 @@ def main():
     n_in = n_u * (1.0 - cfg.corruption_ratio)
     a_user = algorithmic_bytes_per_user(K, n_u, n_in, cfg.num_neg)
     value = users_total / elapsed
-    # roofline of the dominant kernel (decode_rows_kernel), rank 0's launches
+    # roofline of the dominant kernel (decode), rank 0's launches
     ex_per_launch = acc["examples"] / max(1, acc["batches"])
+    users_per_launch = acc["users"] / max(1, acc["batches"])
     ms_per_launch = acc["ms_decode"] / max(1, acc["launches_decode"])
-    alg_bytes_launch = decode_bytes_per_example(K) * ex_per_launch
-    achieved = alg_bytes_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-    traffic = measured_traffic(args.shape, K, B)
+    Kp = 64 * (1 if K <= 64 else 2 if K <= 128 else 4 if K <= 256 else 8)
     if args.full_output:
         # dominant kernels: the three bf16 MFMA contractions, 6 K I flop per user, timed as one family
         MFMA_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-        flops_launch = 6.0 * K * data.num_items * (acc["users"] / max(1, acc["batches"]))
+        flops_launch = 6.0 * K * data.num_items * users_per_launch
         achieved_tf = flops_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "full_decode_fused_kernel + gemm_nt_bf16_kernel (+ bf16 operand copies, rated-items bitmap)",
                     "achieved": achieved_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_PEAK_TFLOPS,
                     "traffic": None, "algorithmic_flops_per_launch": flops_launch, "avg_launch_ms": ms_per_launch}
-        workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "
-                    f"FULL-OUTPUT decode (every unrated item a negative), CE loss, AdaGrad, q=0.5 scaled")
+        workload = f"{shape_note}, nnz_train={data.nnz_train}, K={K}, FULL-OUTPUT decode (every unrated item a negative), CE loss, AdaGrad, q=0.5 scaled"
     else:
+        # HBM roofline on the bytes the launch MUST move (never above 1); what actually bounds the kernel is stated beside it
+        comp = compulsory_decode_bytes(K, Kp, data.num_items, ex_per_launch, users_per_launch)
+        achieved = comp / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        traffic = measured_traffic(args.shape, K, B)
+        top_share = float(np.bincount(data.train_col, minlength=data.num_items).max()) / data.num_users
+        chain = users_per_launch * top_share * (1.0 + 0.05)            # positives of the most popular row + its few negatives
+        CYC_PER_EXAMPLE, CLOCK_GHZ = 500.0, 2.4                         # profiles/r01_decode_bisect.txt (lone-wave dependent chain)
+        trans_us = ex_per_launch * 2.0 * Kp / (256 * 4 * 4 * CLOCK_GHZ * 1e3)    # sqrt + rcp per element, quarter rate, 1024 SIMDs x 4 lanes/clk
+        valu_us = ex_per_launch * 7.0 * Kp / (256 * 4 * 16 * CLOCK_GHZ * 1e3)    # 7 full-rate fp32 ops per element (dot, grad, AdaGrad)
         roofline = {"bound": "hbm", "kernel": "decode_hybrid_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": ms_per_launch,
-                    "whole_step_fraction_of_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS}
-        workload = (f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} per GPU, nnz_train={data.nnz_train}, K={K}, "
-                    f"num_neg=5, CE loss, AdaGrad, q=0.5 scaled")
+                    "compulsory_bytes_per_launch": comp, "avg_launch_ms": ms_per_launch,
+                    "note": "the kernel is NOT bandwidth-bound: rows stay in registers for the whole batch; see `other_bounds`",
+                    "other_bounds": {"top_row_serial_chain_us": chain * CYC_PER_EXAMPLE / (CLOCK_GHZ * 1e3),
+                                     "valu_issue_floor_us": trans_us + valu_us,
+                                     "frac_of_launch_explained_by_larger": max(chain * CYC_PER_EXAMPLE / (CLOCK_GHZ * 1e3), trans_us + valu_us)
+                                     / (ms_per_launch * 1e3) if ms_per_launch > 0 else None},
+                    "reference_algorithmic_bytes_per_launch": decode_bytes_per_example(K) * ex_per_launch,
+                    "whole_step_users_per_s_over_reference_hbm_roof": value / args.gpus * a_user / 1e9 / HBM_PEAK_GBS}
+        workload = f"{shape_note}, nnz_train={data.nnz_train}, K={K}, num_neg=5, CE loss, AdaGrad, q=0.5 scaled"
+    if not exchanging:
+        exchange = "none"
+    elif args.exchange_every > 0:
+        exchange = (f"library-owned RCCL all-reduce(sum) of shared-parameter deltas every {args.exchange_every} batches, pipelined "
+                    f"(merged one period late)" + (f" ({exchange_note})" if exchange_note else ""))
+    else:
+        exchange = "library-owned RCCL all-reduce(sum) of shared-parameter deltas after every batch (synchronous)"
     out = {
         # BASELINE.json's metric on its own workload; other shapes / K (developer runs) are named as what they are
         "metric": ("users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity" if (args.shape == "ml10m" and args.num_dim == 200)
                    else f"users/sec (whole node) K={args.num_dim} {args.shape}-shape"),
         "value": value, "unit": "users/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling if args.gpus > 1 else "weak",
         "vs_baseline": None, "dtype": "bf16" if args.full_output else "f32", "data": "synthetic",
         "config": {"workload": workload, "batch_users": B, "global_batch": B * args.gpus, "parallelism": f"dp{args.gpus}",
-                   "exchange": ("none" if (pipe is None and exch is None) else
-                                f"pipelined all-reduce(sum) of shared-parameter deltas every {args.exchange_every} batches, merged one period late"
-                                + (f" ({exchange_note})" if exchange_note else "")
-                                if args.exchange_every > 0 else "synchronous all-reduce(sum) of shared-parameter deltas every batch")},
+                   "exchange": exchange,
+                   "accuracy": ("batch_users within the single-GPU envelope of tests/test_gpu_accuracy.py" if args.gpus == 1 and B <= DEFAULT_BATCH_USERS
+                                else "single GPU, batch_users ABOVE the accuracy envelope (throughput only)" if args.gpus == 1
+                                else "data-parallel delta exchange: OUTSIDE the +-0.002 Recall@10 envelope (DESIGN.md §7 table); throughput only")},
         "roofline": roofline,
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
         "profiled_steps": int(acc["launches_decode"]),
     }
     if not args.no_cpu_baseline and args.gpus == 1:          # reported at N = 1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(data, cfg, args)
+    model.close()
     if dist is not None:
         dist.destroy_process_group()
         import ctypes

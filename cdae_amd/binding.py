@@ -79,7 +79,27 @@ EXPORTS = {
     "cdae_hip_delta_recv_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_delta_merge": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_merge_stage": (C.c_int, [C.c_void_p]),
+    "cdae_hip_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "cdae_hip_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "cdae_hip_exchange_configure": (C.c_int, [C.c_void_p, C.c_int]),
+    "cdae_hip_exchange_step": (C.c_int, [C.c_void_p]),
+    "cdae_hip_exchange_flush": (C.c_int, [C.c_void_p]),
+    "cdae_hip_exchange_time_all_reduce": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "cdae_hip_multi_create": (C.c_int, [C.POINTER(_Config), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "cdae_hip_multi_destroy": (C.c_int, [C.c_void_p]),
+    "cdae_hip_multi_num_shards": (C.c_int, [C.c_void_p]),
+    "cdae_hip_multi_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cdae_hip_multi_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "cdae_hip_multi_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "cdae_hip_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_int]),
+    "cdae_hip_multi_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
+    "cdae_hip_multi_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
+    "cdae_hip_multi_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "cdae_hip_multi_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "cdae_hip_multi_get_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "cdae_hip_multi_set_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
 }
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -341,3 +361,110 @@ class CDAE:
 
     def delta_merge_stage(self):
         _chk(self.lib, self.lib.cdae_hip_delta_merge_stage(self.h))
+
+    # ---- library-owned communicator + exchange schedule (one process per GPU) ---------------------------------------
+    def comm_init_rank(self, world_size: int, rank: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _chk(self.lib, self.lib.cdae_hip_comm_init_rank(self.h, world_size, rank, buf, COMM_ID_BYTES))
+
+    def exchange_configure(self, period: int):
+        _chk(self.lib, self.lib.cdae_hip_exchange_configure(self.h, period))
+
+    def exchange_step(self):
+        _chk(self.lib, self.lib.cdae_hip_exchange_step(self.h))
+
+    def exchange_flush(self):
+        _chk(self.lib, self.lib.cdae_hip_exchange_flush(self.h))
+
+    def exchange_time_all_reduce(self, repeats: int = 5) -> float:
+        v = C.c_double()
+        _chk(self.lib, self.lib.cdae_hip_exchange_time_all_reduce(self.h, repeats, C.byref(v)))
+        return v.value
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the library: rank 0 makes it, every rank passes it to CDAE.comm_init_rank."""
+    lib = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _chk(lib, lib.cdae_hip_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
+
+
+class MultiCDAE:
+    """Several user shards behind one handle (cdae_hip_multi_*): the data-parallel form of libcf::CDAE in one process.
+
+    devices = [0, 1, ..., N-1]: one shard per GPU (RCCL); devices = [0] * N: N logical shards of GPU 0 (tests, accuracy
+    envelope).  exchange_every: 0 = synchronous exchange of the shared-parameter deltas at every step, k >= 1 = pipelined."""
+
+    def __init__(self, mcfg: CDAEConfig, devices, exchange_every: int = 0):
+        self.lib = load_library()
+        self.cfg = mcfg
+        c = _Config(C.sizeof(_Config), mcfg.num_dim, mcfg.num_neg, mcfg.num_corruptions, mcfg.lt,
+                    int(mcfg.using_adagrad), int(mcfg.asymmetric), int(mcfg.user_factor), int(mcfg.linear),
+                    int(mcfg.scaled), int(mcfg.tanh), mcfg.batch_users, int(mcfg.full_output), int(mcfg.linear_function),
+                    mcfg.lambda_, mcfg.learn_rate, mcfg.corruption_ratio, mcfg.beta)
+        devs = (C.c_int * len(devices))(*devices)
+        self.h = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_multi_create(C.byref(c), len(devices), devs, C.byref(self.h)))
+        _chk(self.lib, self.lib.cdae_hip_multi_set_exchange(self.h, exchange_every))
+        self.num_users = self.num_items = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cdae_hip_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_exchange(self, period: int):
+        _chk(self.lib, self.lib.cdae_hip_multi_set_exchange(self.h, period))
+
+    def set_interactions(self, num_users, num_items, row_ptr, col_idx):
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_multi_set_interactions(self.h, num_users, num_items, rp.ctypes.data, ci.ctypes.data))
+        self.num_users, self.num_items = int(num_users), int(num_items)
+
+    def reset(self, train, seed: int = 0):
+        self.set_interactions(train.num_users, train.num_items, train.train_ptr, train.train_col)
+        self.init_params(seed)
+
+    def init_params(self, seed: int):
+        _chk(self.lib, self.lib.cdae_hip_multi_init_params(self.h, seed))
+
+    def shards(self):
+        """[(u_begin, u_end)] of every shard"""
+        out = []
+        for s in range(self.lib.cdae_hip_multi_num_shards(self.h)):
+            a, b = C.c_uint64(), C.c_uint64()
+            _chk(self.lib, self.lib.cdae_hip_multi_shard(self.h, s, None, C.byref(a), C.byref(b)))
+            out.append((a.value, b.value))
+        return out
+
+    def train_one_iteration(self, seed: int, epoch: int) -> Stats:
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_multi_train_epoch(self.h, seed, epoch, C.byref(st)))
+        return st
+
+    def current_loss(self, seed: int, epoch: int) -> float:
+        a, b = C.c_double(), C.c_double()
+        _chk(self.lib, self.lib.cdae_hip_multi_data_loss(self.h, seed, epoch, C.byref(a)))
+        _chk(self.lib, self.lib.cdae_hip_multi_penalty_loss(self.h, C.byref(b)))
+        return a.value + b.value
+
+    def recommend_all(self, topk: int = 10, u_begin: int = 0, u_end=None) -> np.ndarray:
+        u_end = self.num_users if u_end is None else u_end
+        out = np.empty((u_end - u_begin, topk), dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_multi_recommend_all(self.h, u_begin, u_end, topk, out.ctypes.data))
+        return out
+
+    _shape = CDAE._shape
+
+    def get(self, which) -> np.ndarray:
+        out = np.empty(self._shape(which), dtype=np.float32)
+        _chk(self.lib, self.lib.cdae_hip_multi_get_param(self.h, which, out.ctypes.data, out.size))
+        return out
+
+    def set(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32).reshape(self._shape(which))
+        _chk(self.lib, self.lib.cdae_hip_multi_set_param(self.h, which, a.ctypes.data, a.size))

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/cdae_hip.h"
+#include "cdae_internal.hpp"
 #include "cdae_kernels.hpp"
 #include "cdae_full_kernels.hpp"
 #include "cdae_recommend_kernels.hpp"
@@ -156,7 +157,8 @@ struct cdae_hip {
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
 
   // data-parallel exchange
-  float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr;
+  float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr; float* d_snap = nullptr;   // agreed state, staged delta, all-reduced delta, parameters at the last stage
+  void* xchg = nullptr; void (*xchg_free)(void*) = nullptr;   // communicator + schedule of the exchange (cdae_multi.hip)
 
   uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q & 1
   bool pre_valid = false;               // set (seq & 1) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
@@ -238,7 +240,7 @@ void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
-                  h->d_base, h->d_delta, h->d_recv, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
+                  h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
@@ -264,7 +266,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
-                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
+                   (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
@@ -706,6 +708,7 @@ int cdae_hip_destroy(cdae_hip_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->xchg && h->xchg_free) { h->xchg_free(h->xchg); h->xchg = nullptr; }
   free_all(h);
   delete h;
   return 0;
@@ -1140,7 +1143,7 @@ template <int MODE>
 int launch_pipe(cdae_hip* h) {
   const PipeGeom g = pipe_geom(h);
   hipLaunchKernelGGL(cdae::delta_pipe_kernel<MODE>, dim3((uint32_t)((g.threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
-                     h->d_base, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, g.n_tail);
+                     h->d_base, h->d_snap, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, g.n_tail);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1312,24 +1315,10 @@ int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out
 
 int cdae_hip_penalty_loss(cdae_hip_t* h, double* out) {
   if (!h || !h->d_shared || !out) return fail("bad argument");
-  HIPCHK(hipSetDevice(h->device));
-  CHK(join_aux(h));
-  HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
-  auto add = [&](const float* p, size_t n) {
-    if (p && n) hipLaunchKernelGGL(cdae::sqnorm_kernel, dim3((uint32_t)std::min<size_t>(2048, (n + 255) / 256)), dim3(256), 0,
-                                   h->stream, p, n, h->d_scalar);
-  };
-  // cdae.hpp:104-106: W, V, Wu, b, b_prime (pad lanes are zero)
-  add(h->P(CDAE_P_W), h->cnt[CDAE_P_W]);
-  add(h->P(CDAE_P_V), h->cnt[CDAE_P_V]);
-  if (h->cfg.user_factor) add(h->d_Wu, h->cnt[CDAE_P_WU]);
-  add(h->P(CDAE_P_B), h->cnt[CDAE_P_B]);
-  add(h->P(CDAE_P_BP), h->cnt[CDAE_P_BP]);
-  HIPCHK(hipGetLastError());
-  double v = 0;
-  HIPCHK(hipMemcpyAsync(&v, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  *out = 0.5 * h->cfg.lambda * v;
+  double a = 0, b = 0;
+  CHK(cdae_internal::shared_penalty(h, &a));
+  CHK(cdae_internal::private_penalty(h, &b));
+  *out = a + b;
   return 0;
 }
 
@@ -1518,6 +1507,7 @@ int cdae_hip_delta_stage(cdae_hip_t* h) {
   CHK(join_aux(h));
   if (!h->d_recv) {
     CHK(dev_alloc(&h->d_recv, h->n_shared + 4096));            // slack: collectives may round the count up
+    CHK(dev_alloc(&h->d_snap, h->n_shared));
     HIPCHK(hipMemsetAsync(h->d_recv, 0, (h->n_shared + 4096) * sizeof(float), h->stream));
   }
   return launch_pipe<cdae::DELTA_STAGE>(h);
@@ -1545,3 +1535,55 @@ int cdae_hip_delta_merge_stage(cdae_hip_t* h) {
 }
 
 }  // extern "C"
+
+// ---- accessor surface for cdae_multi.hip (cdae_internal.hpp) --------------------------------------------------------
+namespace cdae_internal {
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+int device_of(const cdae_hip_t* h) { return h->device; }
+hipStream_t main_stream(cdae_hip_t* h) { return h->stream; }
+hipStream_t aux_stream(cdae_hip_t* h) { return h->aux; }
+uint64_t num_users(const cdae_hip_t* h) { return h->U; }
+uint64_t num_items(const cdae_hip_t* h) { return h->I; }
+uint32_t batch_users(const cdae_hip_t* h) { return (uint32_t)std::min<uint64_t>(h->B, h->U); }
+bool ready(const cdae_hip_t* h) { return h->d_shared != nullptr; }
+float* send_buf(cdae_hip_t* h) { return h->d_delta; }
+float* recv_buf(cdae_hip_t* h) { return h->d_recv; }
+size_t compact_count(const cdae_hip_t* h) { return pipe_geom(h).n_compact; }
+void*& exchange_slot(cdae_hip_t* h) { return h->xchg; }
+void set_exchange_deleter(cdae_hip_t* h, void (*deleter)(void*)) { h->xchg_free = deleter; }
+
+static int sqnorm_sum(cdae_hip* h, std::initializer_list<std::pair<const float*, size_t>> parts, double* out) {
+  HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
+  HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
+  for (auto& pr : parts)
+    if (pr.first && pr.second)
+      hipLaunchKernelGGL(cdae::sqnorm_kernel, dim3((uint32_t)std::min<size_t>(2048, (pr.second + 255) / 256)), dim3(256), 0, h->stream,
+                         pr.first, pr.second, h->d_scalar);
+  HIPCHK(hipGetLastError());
+  double v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *out = 0.5 * h->cfg.lambda * v;
+  return 0;
+}
+// cdae.hpp:104-106: W, V, Wu, b, b_prime (pad lanes are zero)
+int shared_penalty(cdae_hip_t* h, double* out) {
+  return sqnorm_sum(h, {{h->P(CDAE_P_W), h->cnt[CDAE_P_W]}, {h->P(CDAE_P_V), h->cnt[CDAE_P_V]}, {h->P(CDAE_P_B), h->cnt[CDAE_P_B]},
+                        {h->P(CDAE_P_BP), h->cnt[CDAE_P_BP]}}, out);
+}
+int private_penalty(cdae_hip_t* h, double* out) {
+  if (!h->cfg.user_factor) { *out = 0.; return 0; }
+  return sqnorm_sum(h, {{h->d_Wu, h->cnt[CDAE_P_WU]}}, out);
+}
+
+}  // namespace cdae_internal

@@ -1472,31 +1472,40 @@ apply_delta_kernel(float* __restrict__ cur, const float* __restrict__ base, cons
 }
 
 // Pipelined exchange (cdae_hip_delta_stage / _merge / _merge_stage): peers' contributions arrive one exchange period late.
-//   STAGE:        send = recv = cur - base ; base = cur         (recv is all-reduced in place while training continues)
-//   MERGE:        cur += recv - send ; base += recv - send      (the other ranks' part of the summed delta)
-//   MERGE_STAGE:  both at one boundary in a single pass: p = recv - send; d = cur - base; cur = base = cur + p; send = recv = d
+// Per element: cur = this replica's parameter, A (`base`) = the state all replicas AGREE on bit for bit, snap = cur as it was
+// when the last delta was staged.
+//   STAGE:        send = recv = cur - A ; snap = cur                  (recv is all-reduced in place while training continues)
+//   MERGE:        A += recv ; cur = A + (cur - snap)                  (everybody's staged deltas, then this replica's progress since)
+//   MERGE_STAGE:  MERGE of the previous period, then STAGE of this one, in a single pass over the block
+// A moves only by the all-reduced sums, which are the same bits on every rank, so the replicas' A never drift apart; and
+// whenever nothing was trained between a STAGE and its MERGE (the synchronous exchange, and the flush that ends an epoch)
+// cur - snap is exactly 0 and cur == A on every replica, bit for bit.  (The first version folded the peers' part in as
+// cur += recv - send: algebraically the same, but each replica rounded differently and the copies drifted by ulps.)
 // send / recv are COMPACT: the matrices' pad columns (56 of 256 at K = 200) are neither staged nor all-reduced — row r of a
 // matrix occupies Kc = round_up(K, 4) floats there — followed by the block's tail [b' | b'_ag | b | b_ag] as it is.
 enum { DELTA_STAGE = 0, DELTA_MERGE = 1, DELTA_MERGE_STAGE = 2 };
 
 template <int MODE>
-__device__ __forceinline__ void delta_pipe_elem(float& c, float& b, float& s, float& r) {
+__device__ __forceinline__ void delta_pipe_elem(float& c, float& A, float& snap, float& s, float& r) {
   if (MODE == DELTA_STAGE) {
-    const float d = c - b;
-    s = d; r = d; b = c;
+    const float d = c - A;
+    s = d; r = d; snap = c;
   } else if (MODE == DELTA_MERGE) {
-    const float p = r - s;
-    c += p; b += p;
+    A += r;
+    c = A + (c - snap);
   } else {
-    const float p = r - s, d = c - b, x = c + p;
-    c = x; b = x; s = d; r = d;
+    A += r;
+    c = A + (c - snap);
+    const float d = c - A;
+    s = d; r = d; snap = c;
   }
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(256)
-delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ send, float* __restrict__ recv,
-                  size_t n_matrix /* padded floats of all matrices */, uint32_t Kp, uint32_t Kc, size_t n_tail) {
+delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ snap, float* __restrict__ send,
+                  float* __restrict__ recv, size_t n_matrix /* padded floats of all matrices */, uint32_t Kp, uint32_t Kc,
+                  size_t n_tail) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t q_per_row = Kc / 4;
   const size_t n_rows = n_matrix / Kp, n_mat4 = n_rows * q_per_row, n_tail4 = n_tail / 4;
@@ -1515,22 +1524,25 @@ delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __re
   } else {
     return;
   }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (width == 4) {
     float4 c = *reinterpret_cast<float4*>(cur + pad_off), b = *reinterpret_cast<float4*>(base + pad_off);
-    float4 s = MODE == DELTA_STAGE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(send + cmp_off);
-    float4 r = MODE == DELTA_STAGE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<float4*>(recv + cmp_off);
-    delta_pipe_elem<MODE>(c.x, b.x, s.x, r.x); delta_pipe_elem<MODE>(c.y, b.y, s.y, r.y);
-    delta_pipe_elem<MODE>(c.z, b.z, s.z, r.z); delta_pipe_elem<MODE>(c.w, b.w, s.w, r.w);
-    if (MODE != DELTA_STAGE) *reinterpret_cast<float4*>(cur + pad_off) = c;
-    *reinterpret_cast<float4*>(base + pad_off) = b;
-    if (MODE != DELTA_MERGE) { *reinterpret_cast<float4*>(send + cmp_off) = s; *reinterpret_cast<float4*>(recv + cmp_off) = r; }
+    float4 sn = MODE == DELTA_STAGE ? zero4 : *reinterpret_cast<float4*>(snap + pad_off);
+    float4 s = zero4;
+    float4 r = MODE == DELTA_STAGE ? zero4 : *reinterpret_cast<float4*>(recv + cmp_off);
+    delta_pipe_elem<MODE>(c.x, b.x, sn.x, s.x, r.x); delta_pipe_elem<MODE>(c.y, b.y, sn.y, s.y, r.y);
+    delta_pipe_elem<MODE>(c.z, b.z, sn.z, s.z, r.z); delta_pipe_elem<MODE>(c.w, b.w, sn.w, s.w, r.w);
+    if (MODE != DELTA_STAGE) { *reinterpret_cast<float4*>(cur + pad_off) = c; *reinterpret_cast<float4*>(base + pad_off) = b; }
+    if (MODE != DELTA_MERGE) {
+      *reinterpret_cast<float4*>(snap + pad_off) = sn;
+      *reinterpret_cast<float4*>(send + cmp_off) = s; *reinterpret_cast<float4*>(recv + cmp_off) = r;
+    }
   } else {
     float c = cur[pad_off], b = base[pad_off];
-    float s = MODE == DELTA_STAGE ? 0.f : send[cmp_off], r = MODE == DELTA_STAGE ? 0.f : recv[cmp_off];
-    delta_pipe_elem<MODE>(c, b, s, r);
-    if (MODE != DELTA_STAGE) cur[pad_off] = c;
-    base[pad_off] = b;
-    if (MODE != DELTA_MERGE) { send[cmp_off] = s; recv[cmp_off] = r; }
+    float sn = MODE == DELTA_STAGE ? 0.f : snap[pad_off], s = 0.f, r = MODE == DELTA_STAGE ? 0.f : recv[cmp_off];
+    delta_pipe_elem<MODE>(c, b, sn, s, r);
+    if (MODE != DELTA_STAGE) { cur[pad_off] = c; base[pad_off] = b; }
+    if (MODE != DELTA_MERGE) { snap[pad_off] = sn; send[cmp_off] = s; recv[cmp_off] = r; }
   }
 }
 

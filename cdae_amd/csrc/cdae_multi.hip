@@ -1,0 +1,555 @@
+// cdae_multi.hip — data parallelism behind the C ABI (include/cdae_hip.h, "multi-GPU" section).
+//
+// The reference trains one user after the other in one thread (cdae.hpp:136-146); Solver<CDAE>::train
+// (solver-inl.hpp:51-55) calls train_one_iteration once per epoch.  Here an epoch may be split over several user shards:
+//   * users are cut into contiguous ranges balanced by interactions; shard s holds its CSR rows and its private Wu / Wu_ag
+//     rows (they never leave their GPU) and a replica of the shared block [W | W_ag | (V | V_ag) | b' | b'_ag | b | b_ag];
+//   * every step each shard trains <= batch_users of its users, then the shards exchange the accumulated DELTA of the
+//     shared block (cdae_kernels.hpp delta_pipe_kernel): synchronously (period 0) or pipelined — the all-reduce of one
+//     period overlaps the next period's training and the peers' part is merged one period late;
+//   * the all-reduce(sum) is RCCL on a library-owned communicator and stream (ncclCommInitAll for the shards of one
+//     process, ncclCommInitRank when every rank is its own process: bench.py), or — shards that share ONE device, the
+//     form the single-GPU tests and the accuracy envelope use — a fixed-order sum kernel over the peers' staged buffers.
+// No torch, no Python in this path.  Accuracy of the data-parallel schedule: DESIGN.md §7 (it is NOT inside the +-0.002
+// Recall@10 envelope of the single-GPU schedule; the table there says by how much).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cdae_internal.hpp"
+
+using cdae_internal::fail;
+
+#define HIPCHK(expr)                                                                           \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+#define NCCLCHK(expr)                                                                            \
+  do {                                                                                           \
+    ncclResult_t r__ = (expr);                                                                   \
+    if (r__ != ncclSuccess)                                                                      \
+      return fail("%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r__), __FILE__, __LINE__);  \
+  } while (0)
+#define CHK(expr)            \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+namespace {
+
+// recv[i] = sum over the peers' staged buffers, in shard order (deterministic; the single-device stand-in for ncclAllReduce)
+constexpr int MAX_LOCAL_PEERS = 16;
+struct PeerPtrs { const float* p[MAX_LOCAL_PEERS]; };
+__global__ void __launch_bounds__(256)
+local_sum_kernel(PeerPtrs peers, int n_peers, float* __restrict__ out, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    float4 acc = *reinterpret_cast<const float4*>(peers.p[0] + i);
+    for (int r = 1; r < n_peers; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(peers.p[r] + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = acc;
+  } else {
+    for (size_t j = i; j < n; ++j) {
+      float acc = peers.p[0][j];
+      for (int r = 1; r < n_peers; ++r) acc += peers.p[r][j];
+      out[j] = acc;
+    }
+  }
+}
+
+// Exchange state of one handle (rank).
+struct Exchange {
+  cdae_hip_t* h = nullptr;
+  int world = 1, rank = 0;
+  ncclComm_t comm = nullptr;             // RCCL communicator (nullptr: single rank, or a local group)
+  bool owns_comm = false;
+  std::vector<Exchange*> local;          // non-empty: the ranks of a single-device group, in shard order (includes this one)
+  hipStream_t cstream = nullptr;         // the collective runs here, beside the training kernels
+  bool owns_stream = true;
+  hipEvent_t ev_staged = nullptr, ev_reduced = nullptr;
+  int period = 0;                        // 0: synchronous exchange after every step; k >= 1: pipelined, every k steps
+  uint64_t steps = 0;
+  bool pending = false;                  // an all-reduce of a staged delta is in flight / not merged yet
+  bool begun = false;
+};
+
+void free_exchange(void* p) {
+  Exchange* x = (Exchange*)p;
+  if (!x) return;
+  (void)hipSetDevice(cdae_internal::device_of(x->h));
+  if (x->cstream) { (void)hipStreamSynchronize(x->cstream); if (x->owns_stream) (void)hipStreamDestroy(x->cstream); }
+  if (x->ev_staged) (void)hipEventDestroy(x->ev_staged);
+  if (x->ev_reduced) (void)hipEventDestroy(x->ev_reduced);
+  if (x->comm && x->owns_comm) (void)ncclCommDestroy(x->comm);
+  delete x;
+}
+
+int make_exchange(cdae_hip_t* h, Exchange** out) {
+  if (cdae_internal::exchange_slot(h)) { *out = (Exchange*)cdae_internal::exchange_slot(h); return 0; }
+  HIPCHK(hipSetDevice(cdae_internal::device_of(h)));
+  Exchange* x = new Exchange();
+  x->h = h;
+  hipError_t e = hipSuccess;
+  // The collective runs on the handle's SECOND stream (idle in the sampled path; the full-output path's b recurrence lives
+  // there).  A fourth library stream is poison on this stack: with more than four hardware queues every kernel of the
+  // step ran ~3x slower as soon as it existed and carried cross-stream waits (0.132 -> 0.395 ms per 256-user step with no
+  // communicator at all; profiles/r02_exchange_streams.txt).  CDAE_XCHG_STREAM = own | main are developer switches.
+  const char* sel = std::getenv("CDAE_XCHG_STREAM");
+  if (sel && !std::strcmp(sel, "own")) e = hipStreamCreateWithFlags(&x->cstream, hipStreamNonBlocking);
+  else if (sel && !std::strcmp(sel, "main")) { x->cstream = cdae_internal::main_stream(h); x->owns_stream = false; }
+  else { x->cstream = cdae_internal::aux_stream(h); x->owns_stream = false; }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_staged, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&x->ev_reduced, hipEventDisableTiming);
+  if (e != hipSuccess) { free_exchange(x); return fail("exchange set-up failed: %s", hipGetErrorString(e)); }
+  cdae_internal::exchange_slot(h) = x;
+  cdae_internal::set_exchange_deleter(h, free_exchange);
+  *out = x;
+  return 0;
+}
+
+int begin_if_needed(Exchange* x) {
+  if (x->begun) return 0;
+  CHK(cdae_hip_delta_begin(x->h));       // base = current
+  CHK(cdae_hip_delta_stage(x->h));       // allocates send / recv (stages a zero delta)
+  x->begun = true;
+  x->pending = false;
+  return 0;
+}
+
+// phase 1 of a boundary, on the handle's main stream: fold the previous period's peers in and / or stage this period's delta
+int boundary_stage(Exchange* x, bool start_next) {
+  HIPCHK(hipSetDevice(cdae_internal::device_of(x->h)));
+  hipStream_t st = cdae_internal::main_stream(x->h);
+  if (x->pending) {
+    // the reduced buffer must be complete; in a local group nobody may restage (overwrite its send buffer) before every
+    // peer's sum kernel has read it
+    if (x->local.empty()) HIPCHK(hipStreamWaitEvent(st, x->ev_reduced, 0));
+    else for (Exchange* p : x->local) HIPCHK(hipStreamWaitEvent(st, p->ev_reduced, 0));
+  }
+  if (x->pending && start_next) CHK(cdae_hip_delta_merge_stage(x->h));
+  else if (x->pending) CHK(cdae_hip_delta_merge(x->h));
+  else if (start_next) CHK(cdae_hip_delta_stage(x->h));
+  x->pending = false;
+  if (start_next) HIPCHK(hipEventRecord(x->ev_staged, st));
+  return 0;
+}
+
+// phase 2: the all-reduce(sum) of the staged deltas on the collective stream (every rank's phase 1 has been ENQUEUED:
+// trivially true across processes / threads with RCCL, guaranteed by the caller's ordering in a local group)
+int boundary_reduce(Exchange* x) {
+  HIPCHK(hipSetDevice(cdae_internal::device_of(x->h)));
+  const size_t n = cdae_internal::compact_count(x->h);
+  float* recv = cdae_internal::recv_buf(x->h);
+  if (!x->local.empty()) {
+    PeerPtrs pp{};
+    for (size_t r = 0; r < x->local.size(); ++r) {
+      HIPCHK(hipStreamWaitEvent(x->cstream, x->local[r]->ev_staged, 0));
+      pp.p[r] = cdae_internal::send_buf(x->local[r]->h);
+    }
+    hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, x->cstream, pp, (int)x->local.size(), recv, n);
+    HIPCHK(hipGetLastError());
+  } else {
+    HIPCHK(hipStreamWaitEvent(x->cstream, x->ev_staged, 0));
+    if (x->comm && x->world > 1) NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
+    else if (x->comm) NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));   // one rank: identity, same stream semantics
+  }
+  HIPCHK(hipEventRecord(x->ev_reduced, x->cstream));
+  x->pending = true;
+  return 0;
+}
+
+// a whole boundary of ONE rank that does not share its device with peers (RCCL or single rank)
+int boundary(Exchange* x, bool start_next) {
+  CHK(boundary_stage(x, start_next));
+  if (start_next) CHK(boundary_reduce(x));
+  return 0;
+}
+
+int step_single(Exchange* x) {
+  CHK(begin_if_needed(x));
+  x->steps++;
+  if (x->period == 0) { CHK(boundary(x, true)); CHK(boundary(x, false)); }
+  else if (x->steps % (uint64_t)x->period == 0) CHK(boundary(x, true));
+  return 0;
+}
+int flush_single(Exchange* x) {
+  CHK(begin_if_needed(x));
+  if (x->period != 0 || x->pending) { CHK(boundary(x, true)); CHK(boundary(x, false)); }
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-handle communicator and exchange schedule (one process per GPU: bench.py --gpus N)
+extern "C" {
+
+int cdae_hip_comm_unique_id(void* out, size_t bytes) {
+  if (!out || bytes < sizeof(ncclUniqueId)) return fail("unique id buffer must hold %zu bytes", sizeof(ncclUniqueId));
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  std::memset(out, 0, bytes);
+  std::memcpy(out, &id, sizeof id);
+  return 0;
+}
+
+int cdae_hip_comm_init_rank(cdae_hip_t* h, int world_size, int rank, const void* unique_id, size_t bytes) {
+  if (!h) return fail("null handle");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return fail("bad rank %d of %d", rank, world_size);
+  if (!unique_id || bytes < sizeof(ncclUniqueId)) return fail("unique id must hold %zu bytes", sizeof(ncclUniqueId));
+  Exchange* x = nullptr;
+  CHK(make_exchange(h, &x));
+  if (x->comm || !x->local.empty()) return fail("this handle already has a communicator");
+  HIPCHK(hipSetDevice(cdae_internal::device_of(h)));
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  NCCLCHK(ncclCommInitRank(&x->comm, world_size, id, rank));
+  x->owns_comm = true;
+  x->world = world_size; x->rank = rank;
+  return 0;
+}
+
+int cdae_hip_exchange_configure(cdae_hip_t* h, int period) {
+  if (!h) return fail("null handle");
+  if (period < 0) return fail("exchange period must be >= 0");
+  Exchange* x = nullptr;
+  CHK(make_exchange(h, &x));
+  if (!x->local.empty()) return fail("this handle belongs to a multi-shard group: use cdae_hip_multi_set_exchange");
+  if (x->pending) CHK(flush_single(x));
+  x->period = period;
+  x->steps = 0;
+  return 0;
+}
+
+int cdae_hip_exchange_step(cdae_hip_t* h) {
+  if (!h || !cdae_internal::ready(h)) return fail("set_interactions must be called first");
+  Exchange* x = nullptr;
+  CHK(make_exchange(h, &x));
+  if (!x->local.empty()) return fail("this handle belongs to a multi-shard group");
+  return step_single(x);
+}
+
+int cdae_hip_exchange_flush(cdae_hip_t* h) {
+  if (!h || !cdae_internal::ready(h)) return fail("set_interactions must be called first");
+  Exchange* x = nullptr;
+  CHK(make_exchange(h, &x));
+  if (!x->local.empty()) return fail("this handle belongs to a multi-shard group");
+  return flush_single(x);
+}
+
+int cdae_hip_exchange_time_all_reduce(cdae_hip_t* h, int repeats, double* seconds) {
+  if (!h || !cdae_internal::ready(h) || !seconds) return fail("bad argument");
+  if (repeats < 1) repeats = 1;
+  Exchange* x = nullptr;
+  CHK(make_exchange(h, &x));
+  if (!x->local.empty()) return fail("this handle belongs to a multi-shard group");
+  CHK(flush_single(x));
+  CHK(cdae_hip_synchronize(h));
+  HIPCHK(hipSetDevice(cdae_internal::device_of(h)));
+  HIPCHK(hipStreamSynchronize(x->cstream));
+  *seconds = 0.;
+  if (!x->comm) return 0;
+  const size_t n = cdae_internal::compact_count(h);
+  float* recv = cdae_internal::recv_buf(h);
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  for (int i = 0; i < 2; ++i) NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
+  HIPCHK(hipEventRecord(a, x->cstream));
+  for (int i = 0; i < repeats; ++i) NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
+  HIPCHK(hipEventRecord(b, x->cstream));
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *seconds = 1e-3 * ms / repeats;
+  // the timing runs summed garbage into the receive buffer: restart from a fresh base with a zero staged delta
+  x->begun = false; x->pending = false; x->steps = 0;
+  CHK(begin_if_needed(x));
+  CHK(cdae_hip_synchronize(h));
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// several shards behind one handle (one process): Solver<CDAE>::train on N GPUs
+struct cdae_hip_multi {
+  cdae_hip_config cfg{};
+  std::vector<int> devices;
+  std::vector<cdae_hip_t*> shard;
+  std::vector<uint64_t> cut;             // users of shard s: [cut[s], cut[s+1])
+  std::vector<ncclComm_t> comms;         // ncclCommInitAll (distinct devices)
+  bool single_device = false;            // all shards on one device: in-process sum instead of RCCL, one driver thread
+  uint64_t U = 0, I = 0;
+  int period = 0;
+  uint32_t B = 0;
+};
+
+namespace {
+
+Exchange* xof(cdae_hip_t* h) { return (Exchange*)cdae_internal::exchange_slot(h); }
+
+// one step of every shard's epoch: shard s trains users [a, b) of its own
+struct StepPlan { uint64_t steps; std::vector<uint64_t> per; };
+StepPlan plan_of(const cdae_hip_multi* m) {
+  StepPlan p;
+  uint64_t longest = 0;
+  for (size_t s = 0; s < m->shard.size(); ++s) longest = std::max(longest, m->cut[s + 1] - m->cut[s]);
+  p.steps = std::max<uint64_t>(1, (longest + m->B - 1) / m->B);
+  for (size_t s = 0; s < m->shard.size(); ++s) p.per.push_back((m->cut[s + 1] - m->cut[s] + p.steps - 1) / p.steps);   // all shards finish together
+  return p;
+}
+
+// the epoch of ONE shard that owns its device (RCCL group): runs on its own host thread
+int shard_epoch(cdae_hip_multi* m, size_t s, const StepPlan& pl, uint64_t seed, uint32_t epoch) {
+  cdae_hip_t* h = m->shard[s];
+  Exchange* x = xof(h);
+  const uint64_t n = m->cut[s + 1] - m->cut[s];
+  x->period = m->period;
+  for (uint64_t t = 0; t < pl.steps; ++t) {
+    const uint64_t a = std::min(n, t * pl.per[s]), b = std::min(n, (t + 1) * pl.per[s]);
+    if (b > a) CHK(cdae_hip_enqueue_users(h, seed, epoch, a, b));
+    const uint64_t a2 = std::min(n, (t + 1) * pl.per[s]), b2 = std::min(n, (t + 2) * pl.per[s]);
+    if (b2 > a2) CHK(cdae_hip_prefetch_users(h, seed, epoch, a2, b2));
+    CHK(step_single(x));                                   // every shard takes every step: the collective needs all ranks
+  }
+  CHK(flush_single(x));                                    // the epoch ends with identical shared parameters everywhere
+  return cdae_hip_synchronize(h);
+}
+
+// all shards on ONE device: one driver thread, boundaries in lockstep (phase 1 of every shard, then phase 2 of every shard)
+int local_boundary(cdae_hip_multi* m, bool start_next) {
+  for (cdae_hip_t* h : m->shard) CHK(boundary_stage(xof(h), start_next));
+  if (start_next) for (cdae_hip_t* h : m->shard) CHK(boundary_reduce(xof(h)));
+  return 0;
+}
+int local_epoch(cdae_hip_multi* m, const StepPlan& pl, uint64_t seed, uint32_t epoch) {
+  for (cdae_hip_t* h : m->shard) CHK(begin_if_needed(xof(h)));
+  uint64_t steps = 0;
+  for (uint64_t t = 0; t < pl.steps; ++t) {
+    for (size_t s = 0; s < m->shard.size(); ++s) {
+      const uint64_t n = m->cut[s + 1] - m->cut[s];
+      const uint64_t a = std::min(n, t * pl.per[s]), b = std::min(n, (t + 1) * pl.per[s]);
+      if (b > a) CHK(cdae_hip_enqueue_users(m->shard[s], seed, epoch, a, b));
+    }
+    ++steps;
+    if (m->period == 0) { CHK(local_boundary(m, true)); CHK(local_boundary(m, false)); }
+    else if (steps % (uint64_t)m->period == 0) CHK(local_boundary(m, true));
+  }
+  if (m->period != 0 || xof(m->shard[0])->pending) { CHK(local_boundary(m, true)); CHK(local_boundary(m, false)); }
+  for (cdae_hip_t* h : m->shard) CHK(cdae_hip_synchronize(h));
+  return 0;
+}
+
+int check_multi(const cdae_hip_multi* m, bool need_data) {
+  if (!m) return fail("null multi handle");
+  if (need_data && m->U == 0) return fail("cdae_hip_multi_set_interactions must be called first");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cdae_hip_multi_create(const cdae_hip_config* cfg, int n_shards, const int* device_ids, cdae_hip_multi_t** out) {
+  if (!cfg || !out || !device_ids) return fail("null argument");
+  if (n_shards < 1 || n_shards > MAX_LOCAL_PEERS) return fail("n_shards must be in [1, %d]", MAX_LOCAL_PEERS);
+  std::vector<int> devs(device_ids, device_ids + n_shards), uniq(devs);
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  const bool single = uniq.size() == 1;
+  if (!single && (int)uniq.size() != n_shards)
+    return fail("device_ids must be all distinct (one shard per GPU, RCCL) or all equal (logical shards of one GPU)");
+  std::unique_ptr<cdae_hip_multi> m(new cdae_hip_multi());
+  m->cfg = *cfg; m->devices = devs; m->single_device = single;
+  for (int s = 0; s < n_shards; ++s) {
+    cdae_hip_t* h = nullptr;
+    int rc = cdae_hip_create(cfg, devs[s], &h);
+    if (rc) { for (cdae_hip_t* q : m->shard) cdae_hip_destroy(q); return rc; }
+    m->shard.push_back(h);
+  }
+  *out = m.release();
+  return 0;
+}
+
+int cdae_hip_multi_destroy(cdae_hip_multi_t* m) {
+  if (!m) return 0;
+  for (cdae_hip_t* h : m->shard) cdae_hip_destroy(h);      // (exchange state goes with the handle; communicators below)
+  for (ncclComm_t c : m->comms) if (c) (void)ncclCommDestroy(c);
+  delete m;
+  return 0;
+}
+
+int cdae_hip_multi_num_shards(const cdae_hip_multi_t* m) { return m ? (int)m->shard.size() : 0; }
+
+int cdae_hip_multi_shard(cdae_hip_multi_t* m, int shard, cdae_hip_t** handle, uint64_t* u_begin, uint64_t* u_end) {
+  CHK(check_multi(m, false));
+  if (shard < 0 || shard >= (int)m->shard.size()) return fail("shard %d out of range", shard);
+  if (handle) *handle = m->shard[shard];
+  if (u_begin) *u_begin = m->cut.size() ? m->cut[shard] : 0;
+  if (u_end) *u_end = m->cut.size() ? m->cut[shard + 1] : 0;
+  return 0;
+}
+
+int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t U, uint64_t I, const int64_t* row_ptr, const uint32_t* col) {
+  CHK(check_multi(m, false));
+  if (!row_ptr || U == 0) return fail("bad argument");
+  const size_t S = m->shard.size();
+  if (U < S) return fail("%llu users cannot be split into %zu shards", (unsigned long long)U, S);
+  // contiguous user ranges balanced by interactions; every shard gets at least one user
+  m->cut.assign(S + 1, 0);
+  const int64_t nnz = row_ptr[U];
+  for (size_t s = 1; s < S; ++s) {
+    const int64_t want = (int64_t)(((__int128)nnz * (int64_t)s + (int64_t)S - 1) / (int64_t)S);    // first user whose prefix reaches s/S of the interactions
+    uint64_t u = (uint64_t)(std::lower_bound(row_ptr, row_ptr + U + 1, want) - row_ptr);
+    u = std::max<uint64_t>(u, m->cut[s - 1] + 1);
+    u = std::min<uint64_t>(u, U - (S - s));
+    m->cut[s] = u;
+  }
+  m->cut[S] = U;
+  std::vector<int64_t> rp;
+  for (size_t s = 0; s < S; ++s) {
+    const uint64_t a = m->cut[s], b = m->cut[s + 1];
+    rp.assign(row_ptr + a, row_ptr + b + 1);
+    const int64_t base = rp[0];
+    for (int64_t& v : rp) v -= base;
+    CHK(cdae_hip_set_interactions(m->shard[s], b - a, I, rp.data(), col + base));
+    CHK(cdae_hip_set_user_id_offset(m->shard[s], a));      // random streams and Wu init keyed by GLOBAL user id
+  }
+  m->U = U; m->I = I;
+  m->B = cdae_internal::batch_users(m->shard[0]);
+  for (cdae_hip_t* h : m->shard) m->B = std::min(m->B, cdae_internal::batch_users(h));
+  // exchange state: a local group (one device) or one RCCL communicator per shard
+  std::vector<Exchange*> xs(S, nullptr);
+  for (size_t s = 0; s < S; ++s) CHK(make_exchange(m->shard[s], &xs[s]));
+  if (S > 1 && m->single_device) {
+    for (Exchange* x : xs) { x->local = xs; x->world = (int)S; }
+    for (size_t s = 0; s < S; ++s) xs[s]->rank = (int)s;
+  } else if (S > 1 && m->comms.empty()) {
+    m->comms.assign(S, nullptr);
+    NCCLCHK(ncclCommInitAll(m->comms.data(), (int)S, m->devices.data()));
+    for (size_t s = 0; s < S; ++s) { xs[s]->comm = m->comms[s]; xs[s]->owns_comm = false; xs[s]->world = (int)S; xs[s]->rank = (int)s; }
+  }
+  for (Exchange* x : xs) { x->begun = false; x->pending = false; x->steps = 0; }
+  return 0;
+}
+
+int cdae_hip_multi_init_params(cdae_hip_multi_t* m, uint64_t seed) {
+  CHK(check_multi(m, true));
+  for (cdae_hip_t* h : m->shard) CHK(cdae_hip_init_params(h, seed));     // identical shared blocks; Wu rows by global user id
+  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); x->begun = false; x->pending = false; x->steps = 0; }
+  return 0;
+}
+
+int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period) {
+  CHK(check_multi(m, false));
+  if (period < 0) return fail("exchange period must be >= 0");
+  m->period = period;
+  return 0;
+}
+
+int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats) {
+  CHK(check_multi(m, true));
+  const auto t0 = std::chrono::steady_clock::now();
+  const StepPlan pl = plan_of(m);
+  const size_t S = m->shard.size();
+  if (S == 1) {
+    CHK(cdae_hip_train_epoch(m->shard[0], seed, epoch, stats));
+    return 0;
+  }
+  if (m->single_device) {
+    CHK(local_epoch(m, pl, seed, epoch));
+  } else {
+    // one host thread per device: the launches of a step cost tens of microseconds of host time per shard
+    std::vector<int> rc(S, 0);
+    std::vector<std::string> err(S);
+    std::vector<std::thread> th;
+    for (size_t s = 0; s < S; ++s)
+      th.emplace_back([&, s] {
+        rc[s] = shard_epoch(m, s, pl, seed, epoch);
+        if (rc[s]) err[s] = cdae_hip_last_error();         // thread-local: carry it to the caller's thread
+      });
+    for (std::thread& t : th) t.join();
+    for (size_t s = 0; s < S; ++s) if (rc[s]) return fail("shard %zu: %s", s, err[s].c_str());
+  }
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    for (cdae_hip_t* h : m->shard) {
+      cdae_hip_stats st;
+      CHK(cdae_hip_collect_stats(h, &st));
+      stats->users += st.users; stats->examples += st.examples; stats->batches += st.batches;
+    }
+    stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return 0;
+}
+
+int cdae_hip_multi_data_loss(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, double* out) {
+  CHK(check_multi(m, true));
+  if (!out) return fail("null argument");
+  double total = 0;
+  for (cdae_hip_t* h : m->shard) { double v = 0; CHK(cdae_hip_data_loss(h, seed, epoch, &v)); total += v; }   // sum over users, cdae.hpp:99
+  *out = total;
+  return 0;
+}
+
+int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out) {
+  CHK(check_multi(m, true));
+  if (!out) return fail("null argument");
+  double total = 0, v = 0;
+  CHK(cdae_internal::shared_penalty(m->shard[0], &v)); total += v;         // replicas agree after every epoch's flush
+  for (cdae_hip_t* h : m->shard) { CHK(cdae_internal::private_penalty(h, &v)); total += v; }
+  *out = total;
+  return 0;
+}
+
+int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out) {
+  CHK(check_multi(m, true));
+  if (u_begin > u_end || u_end > m->U || !out) return fail("bad user range");
+  for (size_t s = 0; s < m->shard.size(); ++s) {
+    const uint64_t a = std::max(u_begin, m->cut[s]), b = std::min(u_end, m->cut[s + 1]);
+    if (b > a) CHK(cdae_hip_recommend_all(m->shard[s], a - m->cut[s], b - m->cut[s], topk, out + (a - u_begin) * topk));
+  }
+  return 0;
+}
+
+static bool is_private(uint32_t which) { return which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG; }
+
+int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, size_t count) {
+  CHK(check_multi(m, true));
+  if (!is_private(which)) return cdae_hip_get_param(m->shard[0], which, host, count);
+  const size_t K = m->cfg.num_dim;
+  if (count != m->U * K) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->U * K), count);
+  for (size_t s = 0; s < m->shard.size(); ++s)
+    CHK(cdae_hip_get_param(m->shard[s], which, host + m->cut[s] * K, (m->cut[s + 1] - m->cut[s]) * K));
+  return 0;
+}
+
+int cdae_hip_multi_set_param(cdae_hip_multi_t* m, uint32_t which, const float* host, size_t count) {
+  CHK(check_multi(m, true));
+  if (!is_private(which)) {
+    for (cdae_hip_t* h : m->shard) CHK(cdae_hip_set_param(h, which, host, count));
+  } else {
+    const size_t K = m->cfg.num_dim;
+    if (count != m->U * K) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->U * K), count);
+    for (size_t s = 0; s < m->shard.size(); ++s)
+      CHK(cdae_hip_set_param(m->shard[s], which, host + m->cut[s] * K, (m->cut[s + 1] - m->cut[s]) * K));
+  }
+  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); if (x) { x->begun = false; x->pending = false; x->steps = 0; } }
+  return 0;
+}
+
+}  // extern "C"

@@ -188,8 +188,8 @@ class HostPipelinedDeltaExchange:
     def __init__(self, get_shared, set_shared, dist, world: int, period: int = 2):
         self.get_shared, self.set_shared, self.dist, self.world = get_shared, set_shared, dist, world
         self.period = max(1, int(period))
-        self.base = get_shared().clone()
-        self.send = None
+        self.base = get_shared().clone()                        # A: the state every replica agrees on, bit for bit
+        self.snap = None                                        # parameters when the last delta was staged
         self.recv = None
         self.work = None
         self.batches = 0
@@ -200,18 +200,16 @@ class HostPipelinedDeltaExchange:
             self._boundary(True)
 
     def _boundary(self, start_next: bool):
-        if self.recv is not None:
+        if self.recv is not None:                               # delta_pipe_kernel<MERGE>: A += recv ; cur = A + (cur - snap)
             if self.work is not None:
                 self.work.wait()
-            peers = self.recv - self.send                       # delta_merge_kernel
-            self.set_shared(self.get_shared() + peers)
-            self.base = self.base + peers
-            self.recv = self.send = self.work = None
-        if start_next:
+            self.base = self.base + self.recv
+            self.set_shared(self.base + (self.get_shared() - self.snap))
+            self.recv = self.snap = self.work = None
+        if start_next:                                          # delta_pipe_kernel<STAGE>: send = recv = cur - A ; snap = cur
             cur = self.get_shared()
-            self.send = cur - self.base                         # delta_stage_kernel
-            self.recv = self.send.clone()
-            self.base = cur.clone()
+            self.recv = cur - self.base
+            self.snap = cur.clone()
             self.work = self.dist.all_reduce(self.recv, op=self.dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
 
     def flush(self):

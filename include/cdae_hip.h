@@ -23,7 +23,8 @@
  *   CDAE::data_loss                      cdae.hpp:78-101     cdae_hip_data_loss
  *   CDAE::penalty_loss                   cdae.hpp:103-107    cdae_hip_penalty_loss
  *   CDAE::recommend (all users, top-k)   cdae.hpp:162-196    cdae_hip_recommend_all
- *   (data-parallel exchange; no reference counterpart)       cdae_hip_delta_* / cdae_hip_shared_*
+ *   (data-parallel exchange; no reference counterpart)       cdae_hip_delta_*, cdae_hip_comm_*, cdae_hip_exchange_*,
+ *                                                            cdae_hip_multi_* (Solver<CDAE>::train on N GPUs)
  *
  * Conventions: every function returns 0 on success, non-zero on failure; cdae_hip_last_error()
  * returns a thread-local message for the last failure.  No exceptions cross the boundary.  All
@@ -44,8 +45,9 @@ extern "C" {
 
 /* 2: cdae_hip_config.linear_function (in what was tail padding of the uint32 block: zero the struct before filling it),
  *    parameters CDAE_P_UU / CDAE_P_UU_AG; pipelined delta exchange entry points */
-/* 3: cdae_hip_debug_sample_batch (integer-parity test hook) */
-#define CDAE_HIP_ABI_VERSION 3
+/* 3: cdae_hip_debug_sample_batch (integer-parity test hook), cdae_hip_recommend_user
+ * 4: library-owned RCCL communicator + exchange schedule (cdae_hip_comm_*, cdae_hip_exchange_*), cdae_hip_multi_* */
+#define CDAE_HIP_ABI_VERSION 4
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -222,17 +224,58 @@ int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_fl
 int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule);
 
 /* Pipelined form of the same exchange (sum rule): the all-reduce of one period's deltas overlaps the next period's
- * training, and the other ranks' part is folded in one period late.  After cdae_hip_delta_begin():
- *   cdae_hip_delta_stage : send = recv = current - base ; base = current
+ * training, and the other ranks' part is folded in one period late.  After cdae_hip_delta_begin() (agreed state A = current):
+ *   cdae_hip_delta_stage : send = recv = current - A ; snap = current
  *   (caller all-reduces the recv buffer, cdae_hip_delta_recv_device_ptr, n floats, asynchronously; the buffer is
  *    compact: the matrices' pad columns are not exchanged)
- *   cdae_hip_delta_merge : current += recv - send ; base += recv - send     (before the next _stage)
- * Every rank ends at  initial + sum over periods and ranks of the staged deltas  once the last merge has run.
- * Stream-ordered on cdae_hip_stream like the calls above. */
+ *   cdae_hip_delta_merge : A += recv ; current = A + (current - snap)     (before the next _stage)
+ * A moves only by the all-reduced sums, so it is the same BITS on every rank; when nothing was trained between a stage and
+ * its merge (synchronous exchange, final flush) every rank ends with current == A, bit for bit.
+ * Stream-ordered on cdae_hip_stream like the calls above.  (cdae_hip_exchange_* below drive these with a library-owned
+ * RCCL communicator; these entry points remain for hosts that bring their own collective.) */
 int cdae_hip_delta_stage(cdae_hip_t* h);
 int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);
 int cdae_hip_delta_merge(cdae_hip_t* h);
 int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous period then _stage of this one, in one pass */
+
+/* ---- library-owned RCCL communicator and exchange schedule (one process per GPU: bench.py --gpus N) -----------------
+ * The all-reduce of the staged deltas runs inside the library, on its own communicator and HIP stream, overlapped with the
+ * training kernels; the host application only distributes the 128-byte unique id (any channel: bench.py uses a gloo
+ * broadcast) and calls _exchange_step after every enqueued batch.  period 0: synchronous exchange at every step (stage,
+ * all-reduce, merge); period k >= 1: pipelined — every k steps the accumulated delta is staged and reduced asynchronously,
+ * the other ranks' part is merged k steps later.  _exchange_flush reduces and merges what is outstanding: afterwards every
+ * rank holds the same shared parameters.  A handle without a communicator behaves as a one-rank group.
+ * _exchange_time_all_reduce: seconds per all-reduce of the exchange buffer with the device otherwise idle (call it before
+ * the deltas matter: it flushes, and restarts the exchange from the current parameters). */
+#define CDAE_COMM_ID_BYTES 128
+int cdae_hip_comm_unique_id(void* out, size_t bytes);
+int cdae_hip_comm_init_rank(cdae_hip_t* h, int world_size, int rank, const void* unique_id, size_t bytes);
+int cdae_hip_exchange_configure(cdae_hip_t* h, int period);
+int cdae_hip_exchange_step(cdae_hip_t* h);
+int cdae_hip_exchange_flush(cdae_hip_t* h);
+int cdae_hip_exchange_time_all_reduce(cdae_hip_t* h, int repeats, double* seconds);
+
+/* ---- several user shards behind one handle (one process, N GPUs): what Solver<CDAE>::train (solver-inl.hpp:51-55) drives
+ * when src/model/recsys/cdae.hpp is given CDAE_DEVICES=0,1,... ------------------------------------------------------------
+ * device_ids all distinct: one shard per GPU, one host thread per shard during an epoch, RCCL communicator from
+ * ncclCommInitAll.  device_ids all equal: logical shards of ONE GPU — same schedule, the all-reduce is a fixed-order sum kernel
+ * (tests, accuracy envelope).  Users are cut into contiguous ranges balanced by interactions; Wu / Wu_ag stay on their
+ * shard; get/set_param address the global matrices.  Every entry point mirrors its single-handle namesake. */
+typedef struct cdae_hip_multi cdae_hip_multi_t;
+int cdae_hip_multi_create(const cdae_hip_config* cfg, int n_shards, const int* device_ids, cdae_hip_multi_t** out);
+int cdae_hip_multi_destroy(cdae_hip_multi_t* m);
+int cdae_hip_multi_num_shards(const cdae_hip_multi_t* m);
+int cdae_hip_multi_shard(cdae_hip_multi_t* m, int shard, cdae_hip_t** handle, uint64_t* u_begin, uint64_t* u_end);
+int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t num_users, uint64_t num_items, const int64_t* row_ptr,
+                                    const uint32_t* col_idx);
+int cdae_hip_multi_init_params(cdae_hip_multi_t* m, uint64_t seed);
+int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period);
+int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
+int cdae_hip_multi_data_loss(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, double* out);
+int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out);
+int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out);
+int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, size_t count);
+int cdae_hip_multi_set_param(cdae_hip_multi_t* m, uint32_t which, const float* host, size_t count);
 
 #ifdef __cplusplus
 }

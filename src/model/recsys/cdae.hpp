@@ -16,7 +16,11 @@
 // Environment knobs (not in the reference): CDAE_BATCH_USERS (users per parameter snapshot; 1 = the
 // reference's strictly sequential schedule), CDAE_FULL_OUTPUT (1: every unrated item is a negative — dense MFMA
 // decode; num_neg ignored), CDAE_SEED (fixes the counter-stream seed; default: one draw of
-// libcf::Random, i.e. time-seeded like yelp.cpp:107), CDAE_DEVICE (HIP device index).
+// libcf::Random, i.e. time-seeded like yelp.cpp:107), CDAE_DEVICE (HIP device index), CDAE_DEVICES (comma list, e.g.
+// 0,1,2,3: Solver<CDAE>::train runs data-parallel over these GPUs through cdae_hip_multi_* — users sharded, shared
+// parameters exchanged by RCCL inside the library; a repeated id, e.g. 0,0, makes logical shards of one GPU),
+// CDAE_EXCHANGE_EVERY (0 = synchronous exchange at every step, the default; k = pipelined every k steps).
+// The data-parallel schedule is NOT inside the accuracy envelope of the single-GPU one.
 #ifndef CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 #define CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 
@@ -93,24 +97,37 @@ class CDAE : public RecsysModelBase {
     c.full_output = static_cast<uint32_t>(env_u64("CDAE_FULL_OUTPUT", 0));   // north-star extension, not in CDAEConfig
     c.linear_function = cfg_.linear_function;
     c.lambda = cfg_.lambda; c.learn_rate = cfg_.learn_rate; c.corruption_ratio = cfg_.corruption_ratio; c.beta = cfg_.beta;
-    cdae_hip_t* raw = nullptr;
-    CDAE_HIP_CHECK(cdae_hip_create(&c, static_cast<int>(env_u64("CDAE_DEVICE", 0)), &raw));
-    dev_.reset(raw, [](cdae_hip_t* h) { cdae_hip_destroy(h); });
     std::shared_ptr<Csr> csr = std::make_shared<Csr>();
     data_->to_csr(0, 1, csr->row_ptr, csr->col);           // uid -> sorted {iid}; labels are all 1 (yelp.cpp:66)
-    CDAE_HIP_CHECK(cdae_hip_set_interactions(dev_.get(), num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
     train_csr_ = csr;
     seed_ = std::getenv("CDAE_SEED") ? env_u64("CDAE_SEED", 0) : Random::next_u64();
-    CDAE_HIP_CHECK(cdae_hip_init_params(dev_.get(), seed_));
+    const std::vector<int> devices = env_devices();
+    dev_.reset(); multi_.reset();
+    if (devices.size() > 1) {                              // data-parallel over several shards (cdae_hip_multi_*)
+      cdae_hip_multi_t* raw = nullptr;
+      CDAE_HIP_CHECK(cdae_hip_multi_create(&c, static_cast<int>(devices.size()), devices.data(), &raw));
+      multi_.reset(raw, [](cdae_hip_multi_t* m) { cdae_hip_multi_destroy(m); });
+      CDAE_HIP_CHECK(cdae_hip_multi_set_exchange(raw, static_cast<int>(env_u64("CDAE_EXCHANGE_EVERY", 0))));
+      CDAE_HIP_CHECK(cdae_hip_multi_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
+      CDAE_HIP_CHECK(cdae_hip_multi_init_params(raw, seed_));
+      LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES), exchange every " << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
+    } else {
+      cdae_hip_t* raw = nullptr;
+      CDAE_HIP_CHECK(cdae_hip_create(&c, devices.empty() ? static_cast<int>(env_u64("CDAE_DEVICE", 0)) : devices[0], &raw));
+      dev_.reset(raw, [](cdae_hip_t* h) { cdae_hip_destroy(h); });
+      CDAE_HIP_CHECK(cdae_hip_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
+      CDAE_HIP_CHECK(cdae_hip_init_params(raw, seed_));
+    }
     epoch_ = 0;
     rec_.reset();
   }
 
   // ---- training: cdae.hpp:136-146 -----------------------------------------------------------------------
   void train_one_iteration(const Data&) {
-    CHECK(dev_ != nullptr) << "reset() must be called first";
+    CHECK(ready()) << "reset() must be called first";
     cdae_hip_stats st;
-    CDAE_HIP_CHECK(cdae_hip_train_epoch(dev_.get(), seed_, epoch_++, &st));
+    if (multi_) CDAE_HIP_CHECK(cdae_hip_multi_train_epoch(multi_.get(), seed_, epoch_++, &st));
+    else CDAE_HIP_CHECK(cdae_hip_train_epoch(dev_.get(), seed_, epoch_++, &st));
     LOG(INFO) << "CDAE epoch " << epoch_ << ": " << st.users << " users in " << st.wall_seconds << " s ("
               << static_cast<double>(st.users) / st.wall_seconds << " users/s, " << st.batches << " batches)";
     rec_.reset();
@@ -119,26 +136,29 @@ class CDAE : public RecsysModelBase {
   // cdae.hpp:198-358 with the caller's corrupted input set; negatives drawn like cdae.hpp:217-220
   void train_one_user_corruption(size_t uid, const std::unordered_map<size_t, double>& input_set,
                                  const std::unordered_map<size_t, double>& output_set) {
-    CHECK(dev_ != nullptr) << "reset() must be called first";
+    CHECK(ready()) << "reset() must be called first";
     // the device decodes the user's TRAIN row as the positives (that is what train_one_iteration passes, cdae.hpp:143)
     CHECK(is_train_row(uid, output_set)) << "train_one_user_corruption: output_set must be the user's train row";
     std::vector<uint32_t> in, neg(output_set.size() * cfg_.num_neg);
     for (auto& p : input_set) in.push_back(static_cast<uint32_t>(p.first));
     for (auto& n : neg) n = static_cast<uint32_t>(sample_negative_item(output_set));
+    CHECK(!multi_) << "train_one_user_corruption steps ONE replica's shared parameters: not available with CDAE_DEVICES";
     CDAE_HIP_CHECK(cdae_hip_train_one_user_corruption(dev_.get(), uid, in.data(), in.size(), neg.data(), neg.size()));
     rec_.reset();
   }
 
   // ---- reported loss: cdae.hpp:78-107 -------------------------------------------------------------------
   double data_loss(const Data&, size_t = 0) const {
-    CHECK(dev_ != nullptr) << "reset() must be called first";
+    CHECK(ready()) << "reset() must be called first";
     double v = 0;
-    CDAE_HIP_CHECK(cdae_hip_data_loss(dev_.get(), seed_, epoch_, &v));
+    if (multi_) CDAE_HIP_CHECK(cdae_hip_multi_data_loss(multi_.get(), seed_, epoch_, &v));
+    else CDAE_HIP_CHECK(cdae_hip_data_loss(dev_.get(), seed_, epoch_, &v));
     return v;
   }
   double penalty_loss() const {
     double v = 0;
-    CDAE_HIP_CHECK(cdae_hip_penalty_loss(dev_.get(), &v));
+    if (multi_) CDAE_HIP_CHECK(cdae_hip_multi_penalty_loss(multi_.get(), &v));
+    else CDAE_HIP_CHECK(cdae_hip_penalty_loss(dev_.get(), &v));
     return v;
   }
 
@@ -147,7 +167,17 @@ class CDAE : public RecsysModelBase {
     std::vector<uint32_t> uids(num_users_);
     for (size_t u = 0; u < num_users_; ++u) uids[u] = static_cast<uint32_t>(u);
     std::vector<float> z(num_users_ * cfg_.num_dim);
-    CDAE_HIP_CHECK(cdae_hip_encode(dev_.get(), seed_, epoch_, 0, uids.data(), uids.size(), z.data()));
+    if (multi_) {
+      for (int s = 0; s < cdae_hip_multi_num_shards(multi_.get()); ++s) {       // every shard encodes its own users
+        cdae_hip_t* h = nullptr; uint64_t a = 0, b = 0;
+        CDAE_HIP_CHECK(cdae_hip_multi_shard(multi_.get(), s, &h, &a, &b));
+        std::vector<uint32_t> local(b - a);
+        for (uint64_t u = a; u < b; ++u) local[u - a] = static_cast<uint32_t>(u - a);
+        CDAE_HIP_CHECK(cdae_hip_encode(h, seed_, epoch_, 0, local.data(), local.size(), z.data() + a * cfg_.num_dim));
+      }
+    } else {
+      CDAE_HIP_CHECK(cdae_hip_encode(dev_.get(), seed_, epoch_, 0, uids.data(), uids.size(), z.data()));
+    }
     DMatrix out(num_users_, cfg_.num_dim);
     for (size_t i = 0; i < z.size(); ++i) out.data()[i] = z[i];
     return out;
@@ -170,8 +200,17 @@ class CDAE : public RecsysModelBase {
     std::vector<uint32_t> ids(topk);
     {
       std::lock_guard<std::mutex> lk(*mu_);
-      CHECK(dev_ != nullptr) << "reset() must be called first";
-      CDAE_HIP_CHECK(cdae_hip_recommend_user(dev_.get(), uid, rated.data(), rated.size(), static_cast<uint32_t>(topk), ids.data()));
+      CHECK(ready()) << "reset() must be called first";
+      cdae_hip_t* h = dev_.get();
+      uint64_t local = uid;
+      if (multi_) {                                          // the shard that owns the user (its Wu row lives there)
+        for (int s = 0; s < cdae_hip_multi_num_shards(multi_.get()); ++s) {
+          uint64_t a = 0, b = 0;
+          CDAE_HIP_CHECK(cdae_hip_multi_shard(multi_.get(), s, &h, &a, &b));
+          if (uid >= a && uid < b) { local = uid - a; break; }
+        }
+      }
+      CDAE_HIP_CHECK(cdae_hip_recommend_user(h, local, rated.data(), rated.size(), static_cast<uint32_t>(topk), ids.data()));
     }
     return std::vector<size_t>(ids.begin(), ids.end());
   }
@@ -204,14 +243,29 @@ class CDAE : public RecsysModelBase {
   std::shared_ptr<const Table> ensure_table(size_t topk) const {
     std::lock_guard<std::mutex> lk(*mu_);
     if (!rec_ || rec_->topk != topk) {
-      CHECK(dev_ != nullptr) << "reset() must be called first";
+      CHECK(ready()) << "reset() must be called first";
       auto t = std::make_shared<Table>();
       t->topk = topk;
       t->ids.resize(num_users_ * topk);
-      CDAE_HIP_CHECK(cdae_hip_recommend_all(dev_.get(), 0, num_users_, static_cast<uint32_t>(topk), t->ids.data()));
+      if (multi_) CDAE_HIP_CHECK(cdae_hip_multi_recommend_all(multi_.get(), 0, num_users_, static_cast<uint32_t>(topk), t->ids.data()));
+      else CDAE_HIP_CHECK(cdae_hip_recommend_all(dev_.get(), 0, num_users_, static_cast<uint32_t>(topk), t->ids.data()));
       rec_ = t;
     }
     return rec_;
+  }
+  bool ready() const { return dev_ != nullptr || multi_ != nullptr; }
+  static std::vector<int> env_devices() {                    // CDAE_DEVICES=0,1,2,3
+    std::vector<int> out;
+    const char* v = std::getenv("CDAE_DEVICES");
+    if (!v) return out;
+    for (const char* p = v; *p;) {
+      char* end = nullptr;
+      const long d = std::strtol(p, &end, 10);
+      if (end == p) break;
+      out.push_back(static_cast<int>(d));
+      p = (*end == ',') ? end + 1 : end;
+    }
+    return out;
   }
   static uint64_t env_u64(const char* name, uint64_t dflt) {
     const char* v = std::getenv(name);
@@ -220,6 +274,7 @@ class CDAE : public RecsysModelBase {
 
   CDAEConfig cfg_;
   std::shared_ptr<cdae_hip_t> dev_;                  // shared by copies: Solver copies the model (solver.hpp:17)
+  std::shared_ptr<cdae_hip_multi_t> multi_;          // instead of dev_ when CDAE_DEVICES names several shards
   std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
   mutable std::shared_ptr<const Table> rec_;
   std::shared_ptr<const Csr> train_csr_;             // host copy of the train rows (recommend: is the caller's set the train row?)

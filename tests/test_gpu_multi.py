@@ -1,0 +1,187 @@
+"""-m gpu: data parallelism behind the C ABI (cdae_hip_multi_*, cdae_hip_comm_*, cdae_hip_exchange_*; cdae_multi.hip).
+
+One MI355X is all a test box has, so the multi-shard handle runs as LOGICAL shards of GPU 0 (device_ids all equal: same
+schedule as one shard per GPU, the all-reduce is the library's fixed-order sum kernel instead of RCCL), and RCCL itself is
+exercised through a one-rank communicator owned by the library.  What is asserted:
+  * the multi handle == N single handles driven by hand through cdae_hip_delta_stage / _merge with a sum in between —
+    bit for bit, synchronous and pipelined (the protocol of cdae_amd/distributed.py, now inside the library);
+  * one shard == the plain single handle; get / set_param address global matrices; loss and top-k are the sharded sums;
+  * a one-rank RCCL exchange is the identity and leaves the parameters bit-identical to a run without exchange.
+"""
+import numpy as np
+import pytest
+
+import cdae_amd
+from cdae_amd import synth
+from cdae_amd.distributed import _DeviceBuffer
+
+pytestmark = pytest.mark.gpu
+
+HYPER = dict(num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01)
+SHARED = [cdae_amd.P_W, cdae_amd.P_W_AG, cdae_amd.P_B, cdae_amd.P_B_AG, cdae_amd.P_BP, cdae_amd.P_BP_AG]
+
+
+@pytest.fixture(scope="module")
+def small(built):
+    return synth.generate(1200, 500, 60_000, seed=9)
+
+
+def cfg_of(K=24, B=32, **kw):
+    return cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, **{**HYPER, **kw})
+
+
+def emulate(d, cfg, cuts, init_seed, seed, epochs, period):
+    """N single handles + the stage / sum / merge protocol by hand (what cdae_multi.hip's local_epoch does)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    ms, sends, recvs = [], [], []
+    for u0, u1 in cuts:
+        sd = d.user_range(u0, u1)
+        m = cdae_amd.CDAE(cfg)
+        m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
+        m.init_params(init_seed)
+        m.delta_begin(); m.delta_stage(); m.synchronize()
+        ps, _ = m.delta_device_ptr()
+        pr, n = m.delta_recv_device_ptr()
+        sends.append(torch.as_tensor(_DeviceBuffer(ps, n), device=dev))
+        recvs.append(torch.as_tensor(_DeviceBuffer(pr, n), device=dev))
+        ms.append(m)
+    sizes = [u1 - u0 for u0, u1 in cuts]
+    B = min(cfg.batch_users, min(sizes))
+    steps = -(-max(sizes) // B)
+    per = [-(-n // steps) for n in sizes]
+
+    def boundary(pending, start_next):
+        for m in ms:
+            (m.delta_merge_stage if pending and start_next else m.delta_merge if pending else m.delta_stage)()
+        if start_next:
+            for m in ms:
+                m.synchronize()
+            total = sends[0].clone()
+            for t in sends[1:]:
+                total += t
+            for t in recvs:
+                t.copy_(total)
+            torch.cuda.synchronize()
+
+    for ep in range(epochs):
+        pending, n = False, 0
+        for t in range(steps):
+            for r, m in enumerate(ms):
+                a, b = min(sizes[r], t * per[r]), min(sizes[r], (t + 1) * per[r])
+                if b > a:
+                    m.enqueue_users(seed, ep, a, b)
+            n += 1
+            if period == 0:
+                boundary(False, True); boundary(True, False)
+            elif n % period == 0:
+                boundary(pending, True); pending = True
+        if period:
+            boundary(pending, True); boundary(True, False)
+        for m in ms:
+            m.synchronize()
+    return ms
+
+
+@pytest.mark.parametrize("period", [0, 1, 3])
+@pytest.mark.parametrize("shards", [2, 5])
+def test_multi_handle_equals_the_hand_driven_protocol_bit_for_bit(small, shards, period):
+    cfg = cfg_of()
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards, exchange_every=period)
+    mm.reset(small, seed=11)
+    cuts = mm.shards()
+    assert cuts[0][0] == 0 and cuts[-1][1] == small.num_users and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    nnz = [int(small.train_ptr[b] - small.train_ptr[a]) for a, b in cuts]
+    assert max(nnz) - min(nnz) < 0.1 * sum(nnz) / shards          # balanced by interactions
+    st = None
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+    assert st.users == small.num_users
+    ref = emulate(small, cfg, cuts, 11, 3, 2, period)
+    for which in SHARED:
+        got = mm.get(which)
+        for r in ref:                                            # every replica ends an epoch with the same shared block
+            np.testing.assert_array_equal(got, r.get(which))
+    np.testing.assert_array_equal(mm.get(cdae_amd.P_WU), np.concatenate([r.get(cdae_amd.P_WU) for r in ref]))
+    np.testing.assert_array_equal(mm.get(cdae_amd.P_WU_AG), np.concatenate([r.get(cdae_amd.P_WU_AG) for r in ref]))
+    # the reported loss and the top-10 lists are the shards' own, put together
+    loss = sum(r.data_loss(5, 0) for r in ref) + ref[0].penalty_loss() + sum(
+        0.5 * HYPER["lambda_"] * float((r.get(cdae_amd.P_WU).astype(np.float64) ** 2).sum()) for r in ref[1:])
+    assert abs(mm.current_loss(5, 0) - loss) <= 1e-6 * abs(loss)
+    np.testing.assert_array_equal(mm.recommend_all(10), np.concatenate([r.recommend_all(10) for r in ref]))
+    np.testing.assert_array_equal(mm.recommend_all(7, 100, 900), np.concatenate([r.recommend_all(7) for r in ref])[100:900])
+
+
+def test_one_shard_is_the_single_handle(small):
+    cfg = cfg_of(B=64)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0])
+    mm.reset(small, seed=11)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(small, seed=11)
+    for ep in range(2):
+        mm.train_one_iteration(3, ep)
+        one.train_one_iteration(3, ep)
+    for which in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]:
+        np.testing.assert_array_equal(mm.get(which), one.get(which))
+
+
+def test_sharded_init_and_random_streams_are_those_of_the_single_gpu_run(small):
+    """Wu rows and the masks / negatives of a shard are keyed by GLOBAL user id: with a one-user-per-step schedule nothing but
+    the exchange differs from the single run, and at epoch 0 / step 0 not even that."""
+    cfg = cfg_of(B=16)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0, 0, 0])
+    mm.reset(small, seed=11)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(small, seed=11)
+    for which in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]:
+        np.testing.assert_array_equal(mm.get(which), one.get(which))
+    # set_param scatters the private rows to their shards and broadcasts the shared block
+    rng = np.random.default_rng(0)
+    wu = rng.normal(size=(small.num_users, cfg.num_dim)).astype(np.float32)
+    w = rng.normal(size=(small.num_items, cfg.num_dim)).astype(np.float32)
+    mm.set(cdae_amd.P_WU, wu); mm.set(cdae_amd.P_W, w)
+    one.set(cdae_amd.P_WU, wu); one.set(cdae_amd.P_W, w)
+    np.testing.assert_array_equal(mm.get(cdae_amd.P_WU), wu)
+    np.testing.assert_array_equal(mm.get(cdae_amd.P_W), w)
+    assert abs(mm.current_loss(5, 0) - one.current_loss(5, 0)) <= 1e-6 * abs(one.current_loss(5, 0))
+    np.testing.assert_array_equal(mm.recommend_all(10), one.recommend_all(10))
+
+
+@pytest.mark.parametrize("period", [0, 2])
+def test_library_owned_rccl_communicator_with_one_rank(small, period):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce inside the library, beside the training kernels: a one-rank group
+    sums nothing in, so training with the exchange on must give the parameters of training without it — to fp32 rounding:
+    the merge rebuilds cur as A + (cur - A) (that form is what keeps REPLICAS bit-identical, see delta_pipe_kernel)."""
+    cfg = cfg_of(B=64)
+    a = cdae_amd.CDAE(cfg)
+    a.reset(small, seed=11)
+    uid = cdae_amd.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    a.comm_init_rank(1, 0, uid)
+    with pytest.raises(cdae_amd.CDAEError):
+        a.comm_init_rank(1, 0, uid)                              # one communicator per handle
+    t = a.exchange_time_all_reduce(3)
+    assert 0.0 < t < 0.1
+    a.exchange_configure(period)
+    b = cdae_amd.CDAE(cfg)
+    b.reset(small, seed=11)
+    for lo in range(0, small.num_users, 64):
+        hi = min(small.num_users, lo + 64)
+        a.enqueue_users(3, 0, lo, hi)
+        a.exchange_step()
+        b.enqueue_users(3, 0, lo, hi)
+    a.exchange_flush()
+    a.synchronize(); b.synchronize()
+    for which in SHARED + [cdae_amd.P_WU]:
+        ref = b.get(which)
+        np.testing.assert_allclose(a.get(which), ref, rtol=0, atol=2e-5 * max(1e-3, float(np.abs(ref).max())))
+
+
+def test_bad_shard_layouts_are_rejected(built):
+    with pytest.raises(cdae_amd.CDAEError):
+        cdae_amd.MultiCDAE(cfg_of(), devices=[])
+    with pytest.raises(cdae_amd.CDAEError):
+        cdae_amd.MultiCDAE(cfg_of(), devices=[0, 0, 7])           # neither all distinct nor all equal
+    m = cdae_amd.MultiCDAE(cfg_of(), devices=[0, 0])
+    with pytest.raises(cdae_amd.CDAEError):
+        m.train_one_iteration(1, 0)                              # no data yet

@@ -148,3 +148,30 @@ def test_reference_yelp_app_trains_cdae_full_output_k50(host_bins, tmp_path):
     assert all(np.isfinite(losses))
     pop_r10 = float(rows[1].split("|")[8])
     assert max(float(r.split("|")[8]) for r in rows[2:]) > pop_r10
+
+
+@pytest.mark.gpu
+def test_reference_yelp_app_trains_data_parallel_through_the_c_abi(host_bins, tmp_path):
+    """CDAE_DEVICES=0,0: the UNMODIFIED yelp app drives Solver<CDAE>::train over two user shards through cdae_hip_multi_*
+    (logical shards of GPU 0 here; distinct ids = one shard per GPU with a library-owned RCCL communicator), synchronous
+    and pipelined exchange.  Loss and TOPN rows come from the sharded model; identical seeds give identical tables."""
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    tables = []
+    for env in ({"CDAE_DEVICES": "0,0"}, {"CDAE_DEVICES": "0,0"}, {"CDAE_DEVICES": "0,0,0", "CDAE_EXCHANGE_EVERY": "2"}):
+        rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.4", "--scaled=true",
+                       "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "32", **env})
+        assert rc == 0, out[-3000:]
+        assert f"{len(env['CDAE_DEVICES'].split(','))} user shards" in out
+        rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+        assert len(rows) == 2 + 51
+        losses = [float(r.split("|")[2]) for r in rows[3:]]
+        assert all(np.isfinite(losses))
+        pop_r10 = float(rows[1].split("|")[8])
+        assert max(float(r.split("|")[8]) for r in rows[2:]) > pop_r10
+        tables.append([r.split("|")[2:10] for r in rows[2:]])      # loss + the eight TOPN columns (not the time columns)
+    assert tables[0] == tables[1]                                  # deterministic: same shards, same seed, same table

@@ -56,8 +56,22 @@ def shard_cuts(row_ptr, num_users, shards):
     return [shard_bounds(num_users, shards, r, row_ptr) for r in range(shards)]
 
 
+def run_multi(d, seed, K, lt, B, epochs, shards, period):
+    """the product path: cdae_hip_multi_* with `shards` logical shards of GPU 0 (same schedule as one shard per GPU; the
+    all-reduce is the library's fixed-order sum kernel instead of RCCL)"""
+    m = cdae_amd.MultiCDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER), devices=[0] * shards, exchange_every=period)
+    m.reset(d, seed=seed)
+    rec, loss, secs = [], [], 0.0
+    for ep in range(epochs):
+        secs += m.train_one_iteration(seed, ep).wall_seconds
+        loss.append(m.current_loss(seed, ep))
+        rec.append(float(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5]))
+    m.close()
+    return rec, loss, d.num_users * epochs / secs
+
+
 def run_sharded(d, seed, K, lt, B, epochs, shards, period, rule=0):
-    """`shards` single-GPU handles on cuda:0 driven through the same C-ABI calls (cdae_hip_delta_stage / _merge) as the
+    """(touch-mean experiments only; the sum rule runs through run_multi) `shards` single-GPU handles on cuda:0 driven through the same C-ABI calls (cdae_hip_delta_stage / _merge) as the
     data-parallel ranks; the all-reduce(sum) between them is a torch sum over the staged buffers.  period 0 = synchronous."""
     import torch
     from cdae_amd.distributed import _DeviceBuffer
@@ -172,6 +186,8 @@ def main():
                 for B in args.batch_users:
                     if shards == 1:
                         rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep)
+                    elif args.rule == 0:
+                        rec, loss, ups = run_multi(d, seed, args.num_dim, lt, B, ep, shards, period)
                     else:
                         rec, loss, ups = run_sharded(d, seed, args.num_dim, lt, B, ep, shards, period, args.rule)
                     dr = np.abs(np.array(rec) - ref_r)
