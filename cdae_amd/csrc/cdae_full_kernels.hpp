@@ -59,6 +59,9 @@ struct GemmEpilogue {
   uint32_t rows_live, cols_live, loss_type;
   // EPI_ATOMIC / EPI_STORE: fp32 C with row stride ldc (ATOMIC: only rows < rows_live)
   float* Cout; uint32_t ldc;
+  // EPI_STORE with a split contraction: split z stores its partial product at Cout + z * split_stride (summed in fixed order
+  // by the consumer: deterministic, unlike EPI_ATOMIC); 0 when the contraction is not split
+  size_t split_stride;
 };
 
 // Epilogue of one wavefront's 64 x 64 tile (2 x 2 MFMA tiles), shared by the direct and the LDS-staged kernel.
@@ -303,7 +306,9 @@ gemm_nt_bf16_lds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__
     return;
   } else {
     if (m_base >= M || n_base >= N) return;
-    gemm_tile_epilogue<EPI>(acc, m_base, n_base, lane, ep);
+    GemmEpilogue es = ep;
+    if constexpr (EPI == EPI_STORE) es.Cout += (size_t)zt * ep.split_stride;
+    gemm_tile_epilogue<EPI>(acc, m_base, n_base, lane, es);
   }
 }
 
@@ -464,7 +469,9 @@ gemm_nt_bf16_lds3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict_
     }
   } else {
     if (m_base >= M || n_base >= N) return;
-    gemm_tile_epilogue<EPI>(acc, m_base, n_base, lane, ep);
+    GemmEpilogue es = ep;
+    if constexpr (EPI == EPI_STORE) es.Cout += (size_t)zt * ep.split_stride;
+    gemm_tile_epilogue<EPI>(acc, m_base, n_base, lane, es);
   }
 }
 
@@ -530,7 +537,8 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
   // staging: D rows = STEP rows x Kp bf16 (Kp / 8 sixteen-byte pieces per row), D^T = Kp rows x STEP items (STEP / 8 pieces)
   constexpr int D_PIECES = STEP * Kp / 8, T_PIECES = Kp * STEP / 8, T_PER_ROW = STEP / 8;
   constexpr int D_PER = (D_PIECES + 255) / 256, T_PER = (T_PIECES + 255) / 256;
-  bf16x8 sd[D_PER], stt[T_PER];
+  static_assert(D_PER == T_PER, "one staging register set serves both halves");
+  bf16x8 sd[D_PER];
   float sb = 0.f;
   uint32_t sw = 0u;
   // per-thread piece addresses are fixed up to the step's offset: computed once, advanced by a constant per step
@@ -546,10 +554,13 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
     t_src[q] = r * Ip + 8 * c; t_dst[q] = r * TROW + 8 * c;
   }
   const uint32_t w_user = blockIdx.y * 128u + (threadIdx.x & 127u), w_sub = threadIdx.x >> 7;   // 256 threads = FUSED_SUB x 128 users
-  auto fetch = [&](uint32_t st) {
+  // The next step's operands are fetched into registers in two halves — the D rows (+ b', target words) while the first tile
+  // of the current step computes, the D^T rows while the second one does — so that only 32 staging registers are live at a
+  // time (all 64 at once, beside zf, hg and the fragments, spilled to scratch at Kp = 256).  Both halves are committed to the
+  // other LDS buffer inside the same step: every wavefront left that buffer at the barrier that ended the previous step.
+  auto fetch_d = [&](uint32_t st) {
     const uint32_t i0 = st * STEP;
     const __bf16* dsrc = Db + (size_t)i0 * Kp;
-    const __bf16* tsrc = DTb + i0;
     if (threadIdx.x < (uint32_t)STEP) sb = bp[i0 + threadIdx.x];               // in bounds up to Ip: b'_ag, b, b_ag follow b'
     {
       const uint32_t t = st * FUSED_SUB + w_sub;
@@ -558,36 +569,45 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
     for (int q = 0; q < D_PER; ++q)
       if (threadIdx.x + 256u * q < (uint32_t)D_PIECES) sd[q] = *reinterpret_cast<const bf16x8*>(dsrc + d_src[q]);
+  };
+  auto fetch_t = [&](uint32_t st) {
+    const __bf16* tsrc = DTb + st * STEP;
 #pragma unroll
     for (int q = 0; q < T_PER; ++q)
-      if (threadIdx.x + 256u * q < (uint32_t)T_PIECES) stt[q] = *reinterpret_cast<const bf16x8*>(tsrc + t_src[q]);
+      if (threadIdx.x + 256u * q < (uint32_t)T_PIECES) sd[q] = *reinterpret_cast<const bf16x8*>(tsrc + t_src[q]);
   };
-  auto commit = [&](int buf) {
+  auto commit_d = [&](int buf) {
     if (threadIdx.x < (uint32_t)STEP) bpt[buf * STEP + threadIdx.x] = sb;
     wt[buf * FUSED_SUB * 128 + threadIdx.x] = sw;
     __bf16* ddst = dt + (size_t)buf * STEP * DROW;
-    __bf16* tdst = dtt + (size_t)buf * Kp * TROW;
 #pragma unroll
     for (int q = 0; q < D_PER; ++q)
       if (threadIdx.x + 256u * q < (uint32_t)D_PIECES) *reinterpret_cast<bf16x8*>(ddst + d_dst[q]) = sd[q];
+  };
+  auto commit_t = [&](int buf) {
+    __bf16* tdst = dtt + (size_t)buf * Kp * TROW;
 #pragma unroll
     for (int q = 0; q < T_PER; ++q)
       if (threadIdx.x + 256u * q < (uint32_t)T_PIECES) {
         // rows are 8 (mod 16) bytes apart: two 8-byte stores
-        const bf16x4 lo = {stt[q][0], stt[q][1], stt[q][2], stt[q][3]}, hi = {stt[q][4], stt[q][5], stt[q][6], stt[q][7]};
+        const bf16x4 lo = {sd[q][0], sd[q][1], sd[q][2], sd[q][3]}, hi = {sd[q][4], sd[q][5], sd[q][6], sd[q][7]};
         *reinterpret_cast<bf16x4*>(tdst + t_dst[q]) = lo;
         *reinterpret_cast<bf16x4*>(tdst + t_dst[q] + 4) = hi;
       }
   };
-  fetch(s_begin);
-  commit(0);
+  fetch_d(s_begin);
+  commit_d(0);
+  fetch_t(s_begin);
+  commit_t(0);
   __syncthreads();
 
   for (uint32_t st = s_begin; st < s_end; ++st) {
     const int buf = (int)((st - s_begin) & 1u);
-    if (st + 1 < s_end) fetch(st + 1);
+    const bool more = st + 1 < s_end;                                          // workgroup-uniform
+    if (more) fetch_d(st + 1);
 #pragma unroll
     for (int sub = 0; sub < FUSED_SUB; ++sub) {
+      if (sub == FUSED_SUB - 1 && more) { commit_d(buf ^ 1); fetch_t(st + 1); }
       const uint32_t t = st * FUSED_SUB + sub;                                 // global 32-item tile index
       const uint32_t word = wt[(buf * FUSED_SUB + sub) * 128 + wave * 32u + col];          // the user's training items in the tile
       // product 1: C1[item][user]
@@ -597,13 +617,19 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
       for (int r = 0; r < 16; ++r) { c1[r] = 0.f; c1b[r] = 0.f; }
       const __bf16* arow = dt + (size_t)buf * STEP * DROW + (sub * FUSED_TILE + col) * DROW + 8 * half;
-      bf16x8 af[NKS];
+      // fragments in groups of <= 8 (at Kp = 256 all 16 at once, next to zf, hg and the staging registers, overflowed the 256
+      // architectural VGPRs: 9 dwords of scratch spills inside this loop)
+      constexpr int AG = NKS < 8 ? NKS : 8;
 #pragma unroll
-      for (int s = 0; s < NKS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(arow + 16 * s);
+      for (int s0 = 0; s0 < NKS; s0 += AG) {
+        bf16x8 af[AG];
 #pragma unroll
-      for (int s = 0; s < NKS; s += 2) {
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], zf[s], c1, 0, 0, 0);
-        if (s + 1 < NKS) c1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s + 1], zf[s + 1], c1b, 0, 0, 0);
+        for (int s = 0; s < AG; ++s) af[s] = *reinterpret_cast<const bf16x8*>(arow + 16 * (s0 + s));
+#pragma unroll
+        for (int s = 0; s < AG; s += 2) {
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], zf[s0 + s], c1, 0, 0, 0);
+          if (s + 1 < AG) c1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s + 1], zf[s0 + s + 1], c1b, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) c1[r] += c1b[r];
@@ -644,7 +670,7 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) hg[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks], bf[ks][nt], hg[nt], 0, 0, 0);
     }
-    if (st + 1 < s_end) commit(buf ^ 1);
+    if (more) commit_t(buf ^ 1);
     __syncthreads();
   }
   // C layout: column n = lane & 31 (hidden index 32 nt + n), rows = users 8 (r / 4) + 4 half + (r % 4) of the wave's 32

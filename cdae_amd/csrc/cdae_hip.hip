@@ -461,6 +461,13 @@ int launch_gemm_lds(cdae_hip* h, hipStream_t st, const __bf16* A, const __bf16* 
   return 0;
 }
 
+// contraction split of GEMM 2 (hg = G D, K > 256 / unfused path): about 2048 workgroups in all, splits a multiple of 64 items
+uint32_t gemm2_k_per_split(const cdae_hip* h) {
+  const uint32_t tiles2 = ((h->Kp + 127) / 128) * (h->Bp / 128);
+  const uint32_t want = std::max<uint32_t>(1, std::min<uint32_t>(h->Ip / 64, (2048 + tiles2 - 1) / tiles2));
+  return (((h->Ip + want - 1) / want + 63) / 64) * 64;
+}
+
 // Full-output decode of one batch (MFMA path, cdae_full_kernels.hpp).  The example list holds the positives only.
 int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
   using namespace cdae;
@@ -490,7 +497,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // bf16 operand copies Z, Z^T (rows >= nb zero)
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
   const bool fused = Kp <= 256 && !h->full_unfused;
-  uint32_t hg_parts = 0;                         // slabs of HGpart holding hg (0: accumulated into HG by atomics)
+  uint32_t hg_parts = 0, hg_rows = nb;           // slabs of HGpart holding hg and their row count (0: accumulated into HG by atomics)
   if (fused) {
     // targets: one bit per (batch user, item); then forward + loss' + hidden gradient in one launch (cdae_full_kernels.hpp)
     const uint32_t words = (I + 31) / 32, slices = h->full_slices, tiles = Ip / (32 * FUSED_SUB);   // staged steps of 64 items
@@ -527,20 +534,23 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
                      h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
-  // GEMM 2: hg = G D  (contraction over items, split; fp32 atomics into the zeroed HG)
+  // GEMM 2: hg = G D  (contraction over items, split).  Every split stores its partial [Bp x Kp] product into its own slab of
+  // HGpart and hidden_finish_kernel adds the slabs in fixed order: deterministic (the first version accumulated with fp32
+  // atomics into HG, whose order — and therefore rounding — changed from run to run)
   {
-    // contraction splits: about 2048 workgroups in all (every split ends in 128 x 128 fp32 atomics per tile: with the 2048-item
-    // splits of the first version, 1 M items meant 256 M atomics per block, 1.7 ms)
-    const uint32_t tiles2 = ((Kp + 127) / 128) * (Bp / 128);
-    const uint32_t want = std::max<uint32_t>(1, std::min<uint32_t>(Ip / 64, (2048 + tiles2 - 1) / tiles2));
-    const uint32_t kps = h->gemm_direct ? 2048 : (((Ip + want - 1) / want + 63) / 64) * 64;
+    const uint32_t kps = gemm2_k_per_split(h);
     GemmEpilogue e2{};
-    e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
-    if (h->gemm_direct)
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + kps - 1) / kps), blk, 0, st, h->d_Gb,
-                         h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2);
-    else
-      CHK(launch_gemm_lds<EPI_ATOMIC>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, (Ip + kps - 1) / kps, 2));
+    if (h->gemm_direct) {
+      e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + 2047) / 2048), blk, 0, st, h->d_Gb,
+                         h->d_DTb, Bp, Kp, Ip, Ip, Ip, 2048u, e2);
+    } else {
+      const uint32_t splits = (Ip + kps - 1) / kps;
+      e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
+      CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
+      hg_parts = splits;
+      hg_rows = Bp;
+    }
   }
   }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
@@ -551,7 +561,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     Prof pa;
     CHK(pa.begin(h, F_HIDDEN, h->aux));
     DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, hg_parts ? (const uint32_t*)h->d_iota : uptr,
-                hg_parts ? nb : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts,
+                hg_parts ? hg_rows : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts,
                 h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
     CHK(pa.end());
   }
@@ -910,7 +920,15 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       if (const char* ev = std::getenv("CDAE_FULL_SLICES")) h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)std::atoi(ev)));
     }
   }
-  CHK(dev_alloc(&h->d_HGpart, std::max<size_t>(8 * (size_t)h->unit_cap, h->cfg.full_output ? (size_t)h->full_slices * B : 0) * h->Kp));
+  {
+    size_t rows = 8 * (size_t)h->unit_cap;
+    if (h->cfg.full_output) {
+      rows = std::max(rows, (size_t)h->full_slices * B);
+      const uint32_t kps = gemm2_k_per_split(h);                                 // unfused path: one [Bp x Kp] slab per contraction split
+      rows = std::max(rows, (size_t)((h->Ip + kps - 1) / kps) * h->Bp);
+    }
+    CHK(dev_alloc(&h->d_HGpart, rows * h->Kp));
+  }
   CHK(dev_alloc(&h->d_touched, (size_t)I));
   HIPCHK(hipMemset(h->d_touched, 0, (size_t)I * sizeof(uint32_t)));
   CHK(dev_alloc(&h->d_uids, (size_t)B));
