@@ -56,13 +56,24 @@ def shard_cuts(row_ptr, num_users, shards):
     return [shard_bounds(num_users, shards, r, row_ptr) for r in range(shards)]
 
 
-def run_multi(d, seed, K, lt, B, epochs, shards, period):
+def run_multi(d, seed, K, lt, B, epochs, shards, period, warm_epochs=0, warm_batch=256):
     """the product path: cdae_hip_multi_* with `shards` logical shards of GPU 0 (same schedule as one shard per GPU; the
-    all-reduce is the library's fixed-order sum kernel instead of RCCL)"""
+    all-reduce is the library's fixed-order sum kernel instead of RCCL).  warm_epochs > 0: the first epochs run the
+    single-GPU schedule (batch_users = warm_batch) and its parameters are handed to the shards."""
     m = cdae_amd.MultiCDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER), devices=[0] * shards, exchange_every=period)
     m.reset(d, seed=seed)
     rec, loss, secs = [], [], 0.0
-    for ep in range(epochs):
+    if warm_epochs:
+        one = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=warm_batch, **HYPER))
+        one.reset(d, seed=seed)
+        for ep in range(warm_epochs):
+            one.train_one_iteration(seed, ep)
+            loss.append(one.current_loss(seed, ep))
+            rec.append(float(orc.eval_topn(one.recommend_all(10), d.test_ptr, d.test_col)[5]))
+        for w in (cdae_amd.P_W, cdae_amd.P_W_AG, cdae_amd.P_B, cdae_amd.P_B_AG, cdae_amd.P_BP, cdae_amd.P_BP_AG, cdae_amd.P_WU, cdae_amd.P_WU_AG):
+            m.set(w, one.get(w))
+        one.close()
+    for ep in range(warm_epochs, epochs):
         secs += m.train_one_iteration(seed, ep).wall_seconds
         loss.append(m.current_loss(seed, ep))
         rec.append(float(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5]))
@@ -169,6 +180,7 @@ def main():
     ap.add_argument("--shards", type=int, nargs="+", default=[1])
     ap.add_argument("--period", type=int, nargs="+", default=[0], help="exchange period of the sharded runs (0 = synchronous)")
     ap.add_argument("--rule", type=int, default=0, help="0 sum, 1 touch-mean (synchronous only)")
+    ap.add_argument("--warm-epochs", type=int, default=0, help="sharded runs: first N epochs on the single-GPU schedule (batch_users 256)")
     args = ap.parse_args()
     lt = cdae_amd.CROSS_ENTROPY if args.loss == "CE" else cdae_amd.SQUARE
     fx = fixtures(args.shape, args.num_dim, args.loss, args.seeds)
@@ -187,12 +199,12 @@ def main():
                     if shards == 1:
                         rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep)
                     elif args.rule == 0:
-                        rec, loss, ups = run_multi(d, seed, args.num_dim, lt, B, ep, shards, period)
+                        rec, loss, ups = run_multi(d, seed, args.num_dim, lt, B, ep, shards, period, args.warm_epochs)
                     else:
                         rec, loss, ups = run_sharded(d, seed, args.num_dim, lt, B, ep, shards, period, args.rule)
                     dr = np.abs(np.array(rec) - ref_r)
                     dl = np.array(loss) / ref_l - 1.0
-                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "rule": args.rule, "batch_users": B,
+                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "rule": args.rule, "warm_epochs": args.warm_epochs if shards > 1 else 0, "batch_users": B,
                                       "recall10": [round(x, 5) for x in rec], "abs_d_recall": [round(float(x), 5) for x in dr],
                                       "max_abs_d_recall": round(float(dr.max()), 5), "rel_d_loss": [round(float(x), 4) for x in dl],
                                       "users_per_s": round(ups)}), flush=True)
