@@ -83,6 +83,13 @@ def main():
                          "ONE data set of the named shape, users sharded over the ranks by interactions (BASELINE configs[3]: "
                          "--shape netflix --scaling strong).  Either way the ranks exchange shared-parameter deltas, which is "
                          "OUTSIDE the single-GPU accuracy envelope (DESIGN.md §7): the N > 1 value is a throughput figure")
+    ap.add_argument("--layout", choices=["users", "item-rows"], default="users",
+                    help="item-rows (with --full-output): the GPUs cut the ITEM rows of W / b' and of the three decode products instead of "
+                         "the users (BASELINE configs[4]: --full-output --shape cfg5_items --num-dim 512 --layout item-rows); exact "
+                         "single-GPU schedule, two [batch x K] all-reduces per batch.  One process drives all N GPUs through "
+                         "cdae_hip_multi_* (rank 0 when launched by torch.distributed.run; the other ranks only keep the barriers)")
+    ap.add_argument("--logical-shards", type=int, default=0, help="--layout item-rows on ONE GPU: this many logical shards of cuda:0 "
+                    "(the all-reduce is a sum kernel) — measures the cost of the phase structure without a second GPU")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test of the N > 1 path on one GPU; "
                     "RCCL refuses two ranks on one device, so the exchange runs as one-rank groups)")
     ap.add_argument("--exchange-every", type=int, default=-1, help="N > 1: batches between exchanges of the shared-parameter "
@@ -108,6 +115,8 @@ def main():
     from cdae_amd import synth
     from cdae_amd.distributed import shard_bounds
 
+    if args.layout == "item-rows":
+        return bench_item_rows(args, rank, world)
     if args.scaling == "strong" and world > 1:
         whole = synth.generate_shape(args.shape, seed=args.seed)          # the same data set on every rank ...
         u0, u1 = shard_bounds(whole.num_users, world, rank, whole.train_ptr)
@@ -304,6 +313,69 @@ def main():
         dist.destroy_process_group()
         import ctypes
         ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+
+
+def bench_item_rows(args, rank, world):
+    """--layout item-rows: ONE process (rank 0) drives all N GPUs through cdae_hip_multi_* with CDAE_LAYOUT_ITEM_ROWS."""
+    import torch
+    import cdae_amd
+    from cdae_amd import synth
+    if not args.full_output:
+        raise SystemExit("--layout item-rows is a layout of the full-output decode: add --full-output")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank != 0:                        # the other ranks own no GPU work in this layout: they keep the job's barriers
+        dist.barrier(); dist.barrier()
+        dist.destroy_process_group()
+        return
+    devices = [0] * args.logical_shards if args.logical_shards else list(range(world))
+    data = synth.generate_shape(args.shape, seed=args.seed)
+    K, B = args.num_dim, min(args.batch_users, data.num_users)
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True,
+                              learn_rate=0.1, beta=1.0, lambda_=0.01, using_adagrad=True, user_factor=True, batch_users=B, full_output=True)
+    model = cdae_amd.MultiCDAE(cfg, devices=devices, item_rows=True)
+    model.reset(data, seed=args.seed)
+    n_batches = (data.num_users + B - 1) // B
+
+    def step(i):
+        b = i % n_batches
+        return model.train_users(args.seed, i // n_batches, b * B, min(data.num_users, (b + 1) * B))      # synchronises at its end
+
+    for i in range(args.warmup):
+        step(i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    users = 0
+    for i in range(args.warmup, args.warmup + args.steps):
+        users += step(i).users
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    n_gpus = len(set(devices))
+    MFMA_PEAK_TFLOPS = 2500.0
+    flops_step = 6.0 * K * data.num_items * B
+    achieved = flops_step * args.steps / elapsed / 1e12 / n_gpus          # per GPU, whole step (not the decode family alone)
+    out = {"metric": f"users/sec (whole node) K={K} {args.shape}-shape full-output, item-rows layout",
+           "value": users / elapsed, "unit": "users/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} (ONE data set, item rows cut over the GPUs), "
+                                  f"nnz_train={data.nnz_train}, K={K}, FULL-OUTPUT decode, CE loss, AdaGrad, q=0.5 scaled",
+                      "batch_users": B, "global_batch": B, "parallelism": f"item-rows x{len(devices)}" + (" (logical shards of one GPU)" if args.logical_shards else ""),
+                      "exchange": "two all-reduces of [batch_users x row_stride] fp32 per batch (input sums, hidden gradient); no parameter crosses GPUs",
+                      "accuracy": "the single-GPU full-output schedule exactly (tests/test_gpu_multi.py: parameters within 5e-3 of range of the single handle)"},
+           "roofline": {"bound": "mfma", "kernel": "whole step per GPU (three bf16 products over the local item rows + row steps + replicated hidden layer)",
+                        "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None}}
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
     print(json.dumps(out), flush=True)
 
 

@@ -87,12 +87,14 @@ EXPORTS = {
     "cdae_hip_exchange_time_all_reduce": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "cdae_hip_multi_create": (C.c_int, [C.POINTER(_Config), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
     "cdae_hip_multi_destroy": (C.c_int, [C.c_void_p]),
+    "cdae_hip_multi_set_layout": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cdae_hip_multi_num_shards": (C.c_int, [C.c_void_p]),
     "cdae_hip_multi_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cdae_hip_multi_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cdae_hip_multi_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "cdae_hip_multi_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
+    "cdae_hip_multi_train_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "cdae_hip_multi_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "cdae_hip_multi_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "cdae_hip_multi_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
@@ -396,7 +398,8 @@ class MultiCDAE:
     devices = [0, 1, ..., N-1]: one shard per GPU (RCCL); devices = [0] * N: N logical shards of GPU 0 (tests, accuracy
     envelope).  exchange_every: 0 = synchronous exchange of the shared-parameter deltas at every step, k >= 1 = pipelined."""
 
-    def __init__(self, mcfg: CDAEConfig, devices, exchange_every: int = 0):
+    def __init__(self, mcfg: CDAEConfig, devices, exchange_every: int = 0, item_rows: bool = False):
+        """item_rows=True: CDAE_LAYOUT_ITEM_ROWS — the shards cut the item rows (full_output only; exact single-GPU schedule)."""
         self.lib = load_library()
         self.cfg = mcfg
         c = _Config(C.sizeof(_Config), mcfg.num_dim, mcfg.num_neg, mcfg.num_corruptions, mcfg.lt,
@@ -407,6 +410,8 @@ class MultiCDAE:
         self.h = C.c_void_p()
         _chk(self.lib, self.lib.cdae_hip_multi_create(C.byref(c), len(devices), devs, C.byref(self.h)))
         _chk(self.lib, self.lib.cdae_hip_multi_set_exchange(self.h, exchange_every))
+        if item_rows:
+            _chk(self.lib, self.lib.cdae_hip_multi_set_layout(self.h, 1))
         self.num_users = self.num_items = 0
 
     def close(self):
@@ -444,6 +449,11 @@ class MultiCDAE:
     def train_one_iteration(self, seed: int, epoch: int) -> Stats:
         st = Stats()
         _chk(self.lib, self.lib.cdae_hip_multi_train_epoch(self.h, seed, epoch, C.byref(st)))
+        return st
+
+    def train_users(self, seed: int, epoch: int, u_begin: int, u_end: int) -> Stats:
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_multi_train_users(self.h, seed, epoch, u_begin, u_end, C.byref(st)))
         return st
 
     def current_loss(self, seed: int, epoch: int) -> float:

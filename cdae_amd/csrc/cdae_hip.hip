@@ -159,6 +159,13 @@ struct cdae_hip {
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr; float* d_snap = nullptr;   // agreed state, staged delta, all-reduced delta, parameters at the last stage
   void* xchg = nullptr; void (*xchg_free)(void*) = nullptr;   // communicator + schedule of the exchange (cdae_multi.hip)
+  // item-sharded layout (cdae_multi.hip): this handle holds item rows [item0, item0 + I) of I_global; every user,
+  // possibly with no local item.  The two per-user sums that cross shards live in d_Hsum (input sums) and d_HG (hidden gradient).
+  bool item_shard = false; uint64_t item0 = 0, I_global = 0;
+  uint32_t* d_gpos = nullptr;           // item shard: per user (length of the whole row, position of the first local item): the dropout stream's index space
+  float* d_Hsum = nullptr; float* d_hsum_eval = nullptr; uint32_t* d_iota_eval = nullptr; float* d_rec_score = nullptr; size_t rec_score_cap = 0;
+  uint32_t hsum_eval_cap = 0;
+  uint64_t fs_prepped = 0;              // item-sharded training: batches whose example lists have been prepared (buffer set = parity)
 
   uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q & 1
   bool pre_valid = false;               // set (seq & 1) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
@@ -241,7 +248,7 @@ void free_all(cdae_hip* h) {
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
-                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score};
+                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -267,7 +274,8 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
-                   (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score};
+                   (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
+                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -275,7 +283,7 @@ int free_interaction_state(cdae_hip* h) {
     for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
-  h->rec_cap = 0; h->score_cap = 0;
+  h->rec_cap = 0; h->score_cap = 0; h->rec_score_cap = 0; h->hsum_eval_cap = 0;
   h->eval_cap = 0; h->eval_unit_cap = 0; h->bits_cap = 0;
   return 0;
 }
@@ -300,14 +308,20 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   HIPCHK(hipStreamWaitEvent(st, x.released, 0));               // the batch that last used this set is done with it
   CHK(pr.begin(h, F_SAMPLE, st));
   const uint32_t n_units = units_of(h, bt);
+  if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
+    HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(x.dup_count, 0, sizeof(uint32_t), st));
+  } else
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
                      x.seg, h->counting_sort ? 0u : 2u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
-                     h->counting_sort ? x.item_count : (uint32_t*)nullptr);
+                     h->counting_sort ? x.item_count : (uint32_t*)nullptr, (const uint32_t*)h->d_gpos);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st));
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
-  if (h->counting_sort) {
+  if (bt.E == 0) {
+    // nothing to order
+  } else if (h->counting_sort) {
     // item-major order by counting (cdae_sort_kernels.hpp): tickets were taken by sample_kernel
     hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, x.item_count, I, x.prefix, x.rank, x.seg, x.seg + I, x.dup_count);
     if (bt.E) hipLaunchKernelGGL(scatter_kernel, dim3((uint32_t)((bt.E + 255) / 256)), dim3(256), 0, st, x.item, x.val, (uint32_t)bt.E,
@@ -734,6 +748,7 @@ int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t offset) {
 
 int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64_t* row_ptr, const uint32_t* col) {
   if (!h || !row_ptr || (!col && U && row_ptr[U])) return fail("null argument");
+  if (h->item_shard && !h->cfg.full_output) return fail("the item-sharded layout exists for the full-output decode only");
   if (U == 0 || I == 0) return fail("empty interaction matrix (%llu users, %llu items)", (unsigned long long)U, (unsigned long long)I);
   if (I >= (1ull << 30) || U >= (1ull << 30)) return fail("at most 2^30 users and items");
   if (row_ptr[0] != 0) return fail("row_ptr[0] must be 0");
@@ -742,8 +757,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   std::vector<uint64_t> pop(I, 0);
   for (uint64_t u = 0; u < U; ++u) {
     const int64_t a = row_ptr[u], b = row_ptr[u + 1];
-    if (b <= a) return fail("user %llu has no training item (the reference CHECK-fails too, cdae.hpp:139)", (unsigned long long)u);
-    if ((uint64_t)(b - a) >= I) return fail("user %llu rated every item: no negative can be sampled", (unsigned long long)u);
+    if (b < a) return fail("row_ptr is not monotone at user %llu", (unsigned long long)u);
+    if (!h->item_shard) {      // an item shard sees only its slice of every row: empty and full slices are legal there
+      if (b <= a) return fail("user %llu has no training item (the reference CHECK-fails too, cdae.hpp:139)", (unsigned long long)u);
+      if ((uint64_t)(b - a) >= I) return fail("user %llu rated every item: no negative can be sampled", (unsigned long long)u);
+    }
     for (int64_t p = a; p < b; ++p) {
       if (col[p] >= I) return fail("item id %u out of range at position %lld", col[p], (long long)p);
       if (p > a && col[p] <= col[p - 1]) return fail("row %llu is not strictly ascending at position %lld", (unsigned long long)u, (long long)p);
@@ -907,10 +925,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
     CHK(dev_alloc(&h->d_dD, (size_t)h->Ip * h->Kp));
     {
-      std::vector<uint32_t> iota((size_t)B + 1);
+      std::vector<uint32_t> iota((size_t)std::max<uint32_t>(B, h->item_shard ? EVAL_CHUNK : 0u) + 1);
       std::iota(iota.begin(), iota.end(), 0u);
       CHK(dev_alloc(&h->d_iota, iota.size()));
       HIPCHK(hipMemcpy(h->d_iota, iota.data(), iota.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      if (h->item_shard) CHK(dev_alloc(&h->d_Hsum, (size_t)B * h->Kp));
       h->bits_stride = (size_t)B * ((I + 31) / 32);
       CHK(dev_alloc(&h->d_bits_train, 2 * h->bits_stride));                   // one per example-buffer set
       // item slices of the fused decode: slices x Bp/128 workgroups ~ one per CU (measured best at B = 2048: 16 slices; every
@@ -955,7 +974,7 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
   using namespace cdae;
-  const double init_scale = 4. * std::sqrt(6. / (double)(h->I + h->K));          // cdae.hpp:112
+  const double init_scale = 4. * std::sqrt(6. / (double)((h->item_shard ? h->I_global : h->I) + h->K));          // cdae.hpp:112 (an item shard: the whole item space)
   auto blocks = [](size_t n) { return dim3((uint32_t)((n + 255) / 256)); };
   auto init = [&](float* M, size_t rows, uint32_t id, uint64_t row0 = 0) {
     hipLaunchKernelGGL(init_matrix_kernel, blocks(rows * h->Kp), dim3(256), 0, h->stream, M, rows, h->K, h->Kp,
@@ -964,8 +983,8 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   auto fill = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v) {     // accumulator pads are 1, others 0
     hipLaunchKernelGGL(fill_matrix_kernel, blocks(rows * Kp), dim3(256), 0, h->stream, M, rows, K, Kp, v, v == 0.f ? 0.f : 1.f);
   };
-  init(h->P(CDAE_P_W), h->I, CDAE_P_W); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
-  if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
+  init(h->P(CDAE_P_W), h->I, CDAE_P_W, h->item0); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
+  if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V, h->item0); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
   if (h->cfg.user_factor) { init(h->d_Wu, h->U, CDAE_P_WU, h->uid_offset); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }   // :119-122
   else { fill(h->d_Wu, h->U, h->K, h->Kp, 0.f); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }
   fill(h->P(CDAE_P_B), 1, h->K, h->Kp, 0.f); fill(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f);    // :123-124
@@ -1054,6 +1073,7 @@ bool is_prefetched(const cdae_hip* h, const Batch& b, uint64_t seed, uint32_t ep
 // Enqueue (no host synchronisation) one pass over users [u_begin, u_end): a software pipeline in which the
 // sampling + sorting of batch t+1 (prep stream) overlaps the training of batch t (main stream).
 int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end) {
+  if (h->item_shard) return fail("an item shard trains in phases under cdae_hip_multi_train_epoch, not on its own");
   std::vector<Batch> plan;
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
@@ -1134,7 +1154,7 @@ int recommend_general(cdae_hip* h, uint64_t u_begin, uint64_t u_end, uint32_t to
       if (rc) break;
     }
     DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, s0,
-                h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score, (const uint32_t*)d_rated, n_rated);
+                h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score, (const uint32_t*)d_rated, n_rated, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1599,9 +1619,254 @@ int shared_penalty(cdae_hip_t* h, double* out) {
   return sqnorm_sum(h, {{h->P(CDAE_P_W), h->cnt[CDAE_P_W]}, {h->P(CDAE_P_V), h->cnt[CDAE_P_V]}, {h->P(CDAE_P_B), h->cnt[CDAE_P_B]},
                         {h->P(CDAE_P_BP), h->cnt[CDAE_P_BP]}}, out);
 }
+int item_rows_penalty(cdae_hip_t* h, double* out) {
+  return sqnorm_sum(h, {{h->P(CDAE_P_W), h->cnt[CDAE_P_W]}, {h->P(CDAE_P_V), h->cnt[CDAE_P_V]}, {h->P(CDAE_P_BP), h->cnt[CDAE_P_BP]}}, out);
+}
+int hidden_bias_penalty(cdae_hip_t* h, double* out) { return sqnorm_sum(h, {{h->P(CDAE_P_B), h->cnt[CDAE_P_B]}}, out); }
 int private_penalty(cdae_hip_t* h, double* out) {
   if (!h->cfg.user_factor) { *out = 0.; return 0; }
   return sqnorm_sum(h, {{h->d_Wu, h->cnt[CDAE_P_WU]}}, out);
+}
+
+// ---- item-sharded layout: phases of a full-output batch and of the evaluation passes (cdae_internal.hpp) ---------------
+int set_item_shard(cdae_hip_t* h, uint64_t item0, uint64_t num_items_global) {
+  if (!h) return fail("null handle");
+  if (!h->cfg.full_output) return fail("the item-sharded layout exists for the full-output decode only");
+  h->item_shard = true; h->item0 = item0; h->I_global = num_items_global;
+  return 0;
+}
+int set_item_shard_positions(cdae_hip_t* h, const uint32_t* len_and_first /* [2 U] */) {
+  if (!h || !h->d_shared || !h->item_shard || !len_and_first) return fail("set_item_shard and set_interactions must be called first");
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_gpos) CHK(dev_alloc(&h->d_gpos, 2 * (size_t)h->U));
+  HIPCHK(hipMemcpy(h->d_gpos, len_and_first, 2 * (size_t)h->U * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+uint32_t row_stride(const cdae_hip_t* h) { return h->Kp; }
+float* hsum_buf(cdae_hip_t* h) { return h->d_Hsum; }
+float* hg_buf(cdae_hip_t* h) { return h->d_HG; }
+float* ev_hsum_buf(cdae_hip_t* h) { return h->d_hsum_eval; }
+uint32_t eval_chunk() { return EVAL_CHUNK; }
+
+static int fs_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, Batch* bt) {
+  if (!h->d_shared || !h->item_shard) return fail("not an item-sharded handle with data");
+  if (nb == 0 || s0 + nb > h->U || nb > std::min<uint64_t>(h->B, h->U)) return fail("bad batch [%llu, +%u)", (unsigned long long)s0, nb);
+  const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]);
+  if (E > h->Ecap) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
+  *bt = Batch{s0, nb, cidx, E};
+  return 0;
+}
+
+int fs_prep(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_t nb, uint32_t cidx) {
+  HIPCHK(hipSetDevice(h->device));
+  Batch bt;
+  CHK(fs_batch(h, s0, nb, cidx, &bt));
+  h->prof_q = h->seq;
+  CHK(prep_batch(h, (int)(h->fs_prepped & 1), bt, seed, epoch));       // fs_prepped counts prepared batches: set = parity
+  h->fs_prepped++;
+  return 0;
+}
+
+int fs_phase0(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_t nb, uint32_t cidx) {
+  HIPCHK(hipSetDevice(h->device));
+  Batch bt;
+  CHK(fs_batch(h, s0, nb, cidx, &bt));
+  const uint32_t n_units = units_of(h, bt);
+  const uint32_t* uptr = h->d_unit_ptr + s0;
+  if (n_units)
+    DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+                h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Hpart,
+                (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user, (const uint32_t*)h->d_gpos);
+  DISPATCH_NI(h->NI, cdae::unit_sum_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, nb, h->d_Hsum);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
+  using namespace cdae;
+  HIPCHK(hipSetDevice(h->device));
+  Batch bt;
+  CHK(fs_batch(h, s0, nb, 0, &bt));
+  const int b = (int)(h->seq & 1);
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
+  const dim3 blk(256), grid_users((nb + 3) / 4);
+  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  CHK(join_aux(h));
+  // z from the ALL-REDUCED input sums: encode_finish with one "unit" per user (identity prefix)
+  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, h->d_Wu, h->P(CDAE_P_B),
+              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
+  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  uint32_t parts = 0, rows = nb;
+  if (Kp <= 256 && !h->full_unfused) {
+    const uint32_t words = (I + 31) / 32, slices = h->full_slices, tiles = Ip / (32 * FUSED_SUB);
+    const uint32_t* bits = h->d_bits_train + (size_t)b * h->bits_stride;
+    const uint32_t tps = (tiles + slices - 1) / slices;
+    const dim3 grid(slices, Bp / 128);
+    const size_t lds = full_fused_lds_bytes(Kp);
+    if ((uint64_t)Ip * Bp > 0xFFFFFFFFull) return fail("full-output decode: G^T of %u x %u exceeds 2^32 elements; lower batch_users", Ip, Bp);
+#define FS_FUSED2(NKS_, L_)                                                                                                              \
+  do {                                                                                                                                  \
+    HIPCHK(hipFuncSetAttribute((const void*)full_decode_fused_kernel<NKS_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    hipLaunchKernelGGL((full_decode_fused_kernel<NKS_, L_>), grid, blk, lds, st, h->hp, h->d_Zb, h->d_Db, h->d_DTb, Ip, h->P(CDAE_P_BP), \
+                       bits, words, nb, tps, h->d_GTb, Bp, h->d_HGpart);                                                                 \
+  } while (0)
+#define FS_FUSED(NKS_) do { if (h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY) FS_FUSED2(NKS_, 5); else FS_FUSED2(NKS_, 0); } while (0)
+    switch (Kp) { case 64: FS_FUSED(4); break; case 128: FS_FUSED(8); break; default: FS_FUSED(16); break; }
+#undef FS_FUSED
+#undef FS_FUSED2
+    parts = slices; rows = nb;
+  } else {
+    GemmEpilogue ep{};
+    ep.bp = h->P(CDAE_P_BP); ep.G = h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
+    ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
+    CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
+    if (bt.E)
+      hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
+                         h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
+    const uint32_t kps = gemm2_k_per_split(h), splits = (Ip + kps - 1) / kps;
+    GemmEpilogue e2{};
+    e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
+    CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
+    parts = splits; rows = Bp;
+  }
+  // local hidden gradient of the batch, raw: the shards' sums are all-reduced before delta is formed
+  DISPATCH_NI(h->NI, slab_sum_kernel, grid_users, blk, 0, st, h->hp, h->d_HGpart, parts, rows, nb, h->d_HG);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
+  using namespace cdae;
+  HIPCHK(hipSetDevice(h->device));
+  Batch bt;
+  CHK(fs_batch(h, s0, nb, 0, &bt));
+  const int b = (int)(h->seq & 1);
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
+  const dim3 blk(256), grid_users((nb + 3) / 4);
+  HIPCHK(hipEventRecord(h->ev_fork, st));
+  HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
+  // d_HG holds the all-reduced hg: delta, the Wu steps (replicated: every shard steps its copy identically), then the b recurrence
+  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
+              h->d_HG, h->d_Wu, h->d_Wu_ag, 0u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
+  HIPCHK(hipEventRecord(h->ev_delta, h->aux));
+  hipLaunchKernelGGL(hidden_bias_kernel, dim3((Kp + 255u) / 256u), blk, 0, h->aux, h->hp, nb, h->d_HG, h->P(CDAE_P_B), h->P(CDAE_P_B_AG));
+  HIPCHK(hipEventRecord(h->ev_join, h->aux));
+  {
+    GemmEpilogue e3{};
+    e3.Cout = h->d_dD; e3.ldc = Kp;
+    CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp, Bp, e3, 1, 1));
+  }
+  HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
+  if (I >= 32768u)
+    DISPATCH_NI(h->NI, full_rows_wave_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
+                h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
+                h->P(CDAE_P_BP_AG), h->d_touched);
+  else
+    DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
+                h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
+                h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
+  h->join_pending = true;
+  HIPCHK(hipEventRecord(x.released, st));
+  HIPCHK(hipGetLastError());
+  h->seq++;
+  h->acc_examples += bt.E; h->acc_batches++; h->acc_users += nb;
+  return 0;
+}
+
+int ev_phase0(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, uint64_t seed, uint32_t epoch) {
+  HIPCHK(hipSetDevice(h->device));
+  if (!h->d_shared || !h->item_shard) return fail("not an item-sharded handle with data");
+  if (nu == 0 || nu > EVAL_CHUNK || u0 + nu > h->U) return fail("bad evaluation chunk");
+  CHK(join_aux(h));
+  const uint32_t n_units = h->h_unit_ptr[u0 + nu] - h->h_unit_ptr[u0];
+  CHK(ensure_eval_ws(h, nu, std::max<uint32_t>(n_units, 1u)));
+  if (h->hsum_eval_cap < nu) {
+    if (h->d_hsum_eval) HIPCHK(hipFree(h->d_hsum_eval));
+    h->d_hsum_eval = nullptr; h->hsum_eval_cap = 0;
+    CHK(dev_alloc(&h->d_hsum_eval, (size_t)nu * h->Kp));
+    h->hsum_eval_cap = nu;
+  }
+  const uint32_t* uptr = h->d_unit_ptr + u0;
+  if (n_units)
+    DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+                h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, u0, nu, mode, mode ? CDAE_STREAM_LOSS_CORRUPT : CDAE_STREAM_CORRUPT, cidx,
+                seed, epoch, h->d_hpart_eval, (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user, (const uint32_t*)h->d_gpos);
+  DISPATCH_NI(h->NI, cdae::unit_sum_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_hpart_eval, uptr, nu, h->d_hsum_eval);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ev_finish(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode) {
+  HIPCHK(hipSetDevice(h->device));
+  DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_hsum_eval, (const uint32_t*)h->d_iota,
+              h->d_Wu, h->P(CDAE_P_B), (const uint32_t*)nullptr, u0, nu, mode, h->d_zeval, (float*)nullptr, (float*)nullptr, h->d_Uu,
+              (float*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int ev_data_loss(cdae_hip_t* h, uint64_t u0, uint32_t nu, double* sum) {
+  HIPCHK(hipSetDevice(h->device));
+  const uint32_t n_units = h->h_unit_ptr[u0 + nu] - h->h_unit_ptr[u0];
+  if (n_units == 0) return 0;
+  HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
+  DISPATCH_NI(h->NI, cdae::data_loss_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+              h->d_unit_ptr + u0, n_units, (const uint32_t*)h->d_unit_user, u0, nu, h->d_zeval, h->dec(), h->P(CDAE_P_BP), h->d_scalar);
+  HIPCHK(hipGetLastError());
+  double v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->d_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *sum += v;
+  return 0;
+}
+
+int ev_recommend(cdae_hip_t* h, uint64_t u0, uint32_t nu, uint32_t topk, uint32_t* ids, float* scores) {
+  HIPCHK(hipSetDevice(h->device));
+  if (topk == 0 || topk > h->I) return fail("topk %u exceeds the %llu items of this shard", topk, (unsigned long long)h->I);
+  const size_t lds_scores = (size_t)h->I * sizeof(float) + 64;
+  const bool in_lds = lds_scores <= 160 * 1024;
+  const size_t shmem = in_lds ? lds_scores : 64;
+  uint32_t Bq = nu;
+  if (!in_lds) {
+    Bq = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nu, (256ull << 20) / ((uint64_t)h->I * sizeof(float))));
+    if (h->score_cap < (size_t)Bq * h->I) {
+      if (h->d_score) HIPCHK(hipFree(h->d_score));
+      h->d_score = nullptr; h->score_cap = 0;
+      CHK(dev_alloc(&h->d_score, (size_t)Bq * h->I));
+      h->score_cap = (size_t)Bq * h->I;
+    }
+  }
+  if (h->rec_cap < (size_t)Bq * topk) {
+    if (h->d_rec) HIPCHK(hipFree(h->d_rec));
+    h->d_rec = nullptr; h->rec_cap = 0;
+    CHK(dev_alloc(&h->d_rec, (size_t)Bq * topk));
+    h->rec_cap = (size_t)Bq * topk;
+  }
+  if (h->rec_score_cap < (size_t)Bq * topk) {
+    if (h->d_rec_score) HIPCHK(hipFree(h->d_rec_score));
+    h->d_rec_score = nullptr; h->rec_score_cap = 0;
+    CHK(dev_alloc(&h->d_rec_score, (size_t)Bq * topk));
+    h->rec_score_cap = (size_t)Bq * topk;
+  }
+#define SET_SHMEM(NI_) HIPCHK(hipFuncSetAttribute((const void*)cdae::recommend_kernel<NI_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem))
+  switch (h->NI) { case 1: SET_SHMEM(1); break; case 2: SET_SHMEM(2); break; case 4: SET_SHMEM(4); break; default: SET_SHMEM(8); break; }
+#undef SET_SHMEM
+  for (uint32_t c0 = 0; c0 < nu; c0 += Bq) {
+    const uint32_t nb = std::min(Bq, nu - c0);
+    DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, u0 + c0,
+                h->d_zeval + (size_t)c0 * h->Kp, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score,
+                (const uint32_t*)nullptr, 0u, h->d_rec_score);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ids + (size_t)c0 * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(scores + (size_t)c0 * topk, h->d_rec_score, (size_t)nb * topk * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return 0;
 }
 
 }  // namespace cdae_internal

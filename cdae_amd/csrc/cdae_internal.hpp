@@ -29,9 +29,36 @@ size_t compact_count(const cdae_hip_t* h);
 int private_penalty(cdae_hip_t* h, double* out);
 // 0.5 * lambda * (|W|^2 + |V|^2 + |b|^2 + |b'|^2): the shared part
 int shared_penalty(cdae_hip_t* h, double* out);
+// 0.5 * lambda * (|W|^2 + |V|^2 + |b'|^2) (item rows only) and 0.5 * lambda * |b|^2: the pieces an item-sharded model adds up
+int item_rows_penalty(cdae_hip_t* h, double* out);
+int hidden_bias_penalty(cdae_hip_t* h, double* out);
 
 // exchange state owned by cdae_multi.hip, destroyed with the handle
 void*& exchange_slot(cdae_hip_t* h);
 void set_exchange_deleter(cdae_hip_t* h, void (*deleter)(void*));
+
+
+// ---- item-sharded layout (full-output decode) --------------------------------------------------------------
+// A shard is a complete handle over item rows [item0, item0 + I_local) and ALL users (Wu, b replicated and stepped
+// identically everywhere).  Two per-user sums cross shards in every batch — the input sum of the encode and the hidden
+// gradient — so a batch runs in three phases with an all-reduce(sum) of [n_users x row_stride] floats after the first two.
+int set_item_shard(cdae_hip_t* h, uint64_t item0, uint64_t num_items_global);      // before set_interactions
+// per user: (length of the WHOLE train row, position of the first local item in it) — the dropout stream is indexed by position
+// in the whole row, so a shard must know where its slice sits (after set_interactions)
+int set_item_shard_positions(cdae_hip_t* h, const uint32_t* len_and_first /* [2 U] */);
+uint32_t row_stride(const cdae_hip_t* h);
+int fs_prep(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_t nb, uint32_t cidx);   // positives list + bitmap, prep stream
+int fs_phase0(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_t nb, uint32_t cidx); // local input sums -> hsum_buf
+int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb);                                                // z, decode of the local items, local hg -> hg_buf
+int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb);                                                // hidden-layer steps, local row steps
+float* hsum_buf(cdae_hip_t* h);
+float* hg_buf(cdae_hip_t* h);
+// evaluation over users [u0, u0 + nu), nu <= eval_chunk(): mode 0 = inference encode, 1 = loss corruption `cidx`
+uint32_t eval_chunk();
+int ev_phase0(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, uint64_t seed, uint32_t epoch);   // local input sums -> ev_hsum_buf
+float* ev_hsum_buf(cdae_hip_t* h);
+int ev_finish(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode);                                                  // z of the chunk
+int ev_data_loss(cdae_hip_t* h, uint64_t u0, uint32_t nu, double* sum);                                            // += loss of the LOCAL positives
+int ev_recommend(cdae_hip_t* h, uint64_t u0, uint32_t nu, uint32_t topk, uint32_t* ids, float* scores);            // local top-k (local ids) with scores, host arrays
 
 }  // namespace cdae_internal

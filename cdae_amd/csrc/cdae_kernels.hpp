@@ -196,7 +196,8 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               uint32_t* __restrict__ seg /* [seg_words] cleared here for segment_kernel */, uint32_t seg_words,
               uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
               const uint32_t* __restrict__ unit_user /* global unit -> user id */,
-              uint32_t* __restrict__ item_count /* counting sort (cdae_sort_kernels.hpp): per-item example counts, zero on entry; or nullptr */) {
+              uint32_t* __restrict__ item_count /* counting sort (cdae_sort_kernels.hpp): per-item example counts, zero on entry; or nullptr */,
+              const uint32_t* __restrict__ gpos /* item shard: [2 U] (length of the user's WHOLE row, position of the first local item in it); else nullptr */) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
@@ -220,8 +221,10 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   uint32_t* lrow = lds_rows[wid];
   if (staged)
     for (uint32_t p = lane; p < n; p += WAVE) lrow[p] = row[p];           // the whole row: negatives are tested against it
+  // the dropout stream is indexed by the item's position in the user's WHOLE row: an item shard holds a slice of it
+  const uint32_t n_rng = gpos ? gpos[2 * uid] : n, p_rng0 = gpos ? gpos[2 * uid + 1] : 0u;
   for (uint32_t p = p0 + lane; p < p1; p += WAVE) {
-    const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+    const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n_rng + p_rng0 + p), hp.keep_thr);
     const uint64_t e = base + p;
     ex_item[e] = row[p];
     if (ex_key16) ex_key16[e] = (uint16_t)row[p];
@@ -326,7 +329,8 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
                       const uint32_t* __restrict__ uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream,
                       uint32_t cidx, uint64_t seed, uint32_t epoch, float* __restrict__ Hpart,
                       const uint32_t* __restrict__ explicit_in, uint32_t n_explicit,
-                      const uint32_t* __restrict__ unit_user /* nullptr unless uptr is a window of the data set's prefix */) {
+                      const uint32_t* __restrict__ unit_user /* nullptr unless uptr is a window of the data set's prefix */,
+                      const uint32_t* __restrict__ gpos = nullptr /* item shard: see sample_kernel */) {
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
@@ -339,6 +343,7 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, stream);
   const bool none = (mode == 0 && hp.keep_thr == 0x100000000ull);   // cdae.hpp:168-172 (q == 1 -> empty input)
   const uint32_t lo = lane * NI;
+  const uint32_t n_rng = gpos ? gpos[2 * uid] : n, p_rng0 = gpos ? gpos[2 * uid + 1] : 0u;
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
@@ -349,7 +354,7 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
     int keep = 0;
     if (p < p_end) {
       item = row[p];
-      keep = (mode == 0 || explicit_in) ? 1 : cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+      keep = (mode == 0 || explicit_in) ? 1 : cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n_rng + p_rng0 + p), hp.keep_thr);
     }
     unsigned long long mask = __ballot(keep);
     while (mask) {
@@ -1355,7 +1360,8 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
                  uint64_t u0, const float* __restrict__ Z, const float* __restrict__ D,
                  const float* __restrict__ bp, uint32_t topk, uint32_t* __restrict__ out,
                  float* __restrict__ score_ws /* [gridDim.x][num_items] or nullptr */,
-                 const uint32_t* __restrict__ rated_override, uint32_t n_override) {
+                 const uint32_t* __restrict__ rated_override, uint32_t n_override,
+                 float* __restrict__ out_score /* [gridDim.x][topk] scores of the winners, or nullptr (item-sharded top-k merge) */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red_v = reinterpret_cast<float*>(smem_raw);                         // [4]
   uint32_t* red_i = reinterpret_cast<uint32_t*>(red_v + 4);                  // [4] + winner at [4]
@@ -1411,6 +1417,7 @@ recommend_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint
       for (uint32_t w2 = 1; w2 < nw; ++w2)
         if (red_v[w2] > bv || (red_v[w2] == bv && red_i[w2] < bi)) { bv = red_v[w2]; bi = red_i[w2]; }
       out[(size_t)slot * topk + t] = bi;
+      if (out_score) out_score[(size_t)slot * topk + t] = bv;
       red_i[4] = bi;
     }
     __syncthreads();
@@ -1439,6 +1446,48 @@ fill_matrix_kernel(float* __restrict__ M, size_t rows, uint32_t K, uint32_t Kp, 
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * Kp) return;
   M[idx] = (uint32_t)(idx % Kp) < K ? value : pad;
+}
+
+// Item-sharded layout: the per-user input sum and hidden gradient of a shard cover ITS item rows only and are
+// all-reduced across shards, so the two reductions that encode_finish / hidden_finish fold in are also available alone.
+// Hsum[slot] = sum of the slot's unit partials (fixed order), raw: no scale, bias or activation
+template <int NI>
+__global__ void __launch_bounds__(256)
+unit_sum_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t* __restrict__ uptr, uint32_t nb, float* __restrict__ Hsum) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint32_t lo = lane * NI;
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  for (uint32_t u = ub; u < ue; ++u) {
+    float part[NI];
+    vload<NI>(part, Hpart + (size_t)u * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] += part[i];
+  }
+  vstore<NI>(Hsum + (size_t)slot * hp.Kp + lo, acc);
+}
+// HG[slot] = sum over the n_parts slabs of HGpart[x][rows][Kp] (fixed order)
+template <int NI>
+__global__ void __launch_bounds__(256)
+slab_sum_kernel(HyperParams hp, const float* __restrict__ HGpart, uint32_t n_parts, uint32_t rows, uint32_t nb, float* __restrict__ HG) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint32_t lo = lane * NI;
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  for (uint32_t x = 0; x < n_parts; ++x) {
+    float part[NI];
+    vload<NI>(part, HGpart + ((size_t)x * rows + slot) * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] += part[i];
+  }
+  vstore<NI>(HG + (size_t)slot * hp.Kp + lo, acc);
 }
 
 // data-parallel exchange helpers (no reference counterpart; DESIGN.md "Multi-GPU")

@@ -296,6 +296,11 @@ struct cdae_hip_multi {
   uint64_t U = 0, I = 0;
   int period = 0;
   uint32_t B = 0;
+  // CDAE_LAYOUT_ITEM_ROWS: the shards cut the ITEM rows (W / W_ag / V / V_ag / b' and the decode over them); icut = item ranges
+  uint32_t layout = 0;
+  std::vector<uint64_t> icut;
+  float* d_tmp = nullptr; size_t tmp_cap = 0;      // single-device all-reduce: the sum before it is copied back to every shard
+  hipEvent_t ev_done = nullptr;
 };
 
 namespace {
@@ -354,6 +359,85 @@ int local_epoch(cdae_hip_multi* m, const StepPlan& pl, uint64_t seed, uint32_t e
   return 0;
 }
 
+// all-reduce(sum) of one [n]-float buffer per shard, stream-ordered on the shards' main streams (item-sharded layout: the
+// phases of a batch are sequential anyway, nothing to overlap).  Distinct devices: RCCL, one group call from this thread.
+// One device: sum kernel into a scratch buffer on shard 0's stream, copied back to every shard.
+int all_reduce_bufs(cdae_hip_multi* m, const std::vector<float*>& bufs, size_t n) {
+  const size_t S = m->shard.size();
+  if (S == 1) return 0;
+  if (!m->single_device) {
+    NCCLCHK(ncclGroupStart());
+    for (size_t s = 0; s < S; ++s) {
+      ncclResult_t r = ncclAllReduce(bufs[s], bufs[s], n, ncclFloat32, ncclSum, m->comms[s], cdae_internal::main_stream(m->shard[s]));
+      if (r != ncclSuccess) { (void)ncclGroupEnd(); return fail("ncclAllReduce failed: %s", ncclGetErrorString(r)); }
+    }
+    NCCLCHK(ncclGroupEnd());
+    return 0;
+  }
+  HIPCHK(hipSetDevice(m->devices[0]));
+  if (m->tmp_cap < n) {
+    if (m->d_tmp) HIPCHK(hipFree(m->d_tmp));
+    m->d_tmp = nullptr; m->tmp_cap = 0;
+    HIPCHK(hipMalloc((void**)&m->d_tmp, n * sizeof(float)));
+    m->tmp_cap = n;
+  }
+  if (!m->ev_done) HIPCHK(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
+  hipStream_t s0 = cdae_internal::main_stream(m->shard[0]);
+  PeerPtrs pp{};
+  for (size_t s = 0; s < S; ++s) {
+    Exchange* x = xof(m->shard[s]);
+    HIPCHK(hipEventRecord(x->ev_staged, cdae_internal::main_stream(m->shard[s])));
+    HIPCHK(hipStreamWaitEvent(s0, x->ev_staged, 0));
+    pp.p[s] = bufs[s];
+  }
+  hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, s0, pp, (int)S, m->d_tmp, n);
+  HIPCHK(hipGetLastError());
+  for (size_t s = 0; s < S; ++s) HIPCHK(hipMemcpyAsync(bufs[s], m->d_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, s0));
+  HIPCHK(hipEventRecord(m->ev_done, s0));
+  for (size_t s = 1; s < S; ++s) HIPCHK(hipStreamWaitEvent(cdae_internal::main_stream(m->shard[s]), m->ev_done, 0));
+  return 0;
+}
+
+// one epoch of the item-sharded layout: every batch of users runs on EVERY shard (each over its item rows) in three phases
+int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end) {
+  const size_t S = m->shard.size();
+  const uint32_t Kp = cdae_internal::row_stride(m->shard[0]);
+  struct Bt { uint64_t s0; uint32_t nb, c; };
+  std::vector<Bt> plan;
+  for (uint64_t s0 = u_begin; s0 < u_end; s0 += m->B)
+    for (uint32_t c = 0; c < m->cfg.num_corruptions; ++c) plan.push_back(Bt{s0, (uint32_t)std::min<uint64_t>(m->B, u_end - s0), c});
+  if (plan.empty()) return 0;
+  std::vector<float*> hs(S), hg(S);
+  for (size_t s = 0; s < S; ++s) { hs[s] = cdae_internal::hsum_buf(m->shard[s]); hg[s] = cdae_internal::hg_buf(m->shard[s]); }
+  for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[0].s0, plan[0].nb, plan[0].c));
+  for (size_t t = 0; t < plan.size(); ++t) {
+    const Bt& b = plan[t];
+    for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_phase0(h, seed, epoch, b.s0, b.nb, b.c));
+    CHK(all_reduce_bufs(m, hs, (size_t)b.nb * Kp));                       // input sums over ALL item rows
+    if (t + 1 < plan.size())                                             // the next batch's example lists: prep streams, beside the decode
+      for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[t + 1].s0, plan[t + 1].nb, plan[t + 1].c));
+    for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_phase1(h, b.s0, b.nb));
+    CHK(all_reduce_bufs(m, hg, (size_t)b.nb * Kp));                       // hidden gradient over ALL item rows
+    for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_phase2(h, b.s0, b.nb));
+  }
+  for (cdae_hip_t* h : m->shard) CHK(cdae_hip_synchronize(h));
+  return 0;
+}
+
+// z of users [u0, u0 + nu) on every shard (evaluation): local input sums, all-reduce, activation
+int item_encode_chunk(cdae_hip_multi* m, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, uint64_t seed, uint32_t epoch) {
+  const size_t S = m->shard.size();
+  const uint32_t Kp = cdae_internal::row_stride(m->shard[0]);
+  std::vector<float*> bufs(S);
+  for (size_t s = 0; s < S; ++s) {
+    CHK(cdae_internal::ev_phase0(m->shard[s], u0, nu, mode, cidx, seed, epoch));
+    bufs[s] = cdae_internal::ev_hsum_buf(m->shard[s]);
+  }
+  CHK(all_reduce_bufs(m, bufs, (size_t)nu * Kp));
+  for (cdae_hip_t* h : m->shard) CHK(cdae_internal::ev_finish(h, u0, nu, mode));
+  return 0;
+}
+
 int check_multi(const cdae_hip_multi* m, bool need_data) {
   if (!m) return fail("null multi handle");
   if (need_data && m->U == 0) return fail("cdae_hip_multi_set_interactions must be called first");
@@ -389,6 +473,8 @@ int cdae_hip_multi_destroy(cdae_hip_multi_t* m) {
   if (!m) return 0;
   for (cdae_hip_t* h : m->shard) cdae_hip_destroy(h);      // (exchange state goes with the handle; communicators below)
   for (ncclComm_t c : m->comms) if (c) (void)ncclCommDestroy(c);
+  if (m->d_tmp) { (void)hipSetDevice(m->devices[0]); (void)hipFree(m->d_tmp); }
+  if (m->ev_done) (void)hipEventDestroy(m->ev_done);
   delete m;
   return 0;
 }
@@ -399,14 +485,79 @@ int cdae_hip_multi_shard(cdae_hip_multi_t* m, int shard, cdae_hip_t** handle, ui
   CHK(check_multi(m, false));
   if (shard < 0 || shard >= (int)m->shard.size()) return fail("shard %d out of range", shard);
   if (handle) *handle = m->shard[shard];
-  if (u_begin) *u_begin = m->cut.size() ? m->cut[shard] : 0;
-  if (u_end) *u_end = m->cut.size() ? m->cut[shard + 1] : 0;
+  const std::vector<uint64_t>& c = m->layout == CDAE_LAYOUT_ITEM_ROWS ? m->icut : m->cut;    // item ranges in the item-rows layout
+  if (u_begin) *u_begin = c.size() ? c[shard] : 0;
+  if (u_end) *u_end = c.size() ? c[shard + 1] : 0;
+  return 0;
+}
+
+int cdae_hip_multi_set_layout(cdae_hip_multi_t* m, uint32_t layout) {
+  CHK(check_multi(m, false));
+  if (layout > CDAE_LAYOUT_ITEM_ROWS) return fail("unknown layout %u", layout);
+  if (layout == CDAE_LAYOUT_ITEM_ROWS && !m->cfg.full_output) return fail("CDAE_LAYOUT_ITEM_ROWS exists for the full-output decode only");
+  if (m->U) return fail("set the layout before cdae_hip_multi_set_interactions");
+  m->layout = layout;
+  return 0;
+}
+
+static int set_interactions_item_rows(cdae_hip_multi* m, uint64_t U, uint64_t I, const int64_t* row_ptr, const uint32_t* col) {
+  const size_t S = m->shard.size();
+  if (I < S) return fail("%llu items cannot be split into %zu shards", (unsigned long long)I, S);
+  // contiguous item ranges balanced by interactions (column counts)
+  std::vector<uint64_t> cnt(I + 1, 0);
+  const int64_t nnz = row_ptr[U];
+  for (int64_t p = 0; p < nnz; ++p) {
+    if (col[p] >= I) return fail("item id %u out of range at position %lld", col[p], (long long)p);
+    cnt[col[p] + 1]++;
+  }
+  for (uint64_t i = 0; i < I; ++i) cnt[i + 1] += cnt[i];
+  m->icut.assign(S + 1, 0);
+  for (size_t s = 1; s < S; ++s) {
+    const uint64_t want = (uint64_t)(((__int128)nnz * (int64_t)s + (int64_t)S - 1) / (int64_t)S);
+    uint64_t i = (uint64_t)(std::lower_bound(cnt.begin(), cnt.end(), want) - cnt.begin());
+    i = std::max<uint64_t>(i, m->icut[s - 1] + 1);
+    i = std::min<uint64_t>(i, I - (S - s));
+    m->icut[s] = i;
+  }
+  m->icut[S] = I;
+  std::vector<int64_t> rp(U + 1);
+  std::vector<uint32_t> lc, pos(2 * U);
+  for (size_t s = 0; s < S; ++s) {
+    const uint32_t i0 = (uint32_t)m->icut[s], i1 = (uint32_t)m->icut[s + 1];
+    lc.clear();
+    rp[0] = 0;
+    for (uint64_t u = 0; u < U; ++u) {                     // rows are ascending: the slice is one sub-range
+      const uint32_t* a = col + row_ptr[u];
+      const uint32_t* b = col + row_ptr[u + 1];
+      if (b <= a) return fail("user %llu has no training item (the reference CHECK-fails too, cdae.hpp:139)", (unsigned long long)u);
+      const uint32_t* lo = std::lower_bound(a, b, i0);
+      const uint32_t* hi = std::lower_bound(lo, b, i1);
+      for (const uint32_t* q = lo; q < hi; ++q) lc.push_back(*q - i0);
+      rp[u + 1] = (int64_t)lc.size();
+      pos[2 * u] = (uint32_t)(b - a); pos[2 * u + 1] = (uint32_t)(lo - a);
+    }
+    CHK(cdae_internal::set_item_shard(m->shard[s], i0, I));
+    static const uint32_t none = 0;
+    CHK(cdae_hip_set_interactions(m->shard[s], U, i1 - i0, rp.data(), lc.empty() ? &none : lc.data()));
+    CHK(cdae_internal::set_item_shard_positions(m->shard[s], pos.data()));
+  }
+  m->cut.assign(S + 1, 0);
+  m->cut[S] = U;                                           // (user ranges are not used in this layout)
+  m->U = U; m->I = I;
+  m->B = cdae_internal::batch_users(m->shard[0]);
+  std::vector<Exchange*> xs(S, nullptr);
+  for (size_t s = 0; s < S; ++s) CHK(make_exchange(m->shard[s], &xs[s]));
+  if (S > 1 && !m->single_device && m->comms.empty()) {
+    m->comms.assign(S, nullptr);
+    NCCLCHK(ncclCommInitAll(m->comms.data(), (int)S, m->devices.data()));
+  }
   return 0;
 }
 
 int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t U, uint64_t I, const int64_t* row_ptr, const uint32_t* col) {
   CHK(check_multi(m, false));
   if (!row_ptr || U == 0) return fail("bad argument");
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) return set_interactions_item_rows(m, U, I, row_ptr, col);
   const size_t S = m->shard.size();
   if (U < S) return fail("%llu users cannot be split into %zu shards", (unsigned long long)U, S);
   // contiguous user ranges balanced by interactions; every shard gets at least one user
@@ -450,7 +601,7 @@ int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t U, uint64_t I,
 int cdae_hip_multi_init_params(cdae_hip_multi_t* m, uint64_t seed) {
   CHK(check_multi(m, true));
   for (cdae_hip_t* h : m->shard) CHK(cdae_hip_init_params(h, seed));     // identical shared blocks; Wu rows by global user id
-  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); x->begun = false; x->pending = false; x->steps = 0; }
+  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); if (x) { x->begun = false; x->pending = false; x->steps = 0; } }
   return 0;
 }
 
@@ -463,9 +614,31 @@ int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period) {
 
 int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats) {
   CHK(check_multi(m, true));
+  return cdae_hip_multi_train_users(m, seed, epoch, 0, m->U, stats);
+}
+
+int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end, cdae_hip_stats* stats) {
+  CHK(check_multi(m, true));
+  if (u_begin > u_end || u_end > m->U) return fail("bad user range");
+  if (m->layout != CDAE_LAYOUT_ITEM_ROWS && (u_begin != 0 || u_end != m->U))
+    return fail("the user-sharded layout trains whole epochs (every shard walks its own users): use cdae_hip_multi_train_epoch");
   const auto t0 = std::chrono::steady_clock::now();
   const StepPlan pl = plan_of(m);
   const size_t S = m->shard.size();
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
+    CHK(item_epoch(m, seed, epoch, u_begin, u_end));
+    if (stats) {
+      std::memset(stats, 0, sizeof *stats);
+      for (size_t s = 0; s < S; ++s) {
+        cdae_hip_stats st;
+        CHK(cdae_hip_collect_stats(m->shard[s], &st));
+        if (s == 0) { stats->users = st.users; stats->batches = st.batches; }     // every shard sees every user
+        stats->examples += st.examples;
+      }
+      stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
+  }
   if (S == 1) {
     CHK(cdae_hip_train_epoch(m->shard[0], seed, epoch, stats));
     return 0;
@@ -501,6 +674,18 @@ int cdae_hip_multi_data_loss(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch,
   CHK(check_multi(m, true));
   if (!out) return fail("null argument");
   double total = 0;
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {                  // every shard adds the loss of ITS positives, z from the all-reduced sums
+    const uint32_t chunk = cdae_internal::eval_chunk();
+    for (uint64_t u0 = 0; u0 < m->U; u0 += chunk) {
+      const uint32_t nu = (uint32_t)std::min<uint64_t>(chunk, m->U - u0);
+      for (uint32_t c = 0; c < m->cfg.num_corruptions; ++c) {
+        CHK(item_encode_chunk(m, u0, nu, 1, c, seed, epoch));
+        for (cdae_hip_t* h : m->shard) CHK(cdae_internal::ev_data_loss(h, u0, nu, &total));
+      }
+    }
+    *out = total / (double)m->cfg.num_corruptions;           // cdae.hpp:98
+    return 0;
+  }
   for (cdae_hip_t* h : m->shard) { double v = 0; CHK(cdae_hip_data_loss(h, seed, epoch, &v)); total += v; }   // sum over users, cdae.hpp:99
   *out = total;
   return 0;
@@ -510,6 +695,13 @@ int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out) {
   CHK(check_multi(m, true));
   if (!out) return fail("null argument");
   double total = 0, v = 0;
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
+    for (cdae_hip_t* h : m->shard) { CHK(cdae_internal::item_rows_penalty(h, &v)); total += v; }     // every shard's own rows
+    CHK(cdae_internal::hidden_bias_penalty(m->shard[0], &v)); total += v;                             // b and Wu are replicated: once
+    CHK(cdae_internal::private_penalty(m->shard[0], &v)); total += v;
+    *out = total;
+    return 0;
+  }
   CHK(cdae_internal::shared_penalty(m->shard[0], &v)); total += v;         // replicas agree after every epoch's flush
   for (cdae_hip_t* h : m->shard) { CHK(cdae_internal::private_penalty(h, &v)); total += v; }
   *out = total;
@@ -519,6 +711,36 @@ int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out) {
 int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out) {
   CHK(check_multi(m, true));
   if (u_begin > u_end || u_end > m->U || !out) return fail("bad user range");
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
+    // every shard ranks ITS items for the chunk's users (scores kept), the host merges the candidates: descending score, ties to
+    // the lower item id (heap.hpp:44-52 + utils.hpp:16-19 over ascending ids)
+    const size_t S = m->shard.size();
+    for (size_t s = 0; s < S; ++s)
+      if (topk > m->icut[s + 1] - m->icut[s]) return fail("topk %u exceeds the %llu items of shard %zu", topk, (unsigned long long)(m->icut[s + 1] - m->icut[s]), s);
+    const uint32_t chunk = cdae_internal::eval_chunk();
+    std::vector<uint32_t> ids;
+    std::vector<float> sc;
+    std::vector<std::pair<float, uint32_t>> cand(S * topk);
+    for (uint64_t u0 = u_begin; u0 < u_end; u0 += chunk) {
+      const uint32_t nu = (uint32_t)std::min<uint64_t>(chunk, u_end - u0);
+      CHK(item_encode_chunk(m, u0, nu, 0, 0, 0, 0));
+      ids.resize(S * (size_t)nu * topk); sc.resize(ids.size());
+      for (size_t s = 0; s < S; ++s)
+        CHK(cdae_internal::ev_recommend(m->shard[s], u0, nu, topk, ids.data() + s * (size_t)nu * topk, sc.data() + s * (size_t)nu * topk));
+      for (uint32_t u = 0; u < nu; ++u) {
+        for (size_t s = 0; s < S; ++s)
+          for (uint32_t t = 0; t < topk; ++t) {
+            const size_t at = s * (size_t)nu * topk + (size_t)u * topk + t;
+            cand[s * topk + t] = std::make_pair(sc[at], ids[at] == 0xFFFFFFFFu ? 0xFFFFFFFFu : ids[at] + (uint32_t)m->icut[s]);
+          }
+        std::sort(cand.begin(), cand.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+          return a.first > b.first || (a.first == b.first && a.second < b.second);
+        });
+        for (uint32_t t = 0; t < topk; ++t) out[((u0 - u_begin) + u) * topk + t] = cand[t].second;
+      }
+    }
+    return 0;
+  }
   for (size_t s = 0; s < m->shard.size(); ++s) {
     const uint64_t a = std::max(u_begin, m->cut[s]), b = std::min(u_end, m->cut[s + 1]);
     if (b > a) CHK(cdae_hip_recommend_all(m->shard[s], a - m->cut[s], b - m->cut[s], topk, out + (a - u_begin) * topk));
@@ -528,8 +750,20 @@ int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t
 
 static bool is_private(uint32_t which) { return which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG; }
 
+static bool is_item_rows(uint32_t which) {
+  return which == CDAE_P_W || which == CDAE_P_W_AG || which == CDAE_P_V || which == CDAE_P_V_AG || which == CDAE_P_BP || which == CDAE_P_BP_AG;
+}
+
 int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, size_t count) {
   CHK(check_multi(m, true));
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
+    if (!is_item_rows(which)) return cdae_hip_get_param(m->shard[0], which, host, count);          // replicated
+    const size_t w = (which == CDAE_P_BP || which == CDAE_P_BP_AG) ? 1 : m->cfg.num_dim;
+    if (count != m->I * w) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->I * w), count);
+    for (size_t s = 0; s < m->shard.size(); ++s)
+      CHK(cdae_hip_get_param(m->shard[s], which, host + m->icut[s] * w, (m->icut[s + 1] - m->icut[s]) * w));
+    return 0;
+  }
   if (!is_private(which)) return cdae_hip_get_param(m->shard[0], which, host, count);
   const size_t K = m->cfg.num_dim;
   if (count != m->U * K) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->U * K), count);
@@ -540,6 +774,14 @@ int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, s
 
 int cdae_hip_multi_set_param(cdae_hip_multi_t* m, uint32_t which, const float* host, size_t count) {
   CHK(check_multi(m, true));
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
+    if (!is_item_rows(which)) { for (cdae_hip_t* h : m->shard) CHK(cdae_hip_set_param(h, which, host, count)); return 0; }
+    const size_t w = (which == CDAE_P_BP || which == CDAE_P_BP_AG) ? 1 : m->cfg.num_dim;
+    if (count != m->I * w) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->I * w), count);
+    for (size_t s = 0; s < m->shard.size(); ++s)
+      CHK(cdae_hip_set_param(m->shard[s], which, host + m->icut[s] * w, (m->icut[s + 1] - m->icut[s]) * w));
+    return 0;
+  }
   if (!is_private(which)) {
     for (cdae_hip_t* h : m->shard) CHK(cdae_hip_set_param(h, which, host, count));
   } else {

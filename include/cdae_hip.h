@@ -262,6 +262,17 @@ int cdae_hip_exchange_time_all_reduce(cdae_hip_t* h, int repeats, double* second
  * (tests, accuracy envelope).  Users are cut into contiguous ranges balanced by interactions; Wu / Wu_ag stay on their
  * shard; get/set_param address the global matrices.  Every entry point mirrors its single-handle namesake. */
 typedef struct cdae_hip_multi cdae_hip_multi_t;
+/* How the shards divide the model (set before _set_interactions):
+ *   CDAE_LAYOUT_USERS      (default) user shards + exchange of shared-parameter deltas, as described above.
+ *   CDAE_LAYOUT_ITEM_ROWS  full_output only (BASELINE configs[4]: 1 M items x K=512, whose dense delta would be 2 GB): every shard
+ *       owns a contiguous range of ITEM rows — W / W_ag / (V / V_ag) / b' and the three products of the decode over them — and
+ *       sees every user; Wu and b are replicated and stepped identically everywhere.  Per batch two all-reduces of
+ *       [batch_users x row_stride] floats cross the shards (the input sums of the encode, the hidden gradient); no parameter
+ *       ever does.  The schedule is the single-GPU full-output schedule EXACTLY (same steps, same order; only the two sums are
+ *       associated differently), so this layout has no accuracy cost.  _shard() reports item ranges in this layout. */
+#define CDAE_LAYOUT_USERS 0u
+#define CDAE_LAYOUT_ITEM_ROWS 1u
+int cdae_hip_multi_set_layout(cdae_hip_multi_t* m, uint32_t layout);
 int cdae_hip_multi_create(const cdae_hip_config* cfg, int n_shards, const int* device_ids, cdae_hip_multi_t** out);
 int cdae_hip_multi_destroy(cdae_hip_multi_t* m);
 int cdae_hip_multi_num_shards(const cdae_hip_multi_t* m);
@@ -271,6 +282,9 @@ int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t num_users, uin
 int cdae_hip_multi_init_params(cdae_hip_multi_t* m, uint64_t seed);
 int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period);
 int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
+/* users [u_begin, u_end) only — CDAE_LAYOUT_ITEM_ROWS (every shard sees every user); the user-sharded layout trains whole epochs */
+int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end,
+                               cdae_hip_stats* stats);
 int cdae_hip_multi_data_loss(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, double* out);
 int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out);
 int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out);

@@ -19,13 +19,16 @@
 // libcf::Random, i.e. time-seeded like yelp.cpp:107), CDAE_DEVICE (HIP device index), CDAE_DEVICES (comma list, e.g.
 // 0,1,2,3: Solver<CDAE>::train runs data-parallel over these GPUs through cdae_hip_multi_* — users sharded, shared
 // parameters exchanged by RCCL inside the library; a repeated id, e.g. 0,0, makes logical shards of one GPU),
-// CDAE_EXCHANGE_EVERY (0 = synchronous exchange at every step, the default; k = pipelined every k steps).
+// CDAE_EXCHANGE_EVERY (0 = synchronous exchange at every step, the default; k = pipelined every k steps),
+// CDAE_LAYOUT=item_rows (with CDAE_FULL_OUTPUT=1: the shards cut the ITEM rows instead of the users — the exact single-GPU
+// full-output schedule, two small all-reduces per batch, no accuracy cost; BASELINE configs[4]'s layout).
 // The data-parallel schedule is NOT inside the accuracy envelope of the single-GPU one.
 #ifndef CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 #define CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -108,6 +111,9 @@ class CDAE : public RecsysModelBase {
       CDAE_HIP_CHECK(cdae_hip_multi_create(&c, static_cast<int>(devices.size()), devices.data(), &raw));
       multi_.reset(raw, [](cdae_hip_multi_t* m) { cdae_hip_multi_destroy(m); });
       CDAE_HIP_CHECK(cdae_hip_multi_set_exchange(raw, static_cast<int>(env_u64("CDAE_EXCHANGE_EVERY", 0))));
+      const char* layout = std::getenv("CDAE_LAYOUT");      // "item_rows": the shards cut the item rows (full-output decode only; exact)
+      item_rows_ = layout && std::string(layout) == "item_rows";
+      if (item_rows_) CDAE_HIP_CHECK(cdae_hip_multi_set_layout(raw, CDAE_LAYOUT_ITEM_ROWS));
       CDAE_HIP_CHECK(cdae_hip_multi_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
       CDAE_HIP_CHECK(cdae_hip_multi_init_params(raw, seed_));
       LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES), exchange every " << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
@@ -168,6 +174,7 @@ class CDAE : public RecsysModelBase {
     for (size_t u = 0; u < num_users_; ++u) uids[u] = static_cast<uint32_t>(u);
     std::vector<float> z(num_users_ * cfg_.num_dim);
     if (multi_) {
+      CHECK(!item_rows_) << "get_user_representations is not provided in the item-rows layout";
       for (int s = 0; s < cdae_hip_multi_num_shards(multi_.get()); ++s) {       // every shard encodes its own users
         cdae_hip_t* h = nullptr; uint64_t a = 0, b = 0;
         CDAE_HIP_CHECK(cdae_hip_multi_shard(multi_.get(), s, &h, &a, &b));
@@ -203,6 +210,7 @@ class CDAE : public RecsysModelBase {
       CHECK(ready()) << "reset() must be called first";
       cdae_hip_t* h = dev_.get();
       uint64_t local = uid;
+      CHECK(!(multi_ && item_rows_)) << "recommend() with a foreign rated set is not provided in the item-rows layout";
       if (multi_) {                                          // the shard that owns the user (its Wu row lives there)
         for (int s = 0; s < cdae_hip_multi_num_shards(multi_.get()); ++s) {
           uint64_t a = 0, b = 0;
@@ -275,6 +283,7 @@ class CDAE : public RecsysModelBase {
   CDAEConfig cfg_;
   std::shared_ptr<cdae_hip_t> dev_;                  // shared by copies: Solver copies the model (solver.hpp:17)
   std::shared_ptr<cdae_hip_multi_t> multi_;          // instead of dev_ when CDAE_DEVICES names several shards
+  bool item_rows_ = false;
   std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
   mutable std::shared_ptr<const Table> rec_;
   std::shared_ptr<const Csr> train_csr_;             // host copy of the train rows (recommend: is the caller's set the train row?)

@@ -59,3 +59,16 @@ def test_exchange_path_with_a_one_rank_rccl_group(built):
                                               "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     check(d)
     assert d["config"]["exchange"] != "none"
+
+
+def test_item_rows_layout_line(built):
+    """--layout item-rows (the configs[4] layout) on one GPU with logical shards: same contract keys, strong scaling by definition"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shape", "small", "--steps", "4", "--warmup", "1", "--batch-users", "128",
+                          "--num-dim", "64", "--full-output", "--layout", "item-rows", "--logical-shards", "3", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    for k, t in REQUIRED.items():
+        assert k in d, k
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "mfma"
+    assert "item-rows x3" in d["config"]["parallelism"]

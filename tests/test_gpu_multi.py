@@ -185,3 +185,71 @@ def test_bad_shard_layouts_are_rejected(built):
     m = cdae_amd.MultiCDAE(cfg_of(), devices=[0, 0])
     with pytest.raises(cdae_amd.CDAEError):
         m.train_one_iteration(1, 0)                              # no data yet
+
+
+# ---- CDAE_LAYOUT_ITEM_ROWS: the shards cut the item rows (full-output decode; BASELINE configs[4] layout) ---------------------
+def _param_range_err(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / (1e-3 + np.abs(b).max()))
+
+
+@pytest.mark.parametrize("K,B,shards", [(24, 48, 2), (24, 300, 3), (200, 64, 4), (300, 64, 2), (512, 32, 3)])
+def test_item_rows_layout_is_the_single_gpu_full_output_schedule(built, K, B, shards):
+    """Every shard owns a range of item rows and sees every user; two [batch x K] all-reduces per batch.  Same steps in the same
+    order as the single handle — only the two cross-shard sums are associated differently (fp32), and z passes through bf16 on
+    its way into the products, so a last-bit difference in z can move a product by one bf16 ulp: parameters agree to 5e-3 of
+    their range after two epochs (the single handle itself is 2e-2 … 3e-2 from the fp64 oracle, tests/test_gpu_parity.py)."""
+    d = synth.generate_shape("tiny", seed=5)
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, full_output=True, **HYPER)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(d, seed=11)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards, item_rows=True)
+    mm.reset(d, seed=11)
+    cuts = mm.shards()                                          # item ranges in this layout
+    assert cuts[0][0] == 0 and cuts[-1][1] == d.num_items and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    for which in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]:     # W rows are initialised by GLOBAL item id
+        np.testing.assert_array_equal(mm.get(which), one.get(which))
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+        one.train_one_iteration(3, ep)
+        assert st.users == d.num_users and st.examples == d.nnz_train
+    errs = {w: _param_range_err(mm.get(w), one.get(w)) for w in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]}
+    print("\nitem-rows layout vs single handle:", {k: round(v, 6) for k, v in errs.items()})
+    assert max(errs.values()) < 5e-3, errs
+    # reported loss and top-10 of the SAME parameters: copy the single handle's into the shards
+    for which in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]:
+        mm.set(which, one.get(which))
+        np.testing.assert_array_equal(mm.get(which), one.get(which))
+    la, lb = mm.current_loss(5, 0), one.current_loss(5, 0)
+    assert abs(la - lb) <= 2e-5 * abs(lb), (la, lb)
+    topk = 10
+    rec_m, rec_o = mm.recommend_all(topk), one.recommend_all(topk)
+    agree = (rec_m == rec_o).all(axis=1).mean()
+    assert agree > 0.97, agree                                  # near-ties may swap (fp32 sum order of the encode)
+    for u in range(d.num_users):
+        rated = d.train_col[d.train_ptr[u]:d.train_ptr[u + 1]]
+        assert len(set(rec_m[u].tolist())) == topk and not np.intersect1d(rec_m[u], rated).size
+
+
+def test_item_rows_layout_tracks_the_oracle_block_schedule(built):
+    d = synth.generate_shape("tiny", seed=5)
+    import oracle as orc
+    from oracle import binding as ob
+    K, B = 24, 48
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, full_output=True, **HYPER)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0, 0, 0], item_rows=True)
+    mm.reset(d, seed=11)
+    o = orc.Oracle(orc.OracleConfig(num_dim=K, loss_type=ob.LOSS_CE, **HYPER), d.num_users, d.num_items, d.train_ptr, d.train_col)
+    o.init_params(11)
+    for which in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]:
+        o.set(which, mm.get(which).astype(np.float64))
+    for ep in range(2):
+        mm.train_one_iteration(4, ep)
+        o.train_full(4, ep, B)
+    for which in SHARED + [cdae_amd.P_WU]:
+        ref = o.get(which)
+        assert np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()) < 2e-2
+
+
+def test_item_rows_layout_needs_full_output(built):
+    with pytest.raises(cdae_amd.CDAEError):
+        cdae_amd.MultiCDAE(cfg_of(), devices=[0, 0], item_rows=True)

@@ -175,3 +175,26 @@ def test_reference_yelp_app_trains_data_parallel_through_the_c_abi(host_bins, tm
         assert max(float(r.split("|")[8]) for r in rows[2:]) > pop_r10
         tables.append([r.split("|")[2:10] for r in rows[2:]])      # loss + the eight TOPN columns (not the time columns)
     assert tables[0] == tables[1]                                  # deterministic: same shards, same seed, same table
+
+
+@pytest.mark.gpu
+def test_reference_yelp_app_trains_full_output_in_the_item_rows_layout(host_bins, tmp_path):
+    """CDAE_LAYOUT=item_rows + CDAE_FULL_OUTPUT=1 + CDAE_DEVICES: the unmodified yelp app on the configs[4] layout (logical shards of
+    GPU 0).  It is the single-GPU full-output schedule, so its table tracks the single-GPU run's."""
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    tables = []
+    for env in ({}, {"CDAE_DEVICES": "0,0,0", "CDAE_LAYOUT": "item_rows"}):
+        rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.5", "--scaled=true",
+                       "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "64", "CDAE_FULL_OUTPUT": "1", **env})
+        assert rc == 0, out[-3000:]
+        rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+        assert len(rows) == 2 + 51
+        tables.append(np.array([[float(x) for x in r.split("|")[2:10]] for r in rows[2:]]))
+    loss_a, loss_b = tables[0][1:, 0], tables[1][1:, 0]            # (iteration 0 is the untrained model: no loss printed)
+    assert np.abs(loss_b / loss_a - 1).max() < 5e-3                # the same schedule: loss curves coincide
+    assert np.abs(tables[1][:, 6] - tables[0][:, 6]).max() < 0.02  # Recall@10 column (300 users: one hit = 0.003)
