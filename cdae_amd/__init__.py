@@ -4,7 +4,7 @@ Layout: csrc/ (gfx950 kernels + C ABI, built into lib/libcdae_hip.so), binding.p
 libcf::CDAE-shaped host class), synth.py (BASELINE-shaped synthetic data), distributed.py (one process
 per GPU, RCCL all-reduce of the shared-parameter deltas).
 """
-from .binding import (CDAE, MultiCDAE, comm_unique_id, CDAEConfig, CDAEError, CROSS_ENTROPY, SQUARE, LOGISTIC, Stats,  # noqa: F401
+from .binding import (CDAE, MultiCDAE, MF, MFConfig, comm_unique_id, CDAEConfig, HINGE, LOG, P_UB, P_UB_AG, CDAEError, CROSS_ENTROPY, SQUARE, LOGISTIC, Stats,  # noqa: F401
                       load_library, LIB_PATH, EXPORTS, P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG,
                       P_UU, P_UU_AG, P_COUNT)
 from . import synth  # noqa: F401

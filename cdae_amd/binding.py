@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcdae_hip.so")
 SQUARE, LOGISTIC, LOG, HINGE, SQUARED_HINGE, CROSS_ENTROPY, LOGM = range(7)
 
 P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG, P_UU, P_UU_AG = range(12)
-P_COUNT = 12
+P_UB, P_UB_AG = 12, 13
+P_COUNT = 14
 
 DEFAULT_BATCH_USERS = 0        # 0 = the library's default (num_users / 160, within [32, 512])
 
@@ -30,6 +31,11 @@ class _Config(C.Structure):
         "struct_size", "num_dim", "num_neg", "num_corruptions", "loss_type", "using_adagrad",
         "asymmetric", "user_factor", "linear", "scaled", "tanh_act", "batch_users", "full_output", "linear_function")] + [
             (n, C.c_double) for n in ("lambda_", "learn_rate", "corruption_ratio", "beta")]
+
+
+class _MfConfig(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "num_dim", "num_neg", "loss_type", "using_adagrad", "using_bias_term",
+                                          "pairwise", "batch_users")] + [(n, C.c_double) for n in ("lambda_", "learn_rate", "beta")]
 
 
 class Stats(C.Structure):
@@ -47,6 +53,7 @@ EXPORTS = {
     "cdae_hip_last_error": (C.c_char_p, []),
     "cdae_hip_abi_version": (C.c_int, []),
     "cdae_hip_create": (C.c_int, [C.POINTER(_Config), C.c_int, C.POINTER(C.c_void_p)]),
+    "cdae_hip_create_mf": (C.c_int, [C.POINTER(_MfConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "cdae_hip_destroy": (C.c_int, [C.c_void_p]),
     "cdae_hip_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cdae_hip_row_stride": (C.c_uint32, [C.c_void_p]),
@@ -382,6 +389,41 @@ class CDAE:
         v = C.c_double()
         _chk(self.lib, self.lib.cdae_hip_exchange_time_all_reduce(self.h, repeats, C.byref(v)))
         return v.value
+
+
+@dataclass
+class MFConfig:
+    """libcf::IMFConfig / BPRConfig (/root/reference/src/model/recsys/imf.hpp:12-23, bpr.hpp:12-24); pairwise=True is BPR."""
+    learn_rate: float = 0.1
+    beta: float = 1.0
+    lambda_: float = 0.01
+    lt: int = SQUARE
+    num_dim: int = 10
+    num_neg: int = 5
+    using_bias_term: bool = True
+    using_adagrad: bool = True
+    pairwise: bool = False
+    batch_users: int = DEFAULT_BATCH_USERS
+
+
+class MF(CDAE):
+    """Host mirror of libcf::IMF / libcf::BPR over the same C ABI handle (cdae_hip_create_mf).  get / set use P_WU = uv_,
+    P_W = iv_, P_UB = ub_, P_BP = ib_ (and their *_AG accumulators)."""
+
+    def __init__(self, mcfg: MFConfig, device: int = 0):
+        self.lib = load_library()
+        self.cfg = mcfg
+        c = _MfConfig(C.sizeof(_MfConfig), mcfg.num_dim, mcfg.num_neg, mcfg.lt, int(mcfg.using_adagrad), int(mcfg.using_bias_term),
+                      int(mcfg.pairwise), mcfg.batch_users, mcfg.lambda_, mcfg.learn_rate, mcfg.beta)
+        self.h = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_create_mf(C.byref(c), device, C.byref(self.h)))
+        self.num_users = self.num_items = 0
+        self._rec = None
+
+    def _shape(self, which):
+        if which in (P_UB, P_UB_AG):
+            return (self.num_users,)
+        return CDAE._shape(self, which)
 
 
 def comm_unique_id() -> bytes:

@@ -24,6 +24,7 @@
 #include "cdae_full_kernels.hpp"
 #include "cdae_recommend_kernels.hpp"
 #include "cdae_sort_kernels.hpp"
+#include "cdae_mf_kernels.hpp"
 
 #ifdef CDAE_DECODE_TIMING
 #define CDAE_TOUCHED_ARG ((uint32_t*)nullptr)     // the timing build borrows `touched` for its stamps
@@ -159,6 +160,11 @@ struct cdae_hip {
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr; float* d_snap = nullptr;   // agreed state, staged delta, all-reduced delta, parameters at the last stage
   void* xchg = nullptr; void (*xchg_free)(void*) = nullptr;   // communicator + schedule of the exchange (cdae_multi.hip)
+  // IMF / BPR handles (cdae_hip_create_mf, cdae_mf_kernels.hpp): 0 = CDAE, 1 = IMF, 2 = BPR
+  uint32_t mf = 0, mf_bias = 1;
+  uint32_t ex_per_pos = 1;              // examples of the batch's item-sorted list per train interaction (CDAE: 1 + num_neg)
+  float* d_ub = nullptr; float* d_ub_ag = nullptr;   // [U] user bias and its accumulator
+  float* d_UVpre = nullptr;             // [instances of a batch][Kp]: user vector before each instance's step (phase I input)
   // item-sharded layout (cdae_multi.hip): this handle holds item rows [item0, item0 + I) of I_global; every user,
   // possibly with no local item.  The two per-user sums that cross shards live in d_Hsum (input sums) and d_HG (hidden gradient).
   bool item_shard = false; uint64_t item0 = 0, I_global = 0;
@@ -181,6 +187,8 @@ struct cdae_hip {
     if (which == CDAE_P_WU_AG) return d_Wu_ag;
     if (which == CDAE_P_UU) return d_Uu;
     if (which == CDAE_P_UU_AG) return d_Uu_ag;
+    if (which == CDAE_P_UB) return d_ub;
+    if (which == CDAE_P_UB_AG) return d_ub_ag;
     return cnt[which] ? d_shared + off[which] : nullptr;
   }
   float* dec() { return cfg.asymmetric ? P(CDAE_P_V) : P(CDAE_P_W); }
@@ -248,7 +256,7 @@ void free_all(cdae_hip* h) {
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
-                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos};
+                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -275,7 +283,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
-                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos};
+                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -311,6 +319,10 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
     HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(x.dup_count, 0, sizeof(uint32_t), st));
+  } else if (h->mf) {
+    hipLaunchKernelGGL(mf_sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->mf == 2 ? 1u : 0u, h->d_row_ptr, h->d_col,
+                       h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, seed, epoch, x.item, x.val, x.key16, x.seg, 2u * I, x.dup_count,
+                       x.dup_of_ex, h->d_unit_user);
   } else
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
@@ -613,6 +625,40 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   return 0;
 }
 
+// IMF / BPR: one block of users (cdae_mf_kernels.hpp).  A block of one user is the reference loop itself (in place).
+int compute_batch_mf(cdae_hip* h, int b, const Batch& bt) {
+  using namespace cdae;
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I, nb = bt.nb;
+  const dim3 blk(256), grid_users((nb + 3) / 4);
+  Prof pr;
+  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  CHK(pr.begin(h, F_DECODE, st));
+#define MF_USER(NI_, PAIR_, INP_)                                                                                                   \
+  hipLaunchKernelGGL((mf_user_kernel<NI_, PAIR_, INP_>), grid_users, blk, 0, st, h->hp, h->mf_bias, h->d_row_ptr, bt.s0, nb, x.item, \
+                     h->d_Wu, h->d_Wu_ag, h->d_ub, h->d_ub_ag, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), \
+                     h->d_UVpre, h->d_G)
+#define MF_USER_NI(NI_)                                                              \
+  do {                                                                               \
+    if (h->mf == 2) { if (nb == 1) MF_USER(NI_, true, true); else MF_USER(NI_, true, false); }     \
+    else { if (nb == 1) MF_USER(NI_, false, true); else MF_USER(NI_, false, false); }              \
+  } while (0)
+  switch (h->NI) { case 1: MF_USER_NI(1); break; case 2: MF_USER_NI(2); break; case 4: MF_USER_NI(4); break; default: MF_USER_NI(8); break; }
+#undef MF_USER_NI
+#undef MF_USER
+  CHK(pr.end());
+  if (nb > 1) {
+    CHK(pr.begin(h, F_INPUT, st));
+    DISPATCH_NI(h->NI, mf_item_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, h->mf_bias, h->d_item_order, x.seg, x.seg + I, x.sorted_val,
+                h->d_UVpre, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG));
+    CHK(pr.end());
+  }
+  HIPCHK(hipEventRecord(x.released, st));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // z for nb users: a contiguous range [u0, u0+nb) (d_uids == nullptr) or the list d_uids (prefix in d_uptr_tmp)
 int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream_id,
                  uint32_t cidx, uint64_t seed, uint32_t epoch, uint32_t n_units_list = 0, float* z_out = nullptr,
@@ -652,10 +698,11 @@ int ensure_eval_ws(cdae_hip* h, uint32_t users, uint32_t units) {
 int copy_param_out(cdae_hip* h, uint32_t which, float* host, size_t count) {
   float* d = h->P(which);
   if (!d) return count == 0 ? 0 : fail("parameter %u is not allocated in this configuration", which);
-  const bool vec = (which == CDAE_P_BP || which == CDAE_P_BP_AG);
+  const bool vec = (which == CDAE_P_BP || which == CDAE_P_BP_AG || which == CDAE_P_UB || which == CDAE_P_UB_AG);
   const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
   if (vec) {
-    if (count != h->I) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)h->I, count);
+    const size_t want = (which == CDAE_P_UB || which == CDAE_P_UB_AG) ? h->U : h->I;
+    if (count != want) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)want, count);
     HIPCHK(hipMemcpyAsync(host, d, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   } else {
     if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
@@ -691,6 +738,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   HIPCHK(hipGetDeviceCount(&ndev));
   if (device_id < 0 || device_id >= ndev) return fail("device %d not available (%d HIP devices)", device_id, ndev);
   HIPCHK(hipSetDevice(device_id));
+  if (cfg->full_output > 1u) return fail("bad full_output");
   if (cfg->batch_users > cdae::SLOT_MASK) return fail("batch_users %u exceeds the example word's slot field (2^28 - 1)", cfg->batch_users);
   cdae_hip* h = new cdae_hip();
   h->cfg = *cfg;
@@ -735,6 +783,27 @@ int cdae_hip_destroy(cdae_hip_t* h) {
   if (h->xchg && h->xchg_free) { h->xchg_free(h->xchg); h->xchg = nullptr; }
   free_all(h);
   delete h;
+  return 0;
+}
+
+int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out) {
+  if (!mc || !out) return fail("null argument");
+  if (mc->struct_size != sizeof(cdae_mf_config)) return fail("cdae_mf_config size mismatch: got %u, want %zu", mc->struct_size, sizeof(cdae_mf_config));
+  if (mc->loss_type > 3u && mc->loss_type != CDAE_LOSS_CROSS_ENTROPY)
+    return fail("loss_type %u unsupported: SQUARE (0), LOGISTIC (1), LOG (2), HINGE (3), CROSS_ENTROPY (5)", mc->loss_type);
+  if (mc->num_neg == 0) return fail("num_neg must be >= 1");
+  cdae_hip_config c = cdae_hip_config();
+  c.struct_size = sizeof(c);
+  c.num_dim = mc->num_dim; c.num_neg = mc->num_neg; c.num_corruptions = 1;
+  c.loss_type = CDAE_LOSS_SQUARE;                          // (validated above; the MF kernels read hp.loss_type, set below)
+  c.using_adagrad = mc->using_adagrad; c.user_factor = 1; c.batch_users = mc->batch_users;
+  c.lambda = mc->lambda; c.learn_rate = mc->learn_rate; c.corruption_ratio = 0.; c.beta = mc->beta;
+  CHK(cdae_hip_create(&c, device_id, out));
+  cdae_hip* h = *out;
+  h->mf = mc->pairwise ? 2u : 1u;
+  h->mf_bias = mc->using_bias_term ? 1u : 0u;
+  h->hp.loss_type = mc->loss_type;
+  h->hp.lambda = (float)(2.0 * mc->lambda);                // imf.hpp:92-95, bpr.hpp:78-82: the gradients regularise with 2 * lambda
   return 0;
 }
 
@@ -838,7 +907,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint64_t s1 = std::min<uint64_t>(U, s0 + B);
     emax = std::max<uint64_t>(emax, (uint64_t)(row_ptr[s1] - row_ptr[s0]));
   }
-  h->Ecap = emax * (1u + h->hp.num_neg);
+  h->ex_per_pos = h->mf == 2 ? 2u * h->hp.num_neg : 1u + h->hp.num_neg;
+  h->Ecap = emax * h->ex_per_pos;
   h->seq = 0; h->pre_valid = false;
   // opt-in (CDAE_SORT_COUNTING=1): measured slower than rocPRIM's onesweep beside the training kernels (profiles/r02_*)
   h->counting_sort = I <= cdae::COUNTING_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_COUNTING") != nullptr;
@@ -896,12 +966,19 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     // capacity decode falls back to atomics.  Zero-filled once: decode's 16-lane path leaves elements >= 64 NV + 16 NT
     // of a row untouched and the gather reads whole rows.
     const char* ev = std::getenv("CDAE_DUP_CAP");
-    const uint64_t want = ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4);   // small problems: every example
+    const uint64_t want = h->mf ? 1 : (ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4));   // small problems: every example (IMF / BPR have no correction rows)
     h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
     CHK(dev_alloc(&h->d_dup_corr, (size_t)h->dup_cap * h->Kp));
     HIPCHK(hipMemset(h->d_dup_corr, 0, (size_t)h->dup_cap * h->Kp * sizeof(float)));
   }
   CHK(dev_alloc(&h->d_G, h->Ecap));
+  if (h->mf) {
+    const uint64_t inst_cap = emax * (h->mf == 2 ? h->hp.num_neg : 1u + h->hp.num_neg);
+    CHK(dev_alloc(&h->d_UVpre, (size_t)inst_cap * h->Kp));
+    CHK(dev_alloc(&h->d_ub, (size_t)U)); CHK(dev_alloc(&h->d_ub_ag, (size_t)U));
+    h->cnt[CDAE_P_UB] = h->cnt[CDAE_P_UB_AG] = (size_t)U;
+    HIPCHK(hipMemset(h->d_ub, 0, (size_t)U * sizeof(float)));
+  }
   h->sort_bits = 1;
   while ((1ull << h->sort_bits) < I) h->sort_bits++;
   h->sort_tmp_bytes = 0;
@@ -964,6 +1041,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   fillm(h->d_Uu_ag, U, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_BP_AG), I, 1, 1, 1e-4f, 1.f);
+  fillm(h->d_ub_ag, U, 1, 1, 1e-4f, 1.f);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
@@ -983,6 +1061,19 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   auto fill = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v) {     // accumulator pads are 1, others 0
     hipLaunchKernelGGL(fill_matrix_kernel, blocks(rows * Kp), dim3(256), 0, h->stream, M, rows, K, Kp, v, v == 0.f ? 0.f : 1.f);
   };
+  if (h->mf) {                                             // imf.hpp:57-69: Random() * 0.01, accumulators 1e-4, biases 0
+    auto init01 = [&](float* M, size_t rows, uint32_t id, uint64_t row0) {
+      hipLaunchKernelGGL(init_matrix_kernel, blocks(rows * h->Kp), dim3(256), 0, h->stream, M, rows, h->K, h->Kp,
+                         cdae_rng_key(seed, 0, id, CDAE_STREAM_INIT), 0.01, row0);
+    };
+    init01(h->d_Wu, h->U, CDAE_P_WU, h->uid_offset); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f);
+    init01(h->P(CDAE_P_W), h->I, CDAE_P_W, 0); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);
+    fill(h->d_ub, h->U, 1, 1, 0.f); fill(h->d_ub_ag, h->U, 1, 1, 1e-4f);
+    fill(h->P(CDAE_P_BP), h->I, 1, 1, 0.f); fill(h->P(CDAE_P_BP_AG), h->I, 1, 1, 1e-4f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
   init(h->P(CDAE_P_W), h->I, CDAE_P_W, h->item0); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
   if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V, h->item0); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
   if (h->cfg.user_factor) { init(h->d_Wu, h->U, CDAE_P_WU, h->uid_offset); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }   // :119-122
@@ -1005,8 +1096,9 @@ int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t 
   CHK(join_aux(h));
   float* d = h->P(which);
   if (!d) return fail("parameter %u is not allocated in this configuration", which);
-  if (which == CDAE_P_BP || which == CDAE_P_BP_AG) {
-    if (count != h->I) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)h->I, count);
+  if (which == CDAE_P_BP || which == CDAE_P_BP_AG || which == CDAE_P_UB || which == CDAE_P_UB_AG) {
+    const size_t want = (which == CDAE_P_UB || which == CDAE_P_UB_AG) ? h->U : h->I;
+    if (count != want) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)want, count);
     HIPCHK(hipMemcpy(d, host, count * sizeof(float), hipMemcpyHostToDevice));
     return 0;
   }
@@ -1059,7 +1151,7 @@ int make_plan(cdae_hip* h, uint64_t u_begin, uint64_t u_end, std::vector<Batch>&
   const uint32_t B = (uint32_t)std::min<uint64_t>(h->B, h->U);
   for (uint64_t s0 = u_begin; s0 < u_end; s0 += B) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(B, u_end - s0);
-    const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * (1u + h->hp.num_neg);
+    const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]) * h->ex_per_pos;
     if (E > h->Ecap || E > 0xFFFFFFF0ull) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
     for (uint32_t c = 0; c < h->cfg.num_corruptions; ++c) plan.push_back(Batch{s0, nb, c, E});       // cdae.hpp:141
   }
@@ -1084,7 +1176,8 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
     h->prof_q = h->seq + 1;
     if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
     h->prof_q = h->seq;
-    if (h->cfg.full_output) CHK(compute_batch_full(h, (int)(h->seq & 1), plan[t], seed, epoch));
+    if (h->mf) CHK(compute_batch_mf(h, (int)(h->seq & 1), plan[t]));
+    else if (h->cfg.full_output) CHK(compute_batch_full(h, (int)(h->seq & 1), plan[t], seed, epoch));
     else CHK(compute_batch(h, (int)(h->seq & 1), plan[t], seed, epoch));
     h->seq++;
     h->acc_examples += plan[t].E; h->acc_batches++; h->acc_users += plan[t].nb;
@@ -1149,12 +1242,12 @@ int recommend_general(cdae_hip* h, uint64_t u_begin, uint64_t u_end, uint32_t to
                   (const uint32_t*)d_rated, none ? 0u : n_rated, (const uint32_t*)nullptr);
       DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3(1), dim3(256), 0, h->stream, h->hp, h->d_Hpart, (const uint32_t*)h->d_uptr_tmp, h->d_Wu,
                   h->P(CDAE_P_B), (const uint32_t*)nullptr, s0, 1u, 0, h->d_Z, (float*)nullptr, (float*)nullptr, h->d_Uu, (float*)nullptr);
-    } else {
+    } else if (!h->mf) {
       rc = encode_chunk(h, nullptr, s0, nb, 0, CDAE_STREAM_CORRUPT, 0, 0, 0);      // cdae.hpp:167-172
       if (rc) break;
     }
     DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, s0,
-                h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score, (const uint32_t*)d_rated, n_rated, (float*)nullptr);
+                h->mf ? h->d_Wu + (size_t)s0 * h->Kp : h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score, (const uint32_t*)d_rated, n_rated, (float*)nullptr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1250,7 +1343,7 @@ int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, ui
   if (cidx >= h->cfg.num_corruptions) return fail("corruption index %u out of range", cidx);
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
-  const uint64_t E = (uint64_t)(h->h_row_ptr[u_begin + n_users] - h->h_row_ptr[u_begin]) * (1u + h->hp.num_neg);
+  const uint64_t E = (uint64_t)(h->h_row_ptr[u_begin + n_users] - h->h_row_ptr[u_begin]) * h->ex_per_pos;
   if (E > h->Ecap) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
   if (E > *n_examples) return fail("batch has %llu examples, the caller's arrays hold %llu", (unsigned long long)E, (unsigned long long)*n_examples);
   *n_examples = E;
@@ -1307,6 +1400,7 @@ int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_
 
 int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, const uint32_t* uids, size_t n, float* Z) {
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
+  if (h->mf) return fail("cdae_hip_encode does not apply to an IMF / BPR handle");
   if ((!uids || !Z) && n) return fail("null argument");
   if (mode != 0 && mode != 1) return fail("mode must be 0 or 1");
   HIPCHK(hipSetDevice(h->device));
@@ -1330,6 +1424,7 @@ int cdae_hip_encode(cdae_hip_t* h, uint64_t seed, uint32_t epoch, int mode, cons
 
 int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out) {
   if (!h || !h->d_shared || !out) return fail("bad argument");
+  if (h->mf) { *out = 0.; return 0; }                      // IMF / BPR do not override ModelBase::data_loss (model_base.hpp:36-40)
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
   HIPCHK(hipMemsetAsync(h->d_scalar, 0, sizeof(double), h->stream));
@@ -1353,6 +1448,7 @@ int cdae_hip_data_loss(cdae_hip_t* h, uint64_t seed, uint32_t epoch, double* out
 
 int cdae_hip_penalty_loss(cdae_hip_t* h, double* out) {
   if (!h || !h->d_shared || !out) return fail("bad argument");
+  if (h->mf) { *out = 0.; return 0; }                      // ModelBase::penalty_loss default (model_base.hpp:43-45)
   double a = 0, b = 0;
   CHK(cdae_internal::shared_penalty(h, &a));
   CHK(cdae_internal::private_penalty(h, &b));
@@ -1387,15 +1483,17 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
     const size_t lds = cdae::recommend_mfma_lds_bytes((int)nch);
     for (uint64_t c0 = u_begin; c0 < u_end; c0 += UC) {
       const uint32_t nu = (uint32_t)std::min<uint64_t>(UC, u_end - c0);
-      CHK(ensure_eval_ws(h, nu, h->h_unit_ptr[c0 + nu] - h->h_unit_ptr[c0]));
+      if (!h->mf) CHK(ensure_eval_ws(h, nu, h->h_unit_ptr[c0 + nu] - h->h_unit_ptr[c0]));
       HIPCHK(hipMemsetAsync(h->d_bits, 0, (size_t)nu * words * sizeof(uint32_t), h->stream));
       hipLaunchKernelGGL(cdae::rated_bits_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->d_row_ptr, h->d_col, c0, nu, words, h->d_bits);
-      CHK(encode_chunk(h, nullptr, c0, nu, 0, CDAE_STREAM_CORRUPT, 0, 0, 0, 0, h->d_zeval, h->d_hpart_eval, h->eval_unit_cap));   // cdae.hpp:167-172, full rows
+      const float* zsrc = h->d_zeval;
+      if (h->mf) zsrc = h->d_Wu + (size_t)c0 * h->Kp;      // IMF / BPR: score = ub + ib + uv . iv (imf.hpp:117-119); ub does not rank
+      else CHK(encode_chunk(h, nullptr, c0, nu, 0, CDAE_STREAM_CORRUPT, 0, 0, 0, 0, h->d_zeval, h->d_hpart_eval, h->eval_unit_cap));   // cdae.hpp:167-172, full rows
       const dim3 grid((nu + cdae::REC_USERS_PER_BLOCK - 1) / cdae::REC_USERS_PER_BLOCK);
 #define REC_LAUNCH(NCH_)                                                                                                              \
   do {                                                                                                                                \
     HIPCHK(hipFuncSetAttribute((const void*)cdae::recommend_mfma_kernel<NCH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(cdae::recommend_mfma_kernel<NCH_>, grid, dim3(256), lds, h->stream, h->hp, h->d_zeval, nu, h->dec(),           \
+    hipLaunchKernelGGL(cdae::recommend_mfma_kernel<NCH_>, grid, dim3(256), lds, h->stream, h->hp, zsrc, nu, h->dec(),                 \
                        h->P(CDAE_P_BP), h->d_bits, words, topk, h->d_rec);                                                           \
   } while (0)
       switch (nch) { case 4: REC_LAUNCH(4); break; case 8: REC_LAUNCH(8); break; case 16: REC_LAUNCH(16); break; case 25: REC_LAUNCH(25); break; default: REC_LAUNCH(32); break; }
@@ -1415,6 +1513,7 @@ int cdae_hip_recommend_user(cdae_hip_t* h, uint64_t uid, const uint32_t* rated_i
   if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
   if (n_rated && !rated_items) return fail("null argument");
   if (n_rated + topk > h->I) return fail("%zu rated items leave fewer than topk = %u candidates", n_rated, topk);
+  if (h->mf) return fail("cdae_hip_recommend_user does not apply to an IMF / BPR handle (its score does not depend on the rated set)");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
   std::vector<uint32_t> rated(rated_items, rated_items + n_rated);
@@ -1431,6 +1530,7 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (uid >= h->U) return fail("user id %llu out of range", (unsigned long long)uid);
   if (h->cfg.full_output) return fail("train_one_user_corruption takes an explicit negative list; it is not available in full_output mode");
+  if (h->mf) return fail("train_one_user_corruption does not apply to an IMF / BPR handle");
   if ((n_in && !input_items) || (n_neg && !negative_items)) return fail("null argument");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));

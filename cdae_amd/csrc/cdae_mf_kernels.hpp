@@ -1,0 +1,245 @@
+// cdae_mf_kernels.hpp — the reference's sibling SGD models on the same row-step machinery:
+//   IMF  implicit-feedback matrix factorisation   /root/reference/src/model/recsys/imf.hpp:71-119
+//   BPR  pairwise ranking                          /root/reference/src/model/recsys/bpr.hpp:56-106
+// Both walk the users in order; per positive item they take one pointwise instance + num_neg sampled negatives (IMF) or
+// num_neg (positive, sampled negative) pairs (BPR); every instance steps the USER vector and the ITEM row(s) at once.  Unlike
+// CDAE the user side moves with every instance, so a user's chain cannot be transposed away; the block schedule is
+//   phase U  mf_user_kernel: one wavefront per user of the block — uv[u], uv_ag[u], ub[u] live in registers while the user's
+//            instances run strictly in order; the item side is READ (the item rows are not written in this phase, so no
+//            snapshot copy is needed); every instance leaves its loss gradient g and the user vector before its step;
+//   phase I  mf_item_kernel: one wavefront per item row — the row and its accumulators live in registers while the row's
+//            contributions run in (user, instance) order: grad = +-g * uv_before + 2 lambda * row   (the item-major order comes
+//            from the same sort + segment table as CDAE's decode).
+// A block of ONE user runs phase U with IN_PLACE = true: the item rows are stepped at once — the reference loop itself,
+// duplicate negatives of the user included.  tests/test_gpu_mf.py checks both against oracle/mf_oracle.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cdae_kernels.hpp"
+
+namespace cdae {
+
+// loss.hpp gradients of every loss the two models accept (yelp.cpp:122-165): SQUARE 0, LOGISTIC 1, LOG 2, HINGE 3, CROSS_ENTROPY 5
+__device__ __forceinline__ float mf_loss_grad(uint32_t loss_type, float pred, float truth) {
+  switch (loss_type) {
+    case 0u: return -2.f * (truth - pred);                                             // loss.hpp:54
+    case 1u: return (pred - truth) * fast_rcp(pred * (1.f - pred));                    // loss.hpp:95-98 (the reference CHECKs 0 < pred < 1)
+    case 2u: return -truth * fast_rcp(1.f + fast_exp(pred * truth));                   // loss.hpp:189-197 (the +-18 branches are its fp32 limits)
+    case 3u: return pred * truth > 1.f ? 0.f : -truth;                                 // loss.hpp:283-288
+    default: return fast_rcp(1.f + fast_exp(-pred)) - truth;                           // loss.hpp:141-147
+  }
+}
+__device__ __forceinline__ float mf_negative_label(uint32_t loss_type) { return (loss_type == 2u || loss_type == 3u) ? -1.f : 0.f; }
+
+// IN_PLACE reads of rows this wavefront may have just written (a user's duplicate negative): bypass the L1, which a store does
+// not update
+template <int NI>
+__device__ __forceinline__ void vload_coherent(float (&d)[NI], const float* p) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) d[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// K1 for IMF / BPR: the block's instance list, user-major in the order the reference takes them (imf.hpp:77-84, bpr.hpp:62-68):
+//   IMF  instance t of a user = positive p = t / (1 + num_neg) itself when t % (1 + num_neg) == 0, else its (t % .. - 1)-th negative;
+//        one example per instance (index = instance)
+//   BPR  instance (pair) q = p * num_neg + k; two examples per pair: 2 q = (positive item, +), 2 q + 1 = (negative item, -)
+// Negatives: recsys_model_base.hpp:46-57 on the counter stream (draw index p * num_neg + k), as in sample_kernel.
+// val = instance index << 32 | slot | (negative side of a pair ? TARGET_BIT : 0).  One wavefront per work unit of positives.
+__global__ void __launch_bounds__(256)
+mf_sample_kernel(HyperParams hp, uint32_t pairwise, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                 const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb, uint64_t seed, uint32_t epoch,
+                 uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val, uint16_t* __restrict__ ex_key16,
+                 uint32_t* __restrict__ seg, uint32_t seg_words, uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
+                 const uint32_t* __restrict__ unit_user) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *dup_count = 0u;
+  const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (unit >= n_units) return;
+  const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
+  const uint32_t slot = ur.slot;
+  const uint64_t uid = u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint32_t p0 = ur.p0, p1 = min(ur.p1, n);
+  const uint32_t* row = col + r0;
+  const uint32_t per = pairwise ? hp.num_neg : 1u + hp.num_neg;                 // instances per positive
+  const uint64_t inst0 = (uint64_t)(r0 - row_ptr[u0]) * per;                   // first instance of the user in the block
+  const uint64_t key_n = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_NEGATIVE);
+  const uint32_t work = (p1 - p0) * (1u + hp.num_neg);                         // (positive, k) with k = 0: the positive itself
+  for (uint32_t w = lane; w < work; w += WAVE) {
+    const uint32_t p = p0 + w / (1u + hp.num_neg), k = w % (1u + hp.num_neg);
+    const uint32_t item_pos = row[p];
+    uint32_t item = item_pos;
+    if (k) item = cdae_sample_negative(key_n, (uint64_t)p * hp.num_neg + (k - 1u), row, n, hp.num_items);
+    if (!pairwise) {
+      const uint64_t e = inst0 + (uint64_t)p * per + k;
+      ex_item[e] = item;
+      if (ex_key16) ex_key16[e] = (uint16_t)item;
+      ex_val[e] = (e << 32) | (uint64_t)slot;
+      dup_of_ex[e] = DUP_NONE;
+    } else if (k) {
+      const uint64_t q = inst0 + (uint64_t)p * per + (k - 1u), e = 2u * q;
+      ex_item[e] = item_pos; ex_item[e + 1] = item;
+      if (ex_key16) { ex_key16[e] = (uint16_t)item_pos; ex_key16[e + 1] = (uint16_t)item; }
+      ex_val[e] = (q << 32) | (uint64_t)slot;
+      ex_val[e + 1] = (q << 32) | (uint64_t)(slot | TARGET_BIT);
+      dup_of_ex[q] = DUP_NONE;
+    }
+  }
+}
+
+// phase U (and, IN_PLACE, the whole reference loop for a block of one user)
+template <int NI, bool PAIR, bool IN_PLACE>
+__global__ void __launch_bounds__(256)
+mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ row_ptr, uint64_t u0, uint32_t nb,
+               const uint32_t* __restrict__ ex_item, float* __restrict__ UV, float* __restrict__ UV_ag, float* __restrict__ UB,
+               float* __restrict__ UB_ag, float* __restrict__ IV, float* __restrict__ IV_ag, float* __restrict__ IB,
+               float* __restrict__ IB_ag, float* __restrict__ UVpre /* [instances][Kp] */, float* __restrict__ G /* [instances] */) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint32_t per = PAIR ? hp.num_neg : 1u + hp.num_neg;
+  const uint64_t inst0 = (uint64_t)(r0 - row_ptr[u0]) * per;
+  const uint32_t n_inst = n * per;
+  const uint32_t lo = lane * NI;
+  const float lam2 = hp.lambda;                      // the host stores 2 * lambda here (imf.hpp:92-95 regularise with 2 lambda)
+  const float neg_label = mf_negative_label(hp.loss_type);
+  float uv[NI], ua[NI];
+  vload<NI>(uv, UV + (size_t)uid * hp.Kp + lo);
+  vload<NI>(ua, UV_ag + (size_t)uid * hp.Kp + lo);
+  float ub = UB[uid], uba = UB_ag[uid];
+  constexpr int PF = 4;                              // item rows in flight
+  // this lane's item id(s) of the current chunk of 64 instances
+  uint32_t ci = 0, cj = 0;
+  auto load_ids = [&](uint32_t c0) {
+    const uint32_t t = c0 + lane;
+    if (t < n_inst) {
+      if (PAIR) { ci = ex_item[2u * (inst0 + t)]; cj = ex_item[2u * (inst0 + t) + 1u]; }
+      else ci = ex_item[inst0 + t];
+    }
+  };
+  for (uint32_t c0 = 0; c0 < n_inst; c0 += WAVE) {
+    load_ids(c0);
+    const uint32_t cnt = min((uint32_t)WAVE, n_inst - c0);
+    float ri[PF][NI], rj[PF][NI];
+    auto fetch = [&](int s, uint32_t idx) {            // rows of chunk instance idx into ring slot s (IN_PLACE: rows move, no prefetch)
+      const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, idx);
+      if (IN_PLACE) vload_coherent<NI>(ri[s], IV + (size_t)it * hp.Kp + lo); else vload<NI>(ri[s], IV + (size_t)it * hp.Kp + lo);
+      if (PAIR) {
+        const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)cj, idx);
+        if (IN_PLACE) vload_coherent<NI>(rj[s], IV + (size_t)jt * hp.Kp + lo); else vload<NI>(rj[s], IV + (size_t)jt * hp.Kp + lo);
+      }
+    };
+    if (!IN_PLACE)
+      for (int s = 0; s < PF; ++s) if ((uint32_t)s < cnt) fetch(s, (uint32_t)s);
+    for (uint32_t x = 0; x < cnt; ++x) {
+      const int s = (int)(x % PF);
+      const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, x);
+      const uint32_t jt = PAIR ? (uint32_t)__builtin_amdgcn_readlane((int)cj, x) : 0u;
+      if (IN_PLACE) fetch(s, x);
+      float d[NI];                                   // the item-side vector of the user step: iv[i] (IMF) or iv[i] - iv[j] (BPR)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) d[i] = PAIR ? ri[s][i] - rj[s][i] : ri[s][i];
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) dot = fmaf(uv[i], d[i], dot);
+      float pred = wave_sum(dot);
+      float truth;
+      const float ibi = IN_PLACE ? __hip_atomic_load(IB + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : IB[it];
+      if (PAIR) {                                                                  // bpr.hpp:73-76 (ub cancels in the difference)
+        pred += ibi - (IN_PLACE ? __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : IB[jt]);
+        truth = 1.f;
+      } else {                                                                     // imf.hpp:117-119, 80-84
+        pred += ub + ibi;
+        truth = ((c0 + x) % per == 0u) ? 1.f : neg_label;
+      }
+      const float g = mf_loss_grad(hp.loss_type, pred, truth);
+      const uint64_t inst = inst0 + c0 + x;
+      if (!IN_PLACE) {
+        vstore<NI>(UVpre + (size_t)inst * hp.Kp + lo, uv);
+        if (lane == 0) G[inst] = g;
+      } else {
+        // the reference loop: item row(s) stepped at once with the user vector from BEFORE its own step (imf.hpp:94-114)
+        float w[NI], a[NI];
+        vload_coherent<NI>(a, IV_ag + (size_t)it * hp.Kp + lo);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { w[i] = ri[s][i]; ada_step(hp, w[i], a[i], fmaf(g, uv[i], lam2 * w[i])); }
+        vstore<NI>(IV + (size_t)it * hp.Kp + lo, w);
+        vstore<NI>(IV_ag + (size_t)it * hp.Kp + lo, a);
+        if (bias_term && lane == 0) {
+          float b = ibi, ba = __hip_atomic_load(IB_ag + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ada_step(hp, b, ba, fmaf(lam2, b, g)); IB[it] = b; IB_ag[it] = ba;
+        }
+        if (PAIR) {
+          vload_coherent<NI>(a, IV_ag + (size_t)jt * hp.Kp + lo);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) { w[i] = rj[s][i]; ada_step(hp, w[i], a[i], fmaf(-g, uv[i], lam2 * w[i])); }
+          vstore<NI>(IV + (size_t)jt * hp.Kp + lo, w);
+          vstore<NI>(IV_ag + (size_t)jt * hp.Kp + lo, a);
+          if (bias_term && lane == 0) {
+            float b = __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ba = __hip_atomic_load(IB_ag + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ada_step(hp, b, ba, fmaf(lam2, b, -g)); IB[jt] = b; IB_ag[jt] = ba;
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(WAIT_VM0);          // the next instance may hit the same row (duplicate negative): stores first
+      }
+      if (!PAIR && bias_term) ada_step(hp, ub, uba, fmaf(lam2, ub, g));            // imf.hpp:97-101, 108-111 (BPR never steps ub)
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ada_step(hp, uv[i], ua[i], fmaf(g, d[i], lam2 * uv[i]));
+      if (!IN_PLACE && x + PF < cnt) fetch(s, x + PF);
+    }
+  }
+  vstore<NI>(UV + (size_t)uid * hp.Kp + lo, uv);
+  vstore<NI>(UV_ag + (size_t)uid * hp.Kp + lo, ua);
+  if (lane == 0) { UB[uid] = ub; UB_ag[uid] = uba; }
+}
+
+// phase I: one wavefront per item row, contributions in (user, instance) order
+template <int NI>
+__global__ void __launch_bounds__(256)
+mf_item_kernel(HyperParams hp, uint32_t bias_term, const uint32_t* __restrict__ item_order, const uint32_t* __restrict__ seg_begin,
+               const uint32_t* __restrict__ seg_end, const uint64_t* __restrict__ sorted_val, const float* __restrict__ UVpre,
+               const float* __restrict__ G, float* __restrict__ IV, float* __restrict__ IV_ag, float* __restrict__ IB,
+               float* __restrict__ IB_ag) {
+  const uint32_t rank = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (rank >= hp.num_items) return;
+  const uint32_t item = item_order[rank];
+  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  if (beg == end) return;
+  const uint32_t lo = lane * NI;
+  const float lam2 = hp.lambda;
+  float w[NI], a[NI];
+  vload<NI>(w, IV + (size_t)item * hp.Kp + lo);
+  vload<NI>(a, IV_ag + (size_t)item * hp.Kp + lo);
+  float b = IB[item], ba = IB_ag[item];
+  constexpr int PF = 4;
+  for (uint32_t c0 = beg; c0 < end; c0 += WAVE) {
+    const uint32_t cnt = min((uint32_t)WAVE, end - c0);
+    const uint64_t v = c0 + lane < end ? sorted_val[c0 + lane] : 0ull;
+    const uint32_t inst = (uint32_t)(v >> 32);
+    float gl = c0 + lane < end ? G[inst] : 0.f;
+    if ((uint32_t)v & TARGET_BIT) gl = -gl;                                        // the negative item of a pair (bpr.hpp:80, 83)
+    float up[PF][NI];
+    for (int s = 0; s < PF; ++s)
+      if ((uint32_t)s < cnt) vload<NI>(up[s], UVpre + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)inst, s) * hp.Kp + lo);
+    for (uint32_t x = 0; x < cnt; ++x) {
+      const int s = (int)(x % PF);
+      const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), x));
+      if (bias_term) ada_step(hp, b, ba, fmaf(lam2, b, g));                        // imf.hpp:93, 98-100, 110
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, up[s][i], lam2 * w[i]));   // imf.hpp:95, 103-106, 114
+      if (x + PF < cnt) vload<NI>(up[s], UVpre + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)inst, x + PF) * hp.Kp + lo);
+    }
+  }
+  vstore<NI>(IV + (size_t)item * hp.Kp + lo, w);
+  vstore<NI>(IV_ag + (size_t)item * hp.Kp + lo, a);
+  if (lane == 0) { IB[item] = b; IB_ag[item] = ba; }
+}
+
+}  // namespace cdae

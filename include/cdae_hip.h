@@ -46,8 +46,9 @@ extern "C" {
 /* 2: cdae_hip_config.linear_function (in what was tail padding of the uint32 block: zero the struct before filling it),
  *    parameters CDAE_P_UU / CDAE_P_UU_AG; pipelined delta exchange entry points */
 /* 3: cdae_hip_debug_sample_batch (integer-parity test hook), cdae_hip_recommend_user
- * 4: library-owned RCCL communicator + exchange schedule (cdae_hip_comm_*, cdae_hip_exchange_*), cdae_hip_multi_* */
-#define CDAE_HIP_ABI_VERSION 4
+ * 4: library-owned RCCL communicator + exchange schedule (cdae_hip_comm_*, cdae_hip_exchange_*), cdae_hip_multi_*
+ * 5: cdae_hip_create_mf (IMF / BPR handles), CDAE_P_UB / CDAE_P_UB_AG, item-rows layout of cdae_hip_multi_* */
+#define CDAE_HIP_ABI_VERSION 5
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -66,7 +67,9 @@ extern "C" {
 #define CDAE_P_BP_AG 9u
 #define CDAE_P_UU 10u     /* users x K  : per-user gate on the input sum, linear_function only, cdae.hpp:437 */
 #define CDAE_P_UU_AG 11u
-#define CDAE_P_COUNT 12u
+#define CDAE_P_UB 12u     /* users      : user bias ub_ of the IMF / BPR handles (imf.hpp:132); not allocated for CDAE */
+#define CDAE_P_UB_AG 13u
+#define CDAE_P_COUNT 14u
 
 typedef struct cdae_hip_config {
   uint32_t struct_size;      /* sizeof(cdae_hip_config), for ABI checking                  */
@@ -237,6 +240,32 @@ int cdae_hip_delta_stage(cdae_hip_t* h);
 int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);
 int cdae_hip_delta_merge(cdae_hip_t* h);
 int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous period then _stage of this one, in one pass */
+
+/* ---- the sibling SGD models IMF and BPR on the same handle type (yelp.cpp:122-165 --method=MF / BPR) ----
+ *   IMF::reset / BPR::reset        imf.hpp:57-69                cdae_hip_set_interactions + cdae_hip_init_params
+ *   IMF::train_one_iteration       imf.hpp:71-86 (+ :88-115)    cdae_hip_train_epoch / _train_users
+ *   BPR::train_one_iteration       bpr.hpp:56-70 (+ :72-106)    (same; pairwise = 1)
+ *   RecsysModelBase::recommend     recsys_model_base.hpp:77-104 cdae_hip_recommend_all   (score = ub + ib + uv . iv, imf.hpp:117-119)
+ * Parameters through cdae_hip_get/set_param: CDAE_P_WU / _WU_AG = uv_ / uv_ag_ (users x K), CDAE_P_W / _W_AG = iv_ / iv_ag_
+ * (items x K), CDAE_P_UB / _UB_AG = ub_ / ub_ag_, CDAE_P_BP / _BP_AG = ib_ / ib_ag_.  loss_type: 0 SQUARE, 1 LOGISTIC, 2 LOG,
+ * 3 HINGE, 5 CROSS_ENTROPY (loss.hpp:10-18; what yelp.cpp lets these models choose).  batch_users: users whose chains run
+ * concurrently against the block-start item rows; 1 == the reference's strictly sequential loop.  data_loss / penalty_loss are
+ * 0 for these models, as in the reference (ModelBase defaults, model_base.hpp:36-45); cdae_hip_encode, the explicit-input step
+ * and the full-output decode do not apply. */
+typedef struct cdae_mf_config {
+  uint32_t struct_size;      /* sizeof(cdae_mf_config)                                   */
+  uint32_t num_dim;          /* IMFConfig::num_dim          imf.hpp:19                   */
+  uint32_t num_neg;          /* imf.hpp:20                                               */
+  uint32_t loss_type;        /* imf.hpp:17 / bpr.hpp:17                                  */
+  uint32_t using_adagrad;    /* imf.hpp:22                                               */
+  uint32_t using_bias_term;  /* imf.hpp:21                                               */
+  uint32_t pairwise;         /* 0: IMF (pointwise instances), 1: BPR (pairs)             */
+  uint32_t batch_users;      /* 0 -> default                                             */
+  double lambda;             /* imf.hpp:16                                               */
+  double learn_rate;         /* imf.hpp:14                                               */
+  double beta;               /* imf.hpp:15                                               */
+} cdae_mf_config;
+int cdae_hip_create_mf(const cdae_mf_config* cfg, int device_id, cdae_hip_t** out);
 
 /* ---- library-owned RCCL communicator and exchange schedule (one process per GPU: bench.py --gpus N) -----------------
  * The all-reduce of the staged deltas runs inside the library, on its own communicator and HIP stream, overlapped with the

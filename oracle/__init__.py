@@ -2,4 +2,4 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
-from .binding import Oracle, OracleConfig, build, eval_rec_list, eval_topn, OracleHeap  # noqa: F401
+from .binding import Oracle, OracleConfig, MfOracle, MfConfig, build, eval_rec_list, eval_topn, OracleHeap  # noqa: F401

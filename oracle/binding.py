@@ -19,9 +19,10 @@ P_COUNT = 12
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "cdae_oracle.cpp")
+    src2 = os.path.join(_HERE, "mf_oracle.cpp")
     hdr = os.path.join(_HERE, "..", "include", "cdae_rng.h")
     stale = (not os.path.exists(_SO)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, hdr))
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_SO) for p in (src, src2, hdr))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libcdae_oracle.so"])
     return _SO
@@ -60,6 +61,80 @@ class OracleConfig:
                     self.learn_rate, self.corruption_ratio, self.beta)
 
 
+class _MfCfg(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("num_dim", "num_neg", "loss_type", "using_adagrad", "using_bias_term", "pairwise")] + [
+        (n, C.c_double) for n in ("lambda_", "learn_rate", "beta")]
+
+
+LOSS_LOGISTIC, LOSS_LOG, LOSS_HINGE = 1, 2, 3
+MF_UV, MF_UV_AG, MF_IV, MF_IV_AG, MF_UB, MF_UB_AG, MF_IB, MF_IB_AG = range(8)
+
+
+@dataclass
+class MfConfig:
+    """libcf::IMFConfig / BPRConfig (/root/reference/src/model/recsys/imf.hpp:12-23, bpr.hpp:12-24); pairwise = BPR."""
+    num_dim: int = 10
+    num_neg: int = 5
+    loss_type: int = LOSS_SQUARE
+    using_adagrad: bool = True
+    using_bias_term: bool = True
+    pairwise: bool = False
+    lambda_: float = 0.01
+    learn_rate: float = 0.1
+    beta: float = 1.0
+
+
+class MfOracle:
+    """fp64 restatement of IMF / BPR (oracle/mf_oracle.cpp): literal and block schedules."""
+
+    def __init__(self, cfg: MfConfig, num_users, num_items, row_ptr, col_idx):
+        self.lib = _load()
+        self.cfg = cfg
+        self.U, self.I, self.K = int(num_users), int(num_items), int(cfg.num_dim)
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        self.col = np.ascontiguousarray(col_idx, dtype=np.uint32)
+        c = _MfCfg(cfg.num_dim, cfg.num_neg, cfg.loss_type, int(cfg.using_adagrad), int(cfg.using_bias_term), int(cfg.pairwise),
+                   cfg.lambda_, cfg.learn_rate, cfg.beta)
+        self.h = self.lib.mf_oracle_create(C.byref(c), self.U, self.I, _p(self.row_ptr), _p(self.col))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.mf_oracle_destroy(self.h)
+            self.h = None
+
+    def init_params(self, seed):
+        self.lib.mf_oracle_init_params(self.h, seed)
+
+    def get(self, which):
+        n = self.lib.mf_oracle_param_size(self.h, which)
+        out = np.empty(n)
+        assert self.lib.mf_oracle_get_param(self.h, which, _p(out), n) == 0
+        return out
+
+    def set(self, which, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64).ravel()
+        assert self.lib.mf_oracle_set_param(self.h, which, _p(a), a.size) == 0
+
+    def train_literal(self, seed, epoch, u0=0, u1=None):
+        self.lib.mf_oracle_train_literal(self.h, seed, epoch, u0, self.U if u1 is None else u1)
+
+    def train_batched(self, seed, epoch, batch_users, u0=0, u1=None):
+        self.lib.mf_oracle_train_batched(self.h, seed, epoch, u0, self.U if u1 is None else u1, batch_users)
+
+    def predict(self, u, i):
+        return self.lib.mf_oracle_predict(self.h, u, i)
+
+    def loss_grad(self, pred, truth):
+        return self.lib.mf_oracle_loss_grad(self.h, pred, truth)
+
+    def recommend(self, topk=10, u0=0, u1=None, with_scores=False):
+        u1 = self.U if u1 is None else u1
+        out = np.empty((u1 - u0, topk), dtype=np.uint32)
+        sc = np.empty((u1 - u0, topk)) if with_scores else None
+        self.lib.mf_oracle_recommend(self.h, u0, u1, topk, _p(out), _p(sc) if with_scores else None)
+        return (out, sc) if with_scores else out
+
+
 _lib = None
 
 
@@ -95,6 +170,21 @@ def _load():
     lib.oracle_recommend.argtypes = [vp, u64, u64, u32, vp, vp]
     lib.oracle_eval_topn.argtypes = [vp, u32, u64, vp, vp, vp]
     lib.oracle_eval_rec_list.argtypes = [vp, u64, vp, u64, vp]
+    lib.mf_oracle_create.restype = vp
+    lib.mf_oracle_create.argtypes = [C.POINTER(_MfCfg), u64, u64, vp, vp]
+    lib.mf_oracle_destroy.argtypes = [vp]
+    lib.mf_oracle_init_params.argtypes = [vp, u64]
+    lib.mf_oracle_param_size.restype = C.c_size_t
+    lib.mf_oracle_param_size.argtypes = [vp, u32]
+    lib.mf_oracle_get_param.argtypes = [vp, u32, vp, C.c_size_t]
+    lib.mf_oracle_set_param.argtypes = [vp, u32, vp, C.c_size_t]
+    lib.mf_oracle_train_literal.argtypes = [vp, u64, u32, u64, u64]
+    lib.mf_oracle_train_batched.argtypes = [vp, u64, u32, u64, u64, u64]
+    lib.mf_oracle_predict.restype = dbl
+    lib.mf_oracle_predict.argtypes = [vp, u64, u64]
+    lib.mf_oracle_loss_grad.restype = dbl
+    lib.mf_oracle_loss_grad.argtypes = [vp, dbl, dbl]
+    lib.mf_oracle_recommend.argtypes = [vp, u64, u64, u32, vp, vp]
     lib.oracle_heap_create.restype = vp
     lib.oracle_heap_destroy.argtypes = [vp]
     lib.oracle_heap_push.argtypes = [vp, u64, dbl]

@@ -1,7 +1,7 @@
 // Loss functions with the reference's enum values and interface (src/model/loss.hpp:10-33, 348-367).
-// On the GPU path only SQUARE and CROSS_ENTROPY reach the kernels (the two that CDAE's linear output
-// supports); the host classes exist for Loss::create / loss_type() logging and the
-// out-of-scope sibling models.
+// On the GPU path SQUARE and CROSS_ENTROPY reach the CDAE kernels (the two that CDAE's linear output supports,
+// SURVEY.md T5) and SQUARE / LOGISTIC / LOG / HINGE / CROSS_ENTROPY the IMF / BPR kernels (cdae_mf_kernels.hpp); the host
+// classes exist for Loss::create / loss_type() logging, positive_label() / negative_label() and the CPU-side baselines.
 #ifndef CDAE_HOST_MODEL_LOSS_HPP_
 #define CDAE_HOST_MODEL_LOSS_HPP_
 
@@ -77,7 +77,7 @@ struct Hinge : Loss {                      // max(0, 1 - y t), labels +-1
   LossType loss() const { return HINGE; }
   std::string loss_type() const { return "Hinge"; }
   double evaluate(double y, double t) const { return std::max(0., 1. - y * t); }
-  double gradient(double y, double t) const { return y * t < 1. ? -t : 0.; }
+  double gradient(double y, double t) const { return y * t > 1. ? 0. : -t; }      // loss.hpp:283-288 (z == 1 still steps)
   double negative_label() const { return -1.; }
 };
 struct SquaredHinge : Loss {

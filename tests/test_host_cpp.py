@@ -198,3 +198,25 @@ def test_reference_yelp_app_trains_full_output_in_the_item_rows_layout(host_bins
     loss_a, loss_b = tables[0][1:, 0], tables[1][1:, 0]            # (iteration 0 is the untrained model: no loss printed)
     assert np.abs(loss_b / loss_a - 1).max() < 5e-3                # the same schedule: loss curves coincide
     assert np.abs(tables[1][:, 6] - tables[0][:, 6]).max() < 0.02  # Recall@10 column (300 users: one hit = 0.003)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,loss", [("MF", "SQUARE"), ("MF", "CE"), ("BPR", "LOG"), ("BPR", "HINGE")])
+def test_reference_yelp_app_trains_the_sibling_models_on_gpu(host_bins, tmp_path, method, loss):
+    """--method=MF (libcf::IMF) and --method=BPR through the unmodified yelp app (yelp.cpp:122-165): both run on the GPU behind
+    cdae_hip_create_mf.  Train Loss is 0 as in the reference (neither model overrides data_loss); Recall@10 must beat Popularity."""
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    rc, out = run([yelp, "--task=test", f"--method={method}", "--num_dim=20", f"--loss_type={loss}"], tmp_path,
+                  env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "16"})
+    assert rc == 0, out[-3000:]
+    assert ("BPR Model Configure" if method == "BPR" else "IMF Model Configure") in out
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+    assert len(rows) == 2 + 51
+    pop_r10 = float(rows[1].split("|")[8])
+    best = max(float(r.split("|")[8]) for r in rows[2:])
+    assert best > pop_r10, (best, pop_r10)
