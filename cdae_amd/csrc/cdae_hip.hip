@@ -154,6 +154,7 @@ struct cdae_hip {
   float* d_zeval = nullptr; float* d_hpart_eval = nullptr; uint32_t eval_cap = 0, eval_unit_cap = 0;   // evaluation workspace
   uint32_t* d_bits = nullptr; size_t bits_cap = 0;                                                     // recommend: rated-item bitmap
   int sort_bits = 1;
+  bool debug_skip_prep = false;         // CDAE_DEBUG_SKIP_PREP (timing experiment only: batches reuse stale example lists -> WRONG results)
   bool counting_sort = false;           // hand-written counting sort on the prep stream instead of rocPRIM (num_items <= 65536)
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
 
@@ -752,6 +753,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
   h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
+  h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
@@ -1170,11 +1172,11 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
   h->prof_q = h->seq;
-  if (!is_prefetched(h, plan[0], seed, epoch)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
+  if (!is_prefetched(h, plan[0], seed, epoch) && !(h->debug_skip_prep && h->seq >= 4)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
   h->pre_valid = false;
   for (size_t t = 0; t < plan.size(); ++t) {
     h->prof_q = h->seq + 1;
-    if (t + 1 < plan.size()) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
+    if (t + 1 < plan.size() && !(h->debug_skip_prep && h->seq >= 4)) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
     h->prof_q = h->seq;
     if (h->mf) CHK(compute_batch_mf(h, (int)(h->seq & 1), plan[t]));
     else if (h->cfg.full_output) CHK(compute_batch_full(h, (int)(h->seq & 1), plan[t], seed, epoch));
@@ -1318,7 +1320,7 @@ int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64
   if (plan.empty()) return 0;
   if (is_prefetched(h, plan[0], seed, epoch)) return 0;
   h->prof_q = h->seq;
-  CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
+  if (!(h->debug_skip_prep && h->seq >= 4)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
   h->pre_valid = true;
   h->pre_s0 = plan[0].s0; h->pre_nb = plan[0].nb; h->pre_cidx = plan[0].cidx; h->pre_seed = seed; h->pre_epoch = epoch;
   return 0;
