@@ -90,6 +90,7 @@ struct cdae_hip {
   uint32_t* d_col = nullptr;
   uint32_t* d_item_order = nullptr;
   uint32_t hot_rows = 0;            // decode: rows [0, hot_rows) of item_order get a wavefront of their own
+  uint32_t hot_in_rows = 0;         // input rows: rows [0, hot_in_rows) of item_order get a workgroup of their own
   // developer switches, read once in cdae_hip_create (DESIGN.md lists them)
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
   bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
@@ -117,7 +118,8 @@ struct cdae_hip {
 
   // batch workspace
   uint64_t Ecap = 0;
-  // example lists are double-buffered: batch t+1 is sampled and sorted on the `prep` stream while batch t trains
+  // example lists are kept in NSETS sets: batch q uses set q % NSETS.  Batch t+1 (and, with the second prep lane, t+2) is
+  // sampled and sorted on a prep stream while batch t trains
   struct ExBuf {
     uint32_t* item = nullptr; uint64_t* val = nullptr;            // user-major example list
     uint32_t* sorted_item = nullptr; uint64_t* sorted_val = nullptr;   // the same, stably sorted by item
@@ -128,7 +130,10 @@ struct cdae_hip {
     // counting sort (cdae_sort_kernels.hpp; num_items <= 65536): per-item counts / prefix / scatter cursor (`rank`), item-bucketed values
     uint32_t* item_count = nullptr; uint32_t* prefix = nullptr; uint32_t* rank = nullptr; uint64_t* bucketed = nullptr;
     hipEvent_t ready = nullptr, released = nullptr;
-  } ex[2];
+  } ex[3];
+  static constexpr int NSETS = 3;
+  hipStream_t prep2 = nullptr;          // second prep lane (batches with odd sequence number), or nullptr: one lane, look-ahead 1
+  bool prep2_own = false;               // prep2 is a stream of its own (else it aliases `aux`)
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
   float* d_dup_corr = nullptr; uint32_t dup_cap = 0;   // [dup_cap][Kp] hidden-gradient corrections of duplicate negatives
   float* d_HGpart = nullptr;            // [8][B][Kp] per-XCD partial hidden gradients
@@ -137,14 +142,14 @@ struct cdae_hip {
   __bf16 *d_Zb = nullptr, *d_ZTb = nullptr, *d_Db = nullptr, *d_DTb = nullptr, *d_Gb = nullptr, *d_GTb = nullptr;
   float* d_dD = nullptr;
   uint32_t* d_iota = nullptr;           // 0..B: identity unit prefix (fused full-output path: one hg partial row per user)
-  uint32_t* d_bits_train = nullptr;     // [2][B x ceil(I/32)] rated-item bitmap of the batch (targets of the fused full-output decode), per example-buffer set
+  uint32_t* d_bits_train = nullptr;     // [NSETS][B x ceil(I/32)] rated-item bitmap of the batch (targets of the fused full-output decode), per example-buffer set
   size_t bits_stride = 0;
   uint32_t full_slices = 1;
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
   bool join_pending = false;            // full-output path: the aux stream's b recurrence of the last batch has not been joined yet
   hipStream_t prep = nullptr;           // sampling + sorting of the next batch
-  void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0, sort_tmp_stride = 0;   // two workspaces, one per prep lane
   float* d_Z = nullptr; float* d_Dz = nullptr; float* d_HG = nullptr; float* d_G = nullptr;
   uint32_t* d_touched = nullptr;
   double* d_scalar = nullptr;
@@ -175,7 +180,7 @@ struct cdae_hip {
   uint64_t fs_prepped = 0;              // item-sharded training: batches whose example lists have been prepared (buffer set = parity)
 
   uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q & 1
-  bool pre_valid = false;               // set (seq & 1) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
+  bool pre_valid = false;               // set (seq % NSETS) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
   uint64_t pre_s0 = 0, pre_seed = 0; uint32_t pre_nb = 0, pre_cidx = 0, pre_epoch = 0;
   uint64_t acc_users = 0, acc_examples = 0, acc_batches = 0;   // since the last stats collection
   int profiling = 0;                    // 0 off; k >= 1: HIP events around the kernel families of every k-th batch
@@ -267,6 +272,7 @@ void free_all(cdae_hip* h) {
     if (b.released) (void)hipEventDestroy(b.released);
   }
   if (h->prep) (void)hipStreamDestroy(h->prep);
+  if (h->prep2 && h->prep2_own) (void)hipStreamDestroy(h->prep2);
   if (h->aux) (void)hipStreamDestroy(h->aux);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -308,10 +314,12 @@ struct Batch { uint64_t s0; uint32_t nb; uint32_t cidx; uint64_t E; };
 inline uint32_t units_of(const cdae_hip* h, const Batch& b) { return h->h_unit_ptr[b.s0 + b.nb] - h->h_unit_ptr[b.s0]; }
 
 // K1 + sort on the prep stream into example-buffer set `b`
-int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
+// lane 1: the second prep stream with the second half of the sort workspace (two batches are prepared side by side)
+int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch, int lane = 0) {
   using namespace cdae;
   cdae_hip::ExBuf& x = h->ex[b];
-  hipStream_t st = h->prep;
+  hipStream_t st = lane ? h->prep2 : h->prep;
+  void* sort_tmp = (char*)h->d_sort_tmp + (lane ? h->sort_tmp_stride : 0);
   const uint32_t I = (uint32_t)h->I;
   Prof pr;
   HIPCHK(hipStreamWaitEvent(st, x.released, 0));               // the batch that last used this set is done with it
@@ -343,12 +351,12 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
                        x.sorted_val, x.item_count, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
   } else if (x.key16) {
     // 16-bit keys: rocPRIM picks onesweep (2 digit passes) instead of block sort + log2(tiles) merge passes
-    HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.key16, x.sorted_key16, x.val, x.sorted_val,
+    HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.key16, x.sorted_key16, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint16_t>, seg_grid, dim3(256), 0, st, x.sorted_key16, x.sorted_val, (uint32_t)bt.E,
                        x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
   } else {
-    HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
+    HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint32_t>, seg_grid, dim3(256), 0, st, x.sorted_item, x.sorted_val, (uint32_t)bt.E,
                        x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
@@ -412,10 +420,10 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   // K <= 256: hot rows one per wavefront, all others four per wavefront (NV float4 pieces + NT tail scalars per lane)
 #define DECODE_HY(NV_, NT_)                                                                                           \
   do {                                                                                                                \
-    if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);   \
-    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
-    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
-    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);            \
+    if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);   \
+    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);    \
+    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);    \
+    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);            \
   } while (0)
 #define DECODE_HY_NT(NV_)                                                                        \
   do {                                                                                           \
@@ -428,6 +436,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
       const uint32_t hot = std::min<uint32_t>(h->hot_rows, I);
       const uint32_t waves = hot + (I - hot + 3) / 4;
       const dim3 grid_hy((waves + 3) / 4);
+      static const uint32_t dec_lds = std::getenv("CDAE_DEBUG_DECODE_LDS") ? (uint32_t)std::atoi(std::getenv("CDAE_DEBUG_DECODE_LDS")) : 0u;   // occupancy experiment
       const uint32_t nv = K / 64, tail = K % 64;
       const uint32_t nt = tail == 0 ? 0u : (tail < 16 ? 1u : (tail < 32 ? 2u : 4u));   // 16 nt > tail: room for b'
       if (nt == 0) {
@@ -457,9 +466,10 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   CHK(pr.begin(h, F_INPUT, st));
   {
     const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
-    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
+    const uint32_t hot_in = h->NI >= 4 ? std::min<uint32_t>(h->hot_in_rows, I) : 0u;     // popular rows: a workgroup each
+    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + hot_in + (I - hot_in + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
                 x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), CDAE_TOUCHED_ARG, nb, h->P(CDAE_P_B),
-                h->P(CDAE_P_B_AG), h->delta_rows());
+                h->P(CDAE_P_B_AG), h->delta_rows(), hot_in);
   }
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
@@ -758,6 +768,15 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking);
+  {
+    // Second prep lane.  Sampling + sorting a batch is a chain of ~12 small launches (~95 us at 256 users) — longer than the
+    // training step once that drops below it — so consecutive batches are prepared side by side on two streams.  Default: the
+    // handle's aux stream (idle in the sampled path unless an exchange is configured); CDAE_PREP2 = own | aux | off.
+    const char* sel = std::getenv("CDAE_PREP2");
+    if (sel && !std::strcmp(sel, "off")) h->prep2 = nullptr;
+    else if (sel && !std::strcmp(sel, "own")) { if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep2, hipStreamNonBlocking); h->prep2_own = true; }
+    else h->prep2 = h->aux;
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming);
@@ -773,6 +792,11 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act; hp.linear_function = cfg->linear_function;
   hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
   hp.uid_offset = 0; hp.num_items = 0; hp.K = h->K; hp.Kp = h->Kp;
+  if (std::getenv("CDAE_WAVE_TRACE")) {      // developer aid (tools/wave_trace.py): the last training batch's wavefront timeline
+    if (hipMalloc((void**)&hp.trace, 4 * cdae::TRACE_CAP * sizeof(unsigned long long)) != hipSuccess) hp.trace = nullptr;
+    if (hp.trace) (void)hipMemset(hp.trace, 0, 4 * cdae::TRACE_CAP * sizeof(unsigned long long));
+  }
+  hp.debug_skip = std::getenv("CDAE_DEBUG_SKIP_ROLES") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_SKIP_ROLES"), nullptr, 10) : 0u;
   hp.debug_rank = std::getenv("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
   *out = h;
   return 0;
@@ -782,6 +806,13 @@ int cdae_hip_destroy(cdae_hip_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->hp.trace) {      // records of the LAST batch every slot saw
+    std::vector<unsigned long long> rec(4 * cdae::TRACE_CAP);
+    (void)hipMemcpy(rec.data(), h->hp.trace, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (FILE* f = std::fopen(std::getenv("CDAE_WAVE_TRACE"), "wb")) { std::fwrite(rec.data(), sizeof(unsigned long long), rec.size(), f); std::fclose(f); }
+    (void)hipFree(h->hp.trace);
+    h->hp.trace = nullptr;
+  }
   if (h->xchg && h->xchg_free) { h->xchg_free(h->xchg); h->xchg = nullptr; }
   free_all(h);
   delete h;
@@ -876,6 +907,13 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     uint32_t hot = 0;
     while (hot < I && (double)pop[order[hot]] * share >= hot_pos) ++hot;
     h->hot_rows = std::min<uint32_t>((hot + 3u) & ~3u, (uint32_t)I);
+    // input rows: a row whose expected kept inputs per batch fill its wavefront's three-group ring several times over
+    // (CDAE_INPUT_HOT_POS expected positives, default 24) is split over a workgroup (input_rows_kernel)
+    const char* ei = std::getenv("CDAE_INPUT_HOT_POS");
+    const double in_pos = ei ? std::atof(ei) : 24.0;
+    uint32_t hin = 0;
+    while (hin < I && (double)pop[order[hin]] * share >= in_pos) ++hin;
+    h->hot_in_rows = hin;
   }
 
   // parameters
@@ -992,7 +1030,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
                                      (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
     h->sort_tmp_bytes = std::max(h->sort_tmp_bytes, bytes16);
   }
-  CHK(dev_alloc((char**)&h->d_sort_tmp, h->sort_tmp_bytes));
+  h->sort_tmp_stride = (h->sort_tmp_bytes + 255) & ~(size_t)255;
+  CHK(dev_alloc((char**)&h->d_sort_tmp, 2 * h->sort_tmp_stride));
   const size_t BK = (size_t)B * h->Kp;
   CHK(dev_alloc(&h->d_Z, BK)); CHK(dev_alloc(&h->d_Dz, BK)); CHK(dev_alloc(&h->d_HG, BK));
   if (h->cfg.linear_function) { CHK(dev_alloc(&h->d_Ssum, BK)); CHK(dev_alloc(&h->d_delta_rows, BK)); }
@@ -1010,7 +1049,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       HIPCHK(hipMemcpy(h->d_iota, iota.data(), iota.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       if (h->item_shard) CHK(dev_alloc(&h->d_Hsum, (size_t)B * h->Kp));
       h->bits_stride = (size_t)B * ((I + 31) / 32);
-      CHK(dev_alloc(&h->d_bits_train, 2 * h->bits_stride));                   // one per example-buffer set
+      CHK(dev_alloc(&h->d_bits_train, cdae_hip::NSETS * h->bits_stride));     // one per example-buffer set
       // item slices of the fused decode: slices x Bp/128 workgroups ~ one per CU (measured best at B = 2048: 16 slices; every
       // slice adds a [B x Kp] partial of hg)
       const uint32_t tiles = h->Ip / (32 * cdae::FUSED_SUB), ublocks = h->Bp / 128;
@@ -1160,6 +1199,17 @@ int make_plan(cdae_hip* h, uint64_t u_begin, uint64_t u_end, std::vector<Batch>&
   return 0;
 }
 
+inline int set_of(uint64_t q) { return (int)(q % cdae_hip::NSETS); }
+// two lanes only where the second one is free: the sampled CDAE path (the full-output path runs its b recurrence on aux, an
+// item shard trains in phases)
+inline size_t prep_depth(const cdae_hip* h) { return (h->prep2 && !h->mf && !h->cfg.full_output && !h->item_shard) ? 2 : 1; }
+inline int prep_lane(const cdae_hip* h, uint64_t q) { return prep_depth(h) == 2 ? (int)(q & 1) : 0; }
+int sync_prep(cdae_hip* h) {
+  HIPCHK(hipStreamSynchronize(h->prep));
+  if (h->prep2) HIPCHK(hipStreamSynchronize(h->prep2));
+  return 0;
+}
+
 bool is_prefetched(const cdae_hip* h, const Batch& b, uint64_t seed, uint32_t epoch) {
   return h->pre_valid && h->pre_s0 == b.s0 && h->pre_nb == b.nb && h->pre_cidx == b.cidx && h->pre_seed == seed && h->pre_epoch == epoch;
 }
@@ -1171,16 +1221,25 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
   std::vector<Batch> plan;
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
-  h->prof_q = h->seq;
-  if (!is_prefetched(h, plan[0], seed, epoch) && !(h->debug_skip_prep && h->seq >= 4)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
+  // look-ahead: batch t + depth is prepared while batch t trains; with two prep lanes consecutive batches alternate between them
+  const size_t depth = prep_depth(h);
+  const uint64_t q0 = h->seq;
+  auto prep = [&](size_t t) -> int {
+    const uint64_t q = q0 + t;
+    if (h->debug_skip_prep && q >= 2 * cdae_hip::NSETS) return 0;
+    h->prof_q = q;
+    return prep_batch(h, set_of(q), plan[t], seed, epoch, prep_lane(h, q));
+  };
+  for (size_t t = 0; t < depth && t < plan.size(); ++t)
+    if (t > 0 || !is_prefetched(h, plan[0], seed, epoch)) CHK(prep(t));
   h->pre_valid = false;
   for (size_t t = 0; t < plan.size(); ++t) {
-    h->prof_q = h->seq + 1;
-    if (t + 1 < plan.size() && !(h->debug_skip_prep && h->seq >= 4)) CHK(prep_batch(h, (int)((h->seq + 1) & 1), plan[t + 1], seed, epoch));
+    if (t + depth < plan.size()) CHK(prep(t + depth));
     h->prof_q = h->seq;
-    if (h->mf) CHK(compute_batch_mf(h, (int)(h->seq & 1), plan[t]));
-    else if (h->cfg.full_output) CHK(compute_batch_full(h, (int)(h->seq & 1), plan[t], seed, epoch));
-    else CHK(compute_batch(h, (int)(h->seq & 1), plan[t], seed, epoch));
+    const int set = set_of(h->seq);
+    if (h->mf) CHK(compute_batch_mf(h, set, plan[t]));
+    else if (h->cfg.full_output) CHK(compute_batch_full(h, set, plan[t], seed, epoch));
+    else CHK(compute_batch(h, set, plan[t], seed, epoch));
     h->seq++;
     h->acc_examples += plan[t].E; h->acc_batches++; h->acc_users += plan[t].nb;
   }
@@ -1320,7 +1379,7 @@ int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64
   if (plan.empty()) return 0;
   if (is_prefetched(h, plan[0], seed, epoch)) return 0;
   h->prof_q = h->seq;
-  if (!(h->debug_skip_prep && h->seq >= 4)) CHK(prep_batch(h, (int)(h->seq & 1), plan[0], seed, epoch));
+  if (!(h->debug_skip_prep && h->seq >= 2 * cdae_hip::NSETS)) CHK(prep_batch(h, set_of(h->seq), plan[0], seed, epoch, prep_lane(h, h->seq)));
   h->pre_valid = true;
   h->pre_s0 = plan[0].s0; h->pre_nb = plan[0].nb; h->pre_cidx = plan[0].cidx; h->pre_seed = seed; h->pre_epoch = epoch;
   return 0;
@@ -1350,15 +1409,15 @@ int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, ui
   if (E > *n_examples) return fail("batch has %llu examples, the caller's arrays hold %llu", (unsigned long long)E, (unsigned long long)*n_examples);
   *n_examples = E;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->prep));
+  CHK(sync_prep(h));
   h->pre_valid = false;                                   // the set is overwritten: a prefetched batch is gone
-  const int set = (int)(h->seq & 1);
+  const int set = set_of(h->seq);
   const int prof = h->profiling;
   h->profiling = 0;
   const int rc = prep_batch(h, set, Batch{u_begin, n_users, cidx, E}, seed, epoch);
   h->profiling = prof;
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->prep));
+  CHK(sync_prep(h));
   cdae_hip::ExBuf& x = h->ex[set];
   const size_t I = (size_t)h->I;
   auto out = [&](void* dst, const void* src, size_t bytes) -> int {
@@ -1561,8 +1620,8 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   }
   h->pre_valid = false;
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipStreamSynchronize(h->prep));
-  const int set = (int)(h->seq & 1);
+  CHK(sync_prep(h));
+  const int set = set_of(h->seq);
   cdae_hip::ExBuf& x = h->ex[set];
   HIPCHK(hipMemcpyAsync(x.item, items.data(), E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(x.val, vals.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));

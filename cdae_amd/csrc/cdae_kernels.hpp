@@ -45,7 +45,24 @@ struct HyperParams {
   uint32_t K, Kp;            // num_dim and row stride (floats, = 64 * NI)
   uint32_t unit_pos;         // positives per work unit (<= UNIT_POS_MAX), see "Work units" below
   uint32_t debug_rank;       // -DCDAE_DECODE_TIMING builds: the row whose timeline decode_rows_kernel records
+  unsigned long long* trace; // CDAE_WAVE_TRACE (developer aid, tools/wave_trace.py): per-wavefront {tag, start, end, extra} records, or nullptr
+  uint32_t debug_skip;       // CDAE_DEBUG_SKIP_ROLES (timing experiments only, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows
 };
+
+// ------------------------------------------------------------------------------------------------
+// Developer aid: wavefront timeline.  With CDAE_WAVE_TRACE set the handle passes a buffer of four-word records and every traced
+// wavefront fills its own: {tag << 32 | id, start, end, extra} in 100 MHz device time.
+constexpr uint32_t TRACE_ROLES = 16, TRACE_IDS = 1u << 16;   // record slot = role * TRACE_IDS + id (no shared counter: it would serialise the wavefronts)
+constexpr unsigned long long TRACE_CAP = (unsigned long long)TRACE_ROLES * TRACE_IDS;
+__device__ __forceinline__ unsigned long long trace_begin(const HyperParams& hp) {
+  return hp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+}
+__device__ __forceinline__ void trace_end(const HyperParams& hp, uint32_t tag, uint32_t id, unsigned long long t0, uint32_t extra = 0) {
+  if (hp.trace && threadIdx.x % 64 == 0 && id < TRACE_IDS) {
+    unsigned long long* r = hp.trace + 4ull * ((unsigned long long)tag * TRACE_IDS + id);
+    r[0] = ((unsigned long long)tag << 32) | id; r[1] = t0; r[2] = __builtin_amdgcn_s_memrealtime(); r[3] = extra;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // vector access: NI contiguous floats per lane
@@ -334,6 +351,7 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
+  const unsigned long long t0 = trace_begin(hp);
   const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = uids ? (uint64_t)uids[ur.slot] : u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
@@ -379,6 +397,7 @@ encode_partial_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const
     }
   }
   vstore<NI>(Hpart + (size_t)unit * hp.Kp + lo, acc);
+  trace_end(hp, 1, unit, t0);
 }
 
 template <int NI>
@@ -392,22 +411,32 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
+  const unsigned long long t0 = trace_begin(hp);
   const uint64_t uid = uids ? (uint64_t)uids[slot] : u0 + slot;
   const uint32_t lo = lane * NI;
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
-  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
-  for (uint32_t u = ub; u < ue; ++u) {                          // unit order == item order: deterministic sum
-    float part[NI];
-    vload<NI>(part, Hpart + (size_t)u * hp.Kp + lo);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] += part[i];
-  }
-  const float sc = mode == 0 ? 1.f : hp.scale;
+  // b and Wu[u] are requested up front, beside the partial rows (they were one more round trip behind them)
   float bb[NI], wu[NI], z[NI], dz[NI];
   vload<NI>(bb, b + lo);
   if (hp.user_factor) vload<NI>(wu, Wu + (size_t)uid * hp.Kp + lo);
+  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  // unit order == item order: deterministic sum.  UF partial rows are in flight at a time (index clamped, the surplus
+  // added as 0): a user has 2-3 units at ML-10M shape, and one L2 round trip per unit was most of this launch
+  constexpr uint32_t UF = 8;
+  for (uint32_t u = ub; u < ue; u += UF) {
+    float part[UF][NI];
+#pragma unroll
+    for (uint32_t j = 0; j < UF; ++j) vload<NI>(part[j], Hpart + (size_t)min(u + j, ue - 1u) * hp.Kp + lo);
+#pragma unroll
+    for (uint32_t j = 0; j < UF; ++j) {
+      const bool on = u + j < ue;                               // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] += on ? part[j][i] : 0.f;
+    }
+  }
+  const float sc = mode == 0 ? 1.f : hp.scale;
   if (hp.linear_function) {                                  // h1 = Uu[u] (.) h1   cdae.hpp:382-384
     float uu[NI];
     vload<NI>(uu, Uu + (size_t)uid * hp.Kp + lo);
@@ -431,6 +460,7 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
     for (int i = 0; i < NI; ++i) z[i] = 0.f;
     vstore<NI>(HGzero + (size_t)slot * hp.Kp + lo, z);
   }
+  trace_end(hp, 2, slot, t0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -942,10 +972,16 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
   constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   if (wave < hot_rows) {
+    if (hp.debug_skip & 4u) return;
+    const unsigned long long t0 = trace_begin(hp);
     __builtin_amdgcn_s_setprio(2);
     decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
+    trace_end(hp, 3, wave, t0);
   } else {
+    if (hp.debug_skip & 8u) return;
+    const unsigned long long t0 = trace_begin(hp);
     decode_rows16<NV, NT, LOSS, ADAGRAD>(hp, hot_rows + (wave - hot_rows) * 4u, CDAE_DECODE_PASS);
+    trace_end(hp, 4, wave, t0);
   }
 }
 
@@ -971,6 +1007,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
+  const unsigned long long t0 = trace_begin(hp);
   const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
   const uint64_t uid = u0 + ur.slot;
   const int64_t r0 = row_ptr[uid];
@@ -989,7 +1026,12 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
-  constexpr int UN = 8;
+  #ifndef CDAE_GATHER_UN
+#define CDAE_GATHER_UN 12
+#endif
+  // rows in flight per trip: a 64-example chunk holds 8 +- 2.6 rows of this partition, so 12 covers a chunk in one L2 round trip
+  // 19 times in 20 (with 8, every other chunk took a second trip for one or two rows)
+  constexpr int UN = CDAE_GATHER_UN;
   // this lane's (item, g, correction row) of a 64-example chunk; the next chunk is loaded before the current one's rows
   // are gathered, so a wavefront pays one L2 round trip per chunk, not two
   auto load_chunk = [&](uint32_t c, uint32_t& item, float& g, uint32_t& di) {
@@ -1055,6 +1097,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
     for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   }
   vstore<NI>(HGpart + ((size_t)part * n_units + unit) * hp.Kp + lo, acc);
+  trace_end(hp, 5, unit * 8u + part, t0, n_ex);
 }
 
 // K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
@@ -1071,30 +1114,54 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
+  const unsigned long long t0 = trace_begin(hp);
   const uint64_t uid = u0 + slot;
   const uint32_t lo = lane * NI;
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
   vload<NI>(hg, HG + o);
+  // everything the tail needs is requested up front, beside the partial rows (it was two more round trips behind them)
+  const size_t ou = (size_t)uid * hp.Kp + lo;
+  float p[NI], pa[NI];
+  vload<NI>(dz, Dz + o);
+  if (hp.user_factor) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
   const uint32_t ub = n_parts ? uptr[slot] - uptr[0] : 0u, ue = n_parts ? uptr[slot + 1] - uptr[0] : 0u;
-  for (uint32_t u = ub; u < ue; ++u) {                          // fixed order: deterministic
-#pragma unroll 8
-    for (uint32_t x = 0; x < n_parts; ++x) {
-      float part[NI];
-      vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
+  // fixed order (unit-major, then partition): deterministic.  Eight partitions (the training path): two units' 16 partial
+  // rows are in flight per trip (a user has 2-3 units at ML-10M shape; the second unit is clamped and added as 0 past the end)
+  if (n_parts == 8u) {
+    const size_t slab = (size_t)n_units * hp.Kp;
+    for (uint32_t u = ub; u < ue; u += 2) {
+      const bool two = u + 1u < ue;                                // wave-uniform
+      const float* p0 = HGpart + (size_t)u * hp.Kp + lo;
+      const float* p1 = HGpart + (size_t)(two ? u + 1u : u) * hp.Kp + lo;
+      float a0[8][NI], a1[8][NI];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) hg[i] += part[i];
+      for (int x = 0; x < 8; ++x) vload<NI>(a0[x], p0 + x * slab);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) vload<NI>(a1[x], p1 + x * slab);
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += a0[x][i];
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += two ? a1[x][i] : 0.f;
+    }
+  } else {
+    for (uint32_t u = ub; u < ue; ++u) {
+      for (uint32_t x = 0; x < n_parts; ++x) {
+        float part[NI];
+        vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += part[i];
+      }
     }
   }
-  vload<NI>(dz, Dz + o);
 #pragma unroll
   for (int i = 0; i < NI; ++i) delta[i] = hg[i] * dz[i];
   vstore<NI>(HG + o, delta);
   if (hp.user_factor) {
-    const size_t ou = (size_t)uid * hp.Kp + lo;
-    float p[NI], pa[NI];
-    vload<NI>(p, Wu + ou);
-    vload<NI>(pa, Wu_ag + ou);
 #pragma unroll
     for (int i = 0; i < NI; ++i) ada_step(hp, p[i], pa[i], fmaf(hp.lambda, p[i], delta[i]));
     vstore<NI>(Wu + ou, p);
@@ -1104,8 +1171,7 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
     // The input rows take Uu[u] (.) delta (cdae.hpp:339) with Uu[u] from BEFORE its own step (:351-357 comes last).
     // Uu_grad = lambda Uu[u] + sum_k delta (.) W[k] (cdae.hpp:295-299, 340 — no input scale there): the kept rows have
     // not moved since the encode inside one user's step, so the sum is delta (.) Ssum with the encode's own row sum.
-    const size_t ou = (size_t)uid * hp.Kp + lo;
-    float p[NI], pa[NI], ss[NI], dr[NI];
+    float ss[NI], dr[NI];
     vload<NI>(p, Uu + ou);
     vload<NI>(pa, Uu_ag + ou);
     vload<NI>(ss, Ssum + o);
@@ -1118,6 +1184,7 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
     vstore<NI>(Uu + ou, p);
     vstore<NI>(Uu_ag + ou, pa);
   }
+  trace_end(hp, 6, slot, t0);
 }
 
 // K4b  hidden bias b: the one parameter every user updates, strictly in user order (cdae.hpp:301-315).
@@ -1131,24 +1198,33 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
   if (k >= hp.Kp || nb == 0) return;
   hp.adagrad = ADAGRAD;
   float p = b[k], acc = b_ag[k];
-  // One dependent AdaGrad chain per coordinate (7 instructions per user) bounds this role: the loop is branch-free —
-  // the next UN users' deltas are loaded (index clamped, never guarded) before the current UN steps run.
+  // One dependent AdaGrad chain per coordinate (7 instructions per user) bounds this role: the loop is branch-free, and
+  // the deltas run UN users ahead of it in a register ring — slot j is refilled (index clamped, never guarded) as soon as
+  // its value has been taken, so the role holds UN values, not 2 UN (the role's registers set the occupancy of the whole
+  // input_rows_kernel launch).
   constexpr uint32_t UN = 16;
-  float d[UN], dn[UN];
+  float d[UN];
+  // buffer loads: descriptor + 32-bit lane offset + scalar row offset, i.e. no 64-bit address registers per load in flight
+  // (plain pointer arithmetic cost the role 69 VGPRs, and with it the whole launch a third of its occupancy)
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DELTA), 0, (int)(nb * hp.Kp * 4u), 0x00020000);
+  const int voff = (int)(k * 4u);
+  auto delta_of = [&](uint32_t user) -> float {                // user is wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(min(user, nb - 1u) * hp.Kp * 4u), 0));
+  };
 #pragma unroll
-  for (uint32_t j = 0; j < UN; ++j) d[j] = DELTA[(size_t)min(j, nb - 1u) * hp.Kp + k];
-  const uint32_t full = nb / UN;
-  for (uint32_t g = 0; g < full; ++g) {
+  for (uint32_t j = 0; j < UN; ++j) d[j] = delta_of(j);
+  uint32_t u = 0;
+  for (; u + UN <= nb; u += UN) {
 #pragma unroll
-    for (uint32_t j = 0; j < UN; ++j) dn[j] = DELTA[(size_t)min((g + 1u) * UN + j, nb - 1u) * hp.Kp + k];
-#pragma unroll
-    for (uint32_t j = 0; j < UN; ++j) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
-#pragma unroll
-    for (uint32_t j = 0; j < UN; ++j) d[j] = dn[j];
+    for (uint32_t j = 0; j < UN; ++j) {
+      const float x = d[j];
+      d[j] = delta_of(u + UN + j);
+      ada_step(hp, p, acc, fmaf(hp.lambda, p, x));
+    }
   }
 #pragma unroll
   for (uint32_t j = 0; j < UN; ++j)                            // the last nb % UN users
-    if (full * UN + j < nb) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
+    if (u + j < nb) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
   b[k] = p;
   b_ag[k] = acc;
 }
@@ -1160,14 +1236,23 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
 // The row's example words are scanned 64 at a time; the kept inputs among them are taken in groups of UN.
 // Three groups are kept in registers: while the (elementwise, reduction-free) AdaGrad chain of one runs, the
 // delta / z / g loads of the next two are in flight (loads-only loop => counted vmcnt, see K3).
-template <int NI, int UN>
+template <int NE, int UN>
 struct InputGroup {
-  float dl[UN][NI], zz[UN][NI], gg[UN];
-  bool on[UN];
+  float dl[UN][NE], zz[UN][NE], gg[UN];
+  uint32_t cnt;                                                  // kept inputs in the group (wave-uniform); 0: the row is done
 };
 
-template <int NI, bool ADAGRAD>
-__device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t rank, const uint32_t* __restrict__ item_order,
+// One wavefront walks row `rank`; lane holds the NE contiguous elements from `lo`.
+//  * ordinary rows (NE = NI, lo = NI * lane, UN = 4, one group at a time): most rows have one or two kept inputs per batch, so the
+//    wavefront is a short chain of L2 round trips and the launch lives on occupancy — one group keeps it at ~60 VGPRs;
+//  * popular rows (input_rows_kernel's hot workgroups): the row is split over the workgroup's four wavefronts (NE = NI / 4: the
+//    step is elementwise in k) and two groups of UN = 12 alternate, so 24 examples' delta / z rows are in flight while the
+//    (reduction-free) AdaGrad chain of the previous group runs — a popular row has 50+ kept inputs per batch and its chain
+//    of dependent L2 round trips bounded the launch (17.4 -> 13.3 us without the eight most popular rows).
+// A group never straddles a 64-example chunk of the row's example words.
+template <int NE, int UN, bool PIPE, bool ADAGRAD>
+__device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t rank, const uint32_t lo,
+                                               const uint32_t* __restrict__ item_order,
                                                const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
                                                const uint64_t* __restrict__ sorted_val, const float* __restrict__ Z,
                                                const float* __restrict__ DELTA, const float* __restrict__ G,
@@ -1178,88 +1263,83 @@ __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t ra
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[item], end = seg_end[item];
   if (beg == end) return;
-  const uint32_t lo = lane * NI;
-  constexpr int UN = 4;
-  float w[NI], a[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) { w[i] = 0.f; a[i] = 1.f; }
-  bool loaded = false;
 
-  // stream state: next chunk start, and the kept-input mask / words / example ids of the current chunk
+  // stream state: the kept-input mask / words / example ids of the current 64-example chunk; the chunk at `next_chunk` is
+  // already in flight (`ahead`), so moving on to it costs no round trip
   uint32_t next_chunk = beg;
+  uint64_t ahead = beg + lane < end ? sorted_val[beg + lane] : 0ull;
   unsigned long long mask = 0ull;
   uint32_t word = 0u, ex = 0u;
-
-  auto fetch = [&](InputGroup<NI, UN>& grp) -> bool {
-    bool any = false;
+  auto fetch = [&](InputGroup<NE, UN>& grp) {
+    while (mask == 0ull && next_chunk < end) {                   // wave-uniform: move on to the chunk in flight, request the one after
+      word = (uint32_t)ahead;
+      ex = (uint32_t)(ahead >> 32);
+      mask = __ballot((word & INPUT_BIT) != 0u);
+      next_chunk += WAVE;
+      const uint32_t p = next_chunk + lane;
+      ahead = p < end ? sorted_val[p] : 0ull;
+    }
+    grp.cnt = min((uint32_t)__popcll(mask), (uint32_t)UN);
 #pragma unroll
     for (int t = 0; t < UN; ++t) {
-      while (mask == 0ull && next_chunk < end) {               // wave-uniform: refill from the next 64 example words
-        const uint32_t p = next_chunk + lane;
-        const uint64_t val = p < end ? sorted_val[p] : 0ull;
-        word = (uint32_t)val;
-        ex = (uint32_t)(val >> 32);
-        mask = __ballot((word & INPUT_BIT) != 0u);
-        next_chunk += WAVE;
-      }
-      grp.on[t] = mask != 0ull;
-      grp.gg[t] = 0.f;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) { grp.dl[t][i] = 0.f; grp.zz[t][i] = 0.f; }
-      if (grp.on[t]) {
-        any = true;
+      if ((uint32_t)t < grp.cnt) {                               // wave-uniform
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, src) & SLOT_MASK;
         const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ex, src);
         const size_t o = (size_t)slot * hp.Kp + lo;
-        vload<NI>(grp.dl[t], DELTA + o);
-        vload<NI>(grp.zz[t], Z + o);
-        if (!hp.asymmetric) grp.gg[t] = G[e];
+        vload<NE>(grp.dl[t], DELTA + o);
+        vload<NE>(grp.zz[t], Z + o);
+        grp.gg[t] = hp.asymmetric ? 0.f : G[e];
       }
     }
-    return any;
   };
-  auto apply = [&](const InputGroup<NI, UN>& grp) {
-    if (!loaded) {
-      loaded = true;
-      vload<NI>(w, W + (size_t)item * hp.Kp + lo);
-      vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
-    }
+  float w[NE], a[NE];
+  auto apply = [&](const InputGroup<NE, UN>& grp) {
 #pragma unroll
     for (int t = 0; t < UN; ++t) {
-      if (grp.on[t]) {
+      if ((uint32_t)t < grp.cnt) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NE; ++i)
           ada_step(hp, w[i], a[i], fmaf(hp.scale, grp.dl[t][i], fmaf(grp.gg[t], grp.zz[t][i], hp.lambda * w[i])));
       }
     }
   };
 
-  // three groups in a ring: while one group's (elementwise, reduction-free) AdaGrad chain runs, the delta / z / g loads
-  // of the next two are in flight — a popular row has > 100 kept inputs per batch and one L2 round trip per group
-  // would otherwise bound the launch
-  InputGroup<NI, UN> A, B, C;
-  bool hasA = fetch(A);
-  bool hasB = hasA && fetch(B);
-  bool hasC = hasB && fetch(C);
-  while (hasA) {
-    apply(A);
-    hasA = hasC && fetch(A);
-    if (!hasB) break;
-    apply(B);
-    hasB = hasA && fetch(B);
-    if (!hasC) break;
-    apply(C);
-    hasC = hasB && fetch(C);
+  InputGroup<NE, UN> A;
+  fetch(A);
+  if (A.cnt == 0u) return;                                       // no kept input on this row: W is not touched
+  vload<NE>(w, W + (size_t)item * hp.Kp + lo);
+  vload<NE>(a, W_ag + (size_t)item * hp.Kp + lo);
+  if constexpr (PIPE) {
+    InputGroup<NE, UN> B;
+    while (true) {
+      fetch(B);
+      apply(A);
+      if (B.cnt == 0u) break;
+      fetch(A);
+      apply(B);
+      if (A.cnt == 0u) break;
+    }
+  } else {
+    do {
+      apply(A);
+      fetch(A);
+    } while (A.cnt != 0u);
   }
-  if (loaded) {
-    vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
-    vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
-    if (lane == 0 && touched) touched[item] = 1u;
-  }
+  vstore<NE>(W + (size_t)item * hp.Kp + lo, w);
+  vstore<NE>(W_ag + (size_t)item * hp.Kp + lo, a);
+  if (lane == 0 && touched) touched[item] = 1u;
 }
 
+#ifndef CDAE_INPUT_UN
+#define CDAE_INPUT_UN 2
+#endif
+#ifndef CDAE_INPUT_UN_HOT
+#define CDAE_INPUT_UN_HOT 5
+#endif
+// grid: [bias_blocks: K4b] [hot_rows workgroups: one popular row each, split over the four wavefronts (NI >= 4 only)]
+//       [the other rows, one per wavefront]
 template <int NI>
 __global__ void __launch_bounds__(256)
 input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
@@ -1268,17 +1348,39 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                   const float* __restrict__ DELTA, const float* __restrict__ G,
                   float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched,
                   uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag,
-                  const float* __restrict__ DELTA_ROWS /* == DELTA unless linear_function (then Uu[u] (.) delta_u) */) {
+                  const float* __restrict__ DELTA_ROWS /* == DELTA unless linear_function (then Uu[u] (.) delta_u) */,
+                  uint32_t hot_rows /* 0 when NI < 4 */) {
   const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
   if (blockIdx.x < bias_blocks) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hp.debug_skip & 1u) return;
+    const unsigned long long t0 = trace_begin(hp);
     if (hp.adagrad) hidden_bias_role<true>(hp, k, nb, DELTA, b, b_ag);
     else hidden_bias_role<false>(hp, k, nb, DELTA, b, b_ag);
+    trace_end(hp, 7, k / 64u, t0);
     return;
   }
-  const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
-  if (hp.adagrad) input_row_role<NI, true>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
-  else input_row_role<NI, false>(hp, rank, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+  if (hp.debug_skip & 2u) return;
+  const uint32_t wg = blockIdx.x - bias_blocks, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  if (wg < hot_rows) {
+    if constexpr (NI >= 4) {
+      constexpr int NE = NI / 4;
+      const uint32_t rank = __builtin_amdgcn_readfirstlane(wg);
+      const uint32_t lo = wid * (hp.Kp / 4u) + lane * NE;
+      const unsigned long long t0 = trace_begin(hp);
+      if (hp.adagrad) input_row_role<NE, CDAE_INPUT_UN_HOT, true, true>(hp, rank, lo, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+      else input_row_role<NE, CDAE_INPUT_UN_HOT, true, false>(hp, rank, lo, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+      trace_end(hp, 8, rank * 4u + wid, t0);
+    }
+    return;
+  }
+  const uint32_t rank = __builtin_amdgcn_readfirstlane(hot_rows + (wg - hot_rows) * (blockDim.x / WAVE) + wid);
+  if ((hp.debug_skip & 16u) && rank < hp.debug_rank) return;   // experiment: without the debug_rank most popular rows
+  if (hp.debug_skip & 32u) return;                             // experiment: popular rows only
+  const unsigned long long t0 = trace_begin(hp);
+  if (hp.adagrad) input_row_role<NI, CDAE_INPUT_UN, false, true>(hp, rank, lane * NI, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+  else input_row_role<NI, CDAE_INPUT_UN, false, false>(hp, rank, lane * NI, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+  trace_end(hp, 9, rank, t0);
 }
 
 // ------------------------------------------------------------------------------------------------
