@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcdae_hip.so")
+LIB_PATH = os.environ.get("CDAE_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libcdae_hip.so")   # (developer builds: another .so of the same ABI)
 
 # libcf::LossType values (/root/reference/src/model/loss.hpp:10-18)
 SQUARE, LOGISTIC, LOG, HINGE, SQUARED_HINGE, CROSS_ENTROPY, LOGM = range(7)

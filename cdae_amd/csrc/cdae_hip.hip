@@ -984,8 +984,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint32_t one_unit[2] = {0u, 1u};          // explicit-input step: one user, one unit
     HIPCHK(hipMemcpy(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice));
   }
-  if ((uint64_t)B * h->Kp * sizeof(float) > 0xFFFFFFFFull)      // decode addresses z rows with 32-bit byte offsets (cdae_kernels.hpp)
-    return fail("batch_users %u x row stride %u floats exceeds the 4 GiB the batch's Z may occupy; lower batch_users", B, h->Kp);
+  if ((uint64_t)B * h->Kp * sizeof(float) > 0x7FFFFFFFull)      // decode addresses z rows with 31-bit byte offsets (buffer loads, cdae_kernels.hpp)
+    return fail("batch_users %u x row stride %u floats exceeds the 2 GiB the batch's Z may occupy; lower batch_users", B, h->Kp);
   if (h->Ecap > 0xFFFFFFF0ull) return fail("batch of %u users holds %llu examples (> 2^32); lower batch_users", B, (unsigned long long)h->Ecap);
   for (auto& b : h->ex) {
     CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));

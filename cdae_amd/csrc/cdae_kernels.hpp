@@ -501,13 +501,15 @@ constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15 =
 // constant 1 as its "z": its AdaGrad step grad = g*1 + lambda*b' (cdae.hpp:230-237) is then the row step's own
 // arithmetic and y = D[j].z + b'[j] needs no separate add — the per-example chain loses the scalar bias
 // recurrence (two transcendentals).  Memory images of D and D0 keep their pad elements 0.
+// g_park / park_cap: wave-private LDS words where g is parked until the row is finished (nullptr / 0: written out per 64-example
+// chunk, which costs a store + full vmcnt drain — ~1 us of the row's serial chain — per chunk)
 template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
-__device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank, CDAE_DECODE_PARAMS) {
+__device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank, float* __restrict__ g_park, const uint32_t park_cap,
+                                             CDAE_DECODE_PARAMS) {
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[item], end = seg_end[item];
-  if (beg == end) return;
   hp.loss_type = LOSS;                 // compile-time specialisation of the per-example branches
   hp.adagrad = ADAGRAD;
 #ifdef CDAE_DECODE_TIMING   // developer aid (tools/decode_timeline.py): s_memtime stamps of one row's timeline
@@ -520,11 +522,14 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
   CDAE_STAMP();
   const uint32_t lo = lane * NI;
   const bool tied = !hp.asymmetric;
+  // the row is requested beside its segment bounds (one round trip of the chain's prologue instead of two); a row without
+  // examples leaves here with nothing written
   float w[NI], a[NI], wref[NI];
   vload<NI>(w, D + (size_t)item * hp.Kp + lo);
   vload<NI>(a, D_ag + (size_t)item * hp.Kp + lo);
-  vstore<NI>(D0 + (size_t)item * hp.Kp + lo, w);     // batch-start snapshot of this row for the hidden-gradient gather
   float bias = bp[item], bias_ag = bp_ag[item];
+  if (beg == end) return;
+  vstore<NI>(D0 + (size_t)item * hp.Kp + lo, w);     // batch-start snapshot of this row for the hidden-gradient gather
   const bool pad_lane = BIAS_IN_PAD && lane == WAVE - 1;
   const float pad_one = pad_lane ? 1.f : 0.f;
   if (pad_lane) { w[NI - 1] = bias; a[NI - 1] = bias_ag; }
@@ -645,6 +650,14 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     }
     return wave_sum(d0 + d1);
   };
+  // The statements below are INTERLEAVED BY HAND and pinned with scheduling barriers: a wavefront issues in order, so two
+  // independent dependent-chains only overlap if their instructions alternate in the stream.  Left to itself hipcc emits the
+  // scalar chain of example i (y -> sigmoid -> g -> b' step: 13 dependent instructions, 4 of them transcendental) and THEN the
+  // speculative dot + 6-stage DPP reduction of example i+1 (9 dependent instructions, each DPP stage padded with s_nop): 330
+  // cycles per deferred example, 590 per stepping one — the 465-cycle average measured on the most popular row.  Alternating
+  // them hides the reduction (and its DPP wait states) inside the scalar chain, and the row step's five stages carry the b'
+  // step between them.  Same arithmetic, same operands, same order of roundings as loss_grad / ada_step: bit-identical results.
+#define CDAE_SB() __builtin_amdgcn_sched_barrier(0)
   auto fast_group_spec = [&](const uint32_t j0) {
     float sdot = s_valid ? s_carry : row_dot(z[0]);
 #pragma unroll
@@ -652,17 +665,85 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
       const uint32_t idx = j0 + t;
       const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
       const float tgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_t), idx));
-      const float y = sdot + bias;
-      const float g = loss_grad(hp.loss_type, y, tgt);
-      gbuf = lane == idx ? g : gbuf;
-      const float spec = row_dot(z[(t + 1) % PF]);             // next example against the row as it is now
-      ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
-      if ((word & INPUT_BIT) && tied) {                        // deferred: the row did not move, the speculation holds
+      const float (&zn)[NI] = z[(t + 1) % PF];
+      float g, spec;
+      CDAE_SB();
+      {
+        // chain A: y -> g            | chain B: next example against the row as it is now
+        const float y = sdot + bias;
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; i += 2) {
+          d0 = fmaf(w[i], zn[i], d0);
+          if (i + 1 < NI) d1 = fmaf(w[i + 1], zn[i + 1], d1);
+        }
+        float d = d0 + d1;
+        CDAE_SB();
+        if constexpr (LOSS == 5) {                               // loss_grad: rcp(1 + exp(-y)) - t
+          const float e = fast_exp(-y);
+          d = dpp_add<0xB1>(d);
+          CDAE_SB();
+          const float u = 1.f + e;
+          d = dpp_add<0x4E>(d);
+          CDAE_SB();
+          const float sg = fast_rcp(u);
+          d = dpp_add<0x141>(d);
+          CDAE_SB();
+          g = sg - tgt;
+          d = dpp_add<0x140>(d);
+          CDAE_SB();
+        } else {
+          g = -2.f * (tgt - y);
+          d = dpp_add<0xB1>(d);
+          CDAE_SB();
+          d = dpp_add<0x4E>(d);
+          d = dpp_add<0x141>(d);
+          d = dpp_add<0x140>(d);
+          CDAE_SB();
+        }
+        gbuf = lane == idx ? g : gbuf;
+        d = dpp_add<0x142>(d);
+        CDAE_SB();
+        d = dpp_add<0x143>(d);
+        CDAE_SB();
+        spec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
+      }
+      const float gb = fmaf(hp.lambda, bias, g);                 // b' step (cdae.hpp:230-237), staged below
+      if ((word & INPUT_BIT) && tied) {                          // deferred: the row did not move, the speculation holds
+        ada_step(hp, bias, bias_ag, gb);
         sdot = spec;
+      } else if constexpr (ADAGRAD) {
+        // row step in five stages, the b' step riding between them
+        float gr[NI], rr[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) gr[i] = fmaf(g, z[t][i], hp.lambda * w[i]);
+        CDAE_SB();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = fmaf(gr[i], gr[i], a[i]);
+        bias_ag = fmaf(gb, gb, bias_ag);
+        CDAE_SB();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rr[i] = fast_sqrt(a[i]);
+        float rb = fast_sqrt(bias_ag);
+        CDAE_SB();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rr[i] += hp.beta;
+        rb += hp.beta;
+        CDAE_SB();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rr[i] = fast_rcp(rr[i]);
+        rb = fast_rcp(rb);
+        CDAE_SB();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w[i] = fmaf(-hp.lr * gr[i], rr[i], w[i]);
+        CDAE_SB();
+        bias = fmaf(-hp.lr * gb, rb, bias);
+        sdot = row_dot(zn);
       } else {
 #pragma unroll
         for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
-        sdot = row_dot(z[(t + 1) % PF]);
+        ada_step(hp, bias, bias_ag, gb);
+        sdot = row_dot(zn);
       }
       const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)look, (idx + PF) & 63u);
       vload<NI>(z[t], reinterpret_cast<const float*>(Zb + off));
@@ -670,6 +751,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     s_carry = sdot;
     s_valid = true;
   };
+#undef CDAE_SB
 
   CDAE_STAMP();
   for (; c0 < end; c0 += WAVE) {
@@ -707,12 +789,18 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
       }
     }
     CDAE_STAMP();
-    if (lane < cnt) G[cur_e] = gbuf;
-    if (c0 + WAVE < end) __builtin_amdgcn_s_waitcnt(WAIT_VM0);   // (nothing follows the last chunk but the row's own stores)
+    if (c0 - beg + WAVE <= park_cap) {                           // wave-uniform: parked in LDS, written out after the row's last example
+      g_park[c0 - beg + lane] = gbuf;
+    } else {
+      if (lane < cnt) G[cur_e] = gbuf;
+      if (c0 + WAVE < end) __builtin_amdgcn_s_waitcnt(WAIT_VM0);   // (nothing follows the last chunk but the row's own stores)
+    }
     CDAE_STAMP();
     cur_w = nxt_w; cur_e = nxt_e; cur_o = nxt_o;
     nxt_w = (uint32_t)far; nxt_e = (uint32_t)(far >> 32); nxt_o = (nxt_w & SLOT_MASK) * row_bytes;
   }
+  for (uint32_t q = lane; q < min(end - beg, park_cap & ~63u); q += WAVE)       // the parked g: example ids are re-read (coalesced)
+    G[(uint32_t)(sorted_val[beg + q] >> 32)] = g_park[q];
   if (BIAS_IN_PAD) {
     if (pad_lane) {
       bp[item] = w[NI - 1];
@@ -738,7 +826,7 @@ template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
 __global__ void __launch_bounds__(256)
 decode_rows_kernel(HyperParams hp, CDAE_DECODE_PARAMS) {
   const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
-  decode_row64<NI, LOSS, ADAGRAD, BIAS_IN_PAD>(hp, rank, CDAE_DECODE_PASS);
+  decode_row64<NI, LOSS, ADAGRAD, BIAS_IN_PAD>(hp, rank, nullptr, 0u, CDAE_DECODE_PASS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -775,8 +863,12 @@ __device__ __forceinline__ void row16_store(float* __restrict__ base, const floa
   for (int i = 0; i < NT; ++i) base[64 * NV + l + 16 * i] = r[4 * NV + i];
 }
 
+// Wave-private LDS of decode_rows16 (words): example words and example ids of the current and the next 64-example chunk of each
+// of the four groups, and the parked g of the current chunk.
+constexpr uint32_t ROWS16_LDS_WORDS = 4u * 128u + 4u * 128u + 4u * 64u;
+
 template <int NV, int NT, int LOSS, bool ADAGRAD>
-__device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t rank0, CDAE_DECODE_PARAMS) {
+__device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t rank0, uint32_t* __restrict__ lds, CDAE_DECODE_PARAMS) {
   constexpr int GRP = 16, NE = 4 * NV + NT;
   constexpr bool HAS_PAD = NT > 0;
   const uint32_t lane = threadIdx.x % WAVE, l = lane & (GRP - 1), sub = lane / GRP;
@@ -822,48 +914,75 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
 #define CDAE_DECODE16_PF 4
 #endif
   constexpr int PF = CDAE_DECODE16_PF;
-  const uint32_t row_bytes = hp.Kp * 4u;
-  const char* Zc = reinterpret_cast<const char*>(Z);
-  // this lane's four example words / example ids of the group's current 64-example chunk: examples l + 16 j
-  uint32_t cw[4], ce[4];
-  auto load_chunk = [&](uint32_t c0) {
+  static_assert(128 % PF == 0 && 64 % PF == 0, "ring offsets are immediates inside one PF-group");
+  // Example words live in LDS: per group a ring of two 64-example chunks (the current one and the next), staged 64 at a time
+  // from sorted_val (lane l of the group fetches examples l, l+16, l+32, l+48 — coalesced), read back as one broadcast
+  // ds_read per example; g is parked there too and written out once per chunk, so the loop issues global LOADS only (counted
+  // vmcnt, see above) and no per-example select / permute bookkeeping.  Positions past the group's segment hold word 0
+  // (user slot 0: a valid z row that is never consumed).
+  uint32_t* const wl = lds + sub * 128u;                          // words  [128]
+  uint32_t* const el = lds + 512u + sub * 128u;                   // example ids [128]
+  float* const gl = reinterpret_cast<float*>(lds + 1024u + sub * 64u);   // parked g [64]
+  auto stage_chunk = [&](uint32_t c0) {                           // c0: wave-uniform multiple of 64; every lane of the wavefront takes part
+    uint64_t v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t q = c0 + l + GRP * j;
-      const uint64_t v = q < n ? sorted_val[beg + q] : 0ull;
-      cw[j] = (uint32_t)v; ce[j] = (uint32_t)(v >> 32);
+      v[j] = q < n ? sorted_val[beg + q] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t q = (c0 + l + GRP * j) & 127u;
+      wl[q] = (uint32_t)v[j];
+      el[q] = (uint32_t)(v[j] >> 32);
     }
   };
-  // word of the group's example t (t wave-uniform): lane (t & 15) of the group, register (t >> 4) & 3
-  auto word_of = [&](uint32_t t) -> uint32_t {
-    const uint32_t j = (t >> 4) & 3u;
-    const uint32_t src = j == 0 ? cw[0] : (j == 1 ? cw[1] : (j == 2 ? cw[2] : cw[3]));
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & ~(GRP - 1)) | (t & (GRP - 1))) << 2), (int)src);
+  auto flush_chunk = [&](uint32_t c0) {                           // G of the chunk starting at c0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t q = c0 + l + GRP * j;
+      if (q < n) G[el[q & 127u]] = gl[q & 63u];
+    }
   };
-  load_chunk(0);
+  stage_chunk(0);
+  stage_chunk(64);                                               // (unconditional: the look-ahead reads up to PF words past nmax, and LDS starts as garbage)
+  const uint32_t shift = 31u - (uint32_t)__builtin_clz(hp.Kp * 4u);      // row stride is a power of two bytes (Kp = 64 NI)
+  // z rows by buffer loads: descriptor (SGPRs) + one 32-bit offset per piece kind — no 64-bit address arithmetic per example
+  const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z), 0, 0x7FFFFFFF, 0x00020000);
+  const uint32_t lane_v = 16u * l, lane_t = 256u * NV + 4u * l;  // byte offsets of this lane's float4 pieces / tail scalars in a row
+  auto z_load = [&](float (&zz)[NE], uint32_t word) {
+    const uint32_t row = (word & SLOT_MASK) << shift;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const auto raw = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, (int)(row + lane_v + 256u * v), 0, 0);
+      float4 q;                                                  // (indexing the builtin's vector type directly narrows the load to one dword on hipcc 7.2)
+      __builtin_memcpy(&q, &raw, sizeof q);
+      zz[4 * v] = q.x; zz[4 * v + 1] = q.y; zz[4 * v + 2] = q.z; zz[4 * v + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      zz[4 * NV + i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrsrc, (int)(row + lane_t + 64u * i), 0, 0));
+  };
   float z[PF][NE];
   uint32_t zw[PF];                                               // word of the example whose z sits in ring slot
 #pragma unroll
   for (int r = 0; r < PF; ++r) {
-    zw[r] = word_of(min((uint32_t)r, n ? n - 1u : 0u));
-    row16_load<NV, NT>(z[r], reinterpret_cast<const float*>(Zc + (size_t)(zw[r] & SLOT_MASK) * row_bytes), l);
+    zw[r] = wl[r];
+    z_load(z[r], zw[r]);
   }
-  float gbuf[4] = {0.f, 0.f, 0.f, 0.f};
   CDAE_STAMP();
   for (uint32_t t0 = 0; t0 < nmax; t0 += PF) {
     if ((t0 & 15u) == 0u && t0) CDAE_STAMP();
+    if ((t0 & 63u) == 0u && t0 != 0u) {                          // chunk boundary (wave-uniform): write the finished chunk's g, stage the chunk after next
+      flush_chunk(t0 - 64u);
+      __builtin_amdgcn_s_waitcnt(WAIT_VM0);                      // keep the loop's VMEM stream loads-only
+      stage_chunk(t0 + 64u);                                     // (zeros past the segments' ends)
+    }
+    const uint32_t* const wnext = wl + ((t0 + PF) & 127u);       // words of the examples PF ahead: immediates r inside the group
+    float* const gpark = gl + (t0 & 63u);
 #pragma unroll
     for (int r = 0; r < PF; ++r) {
       const uint32_t t = t0 + r;                                 // wave-uniform
-      if ((t & 63u) == 0u && t != 0u) {                          // chunk boundary: flush g, fetch the next 64 example words
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t q = t - 64u + l + GRP * j;
-          if (q < n) G[ce[j]] = gbuf[j];
-        }
-        __builtin_amdgcn_s_waitcnt(WAIT_VM0);                    // keep the loop's VMEM stream loads-only
-        load_chunk(t);
-      }
       const uint32_t word = zw[r];
       if (t < n) {                                               // group-uniform
         if (HAS_PAD) z[r][NE - 1] += pad_one;
@@ -879,16 +998,11 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
         dot = dpp_add<0x141>(dot);                               // row_half_mirror
         float y = dpp_add<0x140>(dot);                           // row_mirror: every lane of the group holds the row sum
         if (!HAS_PAD) y += bias;
-        const float g = loss_grad(hp.loss_type, y, (word & TARGET_BIT) ? 1.f : 0.f);
+        // target 1 / 0: TARGET_BIT is bit 30, i.e. (word & TARGET_BIT) read as a float is 2.0 or 0.0
+        const float tgt = 0.5f * __builtin_bit_cast(float, word & TARGET_BIT);
+        const float g = loss_grad(hp.loss_type, y, tgt);
         if (!HAS_PAD) ada_step(hp, bias, bias_ag, fmaf(hp.lambda, bias, g));
-        {
-          const uint32_t j = (t >> 4) & 3u;
-          const bool mine = l == (t & (GRP - 1));
-          gbuf[0] = (mine && j == 0) ? g : gbuf[0];
-          gbuf[1] = (mine && j == 1) ? g : gbuf[1];
-          gbuf[2] = (mine && j == 2) ? g : gbuf[2];
-          gbuf[3] = (mine && j == 3) ? g : gbuf[3];
-        }
+        gpark[r] = g;                                            // all 16 lanes of the group write the same word
         if (word & (DUP_PREV_BIT | DUP_NEXT_BIT)) {              // duplicate negative of the same user (rare)
           if (word & DUP_PREV_BIT) {
             const uint32_t di = dup_of_pos[beg + t];
@@ -920,29 +1034,13 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
           if (pad_lane) { w[NE - 1] = bw; a[NE - 1] = ba; }
         }
       }
-      // refill ring slot r with the example PF ahead (clamped; never consumed past the segment's end)
-      {
-        const uint32_t tc = min(t + PF, n ? n - 1u : 0u);
-        uint32_t nw;
-        if ((tc >> 6) == (t >> 6)) {                             // its word is in the chunk held in cw[]
-          nw = word_of(tc);
-        } else {                                                 // first PF examples of the next chunk (or a finished group)
-          nw = (uint32_t)sorted_val[beg + tc];
-        }
-        zw[r] = nw;
-        row16_load<NV, NT>(z[r], reinterpret_cast<const float*>(Zc + (size_t)(nw & SLOT_MASK) * row_bytes), l);
-      }
+      // refill ring slot r with the example PF ahead (past the segment: word 0, never consumed)
+      zw[r] = wnext[r];
+      z_load(z[r], zw[r]);
     }
   }
-  // flush g of the chunk the loop ended in (groups that finished before it were flushed at a chunk boundary)
-  {
-    const uint32_t tb = (nmax - 1u) & ~63u;                      // wave-uniform: start of the last chunk the loop entered
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t q = tb + l + GRP * j;
-      if (q < n) G[ce[j]] = gbuf[j];
-    }
-  }
+  // g of the chunk the loop ended in (chunks before it were written at their boundary)
+  flush_chunk((nmax - 1u) & ~63u);
   if (n) {
     if (HAS_PAD) {
       if (pad_lane) { bp[item] = w[NE - 1]; bp_ag[item] = a[NE - 1]; w[NE - 1] = 0.f; a[NE - 1] = 1.f; }
@@ -970,17 +1068,19 @@ __global__ void __launch_bounds__(256)
 decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
   constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
   constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
+  __shared__ uint32_t rows16_lds[4][ROWS16_LDS_WORDS];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   if (wave < hot_rows) {
     if (hp.debug_skip & 4u) return;
     const unsigned long long t0 = trace_begin(hp);
     __builtin_amdgcn_s_setprio(2);
-    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
+    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROWS16_LDS_WORDS,
+                                           CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
     trace_end(hp, 3, wave, t0);
   } else {
     if (hp.debug_skip & 8u) return;
     const unsigned long long t0 = trace_begin(hp);
-    decode_rows16<NV, NT, LOSS, ADAGRAD>(hp, hot_rows + (wave - hot_rows) * 4u, CDAE_DECODE_PASS);
+    decode_rows16<NV, NT, LOSS, ADAGRAD>(hp, hot_rows + (wave - hot_rows) * 4u, rows16_lds[threadIdx.x / WAVE], CDAE_DECODE_PASS);
     trace_end(hp, 4, wave, t0);
   }
 }
@@ -1333,7 +1433,7 @@ __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t ra
 }
 
 #ifndef CDAE_INPUT_UN
-#define CDAE_INPUT_UN 2
+#define CDAE_INPUT_UN 4
 #endif
 #ifndef CDAE_INPUT_UN_HOT
 #define CDAE_INPUT_UN_HOT 5
