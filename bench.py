@@ -210,22 +210,53 @@ def main():
         args.exchange_every = int(host_max(want))
         model.exchange_configure(args.exchange_every)
         exchange_note = f"period chosen at start-up: all-reduce {t_ar * 1e6:.0f} us vs {t_step * 1e6:.0f} us per batch"
-    for i in range(args.warmup):
-        step(i)
+    def run(first, count):
+        # `count` steps from step `first`.  Without an exchange the steps are handed to the library in runs of up to 16
+        # consecutive batches of one epoch per call (as cdae_hip_train_epoch would: the batch loop is the library's, in C);
+        # with an exchange every step is followed by its exchange_step
+        i, end = first, first + count
+        while i < end:
+            if exchanging:
+                step(i)
+                i += 1
+                continue
+            ep, u0, u1 = batch_of(i)
+            c = 1
+            while c < 16 and i + c < end and batch_of(i + c)[0] == ep and batch_of(i + c)[1] == u1:
+                u1 = batch_of(i + c)[2]
+                c += 1
+            model.enqueue_users(args.seed, ep, u0, u1)
+            nep, n0, n1 = batch_of(i + c)
+            model.prefetch_users(args.seed, nep, n0, n1)
+            i += c
+
+    run(0, args.warmup)
     model.collect_stats()
     acc = {k: 0 for k in KEYS}
-    # HIP events on the library's own streams around each kernel family of every `profile_every`-th batch of the timed
-    # region (event records cost ~3 us of stream time each: 42 us per step if every batch carries its 14)
-    model.set_profiling(args.profile_every)
+    # Timed region: HIP events (on the library's own stream) around the DECODE launch of every `profile_every`-th batch — the
+    # roofline's kernel, measured live; an event pair costs ~6 us of stream time, so the other five families (14 records, 42 us
+    # on a profiled step) are timed in an untimed pass after it
+    period = min(args.profile_every, max(1, args.steps // 5)) if args.profile_every else 0      # short runs: at least ~5 timed launches
+    model.set_profiling(period, families=("decode",))
     sync()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
+    run(args.warmup, args.steps)
     if exchanging:
         model.exchange_flush()            # the last period's deltas are reduced and merged inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     add(model.collect_stats())
+    timed = dict(acc)
+    if args.profile_every:
+        # untimed: the other kernel families, every second batch of 32 more steps (kernel_ms_per_step; not part of `value`)
+        model.set_profiling(2)
+        run(args.warmup + args.steps, 32)
+        if exchanging:
+            model.exchange_flush()
+        sync()
+        extra = model.collect_stats()
+        for k in ("ms_sample", "ms_sort", "ms_encode", "ms_hidden", "ms_input"):
+            acc[k] = getattr(extra, k) / max(1, extra.launches_decode) * max(1, timed["launches_decode"])   # per profiled step, on the timed pass's scale
     model.set_profiling(False)
 
     users_total = float(acc["users"])
@@ -305,6 +336,7 @@ def main():
         "roofline": roofline,
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
         "profiled_steps": int(acc["launches_decode"]),
+        "kernel_ms_note": "decode: HIP events inside the timed region; the other families: an untimed pass of 32 steps after it",
     }
     if not args.no_cpu_baseline and args.gpus == 1:          # reported at N = 1 only (rank 0's host cores)
         out["cpu_baseline"] = cpu_baseline(data, cfg, args)

@@ -69,6 +69,7 @@ EXPORTS = {
     "cdae_hip_collect_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "cdae_hip_train_one_user_corruption": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "cdae_hip_set_profiling_families": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cdae_hip_synchronize": (C.c_int, [C.c_void_p]),
     "cdae_hip_debug_sample_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8
                                     + [C.POINTER(C.c_uint64)]),
@@ -247,8 +248,12 @@ class CDAE:
         return p.value, n.value
 
     # ---- training ----------------------------------------------------------------------------------
-    def set_profiling(self, period):
-        """0/False: off; k >= 1 (True = 1): HIP-event kernel timing on every k-th batch."""
+    def set_profiling(self, period, families=None):
+        """0/False: off; k >= 1 (True = 1): HIP-event kernel timing on every k-th batch, of the families named (e.g. ("decode",))
+        or of all of them."""
+        names = ("sample", "sort", "encode", "decode", "hidden", "input")
+        mask = 0xFFFFFFFF if families is None else sum(1 << names.index(f) for f in families)
+        _chk(self.lib, self.lib.cdae_hip_set_profiling_families(self.h, mask))
         _chk(self.lib, self.lib.cdae_hip_set_profiling(self.h, int(period)))
 
     def train_one_iteration(self, seed: int, epoch: int) -> Stats:

@@ -90,7 +90,6 @@ struct cdae_hip {
   uint32_t* d_col = nullptr;
   uint32_t* d_item_order = nullptr;
   uint32_t hot_rows = 0;            // decode: rows [0, hot_rows) of item_order get a wavefront of their own
-  uint32_t hot_in_rows = 0;         // input rows: rows [0, hot_in_rows) of item_order get a workgroup of their own
   // developer switches, read once in cdae_hip_create (DESIGN.md lists them)
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
   bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
@@ -184,6 +183,7 @@ struct cdae_hip {
   uint64_t pre_s0 = 0, pre_seed = 0; uint32_t pre_nb = 0, pre_cidx = 0, pre_epoch = 0;
   uint64_t acc_users = 0, acc_examples = 0, acc_batches = 0;   // since the last stats collection
   int profiling = 0;                    // 0 off; k >= 1: HIP events around the kernel families of every k-th batch
+  uint32_t prof_mask = 0xFFFFFFFFu;     // ... of the families whose bit is set (cdae_hip_set_profiling_families)
   uint64_t prof_q = 0;                  // sequence number of the batch being enqueued (sampling of the profile)
   std::vector<Span> spans;
   std::vector<hipEvent_t> pool;
@@ -224,7 +224,7 @@ int get_event(cdae_hip* h, hipEvent_t* ev) {
 struct Prof {   // RAII-less helper: begin()/end() around one kernel family launch, on the stream it is launched on
   cdae_hip* h; Span s; bool on; hipStream_t st;
   int begin(cdae_hip* hh, int family, hipStream_t stream) {
-    h = hh; on = hh->profiling > 0 && hh->prof_q % (uint64_t)hh->profiling == 0; st = stream; if (!on) return 0;
+    h = hh; on = hh->profiling > 0 && ((hh->prof_mask >> family) & 1u) && hh->prof_q % (uint64_t)hh->profiling == 0; st = stream; if (!on) return 0;
     s.family = family;
     CHK(get_event(h, &s.a)); CHK(get_event(h, &s.b));
     HIPCHK(hipEventRecord(s.a, st));
@@ -466,10 +466,9 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   CHK(pr.begin(h, F_INPUT, st));
   {
     const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
-    const uint32_t hot_in = h->NI >= 4 ? std::min<uint32_t>(h->hot_in_rows, I) : 0u;     // popular rows: a workgroup each
-    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + hot_in + (I - hot_in + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
+    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
                 x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), CDAE_TOUCHED_ARG, nb, h->P(CDAE_P_B),
-                h->P(CDAE_P_B_AG), h->delta_rows(), hot_in);
+                h->P(CDAE_P_B_AG), h->delta_rows());
   }
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
@@ -769,13 +768,15 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking);
   {
-    // Second prep lane.  Sampling + sorting a batch is a chain of ~12 small launches (~95 us at 256 users) — longer than the
-    // training step once that drops below it — so consecutive batches are prepared side by side on two streams.  Default: the
-    // handle's aux stream (idle in the sampled path unless an exchange is configured); CDAE_PREP2 = own | aux | off.
+    // Second prep lane (off by default).  Sampling + sorting a batch is a chain of ~12 small launches, ~88 us at 256 users
+    // when it is the only thing pacing the loop; two lanes (CDAE_PREP2 = aux: the handle's aux stream, idle in the sampled
+    // path unless an exchange is configured; own: a stream of its own) prepare consecutive batches side by side and lift that
+    // floor to the host's launch rate (~65 us per batch).  Measured with the training step at ~100 us: the second lane costs
+    // 5 % (its kernels overlap more of the training kernels) — it pays only once the main stream drops below the floor.
     const char* sel = std::getenv("CDAE_PREP2");
-    if (sel && !std::strcmp(sel, "off")) h->prep2 = nullptr;
-    else if (sel && !std::strcmp(sel, "own")) { if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep2, hipStreamNonBlocking); h->prep2_own = true; }
-    else h->prep2 = h->aux;
+    if (sel && !std::strcmp(sel, "own")) { if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep2, hipStreamNonBlocking); h->prep2_own = true; }
+    else if (sel && !std::strcmp(sel, "aux")) h->prep2 = h->aux;
+    else h->prep2 = nullptr;
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
@@ -907,13 +908,6 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     uint32_t hot = 0;
     while (hot < I && (double)pop[order[hot]] * share >= hot_pos) ++hot;
     h->hot_rows = std::min<uint32_t>((hot + 3u) & ~3u, (uint32_t)I);
-    // input rows: a row whose expected kept inputs per batch fill its wavefront's three-group ring several times over
-    // (CDAE_INPUT_HOT_POS expected positives, default 24) is split over a workgroup (input_rows_kernel)
-    const char* ei = std::getenv("CDAE_INPUT_HOT_POS");
-    const double in_pos = ei ? std::atof(ei) : 24.0;
-    uint32_t hin = 0;
-    while (hin < I && (double)pop[order[hin]] * share >= in_pos) ++hin;
-    h->hot_in_rows = hin;
   }
 
   // parameters
@@ -1172,6 +1166,12 @@ int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, 
 int cdae_hip_set_profiling(cdae_hip_t* h, int enabled) {
   if (!h) return fail("null handle");
   h->profiling = enabled < 0 ? 0 : enabled;
+  return 0;
+}
+
+int cdae_hip_set_profiling_families(cdae_hip_t* h, uint32_t mask) {
+  if (!h) return fail("null handle");
+  h->prof_mask = mask;
   return 0;
 }
 

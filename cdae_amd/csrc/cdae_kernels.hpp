@@ -650,26 +650,49 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     }
     return wave_sum(d0 + d1);
   };
-  // The statements below are INTERLEAVED BY HAND and pinned with scheduling barriers: a wavefront issues in order, so two
-  // independent dependent-chains only overlap if their instructions alternate in the stream.  Left to itself hipcc emits the
-  // scalar chain of example i (y -> sigmoid -> g -> b' step: 13 dependent instructions, 4 of them transcendental) and THEN the
-  // speculative dot + 6-stage DPP reduction of example i+1 (9 dependent instructions, each DPP stage padded with s_nop): 330
-  // cycles per deferred example, 590 per stepping one — the 465-cycle average measured on the most popular row.  Alternating
-  // them hides the reduction (and its DPP wait states) inside the scalar chain, and the row step's five stages carry the b'
-  // step between them.  Same arithmetic, same operands, same order of roundings as loss_grad / ada_step: bit-identical results.
+  // A single wavefront issues about one instruction every 9 cycles on this chain (535 cycles per example measured on the most
+  // popular row ALONE on its SIMD, for ~35 instructions of a deferred example and ~80 of a stepping one — hand-interleaving
+  // the independent chains changed nothing, profiles/r02_main_stream.txt), so the popular rows' serial chain is shortened by
+  // issuing fewer instructions:
+  //  * an example that is DEFERRED (known from its word before anything is computed) overlaps the next example's dot + wave
+  //    reduction with its own scalar chain; an example that steps the row computes that dot once, after the step (round 2's
+  //    first version speculated for every example and redid the reduction for the 53 % that step);
+  //  * the target comes out of the example word on the scalar unit (TARGET_BIT is the bit pattern of 2.0f), the look-ahead z row
+  //    is one buffer load with a scalar row offset (no 64-bit address arithmetic), no per-lane target copy per chunk.
+  // Same arithmetic, same operands, same order of roundings as loss_grad / ada_step: bit-identical results.
 #define CDAE_SB() __builtin_amdgcn_sched_barrier(0)
+  const auto zrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z), 0, 0x7FFFFFFF, 0x00020000);
+  const int zvoff = (int)(lo * 4u);
+  auto z_fetch = [&](float (&zz)[NI], uint32_t soff) {           // soff: wave-uniform byte offset of the user's z row
+    if constexpr (NI == 1) {
+      zz[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zrsrc, zvoff, (int)soff, 0));
+    } else if constexpr (NI == 2) {
+      const auto raw = __builtin_amdgcn_raw_buffer_load_b64(zrsrc, zvoff, (int)soff, 0);
+      float2 q;
+      __builtin_memcpy(&q, &raw, sizeof q);
+      zz[0] = q.x; zz[1] = q.y;
+    } else {
+#pragma unroll
+      for (int v = 0; v < NI / 4; ++v) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, zvoff + 16 * v, (int)soff, 0);
+        float4 q;
+        __builtin_memcpy(&q, &raw, sizeof q);
+        zz[4 * v] = q.x; zz[4 * v + 1] = q.y; zz[4 * v + 2] = q.z; zz[4 * v + 3] = q.w;
+      }
+    }
+  };
   auto fast_group_spec = [&](const uint32_t j0) {
     float sdot = s_valid ? s_carry : row_dot(z[0]);
 #pragma unroll
     for (int t = 0; t < PF; ++t) {
       const uint32_t idx = j0 + t;
       const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur_w, idx);
-      const float tgt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur_t), idx));
+      const float tgt2 = __builtin_bit_cast(float, word & TARGET_BIT);       // 2.0 (positive) or 0.0, on the scalar unit
       const float (&zn)[NI] = z[(t + 1) % PF];
-      float g, spec;
-      CDAE_SB();
-      {
-        // chain A: y -> g            | chain B: next example against the row as it is now
+      float g;
+      if ((word & INPUT_BIT) && tied) {
+        // deferred (cdae.hpp:249-250): the row does not move.  chain A: y -> g -> b' step | chain B: next example's dot
+        float spec;
         const float y = sdot + bias;
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
@@ -689,11 +712,11 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
           const float sg = fast_rcp(u);
           d = dpp_add<0x141>(d);
           CDAE_SB();
-          g = sg - tgt;
+          g = fmaf(-0.5f, tgt2, sg);
           d = dpp_add<0x140>(d);
           CDAE_SB();
         } else {
-          g = -2.f * (tgt - y);
+          g = -2.f * (0.5f * tgt2 - y);
           d = dpp_add<0xB1>(d);
           CDAE_SB();
           d = dpp_add<0x4E>(d);
@@ -701,52 +724,50 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
           d = dpp_add<0x140>(d);
           CDAE_SB();
         }
-        gbuf = lane == idx ? g : gbuf;
+        const float gb = fmaf(hp.lambda, bias, g);               // b' step (cdae.hpp:230-237)
         d = dpp_add<0x142>(d);
         CDAE_SB();
+        if constexpr (ADAGRAD) bias_ag = fmaf(gb, gb, bias_ag);
         d = dpp_add<0x143>(d);
         CDAE_SB();
         spec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
-      }
-      const float gb = fmaf(hp.lambda, bias, g);                 // b' step (cdae.hpp:230-237), staged below
-      if ((word & INPUT_BIT) && tied) {                          // deferred: the row did not move, the speculation holds
-        ada_step(hp, bias, bias_ag, gb);
+        if constexpr (ADAGRAD) bias = fmaf(-hp.lr * gb, fast_rcp(fast_sqrt(bias_ag) + hp.beta), bias);
+        else bias = fmaf(-hp.lr, gb, bias);
         sdot = spec;
-      } else if constexpr (ADAGRAD) {
-        // row step in five stages, the b' step riding between them
-        float gr[NI], rr[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) gr[i] = fmaf(g, z[t][i], hp.lambda * w[i]);
-        CDAE_SB();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) a[i] = fmaf(gr[i], gr[i], a[i]);
-        bias_ag = fmaf(gb, gb, bias_ag);
-        CDAE_SB();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) rr[i] = fast_sqrt(a[i]);
-        float rb = fast_sqrt(bias_ag);
-        CDAE_SB();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) rr[i] += hp.beta;
-        rb += hp.beta;
-        CDAE_SB();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) rr[i] = fast_rcp(rr[i]);
-        rb = fast_rcp(rb);
-        CDAE_SB();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) w[i] = fmaf(-hp.lr * gr[i], rr[i], w[i]);
-        CDAE_SB();
-        bias = fmaf(-hp.lr * gb, rb, bias);
-        sdot = row_dot(zn);
       } else {
+        const float y = sdot + bias;
+        if constexpr (LOSS == 5) g = fmaf(-0.5f, tgt2, fast_rcp(1.f + fast_exp(-y)));
+        else g = -2.f * (0.5f * tgt2 - y);
+        const float gb = fmaf(hp.lambda, bias, g);
+        if constexpr (ADAGRAD) {
+          // row step in five stages, the b' step riding between them
+          float gr[NI], rr[NI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, z[t][i], hp.lambda * w[i]));
-        ada_step(hp, bias, bias_ag, gb);
+          for (int i = 0; i < NI; ++i) gr[i] = fmaf(g, z[t][i], hp.lambda * w[i]);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) a[i] = fmaf(gr[i], gr[i], a[i]);
+          bias_ag = fmaf(gb, gb, bias_ag);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) rr[i] = fast_sqrt(a[i]);
+          float rb = fast_sqrt(bias_ag);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) rr[i] += hp.beta;
+          rb += hp.beta;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) rr[i] = fast_rcp(rr[i]);
+          rb = fast_rcp(rb);
+#pragma unroll
+          for (int i = 0; i < NI; ++i) w[i] = fmaf(-hp.lr * gr[i], rr[i], w[i]);
+          bias = fmaf(-hp.lr * gb, rb, bias);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) w[i] = fmaf(-hp.lr, fmaf(g, z[t][i], hp.lambda * w[i]), w[i]);
+          bias = fmaf(-hp.lr, gb, bias);
+        }
         sdot = row_dot(zn);
       }
-      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)look, (idx + PF) & 63u);
-      vload<NI>(z[t], reinterpret_cast<const float*>(Zb + off));
+      gbuf = lane == idx ? g : gbuf;
+      z_fetch(z[t], (uint32_t)__builtin_amdgcn_readlane((int)look, (idx + PF) & 63u));
     }
     s_carry = sdot;
     s_valid = true;
@@ -1342,15 +1363,14 @@ struct InputGroup {
   uint32_t cnt;                                                  // kept inputs in the group (wave-uniform); 0: the row is done
 };
 
-// One wavefront walks row `rank`; lane holds the NE contiguous elements from `lo`.
-//  * ordinary rows (NE = NI, lo = NI * lane, UN = 4, one group at a time): most rows have one or two kept inputs per batch, so the
-//    wavefront is a short chain of L2 round trips and the launch lives on occupancy — one group keeps it at ~60 VGPRs;
-//  * popular rows (input_rows_kernel's hot workgroups): the row is split over the workgroup's four wavefronts (NE = NI / 4: the
-//    step is elementwise in k) and two groups of UN = 12 alternate, so 24 examples' delta / z rows are in flight while the
-//    (reduction-free) AdaGrad chain of the previous group runs — a popular row has 50+ kept inputs per batch and its chain
-//    of dependent L2 round trips bounded the launch (17.4 -> 13.3 us without the eight most popular rows).
-// A group never straddles a 64-example chunk of the row's example words.
-template <int NE, int UN, bool PIPE, bool ADAGRAD>
+// One wavefront walks row `rank`; lane holds NI contiguous elements.  Most rows have one or two kept inputs per batch, so a
+// wavefront is a short chain of L2 round trips: segment bounds -> example words -> delta / z / W rows -> step -> store; the
+// next 64-example chunk of words is requested while the current one is worked on.  A group never straddles a chunk.
+// Tried and measured slower (round 2, profiles/r02_main_stream.txt): three groups in a register ring (the round-1 form, 140
+// VGPRs: same time), two alternating groups, and splitting the popular rows over a workgroup's four wavefronts (K quarters, 24
+// examples in flight): the launch is bound by the sum of its serial latencies (dispatch 4 us, prologue 3 round trips, the
+// popular rows' 60-odd dependent AdaGrad steps), not by any one of them.
+template <int NE, int UN, bool ADAGRAD>
 __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t rank, const uint32_t lo,
                                                const uint32_t* __restrict__ item_order,
                                                const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
@@ -1411,22 +1431,10 @@ __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t ra
   if (A.cnt == 0u) return;                                       // no kept input on this row: W is not touched
   vload<NE>(w, W + (size_t)item * hp.Kp + lo);
   vload<NE>(a, W_ag + (size_t)item * hp.Kp + lo);
-  if constexpr (PIPE) {
-    InputGroup<NE, UN> B;
-    while (true) {
-      fetch(B);
-      apply(A);
-      if (B.cnt == 0u) break;
-      fetch(A);
-      apply(B);
-      if (A.cnt == 0u) break;
-    }
-  } else {
-    do {
-      apply(A);
-      fetch(A);
-    } while (A.cnt != 0u);
-  }
+  do {
+    apply(A);
+    fetch(A);
+  } while (A.cnt != 0u);
   vstore<NE>(W + (size_t)item * hp.Kp + lo, w);
   vstore<NE>(W_ag + (size_t)item * hp.Kp + lo, a);
   if (lane == 0 && touched) touched[item] = 1u;
@@ -1435,11 +1443,7 @@ __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t ra
 #ifndef CDAE_INPUT_UN
 #define CDAE_INPUT_UN 4
 #endif
-#ifndef CDAE_INPUT_UN_HOT
-#define CDAE_INPUT_UN_HOT 5
-#endif
-// grid: [bias_blocks: K4b] [hot_rows workgroups: one popular row each, split over the four wavefronts (NI >= 4 only)]
-//       [the other rows, one per wavefront]
+// grid: [bias_blocks: K4b] [the rows, one per wavefront, popular rows first]
 template <int NI>
 __global__ void __launch_bounds__(256)
 input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
@@ -1448,8 +1452,7 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
                   const float* __restrict__ DELTA, const float* __restrict__ G,
                   float* __restrict__ W, float* __restrict__ W_ag, uint32_t* __restrict__ touched,
                   uint32_t nb, float* __restrict__ b, float* __restrict__ b_ag,
-                  const float* __restrict__ DELTA_ROWS /* == DELTA unless linear_function (then Uu[u] (.) delta_u) */,
-                  uint32_t hot_rows /* 0 when NI < 4 */) {
+                  const float* __restrict__ DELTA_ROWS /* == DELTA unless linear_function (then Uu[u] (.) delta_u) */) {
   const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
   if (blockIdx.x < bias_blocks) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1461,25 +1464,11 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
     return;
   }
   if (hp.debug_skip & 2u) return;
-  const uint32_t wg = blockIdx.x - bias_blocks, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-  if (wg < hot_rows) {
-    if constexpr (NI >= 4) {
-      constexpr int NE = NI / 4;
-      const uint32_t rank = __builtin_amdgcn_readfirstlane(wg);
-      const uint32_t lo = wid * (hp.Kp / 4u) + lane * NE;
-      const unsigned long long t0 = trace_begin(hp);
-      if (hp.adagrad) input_row_role<NE, CDAE_INPUT_UN_HOT, true, true>(hp, rank, lo, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
-      else input_row_role<NE, CDAE_INPUT_UN_HOT, true, false>(hp, rank, lo, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
-      trace_end(hp, 8, rank * 4u + wid, t0);
-    }
-    return;
-  }
-  const uint32_t rank = __builtin_amdgcn_readfirstlane(hot_rows + (wg - hot_rows) * (blockDim.x / WAVE) + wid);
-  if ((hp.debug_skip & 16u) && rank < hp.debug_rank) return;   // experiment: without the debug_rank most popular rows
-  if (hp.debug_skip & 32u) return;                             // experiment: popular rows only
+  const uint32_t lane = threadIdx.x % WAVE;
+  const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   const unsigned long long t0 = trace_begin(hp);
-  if (hp.adagrad) input_row_role<NI, CDAE_INPUT_UN, false, true>(hp, rank, lane * NI, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
-  else input_row_role<NI, CDAE_INPUT_UN, false, false>(hp, rank, lane * NI, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+  if (hp.adagrad) input_row_role<NI, CDAE_INPUT_UN, true>(hp, rank, lane * NI, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
+  else input_row_role<NI, CDAE_INPUT_UN, false>(hp, rank, lane * NI, item_order, seg_begin, seg_end, sorted_val, Z, DELTA_ROWS, G, W, W_ag, touched);
   trace_end(hp, 9, rank, t0);
 }
 

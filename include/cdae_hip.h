@@ -47,8 +47,9 @@ extern "C" {
  *    parameters CDAE_P_UU / CDAE_P_UU_AG; pipelined delta exchange entry points */
 /* 3: cdae_hip_debug_sample_batch (integer-parity test hook), cdae_hip_recommend_user
  * 4: library-owned RCCL communicator + exchange schedule (cdae_hip_comm_*, cdae_hip_exchange_*), cdae_hip_multi_*
- * 5: cdae_hip_create_mf (IMF / BPR handles), CDAE_P_UB / CDAE_P_UB_AG, item-rows layout of cdae_hip_multi_* */
-#define CDAE_HIP_ABI_VERSION 5
+ * 5: cdae_hip_create_mf (IMF / BPR handles), CDAE_P_UB / CDAE_P_UB_AG, item-rows layout of cdae_hip_multi_*
+ * 6: cdae_hip_set_profiling_families */
+#define CDAE_HIP_ABI_VERSION 6
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -162,6 +163,15 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
 /* Developer/benchmark aid: period 0 = off; k >= 1 = HIP events (on the stream each kernel is launched on) around the
  * kernel families of every k-th batch; cdae_hip_stats.ms_* / launches_decode then cover the sampled batches only. */
 int cdae_hip_set_profiling(cdae_hip_t* h, int period);
+/* ... restricted to the families in `mask` (bit CDAE_FAMILY_*; default all): an event pair costs ~6 us of stream time, so a
+ * benchmark times only the family its roofline needs inside its timed region. */
+#define CDAE_FAMILY_SAMPLE 0
+#define CDAE_FAMILY_SORT 1
+#define CDAE_FAMILY_ENCODE 2
+#define CDAE_FAMILY_DECODE 3
+#define CDAE_FAMILY_HIDDEN 4
+#define CDAE_FAMILY_INPUT 5
+int cdae_hip_set_profiling_families(cdae_hip_t* h, uint32_t mask);
 int cdae_hip_synchronize(cdae_hip_t* h);
 
 /* Test hook for the INTEGER work of the path (bit-exact parity, tests/test_gpu_integer.py): runs the sampling, the
