@@ -8,6 +8,11 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -126,14 +131,16 @@ struct cdae_hip {
     uint16_t* key16 = nullptr; uint16_t* sorted_key16 = nullptr;      // 16-bit sort keys when I <= 65536 (rocPRIM then runs onesweep)
     uint32_t* dup_of_pos = nullptr; uint32_t* dup_of_ex = nullptr;   // duplicate-negative correction rows (segment_kernel)
     uint32_t* dup_count = nullptr;
-    // counting sort (cdae_sort_kernels.hpp; num_items <= 65536): per-item counts / prefix / scatter cursor (`rank`), item-bucketed values
+    // counting sort (cdae_sort_kernels.hpp): per-item counts / prefix / (unused cursor), item-bucketed values, per-tile counts
     uint32_t* item_count = nullptr; uint32_t* prefix = nullptr; uint32_t* rank = nullptr; uint64_t* bucketed = nullptr;
+    uint32_t* tile_hist = nullptr; uint32_t* block_total = nullptr;      // (`rank` holds the in-block item prefix)
     hipEvent_t ready = nullptr, released = nullptr;
   } ex[3];
   static constexpr int NSETS = 3;
   hipStream_t prep2 = nullptr;          // second prep lane (batches with odd sequence number), or nullptr: one lane, look-ahead 1
   bool prep2_own = false;               // prep2 is a stream of its own (else it aliases `aux`)
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
+  uint32_t dup_stripes = 1;             // counters the correction rows are numbered from (cdae_kernels.hpp DUP_STRIPES)
   float* d_dup_corr = nullptr; uint32_t dup_cap = 0;   // [dup_cap][Kp] hidden-gradient corrections of duplicate negatives
   float* d_HGpart = nullptr;            // [8][B][Kp] per-XCD partial hidden gradients
   // full-output decode (MFMA path): bf16 operand copies and the dense gradient, padded to 128-multiples
@@ -158,8 +165,24 @@ struct cdae_hip {
   float* d_zeval = nullptr; float* d_hpart_eval = nullptr; uint32_t eval_cap = 0, eval_unit_cap = 0;   // evaluation workspace
   uint32_t* d_bits = nullptr; size_t bits_cap = 0;                                                     // recommend: rated-item bitmap
   int sort_bits = 1;
+  // prep worker: the ~12 launches that sample + sort a batch are issued by a second host thread (the training loop was bound by
+  // the HOST's launch rate: ~21 runtime calls x 4.5 us per batch on one thread)
+  struct PrepJob { int set; uint64_t s0; uint32_t nb, cidx; uint64_t E; uint64_t seed; uint32_t epoch; int lane; uint64_t prof_q; };
+  bool prep_threaded = true;            // CDAE_PREP_THREAD=0: issue everything from the caller's thread
+  std::thread worker;
+  std::mutex job_mu;
+  std::condition_variable job_cv;
+  std::deque<PrepJob> jobs;
+  bool worker_stop = false;
+  uint64_t jobs_submitted = 0;          // (caller's thread only)
+  std::atomic<uint64_t> jobs_issued{0}; // jobs whose launches + `ready` record have been issued (worker -> caller)
+  std::atomic<int> worker_failed{0};
+  std::string worker_error;             // valid once worker_failed != 0
+  std::mutex prof_mu;                   // spans / event pool are touched by both threads when profiling
+  bool encode_two_launches = false;     // CDAE_ENCODE_TWO_LAUNCHES: the training encode as encode_partial + encode_finish (developer switch)
   bool debug_skip_prep = false;         // CDAE_DEBUG_SKIP_PREP (timing experiment only: batches reuse stale example lists -> WRONG results)
-  bool counting_sort = false;           // hand-written counting sort on the prep stream instead of rocPRIM (num_items <= 65536)
+  bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
+  bool tile_attr_set = false;           // dynamic LDS above 64 KiB allowed for the two tile kernels (per handle: the attribute is per device)
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
 
   // data-parallel exchange
@@ -216,15 +239,32 @@ int join_aux(cdae_hip* h) {
   return 0;
 }
 
+// Events between the library's own streams order work on ONE device: they need no system-scope fence.  A default HIP event
+// writes back and invalidates the caches when it is recorded — measured here as ~14 us of idle main stream per batch around
+// the `released` record and ~3 us at the `ready` wait (profiles/r02_wave_timeline_256.txt: 86 us of kernels in a 100 us step).
+// CDAE_EVENT_SYSTEM_FENCE=1 restores the default.  (The exchange's events in cdae_multi.hip stay system-scope: RCCL peers read.)
+inline unsigned sync_event_flags() {
+  static const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
+  return sys ? (unsigned)hipEventDisableTiming : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
+}
+inline unsigned timing_event_flags() {
+  static const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
+  return sys ? (unsigned)hipEventDefault : (unsigned)hipEventDisableSystemFence;
+}
+
 int get_event(cdae_hip* h, hipEvent_t* ev) {
-  if (!h->pool.empty()) { *ev = h->pool.back(); h->pool.pop_back(); return 0; }
-  HIPCHK(hipEventCreate(ev));
+  {
+    std::lock_guard<std::mutex> lk(h->prof_mu);
+    if (!h->pool.empty()) { *ev = h->pool.back(); h->pool.pop_back(); return 0; }
+  }
+  HIPCHK(hipEventCreateWithFlags(ev, timing_event_flags()));
   return 0;
 }
 struct Prof {   // RAII-less helper: begin()/end() around one kernel family launch, on the stream it is launched on
   cdae_hip* h; Span s; bool on; hipStream_t st;
-  int begin(cdae_hip* hh, int family, hipStream_t stream) {
-    h = hh; on = hh->profiling > 0 && ((hh->prof_mask >> family) & 1u) && hh->prof_q % (uint64_t)hh->profiling == 0; st = stream; if (!on) return 0;
+  int begin(cdae_hip* hh, int family, hipStream_t stream, uint64_t q = ~0ull /* batch sequence number; default: the caller thread's prof_q */) {
+    if (q == ~0ull) q = hh->prof_q;
+    h = hh; on = hh->profiling > 0 && ((hh->prof_mask >> family) & 1u) && q % (uint64_t)hh->profiling == 0; st = stream; if (!on) return 0;
     s.family = family;
     CHK(get_event(h, &s.a)); CHK(get_event(h, &s.b));
     HIPCHK(hipEventRecord(s.a, st));
@@ -233,6 +273,7 @@ struct Prof {   // RAII-less helper: begin()/end() around one kernel family laun
   int end() {
     if (!on) return 0;
     HIPCHK(hipEventRecord(s.b, st));
+    std::lock_guard<std::mutex> lk(h->prof_mu);
     h->spans.push_back(s);
     return 0;
   }
@@ -241,6 +282,7 @@ struct Prof {   // RAII-less helper: begin()/end() around one kernel family laun
 int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
   double ms[F_COUNT] = {0};
   uint64_t launches[F_COUNT] = {0};
+  std::lock_guard<std::mutex> lk(h->prof_mu);
   for (Span& s : h->spans) {
     float t = 0.f;
     HIPCHK(hipEventElapsedTime(&t, s.a, s.b));
@@ -266,7 +308,7 @@ void free_all(cdae_hip* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
-                 b.item_count, b.prefix, b.rank, b.bucketed};
+                 b.item_count, b.prefix, b.rank, b.bucketed, b.tile_hist, b.block_total};
     for (void* p : q) if (p) (void)hipFree(p);
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
@@ -282,6 +324,17 @@ void free_all(cdae_hip* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
+int await_prep(cdae_hip* h);     // (prep worker, below)
+void stop_prep_worker(cdae_hip* h);
+int quiesce(cdae_hip* h) {
+  CHK(await_prep(h));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->prep) HIPCHK(hipStreamSynchronize(h->prep));
+  if (h->prep2) HIPCHK(hipStreamSynchronize(h->prep2));
+  if (h->aux) HIPCHK(hipStreamSynchronize(h->aux));
+  return 0;
+}
+
 int free_interaction_state(cdae_hip* h) {
   void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
                    (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_D0, (void**)&h->d_HGpart, (void**)&h->d_sort_tmp,
@@ -294,7 +347,7 @@ int free_interaction_state(cdae_hip* h) {
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
-                  (void**)&b.item_count, (void**)&b.prefix, (void**)&b.rank, (void**)&b.bucketed};
+                  (void**)&b.item_count, (void**)&b.prefix, (void**)&b.rank, (void**)&b.bucketed, (void**)&b.tile_hist, (void**)&b.block_total};
     for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
@@ -315,7 +368,7 @@ inline uint32_t units_of(const cdae_hip* h, const Batch& b) { return h->h_unit_p
 
 // K1 + sort on the prep stream into example-buffer set `b`
 // lane 1: the second prep stream with the second half of the sort workspace (two batches are prepared side by side)
-int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch, int lane = 0) {
+int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch, int lane = 0, uint64_t prof_q = ~0ull) {
   using namespace cdae;
   cdae_hip::ExBuf& x = h->ex[b];
   hipStream_t st = lane ? h->prep2 : h->prep;
@@ -323,11 +376,11 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   const uint32_t I = (uint32_t)h->I;
   Prof pr;
   HIPCHK(hipStreamWaitEvent(st, x.released, 0));               // the batch that last used this set is done with it
-  CHK(pr.begin(h, F_SAMPLE, st));
+  CHK(pr.begin(h, F_SAMPLE, st, prof_q));
   const uint32_t n_units = units_of(h, bt);
   if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
     HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(x.dup_count, 0, sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), st));
   } else if (h->mf) {
     hipLaunchKernelGGL(mf_sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->mf == 2 ? 1u : 0u, h->d_row_ptr, h->d_col,
                        h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, seed, epoch, x.item, x.val, x.key16, x.seg, 2u * I, x.dup_count,
@@ -336,30 +389,38 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
                      x.seg, h->counting_sort ? 0u : 2u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
-                     h->counting_sort ? x.item_count : (uint32_t*)nullptr, (const uint32_t*)h->d_gpos);
+                     (uint32_t*)nullptr, (const uint32_t*)h->d_gpos);
   CHK(pr.end());
-  CHK(pr.begin(h, F_SORT, st));
+  CHK(pr.begin(h, F_SORT, st, prof_q));
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
   if (bt.E == 0) {
     // nothing to order
   } else if (h->counting_sort) {
-    // item-major order by counting (cdae_sort_kernels.hpp): tickets were taken by sample_kernel
-    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, x.item_count, I, x.prefix, x.rank, x.seg, x.seg + I, x.dup_count);
-    if (bt.E) hipLaunchKernelGGL(scatter_kernel, dim3((uint32_t)((bt.E + 255) / 256)), dim3(256), 0, st, x.item, x.val, (uint32_t)bt.E,
-                                 x.rank, x.sorted_item, x.bucketed);
+    // item-major order by counting, four launches (cdae_sort_kernels.hpp)
+    const uint32_t n_tiles = (uint32_t)((bt.E + TILE_EX - 1) / TILE_EX);
+    const size_t tile_lds = (size_t)I * sizeof(uint32_t);
+    if (tile_lds + 1024 > 64 * 1024 && !h->tile_attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)tile_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+      HIPCHK(hipFuncSetAttribute((const void*)tile_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds + 1024));
+      h->tile_attr_set = true;
+    }
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(n_tiles), dim3(TILE_THREADS), tile_lds / 2 + 4, st, x.item, (uint32_t)bt.E, I, x.tile_hist);
+    hipLaunchKernelGGL(item_tile_scan_kernel, dim3((I + 255) / 256), dim3(256), 0, st, x.tile_hist, n_tiles, I, x.item_count, x.rank, x.block_total);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(n_tiles), dim3(TILE_THREADS), tile_lds + 128 * sizeof(uint32_t), st, x.item, x.val,
+                       (uint32_t)bt.E, I, x.tile_hist, x.item_count, x.rank, x.block_total, x.prefix, x.seg, x.seg + I, x.dup_count, x.bucketed);
     hipLaunchKernelGGL(segment_sort_kernel, dim3((I + SEGSORT_ITEMS - 1) / SEGSORT_ITEMS), dim3(SEGSORT_THREADS), 0, st, I, x.prefix, x.bucketed,
-                       x.sorted_val, x.item_count, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+                       x.sorted_val, x.item_count, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
   } else if (x.key16) {
     // 16-bit keys: rocPRIM picks onesweep (2 digit passes) instead of block sort + log2(tiles) merge passes
     HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.key16, x.sorted_key16, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint16_t>, seg_grid, dim3(256), 0, st, x.sorted_key16, x.sorted_val, (uint32_t)bt.E,
-                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
   } else {
     HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint32_t>, seg_grid, dim3(256), 0, st, x.sorted_item, x.sorted_val, (uint32_t)bt.E,
-                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
   }
   CHK(pr.end());
   if (h->cfg.full_output && h->d_bits_train) {
@@ -388,16 +449,23 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   const dim3 grid_users((nb + 3) / 4), grid_rows((I + 3) / 4);
   Prof pr;
 
+  h->hp.trace_odd = (uint32_t)(h->seq & 1);
   CHK(pr.begin(h, F_ENCODE, st));
   // explicit mode: one user, one unit (the caller's lists need not follow the num_neg proportion)
   const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
   const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
   const dim3 grid_units((n_units + 3) / 4);
-  DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
-              (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
-              explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
-  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  if (!explicit_in && !h->encode_two_launches) {
+    // one launch: a workgroup per user (encode_users_kernel)
+    DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
+                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  } else {
+    DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
+                (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
+                explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
+    DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
+                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  }
   CHK(pr.end());
 
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
@@ -763,6 +831,8 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
+  h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
+  if (const char* ev = std::getenv("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
@@ -778,9 +848,9 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
     else if (sel && !std::strcmp(sel, "aux")) h->prep2 = h->aux;
     else h->prep2 = nullptr;
   }
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, sync_event_flags());
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, sync_event_flags());
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_delta, sync_event_flags());
   if (e != hipSuccess) { free_all(h); delete h; return fail("stream/event setup failed: %s", hipGetErrorString(e)); }
   e = hipMalloc((void**)&h->d_scalar, 8 * sizeof(double));
   if (e != hipSuccess) { free_all(h); delete h; return fail("hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -806,6 +876,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
 int cdae_hip_destroy(cdae_hip_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
+  stop_prep_worker(h);
   (void)hipStreamSynchronize(h->stream);
   if (h->hp.trace) {      // records of the LAST batch every slot saw
     std::vector<unsigned long long> rec(4 * cdae::TRACE_CAP);
@@ -871,6 +942,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       pop[col[p]]++;
     }
   }
+  // nothing may still be reading the old data set: a prefetched batch in the prep worker's queue or in the prep streams included
+  CHK(quiesce(h));
   CHK(free_interaction_state(h));
   if (h->cfg.batch_users == 0) {
     // default: ~U/160 users per parameter snapshot, in [32, 512] — 512 of 70 K users is where Recall@10 still stays
@@ -945,7 +1018,10 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   h->Ecap = emax * h->ex_per_pos;
   h->seq = 0; h->pre_valid = false;
   // opt-in (CDAE_SORT_COUNTING=1): measured slower than rocPRIM's onesweep beside the training kernels (profiles/r02_*)
-  h->counting_sort = I <= cdae::COUNTING_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_COUNTING") != nullptr;
+  // opt-in (CDAE_SORT_TILE=1).  Measured (profiles/r02_tile_sort.txt): the four launches take 72 us against rocPRIM's ten launches / ~100 us
+  // per batch on the prep stream, yet the training step is the same within 1 % at 256 users and 3 % slower at 512 — the prep
+  // stream runs beside the training kernels, and what counts there is how much it disturbs them, not its own length
+  h->counting_sort = I <= cdae::TILE_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_TILE") != nullptr;
   h->h_unit_ptr.assign(U + 1, 0u);
   for (uint64_t u = 0; u < U; ++u)
     h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + h->hp.unit_pos - 1) / h->hp.unit_pos);
@@ -985,13 +1061,14 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));
     CHK(dev_alloc(&b.sorted_item, h->Ecap)); CHK(dev_alloc(&b.sorted_val, h->Ecap));
     CHK(dev_alloc(&b.seg, 2 * (size_t)I));
-    CHK(dev_alloc(&b.dup_of_pos, h->Ecap)); CHK(dev_alloc(&b.dup_of_ex, h->Ecap)); CHK(dev_alloc(&b.dup_count, 1));
+    CHK(dev_alloc(&b.dup_of_pos, h->Ecap)); CHK(dev_alloc(&b.dup_of_ex, h->Ecap)); CHK(dev_alloc(&b.dup_count, cdae::DUP_STRIPES));
     if (h->counting_sort) {
       CHK(dev_alloc(&b.item_count, (size_t)I)); CHK(dev_alloc(&b.prefix, (size_t)I + 1));
-      CHK(dev_alloc(&b.rank, (size_t)I)); CHK(dev_alloc(&b.bucketed, h->Ecap));      // rank: scatter cursor per item
-      HIPCHK(hipMemset(b.item_count, 0, (size_t)I * sizeof(uint32_t)));      // segment_sort_kernel leaves it zero after every batch
+      CHK(dev_alloc(&b.rank, (size_t)I)); CHK(dev_alloc(&b.bucketed, h->Ecap));
+      CHK(dev_alloc(&b.tile_hist, (size_t)((h->Ecap + cdae::TILE_EX - 1) / cdae::TILE_EX + 1) * I));
+      CHK(dev_alloc(&b.block_total, 128));
     } else if (I <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }
-    if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b.released, hipEventDisableTiming)); }
+    if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, sync_event_flags())); HIPCHK(hipEventCreateWithFlags(&b.released, sync_event_flags())); }
     HIPCHK(hipEventRecord(b.released, h->stream));
   }
   CHK(dev_alloc(&h->d_D0, IK));
@@ -1002,6 +1079,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const char* ev = std::getenv("CDAE_DUP_CAP");
     const uint64_t want = h->mf ? 1 : (ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4));   // small problems: every example (IMF / BPR have no correction rows)
     h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
+    h->dup_stripes = std::max<uint32_t>(1u, std::min<uint32_t>(cdae::DUP_STRIPES, h->dup_cap / 4096u));
     CHK(dev_alloc(&h->d_dup_corr, (size_t)h->dup_cap * h->Kp));
     HIPCHK(hipMemset(h->d_dup_corr, 0, (size_t)h->dup_cap * h->Kp * sizeof(float)));
   }
@@ -1204,7 +1282,69 @@ inline int set_of(uint64_t q) { return (int)(q % cdae_hip::NSETS); }
 // item shard trains in phases)
 inline size_t prep_depth(const cdae_hip* h) { return (h->prep2 && !h->mf && !h->cfg.full_output && !h->item_shard) ? 2 : 1; }
 inline int prep_lane(const cdae_hip* h, uint64_t q) { return prep_depth(h) == 2 ? (int)(q & 1) : 0; }
+// ---- prep worker ---------------------------------------------------------------------------------------------------
+// The caller's thread hands a batch's sampling + sorting to the worker (submit_prep) and, before it issues the training
+// kernels that wait on the set's `ready` event, makes sure the worker has ISSUED that record (await_prep: host-side order
+// of hipEventRecord before hipStreamWaitEvent).  The other direction needs no handshake: a set's `released` record is issued
+// by the caller before it submits the job that reuses the set (NSETS > look-ahead depth).
+void prep_worker_main(cdae_hip* h) {
+  (void)hipSetDevice(h->device);
+  for (;;) {
+    cdae_hip::PrepJob j;
+    {
+      std::unique_lock<std::mutex> lk(h->job_mu);
+      h->job_cv.wait(lk, [&] { return h->worker_stop || !h->jobs.empty(); });
+      if (h->jobs.empty()) return;                           // stop requested and nothing left
+      j = h->jobs.front();
+      h->jobs.pop_front();
+    }
+    if (!h->worker_failed.load(std::memory_order_relaxed)) {
+      const int rc = prep_batch(h, j.set, Batch{j.s0, j.nb, j.cidx, j.E}, j.seed, j.epoch, j.lane, j.prof_q);
+      if (rc) {
+        h->worker_error = cdae_hip_last_error();             // (thread-local on the worker; published by the release store below)
+        h->worker_failed.store(1, std::memory_order_release);
+      }
+    }
+    h->jobs_issued.fetch_add(1, std::memory_order_release);
+  }
+}
+
+int submit_prep(cdae_hip* h, int set, const Batch& bt, uint64_t seed, uint32_t epoch, int lane, uint64_t prof_q) {
+  if (!h->prep_threaded) return prep_batch(h, set, bt, seed, epoch, lane, prof_q);
+  if (!h->worker.joinable()) h->worker = std::thread(prep_worker_main, h);
+  {
+    std::lock_guard<std::mutex> lk(h->job_mu);
+    h->jobs.push_back(cdae_hip::PrepJob{set, bt.s0, bt.nb, bt.cidx, bt.E, seed, epoch, lane, prof_q});
+  }
+  h->jobs_submitted++;
+  h->job_cv.notify_one();
+  return 0;
+}
+
+// jobs 1..id have been issued (their launches and their `ready` records are in the prep stream)
+int await_prep_upto(cdae_hip* h, uint64_t id) {
+  if (h->prep_threaded) {
+    uint32_t spins = 0;
+    while (h->jobs_issued.load(std::memory_order_acquire) < id)
+      if (++spins > 64) std::this_thread::yield();
+    if (h->worker_failed.load(std::memory_order_acquire)) return fail("prep worker: %s", h->worker_error.c_str());
+  }
+  return 0;
+}
+int await_prep(cdae_hip* h) { return await_prep_upto(h, h->jobs_submitted); }
+
+void stop_prep_worker(cdae_hip* h) {
+  if (!h->worker.joinable()) return;
+  {
+    std::lock_guard<std::mutex> lk(h->job_mu);
+    h->worker_stop = true;
+  }
+  h->job_cv.notify_one();
+  h->worker.join();
+}
+
 int sync_prep(cdae_hip* h) {
+  CHK(await_prep(h));
   HIPCHK(hipStreamSynchronize(h->prep));
   if (h->prep2) HIPCHK(hipStreamSynchronize(h->prep2));
   return 0;
@@ -1224,17 +1364,19 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
   // look-ahead: batch t + depth is prepared while batch t trains; with two prep lanes consecutive batches alternate between them
   const size_t depth = prep_depth(h);
   const uint64_t q0 = h->seq;
+  std::vector<uint64_t> job_of(plan.size(), h->jobs_submitted);   // the job (count) that must be issued before batch t may train
   auto prep = [&](size_t t) -> int {
     const uint64_t q = q0 + t;
-    if (h->debug_skip_prep && q >= 2 * cdae_hip::NSETS) return 0;
-    h->prof_q = q;
-    return prep_batch(h, set_of(q), plan[t], seed, epoch, prep_lane(h, q));
+    if (!(h->debug_skip_prep && q >= 2 * cdae_hip::NSETS)) CHK(submit_prep(h, set_of(q), plan[t], seed, epoch, prep_lane(h, q), q));
+    job_of[t] = h->jobs_submitted;
+    return 0;
   };
   for (size_t t = 0; t < depth && t < plan.size(); ++t)
     if (t > 0 || !is_prefetched(h, plan[0], seed, epoch)) CHK(prep(t));
   h->pre_valid = false;
   for (size_t t = 0; t < plan.size(); ++t) {
     if (t + depth < plan.size()) CHK(prep(t + depth));
+    CHK(await_prep_upto(h, job_of[t]));                          // the set's `ready` record is in the prep stream
     h->prof_q = h->seq;
     const int set = set_of(h->seq);
     if (h->mf) CHK(compute_batch_mf(h, set, plan[t]));
@@ -1378,8 +1520,7 @@ int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
   if (is_prefetched(h, plan[0], seed, epoch)) return 0;
-  h->prof_q = h->seq;
-  if (!(h->debug_skip_prep && h->seq >= 2 * cdae_hip::NSETS)) CHK(prep_batch(h, set_of(h->seq), plan[0], seed, epoch, prep_lane(h, h->seq)));
+  if (!(h->debug_skip_prep && h->seq >= 2 * cdae_hip::NSETS)) CHK(submit_prep(h, set_of(h->seq), plan[0], seed, epoch, prep_lane(h, h->seq), h->seq));
   h->pre_valid = true;
   h->pre_s0 = plan[0].s0; h->pre_nb = plan[0].nb; h->pre_cidx = plan[0].cidx; h->pre_seed = seed; h->pre_epoch = epoch;
   return 0;
@@ -1432,7 +1573,13 @@ int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, ui
   CHK(out(dup_of_pos, x.dup_of_pos, E * sizeof(uint32_t)));
   CHK(out(dup_of_ex, x.dup_of_ex, E * sizeof(uint32_t)));
   if (sorted_item && E) {
-    if (x.key16) {                                        // I <= 65536: the sort ran on 16-bit copies of the item ids
+    if (h->counting_sort) {                               // the counting sort writes no sorted key array: the segments say the same
+      std::vector<uint32_t> sb(I), se(I);
+      HIPCHK(hipMemcpy(sb.data(), x.seg, I * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(se.data(), x.seg + I, I * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      for (size_t it = 0; it < I; ++it)
+        for (uint32_t q = sb[it]; q < se[it]; ++q) sorted_item[q] = (uint32_t)it;
+    } else if (x.key16) {                                        // I <= 65536: the sort ran on 16-bit copies of the item ids
       std::vector<uint16_t> k16(E);
       HIPCHK(hipMemcpy(k16.data(), x.sorted_key16, E * sizeof(uint16_t), hipMemcpyDeviceToHost));
       for (uint64_t i = 0; i < E; ++i) sorted_item[i] = k16[i];
@@ -1628,11 +1775,11 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val, E, 0u,
                                    (unsigned)h->sort_bits, h->stream));
   HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)h->I * sizeof(uint32_t), h->stream));
-  HIPCHK(hipMemsetAsync(x.dup_count, 0, sizeof(uint32_t), h->stream));
+  HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), h->stream));
   HIPCHK(hipMemsetAsync(x.dup_of_ex, 0xFF, E * sizeof(uint32_t), h->stream));
   hipLaunchKernelGGL(cdae::segment_kernel<uint32_t>, dim3((uint32_t)((E + 256 * cdae::SEG_PER_THREAD - 1) / (256 * cdae::SEG_PER_THREAD))),
                      dim3(256), 0, h->stream, x.sorted_item, x.sorted_val,
-                     (uint32_t)E, x.seg, x.seg + h->I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex);
+                     (uint32_t)E, x.seg, x.seg + h->I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
   HIPCHK(hipEventRecord(x.ready, h->stream));
   const uint32_t one_unit[2] = {0u, 1u};                         // one user, one unit
   HIPCHK(hipMemcpyAsync(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice, h->stream));

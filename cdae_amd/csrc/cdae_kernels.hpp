@@ -30,6 +30,12 @@ constexpr uint32_t SLOT_MASK = 0x0FFFFFFFu;   // example word: slot | dup_prev <
 constexpr uint32_t DUP_PREV_BIT = 1u << 28;   // (set by segment_kernel) the row's previous example is the same user's
 constexpr uint32_t DUP_NEXT_BIT = 1u << 29;   // the row's next example is the same user's
 constexpr uint32_t DUP_NONE = 0xFFFFFFFFu;    // "no correction row" (dup_of_pos / dup_of_ex)
+// Correction rows are numbered by bumping a counter once per workgroup of segment_kernel / segment_sort_kernel.  ONE counter for
+// hundreds of workgroups is a chain of same-address returning atomics (~55 ns each: 37 us of a 660-workgroup launch); the index
+// space is cut into up to DUP_STRIPES stripes of at least 4096 rows with a counter each (workgroup b draws from stripe b mod
+// stripes; a stripe that runs out hands out DUP_NONE and decode falls back to its atomics path for those examples — small
+// problems use one stripe: they must not run out where one counter would not).
+constexpr uint32_t DUP_STRIPES = 64;
 constexpr uint32_t TARGET_BIT = 1u << 30;
 constexpr uint32_t INPUT_BIT = 1u << 31;
 
@@ -46,19 +52,21 @@ struct HyperParams {
   uint32_t unit_pos;         // positives per work unit (<= UNIT_POS_MAX), see "Work units" below
   uint32_t debug_rank;       // -DCDAE_DECODE_TIMING builds: the row whose timeline decode_rows_kernel records
   unsigned long long* trace; // CDAE_WAVE_TRACE (developer aid, tools/wave_trace.py): per-wavefront {tag, start, end, extra} records, or nullptr
+  uint32_t trace_odd;        // (wave trace) 1 on batches with an odd sequence number
   uint32_t debug_skip;       // CDAE_DEBUG_SKIP_ROLES (timing experiments only, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows
 };
 
 // ------------------------------------------------------------------------------------------------
 // Developer aid: wavefront timeline.  With CDAE_WAVE_TRACE set the handle passes a buffer of four-word records and every traced
 // wavefront fills its own: {tag << 32 | id, start, end, extra} in 100 MHz device time.
-constexpr uint32_t TRACE_ROLES = 16, TRACE_IDS = 1u << 16;   // record slot = role * TRACE_IDS + id (no shared counter: it would serialise the wavefronts)
+constexpr uint32_t TRACE_ROLES = 32, TRACE_IDS = 1u << 16;   // record slot = role * TRACE_IDS + id (no shared counter: it would serialise the wavefronts)
 constexpr unsigned long long TRACE_CAP = (unsigned long long)TRACE_ROLES * TRACE_IDS;
 __device__ __forceinline__ unsigned long long trace_begin(const HyperParams& hp) {
   return hp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 }
 __device__ __forceinline__ void trace_end(const HyperParams& hp, uint32_t tag, uint32_t id, unsigned long long t0, uint32_t extra = 0) {
   if (hp.trace && threadIdx.x % 64 == 0 && id < TRACE_IDS) {
+    tag += 16u * hp.trace_odd;                                   // odd batches keep their own records: two consecutive batches survive
     unsigned long long* r = hp.trace + 4ull * ((unsigned long long)tag * TRACE_IDS + id);
     r[0] = ((unsigned long long)tag << 32) | id; r[1] = t0; r[2] = __builtin_amdgcn_s_memrealtime(); r[3] = extra;
   }
@@ -213,12 +221,12 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               uint32_t* __restrict__ seg /* [seg_words] cleared here for segment_kernel */, uint32_t seg_words,
               uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
               const uint32_t* __restrict__ unit_user /* global unit -> user id */,
-              uint32_t* __restrict__ item_count /* counting sort (cdae_sort_kernels.hpp): per-item example counts, zero on entry; or nullptr */,
+              uint32_t* __restrict__ /* unused (round-2 global-atomic counting sort) */,
               const uint32_t* __restrict__ gpos /* item shard: [2 U] (length of the user's WHOLE row, position of the first local item in it); else nullptr */) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *dup_count = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
   const uint32_t wid = threadIdx.x / WAVE;
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
@@ -245,7 +253,6 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     const uint64_t e = base + p;
     ex_item[e] = row[p];
     if (ex_key16) ex_key16[e] = (uint16_t)row[p];
-    if (item_count) atomicAdd(item_count + row[p], 1u);          // no return value used: fire-and-forget
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
@@ -273,7 +280,6 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     }
     ex_item[e] = cand;
     if (ex_key16) ex_key16[e] = (uint16_t)cand;
-    if (item_count) atomicAdd(item_count + cand, 1u);
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)slot;
   }
@@ -290,7 +296,8 @@ template <typename KeyT>
 __global__ void __launch_bounds__(256)
 segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint32_t n_ex, uint32_t* __restrict__ seg_begin,
                uint32_t* __restrict__ seg_end, uint32_t* __restrict__ dup_count, uint32_t dup_cap,
-               uint32_t* __restrict__ dup_of_pos, uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */) {
+               uint32_t* __restrict__ dup_of_pos, uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */,
+               uint32_t stripes /* 1..DUP_STRIPES counters in use */) {
   __shared__ uint32_t blk_count, blk_base;
   if (threadIdx.x == 0) blk_count = 0u;
   __syncthreads();
@@ -315,14 +322,15 @@ segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint3
   const uint32_t mine = (uint32_t)__popc(dups);
   uint32_t off = mine ? atomicAdd(&blk_count, mine) : 0u;        // LDS
   __syncthreads();
-  if (threadIdx.x == 0 && blk_count) blk_base = atomicAdd(dup_count, blk_count);
+  if (threadIdx.x == 0 && blk_count) blk_base = atomicAdd(dup_count + blockIdx.x % stripes, blk_count);
   __syncthreads();
   off += blk_base;
+  const uint32_t stripe_cap = dup_cap / stripes, stripe0 = (blockIdx.x % stripes) * stripe_cap;
   while (dups) {
     const uint32_t i = (uint32_t)__ffs((int)dups) - 1u;
     dups &= dups - 1u;
     const uint32_t p = p0 + i * blockDim.x;
-    const uint32_t idx = off < dup_cap ? off : DUP_NONE;
+    const uint32_t idx = off < stripe_cap ? stripe0 + off : DUP_NONE;
     ++off;
     dup_of_pos[p] = idx;
     dup_of_ex[(uint32_t)(sorted_val[p] >> 32)] = idx;
@@ -460,6 +468,114 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
     for (int i = 0; i < NI; ++i) z[i] = 0.f;
     vstore<NI>(HGzero + (size_t)slot * hp.Kp + lo, z);
   }
+  trace_end(hp, 2, slot, t0);
+}
+
+// K2 (training path, one launch): one WORKGROUP of ENC_WAVES wavefronts per user of the batch.  Wavefront w sums the kept rows of
+// the user's units w, w + ENC_WAVES, ... (each exactly as encode_partial_kernel does), the per-wavefront sums meet in LDS, and
+// wavefront 0 adds them in wavefront order and finishes like encode_finish_kernel.  For a user with at most ENC_WAVES units
+// (1024 positives at 64 per unit) that is the same sum in the same order as the two-launch form: bit-identical z.  It removes a
+// launch boundary and a launch from every training step (8.3 + 1.4 + 4.3 us -> one launch, profiles/r02_main_stream.txt); heavy
+// users are still spread over wavefronts, now of their own workgroup.  The two-launch form stays for arbitrary user lists,
+// caller-supplied input sets and item shards.
+constexpr int ENC_WAVES = 16;
+template <int NI>
+__global__ void __launch_bounds__(ENC_WAVES * WAVE)
+encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                    const float* __restrict__ W, const uint32_t* __restrict__ uptr, uint64_t u0, uint32_t nb,
+                    uint32_t cidx, uint64_t seed, uint32_t epoch, const float* __restrict__ Wu, const float* __restrict__ b,
+                    float* __restrict__ Z, float* __restrict__ Dz, float* __restrict__ HGzero,
+                    const float* __restrict__ Uu /* linear_function only */, float* __restrict__ Ssum /* linear_function only */) {
+  __shared__ float part[ENC_WAVES][64 * NI];
+  const uint32_t slot = blockIdx.x, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  const unsigned long long t0 = trace_begin(hp);
+  const uint64_t uid = u0 + slot;
+  const uint32_t lo = lane * NI;
+  const uint32_t n_units = uptr[slot + 1] - uptr[slot];
+  // wavefront 0 requests what the finish needs before anything else (it was a round trip behind the sums)
+  float bb[NI], wu[NI], uu[NI];
+  if (wid == 0) {
+    vload<NI>(bb, b + lo);
+    if (hp.user_factor) vload<NI>(wu, Wu + (size_t)uid * hp.Kp + lo);
+    if (hp.linear_function) vload<NI>(uu, Uu + (size_t)uid * hp.Kp + lo);
+  }
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  if (wid < n_units) {
+    const int64_t r0 = row_ptr[uid];
+    const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+    const uint32_t* row = col + r0;
+    const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
+    constexpr int UN = 8;
+    for (uint32_t unit = wid; unit < n_units; unit += ENC_WAVES) {
+      const uint32_t p_begin = unit * hp.unit_pos, p_end = min(p_begin + hp.unit_pos, n);
+      float ua[NI];                                              // the unit's own sum first, as encode_partial_kernel forms it
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ua[i] = 0.f;
+      for (uint32_t q0 = p_begin; q0 < p_end; q0 += WAVE) {
+        const uint32_t p = q0 + lane;
+        uint32_t item = 0;
+        int keep = 0;
+        if (p < p_end) {
+          item = row[p];
+          keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+        }
+        unsigned long long mask = __ballot(keep);
+        while (mask) {
+          float v[UN][NI];
+#pragma unroll
+          for (int j = 0; j < UN; ++j) {
+            if (mask) {                                          // wave-uniform
+              const int src = __ffsll((long long)mask) - 1;
+              mask &= mask - 1;
+              const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)item, src);
+              vload<NI>(v[j], W + (size_t)it * hp.Kp + lo);
+            } else {
+#pragma unroll
+              for (int i = 0; i < NI; ++i) v[j][i] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < UN; ++j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) ua[i] += v[j][i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] += ua[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) part[wid][lo + i] = acc[i];
+  __syncthreads();
+  if (wid != 0) return;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const uint32_t nw = min(n_units, (uint32_t)ENC_WAVES);
+  for (uint32_t w = 0; w < nw; ++w)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] += part[w][lo + i];
+  if (hp.linear_function) {                                      // h1 = Uu[u] (.) h1   cdae.hpp:382-384
+    if (Ssum) vstore<NI>(Ssum + (size_t)slot * hp.Kp + lo, acc);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] *= uu[i];
+  }
+  float z[NI], dz[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    float h = fmaf(acc[i], hp.scale, bb[i]);
+    if (hp.user_factor) h += wu[i];
+    const float zz = activate(hp, h);
+    const bool live = lo + i < hp.K;                             // pad elements of z must be 0
+    z[i] = live ? zz : 0.f;
+    dz[i] = live ? act_deriv(hp, zz) : 0.f;
+  }
+  vstore<NI>(Z + (size_t)slot * hp.Kp + lo, z);
+  vstore<NI>(Dz + (size_t)slot * hp.Kp + lo, dz);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) z[i] = 0.f;
+  vstore<NI>(HGzero + (size_t)slot * hp.Kp + lo, z);
   trace_end(hp, 2, slot, t0);
 }
 

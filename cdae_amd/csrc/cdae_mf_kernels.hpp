@@ -53,7 +53,7 @@ mf_sample_kernel(HyperParams hp, uint32_t pairwise, const int64_t* __restrict__ 
                  uint32_t* __restrict__ seg, uint32_t seg_words, uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
                  const uint32_t* __restrict__ unit_user) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *dup_count = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;

@@ -2,24 +2,37 @@
 //
 // The decode is transposed (cdae_kernels.hpp): every item row walks the batch's examples on it in USER order, so the
 // user-major example list that sample_kernel writes (cdae.hpp:217-220, 361-371) has to be turned item-major, stably.  A
-// generic radix sort of (16-bit key, 64-bit value) pairs — rocPRIM onesweep: histogram, scan, two digit passes — cost
-// ~70-85 us of mostly launch latency per batch on the prep stream, as much as the training kernels of a 256-user batch.
-// The keys are item ids below 65 536 and the order wanted inside an item is the order of the (unique) example words, so a
-// counting sort does it in three small launches:
-//   sample_kernel         counts the examples of every item: atomicAdd(item_count[item], 1), no return value
-//   count_scan_kernel     one workgroup: exclusive prefix of item_count -> seg_begin / seg_end, prefix[] (I + 1 entries), cursor[]
-//   scatter_kernel        one thread per example: bucketed_val[atomicAdd(cursor[item], 1)] = val   (arrival order inside an item)
+// generic radix sort of (16-bit key, 64-bit value) pairs — rocPRIM onesweep: histogram, scan, two digit passes, five fills of
+// its own — is 10 launches and ~75 us of mostly launch latency per batch on the prep stream: once the training step dropped
+// below ~95 us it was the prep chain that paced the loop (profiles/r02_wave_timeline_256.txt: decode waiting 12 us for `ready`).
+// The keys are item ids and the order wanted inside an item is the order of the (unique) example words, so a counting sort
+// does it in four small launches and without a single global atomic:
+//   tile_hist_kernel      one workgroup per TILE_EX examples: per-item counts of the tile in LDS -> hist[tile][item]
+//   item_tile_scan_kernel one thread per item: exclusive prefix over the tiles (in place), the item's total -> item_count, and the
+//                         totals' exclusive prefix inside each block of 256 items + the block's sum
+//   tile_scatter_kernel   the tiles again: prefix[item] = scan of the block sums + the in-block prefix (workgroup 0 writes prefix[] /
+//                         seg_begin / seg_end), cursor[item] = prefix[item] + hist[tile][item]; every example takes a ticket from
+//                         its item's cursor (LDS atomic: arrival order inside (item, tile), tiles in order) -> bucketed_val
 //   segment_sort_kernel   per item: order the segment by value (= example index = user order; rank by counting in LDS),
-//                         mark runs of one user's examples (duplicate negatives), number them, clear item_count
+//                         mark runs of one user's examples (duplicate negatives), number them
 // The result is bit-identical to a stable sort by item (tests/test_gpu_integer.py compares with numpy's stable argsort).
-// More than 65 536 items keep the rocPRIM path (cdae_hip.hip: prep_batch).
+// Item spaces above TILE_SORT_MAX_ITEMS (the per-tile cursors must fit LDS) always take the rocPRIM path (cdae_hip.hip: prep_batch).
 //
-// STATUS: opt-in (CDAE_SORT_COUNTING=1), not the default.  Measured on MI355X at ML-10M shape (profiles/r02_counting_sort.txt):
-// the step got SLOWER — 0.117 -> 0.134 ms at 256 users per batch, 0.166 -> 0.217 ms at 512.  The prep stream runs beside the
-// previous batch's training kernels; the same-address atomics of the hot items (the top item takes ~250 tickets per batch)
-// serialise in one L2 channel and slow the decode that overlaps them (64 -> 101 us), while rocPRIM's onesweep passes, although
-// four launches, touch memory in streams and disturb it less.  Kept for the bit-exact order test and as the starting point of
-// an atomics-free variant (positives placed from a static CSC rank, only the negatives counted).
+// STATUS: opt-in (CDAE_SORT_TILE=1), not the default.  Measured on MI355X at ML-10M shape (profiles/r02_tile_sort.txt): the prep
+// chain is shorter — sample 17.5 + hist 6.6 + scan 7.9 + scatter 16.5 + segment sort 23.4 = 72 us against ~100 us with rocPRIM —
+// but the training step does not follow: 0.1001 vs 0.0998 ms at 256 users per batch, 0.146 vs 0.141 at 512.  The prep stream
+// runs beside the training kernels of the previous batch; its kernels are slowed 2-3x by that company and slow the decode in
+// turn, and the wide launches here (1325 workgroups of segment_sort_kernel, 1024-thread tiles) disturb it at least as much as
+// rocPRIM's ~85-workgroup passes.  Variants tried: 2048 / 4096 examples per tile, 256 / 1024 threads per tile, the item prefix
+// as a launch of its own / in every scatter workgroup / two-level, 4 / 8 / 16 items and 64 / 128 / 256 threads per segment-sort
+// workgroup, LDS window 768 / 3072: all within +-4 % of rocPRIM, none consistently better.
+//
+// History: the first counting sort of this round took its tickets with GLOBAL atomics (one counter per item, bumped in
+// sample_kernel and again in a scatter kernel): the ~130-250 same-address atomics of a hot item serialise in one L2 channel
+// (step 0.117 -> 0.134 ms at 256 users; profiles/r02_counting_sort.txt).  Per-tile LDS counters have no such hot spot.  Two
+// findings carried over to the default path: numbering the correction rows from ONE global counter is a chain of same-address
+// returning atomics (now striped, cdae_kernels.hpp DUP_STRIPES), and a rank-by-counting loop with one LDS read in flight made
+// the workgroup that holds the most popular items a 35 us serial tail (now eight reads in flight).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,9 +43,18 @@ namespace cdae {
 
 constexpr uint32_t SCAN_THREADS = 1024;
 constexpr uint32_t COUNTING_SORT_MAX_ITEMS = 65536;     // count_scan_kernel: SCAN_THREADS x 64 counters
-constexpr uint32_t SEGSORT_THREADS = 256;               // small workgroups: they share the chip with the training kernels of the previous batch
-constexpr uint32_t SEGSORT_ITEMS = 16;                   // consecutive items per workgroup
-constexpr uint32_t SEGSORT_WINDOW = 3072;                // examples held in LDS at a time (2 x 24 KiB)
+#ifndef CDAE_SEGSORT_THREADS
+#define CDAE_SEGSORT_THREADS 256
+#endif
+constexpr uint32_t SEGSORT_THREADS = CDAE_SEGSORT_THREADS;               // small workgroups: they share the chip with the training kernels of the previous batch
+#ifndef CDAE_SEGSORT_ITEMS
+#define CDAE_SEGSORT_ITEMS 8
+#endif
+constexpr uint32_t SEGSORT_ITEMS = CDAE_SEGSORT_ITEMS;    // consecutive items per workgroup
+#ifndef CDAE_SEGSORT_WINDOW
+#define CDAE_SEGSORT_WINDOW 3072
+#endif
+constexpr uint32_t SEGSORT_WINDOW = CDAE_SEGSORT_WINDOW;   // examples held in LDS at a time (2 arrays of 8-byte values)
 
 // exclusive prefix over the per-item example counts of the batch; one workgroup.  Wavefront w owns the contiguous item range
 // [w, w+1) * ceil(I / 16 / 64) * 64 and walks it 64 items at a time (coalesced, all loads of the range issued up front: the
@@ -88,19 +110,122 @@ count_scan_kernel(const uint32_t* __restrict__ item_count, uint32_t num_items, u
   if (chunks <= 4) body(std::integral_constant<uint32_t, 4>{});
   else if (chunks <= 16) body(std::integral_constant<uint32_t, 16>{});
   else body(std::integral_constant<uint32_t, SCAN_CHUNKS_MAX>{});
-  if (threadIdx.x == 0) *dup_count = 0u;
+  if (threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
 }
 
+constexpr uint32_t TILE_SORT_MAX_ITEMS = 32768;         // tile_scatter_kernel's cursors: 4 bytes per item of LDS (128 KiB at the limit)
+#ifndef CDAE_TILE_EX
+#define CDAE_TILE_EX 4096
+#endif
+constexpr uint32_t TILE_EX = CDAE_TILE_EX;                // examples per tile (<= 65535: 16-bit counters in tile_hist_kernel)
+constexpr uint32_t TILE_THREADS = 1024;                 // four examples per thread: the scatter is a chain of LDS-atomic -> scattered store per example
+
+__global__ void __launch_bounds__(TILE_THREADS)
+tile_hist_kernel(const uint32_t* __restrict__ ex_item, uint32_t n_ex, uint32_t num_items, uint32_t* __restrict__ hist /* [tiles][I] */) {
+  extern __shared__ uint32_t tile_cnt[];                                   // two 16-bit counters per word (a tile holds TILE_EX <= 65535 examples)
+  const uint32_t words = (num_items + 1u) / 2u;
+  for (uint32_t i = threadIdx.x; i < words; i += TILE_THREADS) tile_cnt[i] = 0u;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * TILE_EX;
+#pragma unroll
+  for (uint32_t j = 0; j < TILE_EX / TILE_THREADS; ++j) {
+    const uint32_t e = base + j * TILE_THREADS + threadIdx.x;
+    if (e < n_ex) {
+      const uint32_t it = ex_item[e];
+      atomicAdd(&tile_cnt[it >> 1], 1u << (16u * (it & 1u)));              // LDS
+    }
+  }
+  __syncthreads();
+  uint32_t* out = hist + (size_t)blockIdx.x * num_items;
+  for (uint32_t i = threadIdx.x; i < num_items; i += TILE_THREADS) out[i] = (tile_cnt[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
+}
+
+// hist[t][i] -> exclusive prefix over t (the tile's first ticket inside item i); item_count[i] = the item's total;
+// local_prefix[i] = exclusive prefix of the totals inside the workgroup's block of 256 items, block_total[b] = the block's sum
+// (tile_scatter_kernel adds the scan of the <= 128 block totals: the item prefix without a pass over all items per workgroup)
 __global__ void __launch_bounds__(256)
-scatter_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __restrict__ ex_val, uint32_t n_ex,
-               uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted_item,
-               uint64_t* __restrict__ bucketed_val /* item-major, arrival order inside an item */) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_ex) return;
-  const uint32_t item = ex_item[e];
-  const uint32_t pos = atomicAdd(cursor + item, 1u);        // one returning atomic per thread: the latency hides behind E threads
-  sorted_item[pos] = item;
-  bucketed_val[pos] = ex_val[e];
+item_tile_scan_kernel(uint32_t* __restrict__ hist, uint32_t n_tiles, uint32_t num_items, uint32_t* __restrict__ item_count,
+                      uint32_t* __restrict__ local_prefix, uint32_t* __restrict__ block_total) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t run = 0;
+  if (i < num_items) {
+    constexpr uint32_t UN = 8;                                             // loads of eight tiles in flight
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += UN) {
+      uint32_t c[UN];
+#pragma unroll
+      for (uint32_t k = 0; k < UN; ++k) c[k] = t0 + k < n_tiles ? hist[(size_t)(t0 + k) * num_items + i] : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < UN; ++k) {
+        if (t0 + k < n_tiles) hist[(size_t)(t0 + k) * num_items + i] = run;
+        run += c[k];
+      }
+    }
+    item_count[i] = run;
+  }
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;
+  uint32_t incl = run;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, WAVE);
+    if ((int)lane >= off) incl += o;
+  }
+  if (lane == WAVE - 1) wave_sum[wid] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wid; ++w) before += wave_sum[w];
+  if (i < num_items) local_prefix[i] = before + incl - run;
+  if (threadIdx.x == 255) block_total[blockIdx.x] = before + incl;
+}
+
+// cursor[item] = (scan of the <= 128 block totals)[item / 256] + local_prefix[item] + hist[tile][item]: every workgroup scans the
+// block totals itself (one wavefront, two values per lane) instead of waiting on a launch of its own; workgroup 0 writes
+// prefix[] and the segment table for the kernels that follow.
+__global__ void __launch_bounds__(TILE_THREADS)
+tile_scatter_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __restrict__ ex_val, uint32_t n_ex, uint32_t num_items,
+                    const uint32_t* __restrict__ hist /* tile prefixes */, const uint32_t* __restrict__ item_count,
+                    const uint32_t* __restrict__ local_prefix, const uint32_t* __restrict__ block_total,
+                    uint32_t* __restrict__ prefix /* [I + 1], written by workgroup 0 */, uint32_t* __restrict__ seg_begin,
+                    uint32_t* __restrict__ seg_end, uint32_t* __restrict__ dup_count,
+                    uint64_t* __restrict__ bucketed_val /* item-major, arrival order inside (item, tile) */) {
+  extern __shared__ uint32_t tile_cur[];                                   // [num_items] cursors, then [128] block bases
+  uint32_t* block_base = tile_cur + num_items;
+  const uint32_t n_blocks = (num_items + 255u) / 256u;                     // <= 128 (TILE_SORT_MAX_ITEMS / 256)
+  if (threadIdx.x < WAVE) {
+    const uint32_t a0 = 2u * threadIdx.x, a1 = a0 + 1u;
+    const uint32_t v0 = a0 < n_blocks ? block_total[a0] : 0u, v1 = a1 < n_blocks ? block_total[a1] : 0u;
+    uint32_t incl = v0 + v1;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off, WAVE);
+      if ((int)threadIdx.x >= off) incl += o;
+    }
+    block_base[a0] = incl - v0 - v1;
+    block_base[a1] = incl - v1;
+  }
+  __syncthreads();
+  const uint32_t* mine_hist = hist + (size_t)blockIdx.x * num_items;
+  for (uint32_t i = threadIdx.x; i < num_items; i += TILE_THREADS) {
+    const uint32_t p = block_base[i >> 8] + local_prefix[i];
+    tile_cur[i] = p + mine_hist[i];                                        // this tile's first ticket of item i
+    if (blockIdx.x == 0) {                                                 // the tables the kernels after this one read
+      const uint32_t c = item_count[i];
+      prefix[i] = p;
+      seg_begin[i] = c ? p : 0u;                                           // items without examples keep (0, 0)
+      seg_end[i] = c ? p + c : 0u;
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) prefix[num_items] = n_ex;
+    if (threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  const uint32_t base = blockIdx.x * TILE_EX;
+#pragma unroll
+  for (uint32_t j = 0; j < TILE_EX / TILE_THREADS; ++j) {
+    const uint32_t e = base + j * TILE_THREADS + threadIdx.x;
+    if (e < n_ex) bucketed_val[atomicAdd(&tile_cur[ex_item[e]], 1u)] = ex_val[e];
+  }
 }
 
 // One workgroup per SEGSORT_ITEMS consecutive items = one contiguous range of sorted positions.  Inside an item the
@@ -114,7 +239,7 @@ __global__ void __launch_bounds__(SEGSORT_THREADS)
 segment_sort_kernel(uint32_t num_items, const uint32_t* __restrict__ prefix, const uint64_t* __restrict__ bucketed_val,
                     uint64_t* __restrict__ sorted_val, uint32_t* __restrict__ item_count, uint32_t* __restrict__ dup_count,
                     uint32_t dup_cap, uint32_t* __restrict__ dup_of_pos,
-                    uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */) {
+                    uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */, uint32_t stripes /* 1..DUP_STRIPES */) {
   __shared__ uint64_t raw[SEGSORT_WINDOW], srt[SEGSORT_WINDOW];
   __shared__ uint32_t item_off[SEGSORT_ITEMS + 1];
   __shared__ uint32_t blk_count, blk_base;
@@ -143,8 +268,17 @@ segment_sort_kernel(uint32_t num_items, const uint32_t* __restrict__ prefix, con
       const uint32_t a = item_off[k] - p0, b = item_off[k + 1] - p0;
       uint32_t rank = 0;
       if (in_lds) {
+        // eight LDS reads in flight (independent counters): a popular item has 100+ examples per batch, and with one read at a
+        // time the workgroup that holds the most popular items was a 35 us serial tail (113 us at 512 users per batch)
         const uint64_t v = raw[q];
-        for (uint32_t j = a; j < b; ++j) rank += raw[j] < v ? 1u : 0u;
+        uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint32_t j = a;
+        for (; j + 8 <= b; j += 8) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) r[t] += raw[j + t] < v ? 1u : 0u;
+        }
+        for (; j < b; ++j) r[0] += raw[j] < v ? 1u : 0u;
+        rank = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
         srt[a + rank] = v;
       } else {
         const uint64_t v = bucketed_val[p0 + q];
@@ -168,14 +302,15 @@ segment_sort_kernel(uint32_t num_items, const uint32_t* __restrict__ prefix, con
     }
     uint32_t off = my_dups ? atomicAdd(&blk_count, my_dups) : 0u;           // LDS
     __syncthreads();
-    if (threadIdx.x == 0) { blk_base = blk_count ? atomicAdd(dup_count, blk_count) : 0u; blk_count = 0u; }
+    if (threadIdx.x == 0) { blk_base = blk_count ? atomicAdd(dup_count + blockIdx.x % stripes, blk_count) : 0u; blk_count = 0u; }
     __syncthreads();
     if (my_dups) {
       off += blk_base;
+      const uint32_t stripe_cap = dup_cap / stripes, stripe0 = (blockIdx.x % stripes) * stripe_cap;
       for (uint32_t q = threadIdx.x; q < n; q += blockDim.x) {             // this thread's own positions again
         const uint64_t v = sorted_val[p0 + q];
         if (!((uint32_t)v & DUP_PREV_BIT)) continue;
-        const uint32_t idx = off < dup_cap ? off : DUP_NONE;
+        const uint32_t idx = off < stripe_cap ? stripe0 + off : DUP_NONE;
         ++off;
         dup_of_pos[p0 + q] = idx;
         dup_of_ex[(uint32_t)(v >> 32)] = idx;

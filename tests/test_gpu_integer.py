@@ -63,7 +63,8 @@ def check_batch(model, o, d, seed, epoch, u0, nb, cidx=0, num_neg=5):
     seg_e[si[last]] = last + 1
     np.testing.assert_array_equal(got["seg_begin"], seg_b)
     np.testing.assert_array_equal(got["seg_end"], seg_e)
-    # ---- duplicate negatives of one user inside a row: flags exact, numbering a bijection onto 0..n-1
+    # ---- duplicate negatives of one user inside a row: flags exact; numbering: distinct correction rows (the index space is
+    # striped over DUP_STRIPES counters, cdae_kernels.hpp, so the numbers are not dense; a stripe that runs out hands out NONE)
     slot = (words[order] & np.uint64(SLOT_MASK)).astype(np.int64)
     same_prev = np.r_[False, (si[1:] == si[:-1]) & (slot[1:] == slot[:-1])]
     same_next = np.r_[same_prev[1:], False]
@@ -72,7 +73,9 @@ def check_batch(model, o, d, seed, epoch, u0, nb, cidx=0, num_neg=5):
     np.testing.assert_array_equal((w & np.uint64(DUP_NEXT)) != 0, same_next)
     n_dup = int(same_prev.sum())
     numbered = got["dup_of_pos"][same_prev]
-    np.testing.assert_array_equal(np.sort(numbered), np.arange(n_dup, dtype=np.uint32))
+    given = numbered[numbered != NONE]
+    assert np.unique(given).size == given.size                      # no correction row is shared
+    assert given.size >= min(n_dup, 8)                              # and the stripes did hand rows out
     assert (got["dup_of_pos"][~same_prev] == NONE).all()
     exp_of_ex = np.full(E, NONE, dtype=np.uint32)
     exp_of_ex[order[same_prev]] = numbered
@@ -156,9 +159,12 @@ def test_user_id_offset_shifts_the_streams_like_a_global_run(built):
         np.testing.assert_array_equal(a[k], b[k])
 
 
-def test_counting_sort_path_gives_the_same_bit_exact_order(built, monkeypatch):
-    """cdae_sort_kernels.hpp (opt-in, CDAE_SORT_COUNTING=1): counting sort + per-item ordering instead of the library sort"""
-    monkeypatch.setenv("CDAE_SORT_COUNTING", "1")
+@pytest.mark.parametrize("tile_sort", [True, False], ids=["tile-counting-sort", "rocprim"])
+def test_both_sort_paths_give_the_same_bit_exact_order(built, monkeypatch, tile_sort):
+    """cdae_sort_kernels.hpp (CDAE_SORT_TILE=1, up to 32 768 items): per-tile LDS counting sort + per-item ordering; default: the
+    library radix sort.  Both must equal numpy's stable sort by item, bit for bit."""
+    if tile_sort:
+        monkeypatch.setenv("CDAE_SORT_TILE", "1")
     d = synth.generate(1200, 500, 60_000, seed=9)
     model, o = make(d, B=96)
     dups = sum(check_batch(model, o, d, 20141119, ep, u0, 96) for ep, u0 in ((0, 0), (3, 96), (1, 1200 - 96)))
@@ -170,3 +176,12 @@ def test_counting_sort_path_gives_the_same_bit_exact_order(built, monkeypatch):
     d2 = synth.Interactions(len(rows), 400, ptr, np.concatenate(rows), np.zeros(len(rows) + 1, np.int64), np.empty(0, np.uint32))
     m2, o2 = make(d2, B=3500, num_neg=1)
     check_batch(m2, o2, d2, 2, 0, 0, 3500, num_neg=1)
+
+
+def test_tile_sort_with_more_than_16384_items(built, monkeypatch):
+    """per-tile cursors above 64 KiB of LDS (dynamic LDS attribute): 20 000 items"""
+    monkeypatch.setenv("CDAE_SORT_TILE", "1")
+    d = synth.generate(600, 20_000, 40_000, seed=4)
+    model, o = make(d, B=128)
+    check_batch(model, o, d, 7, 0, 0, 128)
+    check_batch(model, o, d, 7, 1, 472, 128)

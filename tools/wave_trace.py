@@ -39,23 +39,30 @@ def main():
     rec = rec[rec[:, 1] != 0]
     # slots keep the last batch that wrote them: drop stragglers of earlier batches (ids the last batch did not reach)
     last = rec[:, 2].astype(np.int64).max()
-    rec = rec[last - rec[:, 1].astype(np.int64) < 100_000]           # within 1 ms of the end
-    role = (rec[:, 0] >> np.uint64(32)).astype(np.int64)
+    rec = rec[last - rec[:, 1].astype(np.int64) < 26_000]            # the last two batches (260 us)
+    tag = (rec[:, 0] >> np.uint64(32)).astype(np.int64)
+    role, odd = tag % 16, tag // 16
     t0 = rec[:, 1].astype(np.int64)
     t1 = rec[:, 2].astype(np.int64)
     base = t0.min()
     us = lambda x: 0.01 * x          # 100 MHz ticks -> us
-    print(f"batch_users {B}: {len(rec)} wavefront records, batch span {us(t1.max() - base):.1f} us")
-    print(f"{'role':18s} {'waves':>6s} | start first/median/last (us) | end first/median/last (us) | lifetime min/median/p90/max (us)")
-    for r in sorted(set(role.tolist())):
-        k = role == r
+    print(f"batch_users {B}: {len(rec)} wavefront records of the last two batches, span {us(t1.max() - base):.1f} us")
+    print(f"{'batch role':24s} {'waves':>6s} | start first/median/last (us) | end first/median/last (us) | lifetime min/median/p90/max (us)")
+    order = sorted(set(zip(odd.tolist(), role.tolist())), key=lambda pr: t0[(odd == pr[0]) & (role == pr[1])].min())
+    prev_end = None
+    for o, r in order:
+        k = (odd == o) & (role == r)
         s, e, life = t0[k] - base, t1[k] - base, t1[k] - t0[k]
-        print(f"{ROLES.get(r, str(r)):18s} {k.sum():6d} | {us(s.min()):7.1f} {us(np.median(s)):7.1f} {us(s.max()):7.1f}     | "
+        gap = "" if prev_end is None else f"  (+{us(s.min() - prev_end):.1f} after the previous role's last end)"
+        print(f"{'odd ' if o else 'even'} {ROLES.get(r, str(r)):18s} {k.sum():6d} | {us(s.min()):7.1f} {us(np.median(s)):7.1f} {us(s.max()):7.1f}     | "
               f"{us(e.min()):7.1f} {us(np.median(e)):7.1f} {us(e.max()):7.1f}   | "
-              f"{us(life.min()):6.1f} {us(np.median(life)):6.1f} {us(np.percentile(life, 90)):6.1f} {us(life.max()):6.1f}")
+              f"{us(life.min()):6.1f} {us(np.median(life)):6.1f} {us(np.percentile(life, 90)):6.1f} {us(life.max()):6.1f}{gap}")
+        prev_end = e.max() if r not in (7,) else prev_end
+        if r == 9:
+            prev_end = max(e.max(), (t1[(odd == o) & (role == 7)] - base).max()) if ((odd == o) & (role == 7)).any() else e.max()
     # the ten longest-lived and ten last-finishing wavefronts of every role (id = the kernel's own numbering)
     for r in sorted(set(role.tolist())):
-        k = np.where(role == r)[0]
+        k = np.where((role == r) & (odd == odd[np.argmax(t1)]))[0]
         life = t1[k] - t0[k]
         top = k[np.argsort(-life)[:6]]
         print(f"  {ROLES.get(r, str(r))}: longest " + ", ".join(f"#{int(rec[i, 0] & np.uint64(0xffffffff))}:{us(t0[i]-base):.1f}->{us(t1[i]-base):.1f}" for i in top))
