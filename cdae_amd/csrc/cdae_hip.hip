@@ -139,6 +139,7 @@ struct cdae_hip {
   static constexpr int NSETS = 3;
   hipStream_t prep2 = nullptr;          // second prep lane (batches with odd sequence number), or nullptr: one lane, look-ahead 1
   bool prep2_own = false;               // prep2 is a stream of its own (else it aliases `aux`)
+  bool prep2_auto = false;              // use the second lane only for batches of at most PREP2_AUTO_MAX_USERS users
   float* d_D0 = nullptr;                // decoder matrix at batch start (hidden-gradient gather)
   uint32_t dup_stripes = 1;             // counters the correction rows are numbered from (cdae_kernels.hpp DUP_STRIPES)
   float* d_dup_corr = nullptr; uint32_t dup_cap = 0;   // [dup_cap][Kp] hidden-gradient corrections of duplicate negatives
@@ -838,15 +839,17 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking);
   {
-    // Second prep lane (off by default).  Sampling + sorting a batch is a chain of ~12 small launches, ~88 us at 256 users
-    // when it is the only thing pacing the loop; two lanes (CDAE_PREP2 = aux: the handle's aux stream, idle in the sampled
-    // path unless an exchange is configured; own: a stream of its own) prepare consecutive batches side by side and lift that
-    // floor to the host's launch rate (~65 us per batch).  Measured with the training step at ~100 us: the second lane costs
-    // 5 % (its kernels overlap more of the training kernels) — it pays only once the main stream drops below the floor.
+    // Second prep lane.  Sampling + sorting a batch is a chain of ~12 small launches, ~95 us on the prep stream whatever the
+    // batch size; once a training step is shorter than that the decode waits for `ready` (profiles/r02_wave_timeline_256.txt: 15 us
+    // per step at 256 users).  Two lanes prepare consecutive batches side by side.  Measured (tools/ab_bench.py, same box):
+    // 128 users per batch 0.0972 -> 0.0755 ms per step, 256: 0.0995 -> 0.0942, 512: 0.1409 -> 0.1429 (the prep kernels then
+    // only take issue slots from a step that was not waiting for them).  Default "auto": on up to 384 users per batch, on the
+    // handle's aux stream (idle in the sampled path; an exchange's collective shares it).  CDAE_PREP2 = off | aux | own | auto.
     const char* sel = std::getenv("CDAE_PREP2");
     if (sel && !std::strcmp(sel, "own")) { if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep2, hipStreamNonBlocking); h->prep2_own = true; }
     else if (sel && !std::strcmp(sel, "aux")) h->prep2 = h->aux;
-    else h->prep2 = nullptr;
+    else if (sel && !std::strcmp(sel, "off")) h->prep2 = nullptr;
+    else { h->prep2 = h->aux; h->prep2_auto = true; }
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, sync_event_flags());
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, sync_event_flags());
@@ -1280,7 +1283,12 @@ int make_plan(cdae_hip* h, uint64_t u_begin, uint64_t u_end, std::vector<Batch>&
 inline int set_of(uint64_t q) { return (int)(q % cdae_hip::NSETS); }
 // two lanes only where the second one is free: the sampled CDAE path (the full-output path runs its b recurrence on aux, an
 // item shard trains in phases)
-inline size_t prep_depth(const cdae_hip* h) { return (h->prep2 && !h->mf && !h->cfg.full_output && !h->item_shard) ? 2 : 1; }
+constexpr uint64_t PREP2_AUTO_MAX_USERS = 384;
+inline size_t prep_depth(const cdae_hip* h) {
+  if (!h->prep2 || h->mf || h->cfg.full_output || h->item_shard) return 1;
+  if (h->prep2_auto && std::min<uint64_t>(h->B, h->U) > PREP2_AUTO_MAX_USERS) return 1;
+  return 2;
+}
 inline int prep_lane(const cdae_hip* h, uint64_t q) { return prep_depth(h) == 2 ? (int)(q & 1) : 0; }
 // ---- prep worker ---------------------------------------------------------------------------------------------------
 // The caller's thread hands a batch's sampling + sorting to the worker (submit_prep) and, before it issues the training

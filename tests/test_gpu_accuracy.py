@@ -19,9 +19,9 @@ epoch 1 (the batched schedule is slightly AHEAD after one epoch, 3.5 standard er
 Stated tolerances (each asserted below; six data/stream seeds):
   * per seed, every epoch: |Recall@10_hip - Recall@10_literal| <= 0.005 — the literal schedule's own best-to-worst spread over
     stream seeds; anything larger is not seed noise
-  * MEAN over the seeds of the signed difference: |mean| <= 0.0015 at the final epoch and at every epoch from the second on
-    (the north star's 0.002 with room for the standard error of six seeds, ~0.0006), <= 0.003 at epoch 1 (the measured
-    head start)
+  * MEAN over the seeds of the signed difference: |mean| <= 0.002 (the north star's figure) at the final epoch and at every
+    epoch from the second on, <= 0.003 at epoch 1 (the measured head start).  Measured on the six fixtures: +0.0010 / -0.0007 /
+    -0.0008 / -0.0009 / -0.0012 per epoch, standard error of a six-seed mean ~0.0006
   * reported train loss within 3 % of the literal run's at every epoch, and the curve has the same shape: the
     epoch-to-epoch change agrees in sign wherever the literal curve moves by more than 0.5 %
   * `batch_users` = 1 IS the reference schedule: one full-size epoch reproduces the fixture's Recall@10 to 1e-4 and its loss
@@ -48,7 +48,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RECALL_TOL_SEED = 0.005           # per seed and epoch: the literal schedule's own spread over stream seeds
-RECALL_TOL_MEAN = 0.0015          # mean over seeds, final epoch and every epoch >= 2
+RECALL_TOL_MEAN = 0.002           # mean over seeds, final epoch and every epoch >= 2: the north star's figure
 RECALL_TOL_MEAN_FIRST = 0.003     # mean over seeds, epoch 1
 LOSS_REL_TOL = 0.03
 HYPER = dict(num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01)
