@@ -1287,6 +1287,9 @@ constexpr uint64_t PREP2_AUTO_MAX_USERS = 384;
 inline size_t prep_depth(const cdae_hip* h) {
   if (!h->prep2 || h->mf || h->cfg.full_output || h->item_shard) return 1;
   if (h->prep2_auto && std::min<uint64_t>(h->B, h->U) > PREP2_AUTO_MAX_USERS) return 1;
+  // an exchange runs its collective on the aux stream too, issued by the caller's thread while the worker issues lane 1: whichever
+  // is queued first decides whether the next batch's lists wait behind an all-reduce (measured one-rank: 0.115 -> 0.151 ms)
+  if (h->prep2 == h->aux && h->xchg) return 1;
   return 2;
 }
 inline int prep_lane(const cdae_hip* h, uint64_t q) { return prep_depth(h) == 2 ? (int)(q & 1) : 0; }
