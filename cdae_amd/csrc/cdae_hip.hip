@@ -180,6 +180,7 @@ struct cdae_hip {
   std::atomic<int> worker_failed{0};
   std::string worker_error;             // valid once worker_failed != 0
   std::mutex prof_mu;                   // spans / event pool are touched by both threads when profiling
+  uint32_t gather_halves = 1;           // wavefronts per (unit, item partition) in hidden_gather_kernel (CDAE_GATHER_HALVES = 1 | 2; 2 measured slower)
   bool encode_two_launches = false;     // CDAE_ENCODE_TWO_LAUNCHES: the training encode as encode_partial + encode_finish (developer switch)
   bool debug_skip_prep = false;         // CDAE_DEBUG_SKIP_PREP (timing experiment only: batches reuse stale example lists -> WRONG results)
   bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
@@ -525,11 +526,12 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   CHK(pr.end());
 
   CHK(pr.begin(h, F_HIDDEN, st));
-  DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
+  const uint32_t halves = h->gather_halves;
+  DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
               x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr,
-              explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
+              explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user, halves);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
-              h->d_Wu, h->d_Wu_ag, 8u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
+              h->d_Wu, h->d_Wu_ag, 8u * halves, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
   CHK(pr.end());
   // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
   CHK(pr.begin(h, F_INPUT, st));
@@ -833,6 +835,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
+  if (const char* ev = std::getenv("CDAE_GATHER_HALVES")) h->gather_halves = std::atoi(ev) == 2 ? 2u : 1u;
   if (const char* ev = std::getenv("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
@@ -1133,7 +1136,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     }
   }
   {
-    size_t rows = 8 * (size_t)h->unit_cap;
+    size_t rows = 8 * (size_t)h->gather_halves * h->unit_cap;
     if (h->cfg.full_output) {
       rows = std::max(rows, (size_t)h->full_slices * B);
       const uint32_t kps = gemm2_k_per_split(h);                                 // unfused path: one [Bp x Kp] slab per contraction split

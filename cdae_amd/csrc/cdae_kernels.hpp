@@ -1236,12 +1236,15 @@ __global__ void __launch_bounds__(256)
 hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ uptr,
                      uint32_t n_units, uint64_t u0, uint32_t nb, const uint32_t* __restrict__ ex_item,
                      const float* __restrict__ G, const float* __restrict__ D0,
-                     float* __restrict__ HGpart /* [8][n_units][Kp] */,
+                     float* __restrict__ HGpart /* [8 * halves][n_units][Kp] */,
                      uint32_t explicit_examples /* != 0: one user, one unit, that many examples */,
                      const uint32_t* __restrict__ dup_of_ex, const float* __restrict__ dup_corr,
-                     const uint32_t* __restrict__ unit_user) {
+                     const uint32_t* __restrict__ unit_user,
+                     uint32_t halves /* 1 or 2: wavefronts per (unit, partition), each walking half of the unit's 64-example chunks */) {
   const uint32_t part = blockIdx.x & 7u;
-  const uint32_t unit = (blockIdx.x >> 3) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t rest = blockIdx.x >> 3;
+  const uint32_t half = rest % halves;
+  const uint32_t unit = (rest / halves) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;
   const unsigned long long t0 = trace_begin(hp);
@@ -1279,11 +1282,16 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
     g = in ? G[base + e] : 0.f;
     di = in ? dup_of_ex[base + e] : DUP_NONE;
   };
+  // `halves` = 2: two wavefronts share a (unit, partition), each walking half of its 64-example chunks (9 -> 6 dependent round
+  // trips per wavefront, twice the partial sums).  Measured SLOWER (step 0.0935 -> 0.0973 ms at 256 users, 0.140 -> 0.145 at 512):
+  // the launch moves ~140 MB of rows out of L2 in ~15 us and is bound by that, not by the wavefronts' chains; default 1.
+  const uint32_t chunks_per = ((n_ex + WAVE - 1) / WAVE + halves - 1) / halves;
+  const uint32_t c_begin = half * chunks_per * WAVE, c_end = min(n_ex, c_begin + chunks_per * WAVE);
   uint32_t my_item, my_di, nx_item = 0xFFFFFFFFu, nx_di = DUP_NONE;
   float my_g, nx_g = 0.f;
-  load_chunk(0, my_item, my_g, my_di);
-  for (uint32_t c0 = 0; c0 < n_ex; c0 += WAVE) {
-    if (c0 + WAVE < n_ex) load_chunk(c0 + WAVE, nx_item, nx_g, nx_di);
+  load_chunk(c_begin, my_item, my_g, my_di);
+  for (uint32_t c0 = c_begin; c0 < c_end; c0 += WAVE) {
+    if (c0 + WAVE < c_end) load_chunk(c0 + WAVE, nx_item, nx_g, nx_di);
     const bool mine = my_item != 0xFFFFFFFFu && (my_item & 7u) == part;
     unsigned long long mask = __ballot(mine);
     // duplicate negatives (rare): add decode's correction rows, in example order
@@ -1333,8 +1341,8 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   }
-  vstore<NI>(HGpart + ((size_t)part * n_units + unit) * hp.Kp + lo, acc);
-  trace_end(hp, 5, unit * 8u + part, t0, n_ex);
+  vstore<NI>(HGpart + ((size_t)(part * halves + half) * n_units + unit) * hp.Kp + lo, acc);
+  trace_end(hp, 5, (unit * 8u + part) * halves + half, t0, n_ex);
 }
 
 // K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
@@ -1384,6 +1392,18 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
       for (int x = 0; x < 8; ++x)
 #pragma unroll
         for (int i = 0; i < NI; ++i) hg[i] += two ? a1[x][i] : 0.f;
+    }
+  } else if (n_parts == 16u) {                                     // two wavefronts per (unit, partition): one unit's 16 rows per trip
+    const size_t slab = (size_t)n_units * hp.Kp;
+    for (uint32_t u = ub; u < ue; ++u) {
+      const float* p0 = HGpart + (size_t)u * hp.Kp + lo;
+      float a0[16][NI];
+#pragma unroll
+      for (int x = 0; x < 16; ++x) vload<NI>(a0[x], p0 + x * slab);
+#pragma unroll
+      for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += a0[x][i];
     }
   } else {
     for (uint32_t u = ub; u < ue; ++u) {
