@@ -490,10 +490,10 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   // K <= 256: hot rows one per wavefront, all others four per wavefront (NV float4 pieces + NT tail scalars per lane)
 #define DECODE_HY(NV_, NT_)                                                                                           \
   do {                                                                                                                \
-    if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);   \
-    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);    \
-    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);    \
-    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, dec_lds, st, h->hp, hot, DECODE_TAIL);            \
+    if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);   \
+    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
+    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
+    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);            \
   } while (0)
 #define DECODE_HY_NT(NV_)                                                                        \
   do {                                                                                           \
@@ -506,7 +506,6 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
       const uint32_t hot = std::min<uint32_t>(h->hot_rows, I);
       const uint32_t waves = hot + (I - hot + 3) / 4;
       const dim3 grid_hy((waves + 3) / 4);
-      static const uint32_t dec_lds = std::getenv("CDAE_DEBUG_DECODE_LDS") ? (uint32_t)std::atoi(std::getenv("CDAE_DEBUG_DECODE_LDS")) : 0u;   // occupancy experiment
       const uint32_t nv = K / 64, tail = K % 64;
       const uint32_t nt = tail == 0 ? 0u : (tail < 16 ? 1u : (tail < 32 ? 2u : 4u));   // 16 nt > tail: room for b'
       if (nt == 0) {

@@ -41,8 +41,6 @@
 
 namespace cdae {
 
-constexpr uint32_t SCAN_THREADS = 1024;
-constexpr uint32_t COUNTING_SORT_MAX_ITEMS = 65536;     // count_scan_kernel: SCAN_THREADS x 64 counters
 #ifndef CDAE_SEGSORT_THREADS
 #define CDAE_SEGSORT_THREADS 256
 #endif
@@ -55,63 +53,6 @@ constexpr uint32_t SEGSORT_ITEMS = CDAE_SEGSORT_ITEMS;    // consecutive items p
 #define CDAE_SEGSORT_WINDOW 3072
 #endif
 constexpr uint32_t SEGSORT_WINDOW = CDAE_SEGSORT_WINDOW;   // examples held in LDS at a time (2 arrays of 8-byte values)
-
-// exclusive prefix over the per-item example counts of the batch; one workgroup.  Wavefront w owns the contiguous item range
-// [w, w+1) * ceil(I / 16 / 64) * 64 and walks it 64 items at a time (coalesced, all loads of the range issued up front: the
-// kernel is one L2 round trip plus shuffles, not a chain of dependent loads).
-constexpr uint32_t SCAN_CHUNKS_MAX = COUNTING_SORT_MAX_ITEMS / SCAN_THREADS;   // 64 chunks of 64 items per wavefront
-__global__ void __launch_bounds__(SCAN_THREADS)
-count_scan_kernel(const uint32_t* __restrict__ item_count, uint32_t num_items, uint32_t* __restrict__ prefix /* [I + 1] */,
-                  uint32_t* __restrict__ cursor /* [I]: = prefix, bumped by scatter_kernel */,
-                  uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_end, uint32_t* __restrict__ dup_count) {
-  __shared__ uint32_t wave_tot[SCAN_THREADS / WAVE];
-  constexpr uint32_t NW = SCAN_THREADS / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;
-  const uint32_t chunks = (num_items + NW * WAVE - 1) / (NW * WAVE);        // per wavefront, <= SCAN_CHUNKS_MAX
-  const uint32_t base_item = wid * chunks * WAVE;
-  auto body = [&](auto tag) {
-    constexpr uint32_t NC = decltype(tag)::value;                           // compile-time bound: loads unrolled and in flight together
-    uint32_t c[NC];
-#pragma unroll
-    for (uint32_t k = 0; k < NC; ++k) {
-      const uint32_t i = base_item + k * WAVE + lane;
-      c[k] = (k < chunks && i < num_items) ? item_count[i] : 0u;
-    }
-    uint32_t carry = 0;
-    uint32_t incl[NC];
-#pragma unroll
-    for (uint32_t k = 0; k < NC; ++k) {
-      uint32_t v = c[k];
-#pragma unroll
-      for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, WAVE);
-        if ((int)lane >= off) v += o;
-      }
-      incl[k] = v + carry;
-      carry += __shfl(v, WAVE - 1, WAVE);
-    }
-    if (lane == 0) wave_tot[wid] = carry;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
-#pragma unroll
-    for (uint32_t k = 0; k < NC; ++k) {
-      const uint32_t i = base_item + k * WAVE + lane;
-      if (k < chunks && i < num_items) {
-        const uint32_t excl = before + incl[k] - c[k];
-        prefix[i] = excl;
-        cursor[i] = excl;
-        seg_begin[i] = c[k] ? excl : 0u;                                    // items without examples keep (0, 0)
-        seg_end[i] = c[k] ? excl + c[k] : 0u;
-      }
-    }
-    if (threadIdx.x == SCAN_THREADS - 1) prefix[num_items] = before + carry;   // last wavefront: grand total
-  };
-  if (chunks <= 4) body(std::integral_constant<uint32_t, 4>{});
-  else if (chunks <= 16) body(std::integral_constant<uint32_t, 16>{});
-  else body(std::integral_constant<uint32_t, SCAN_CHUNKS_MAX>{});
-  if (threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
-}
 
 constexpr uint32_t TILE_SORT_MAX_ITEMS = 32768;         // tile_scatter_kernel's cursors: 4 bytes per item of LDS (128 KiB at the limit)
 #ifndef CDAE_TILE_EX

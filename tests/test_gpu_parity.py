@@ -218,6 +218,32 @@ def test_training_is_bit_deterministic_and_handles_reload(tiny, small):
         assert np.array_equal(first[w], second[w]) and np.array_equal(first[w], third[w]), w
 
 
+@pytest.mark.parametrize("env", [dict(CDAE_PREP_THREAD="0"), dict(CDAE_PREP2="off"), dict(CDAE_PREP2="own"), dict(CDAE_EVENT_SYSTEM_FENCE="1"),
+                                 dict(CDAE_ENCODE_TWO_LAUNCHES="1"), dict(CDAE_SORT_TILE="1"), dict(CDAE_GATHER_HALVES="1", CDAE_PREP2="aux")],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_scheduling_switches_do_not_change_a_single_bit(small, monkeypatch, env):
+    """The prep worker thread, the second prep lane, device-scope events, the one-launch encode and the tile counting sort change
+    WHEN work is issued and by which kernel — never the arithmetic or its order: parameters after two epochs are bit-identical
+    to the default configuration's."""
+    cfg = cdae_amd.CDAEConfig(num_dim=40, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=64)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(small, seed=5)
+        for ep in range(2):
+            m.train_one_iteration(5, ep)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        m.close()
+        return out
+
+    base = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = run()
+    for w in base:
+        assert np.array_equal(base[w], other[w]), (env, w)
+
+
 def test_duplicate_correction_overflow_falls_back_to_atomics(tiny, monkeypatch):
     """CDAE_DUP_CAP bounds the duplicate-negative correction buffer; examples beyond it take the atomic path and the
     result is the same trajectory (up to the order of a few fp32 additions)."""
