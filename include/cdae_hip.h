@@ -29,7 +29,8 @@
  * Conventions: every function returns 0 on success, non-zero on failure; cdae_hip_last_error()
  * returns a thread-local message for the last failure.  No exceptions cross the boundary.  All
  * pointers are HOST pointers unless the name says `device`.  The library owns all device memory.
- * A handle is used from one host thread at a time.  Parameters are fp32 row-major with the row
+ * A handle is used from one host thread at a time (internally it owns one worker thread that issues the
+ * sampling + sorting launches of the coming batches; cdae_hip_destroy joins it).  Parameters are fp32 row-major with the row
  * stride returned by cdae_hip_row_stride() (64, 128, 256 or 512 floats — the smallest that holds
  * num_dim; pad lanes are 0, or 1 in the AdaGrad accumulators, and stay so).
  */
