@@ -402,6 +402,26 @@ def test_ragged_rows_multi_unit_users_and_long_rows(ragged, B, K):
     np.testing.assert_array_equal(rec_g[clear], rec_o[clear])
 
 
+@pytest.mark.parametrize("K,B", [(40, 2000), (200, 1500), (64, 700)])
+def test_item_rows_with_thousands_of_examples_per_batch(built, K, B):
+    """Few items, many users per batch: every item row holds hundreds to thousands of examples of ONE batch — the four-rows-per-
+    wavefront decode walks many 64-example chunks through its LDS ring (staging, wrap at 128, g write-out per chunk), the popular
+    rows exceed the LDS room their g is parked in (1280 examples) and fall back to per-chunk stores, input rows scan many chunks."""
+    rng = np.random.default_rng(11)
+    I, U = 60, 2000
+    p = 1.0 / np.arange(1, I + 1) ** 0.8
+    p /= p.sum()
+    rows = [np.sort(rng.choice(I, size=int(rng.integers(4, 14)), replace=False, p=p)).astype(np.uint32) for _ in range(U)]
+    ptr = np.r_[0, np.cumsum([r.size for r in rows])].astype(np.int64)
+    d = synth.Interactions(U, I, ptr, np.concatenate(rows), np.zeros(U + 1, np.int64), np.empty(0, np.uint32))
+    model, o = make_pair(d, K=K, B=B, num_neg=3)
+    for ep in range(2):
+        model.train_one_iteration(seed=4, epoch=ep)
+        o.train_batched(4, ep, B)
+    err, which = max_param_err(model, o)
+    assert err < 3e-4, (err, which)          # (thousands of sequential fp32 steps per row and batch)
+
+
 def _assert_valid_topk(model, data, rec, topk, K):
     """rec[u] must be a correct top-k of the unrated items under fp64 scores z_u . D[j] + b'[j], up to fp32 noise."""
     uids = np.arange(data.num_users, dtype=np.uint32)
