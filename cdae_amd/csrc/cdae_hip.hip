@@ -102,6 +102,7 @@ struct cdae_hip {
   bool gemm_two_stage = false;      // CDAE_GEMM_TWO_STAGE: always the 128 x 128 two-stage LDS kernel (A/B switch)
   bool recommend_per_user = false;  // CDAE_RECOMMEND_PER_USER: recommend_kernel instead of the MFMA path
   std::vector<uint32_t> h_unit_ptr;     // prefix of work units (<= hp.unit_pos positives each) per user
+  uint32_t* d_rank_of = nullptr;        // [I] inverse of d_item_order
   uint32_t* d_unit_user = nullptr;      // [total units] user of every unit (kernels' unit -> user look-up)
   uint32_t* d_unit_ptr = nullptr;
   uint32_t unit_cap = 0;                // most units in any window of batch_users users
@@ -306,7 +307,7 @@ void free_all(cdae_hip* h) {
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
-                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre};
+                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -345,7 +346,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
-                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre};
+                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -381,7 +382,7 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   CHK(pr.begin(h, F_SAMPLE, st, prof_q));
   const uint32_t n_units = units_of(h, bt);
   if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
-    HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)I * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(x.seg, 0, 4 * (size_t)I * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), st));
   } else if (h->mf) {
     hipLaunchKernelGGL(mf_sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->mf == 2 ? 1u : 0u, h->d_row_ptr, h->d_col,
@@ -390,7 +391,7 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   } else
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
-                     x.seg, h->counting_sort ? 0u : 2u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
+                     x.seg, h->counting_sort ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
                      (uint32_t*)nullptr, (const uint32_t*)h->d_gpos);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st, prof_q));
@@ -409,7 +410,8 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
     hipLaunchKernelGGL(tile_hist_kernel, dim3(n_tiles), dim3(TILE_THREADS), tile_lds / 2 + 4, st, x.item, (uint32_t)bt.E, I, x.tile_hist);
     hipLaunchKernelGGL(item_tile_scan_kernel, dim3((I + 255) / 256), dim3(256), 0, st, x.tile_hist, n_tiles, I, x.item_count, x.rank, x.block_total);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(n_tiles), dim3(TILE_THREADS), tile_lds + 128 * sizeof(uint32_t), st, x.item, x.val,
-                       (uint32_t)bt.E, I, x.tile_hist, x.item_count, x.rank, x.block_total, x.prefix, x.seg, x.seg + I, x.dup_count, x.bucketed);
+                       (uint32_t)bt.E, I, x.tile_hist, x.item_count, x.rank, x.block_total, x.prefix, x.seg, x.seg + I, x.dup_count, x.bucketed,
+                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I);
     hipLaunchKernelGGL(segment_sort_kernel, dim3((I + SEGSORT_ITEMS - 1) / SEGSORT_ITEMS), dim3(SEGSORT_THREADS), 0, st, I, x.prefix, x.bucketed,
                        x.sorted_val, x.item_count, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
   } else if (x.key16) {
@@ -417,12 +419,14 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
     HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.key16, x.sorted_key16, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint16_t>, seg_grid, dim3(256), 0, st, x.sorted_key16, x.sorted_val, (uint32_t)bt.E,
-                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
+                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes,
+                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I);
   } else {
     HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint32_t>, seg_grid, dim3(256), 0, st, x.sorted_item, x.sorted_val, (uint32_t)bt.E,
-                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
+                       x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes,
+                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I);
   }
   CHK(pr.end());
   if (h->cfg.full_output && h->d_bits_train) {
@@ -472,7 +476,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
 
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   CHK(pr.begin(h, F_DECODE, st));
-#define DECODE_TAIL h->d_item_order, x.seg, x.seg + I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
+#define DECODE_TAIL h->d_item_order, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
                     h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_D0, h->d_touched, x.dup_of_pos, h->d_dup_corr
 #define DECODE_ARGS h->hp, DECODE_TAIL
 #define DECODE_LA(NI_, L_, A_)                                                                                       \
@@ -536,7 +540,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   CHK(pr.begin(h, F_INPUT, st));
   {
     const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
-    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg, x.seg + I,
+    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I,
                 x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), CDAE_TOUCHED_ARG, nb, h->P(CDAE_P_B),
                 h->P(CDAE_P_B_AG), h->delta_rows());
   }
@@ -978,6 +982,12 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(dev_alloc(&h->d_item_order, (size_t)I));
   HIPCHK(hipMemcpy(h->d_item_order, order.data(), I * sizeof(uint32_t), hipMemcpyHostToDevice));
   {
+    std::vector<uint32_t> rank_of(I);
+    for (uint32_t r = 0; r < I; ++r) rank_of[order[r]] = r;
+    CHK(dev_alloc(&h->d_rank_of, (size_t)I));
+    HIPCHK(hipMemcpy(h->d_rank_of, rank_of.data(), I * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  {
     // hot rows: expected positives per batch (popularity x batch share) of at least CDAE_DECODE_HOT_POS (default 48);
     // every row also receives ~ B * mean(n_u) * num_neg / I uniformly spread negatives
     const char* ev = std::getenv("CDAE_DECODE_HOT_POS");
@@ -1065,7 +1075,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   for (auto& b : h->ex) {
     CHK(dev_alloc(&b.item, h->Ecap)); CHK(dev_alloc(&b.val, h->Ecap));
     CHK(dev_alloc(&b.sorted_item, h->Ecap)); CHK(dev_alloc(&b.sorted_val, h->Ecap));
-    CHK(dev_alloc(&b.seg, 2 * (size_t)I));
+    CHK(dev_alloc(&b.seg, 4 * (size_t)I));                   // first | one-past-last position by item, then the same by popularity rank
     CHK(dev_alloc(&b.dup_of_pos, h->Ecap)); CHK(dev_alloc(&b.dup_of_ex, h->Ecap)); CHK(dev_alloc(&b.dup_count, cdae::DUP_STRIPES));
     if (h->counting_sort) {
       CHK(dev_alloc(&b.item_count, (size_t)I)); CHK(dev_alloc(&b.prefix, (size_t)I + 1));
@@ -1787,12 +1797,13 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
   HIPCHK(hipMemcpyAsync(x.val, vals.data(), E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(rocprim::radix_sort_pairs(h->d_sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val, E, 0u,
                                    (unsigned)h->sort_bits, h->stream));
-  HIPCHK(hipMemsetAsync(x.seg, 0, 2 * (size_t)h->I * sizeof(uint32_t), h->stream));
+  HIPCHK(hipMemsetAsync(x.seg, 0, 4 * (size_t)h->I * sizeof(uint32_t), h->stream));
   HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), h->stream));
   HIPCHK(hipMemsetAsync(x.dup_of_ex, 0xFF, E * sizeof(uint32_t), h->stream));
   hipLaunchKernelGGL(cdae::segment_kernel<uint32_t>, dim3((uint32_t)((E + 256 * cdae::SEG_PER_THREAD - 1) / (256 * cdae::SEG_PER_THREAD))),
                      dim3(256), 0, h->stream, x.sorted_item, x.sorted_val,
-                     (uint32_t)E, x.seg, x.seg + h->I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes);
+                     (uint32_t)E, x.seg, x.seg + h->I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes,
+                     (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)h->I, x.seg + 3 * (size_t)h->I);
   HIPCHK(hipEventRecord(x.ready, h->stream));
   const uint32_t one_unit[2] = {0u, 1u};                         // one user, one unit
   HIPCHK(hipMemcpyAsync(h->d_uptr_tmp, one_unit, sizeof one_unit, hipMemcpyHostToDevice, h->stream));

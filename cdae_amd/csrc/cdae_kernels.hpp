@@ -297,7 +297,10 @@ __global__ void __launch_bounds__(256)
 segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint32_t n_ex, uint32_t* __restrict__ seg_begin,
                uint32_t* __restrict__ seg_end, uint32_t* __restrict__ dup_count, uint32_t dup_cap,
                uint32_t* __restrict__ dup_of_pos, uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */,
-               uint32_t stripes /* 1..DUP_STRIPES counters in use */) {
+               uint32_t stripes /* 1..DUP_STRIPES counters in use */,
+               const uint32_t* __restrict__ rank_of /* item -> popularity rank, or nullptr */,
+               uint32_t* __restrict__ segr_begin /* the same table indexed by RANK (decode / input rows read it beside item_order[rank]: */,
+               uint32_t* __restrict__ segr_end /* one dependent round trip less at the head of every row) */) {
   __shared__ uint32_t blk_count, blk_base;
   if (threadIdx.x == 0) blk_count = 0u;
   __syncthreads();
@@ -309,8 +312,8 @@ segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint3
     if (p >= n_ex) break;
     const uint32_t it = sorted_item[p];
     const bool first = p == 0 || sorted_item[p - 1] != it, last = p + 1 == n_ex || sorted_item[p + 1] != it;
-    if (first) seg_begin[it] = p;
-    if (last) seg_end[it] = p + 1;
+    if (first) { seg_begin[it] = p; if (rank_of) segr_begin[rank_of[it]] = p; }
+    if (last) { seg_end[it] = p + 1; if (rank_of) segr_end[rank_of[it]] = p + 1; }
     const uint64_t v = sorted_val[p];
     const uint32_t slot = (uint32_t)v & SLOT_MASK;
     uint32_t flags = 0;                               // neighbours may be mid-update: only their slot bits are compared
@@ -625,7 +628,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
-  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  const uint32_t beg = seg_begin[rank], end = seg_end[rank];      // (segment tables indexed by rank: read beside item_order[rank])
   hp.loss_type = LOSS;                 // compile-time specialisation of the per-example branches
   hp.adagrad = ADAGRAD;
 #ifdef CDAE_DECODE_TIMING   // developer aid (tools/decode_timeline.py): s_memtime stamps of one row's timeline
@@ -1012,7 +1015,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   const uint32_t rank = rank0 + sub;
   const bool row_ok = rank < hp.num_items;
   const uint32_t item = row_ok ? item_order[rank] : 0u;
-  const uint32_t beg = row_ok ? seg_begin[item] : 0u, end = row_ok ? seg_end[item] : 0u;
+  const uint32_t beg = row_ok ? seg_begin[rank] : 0u, end = row_ok ? seg_end[rank] : 0u;    // (rank-indexed tables)
   const uint32_t n = end - beg;
   // longest segment of the wavefront's four groups (wave-uniform loop bound)
   const uint32_t nmax = max(max((uint32_t)__builtin_amdgcn_readlane((int)n, 0), (uint32_t)__builtin_amdgcn_readlane((int)n, 16)),
@@ -1517,7 +1520,7 @@ __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t ra
   if (rank >= hp.num_items) return;
   hp.adagrad = ADAGRAD;
   const uint32_t item = item_order[rank];
-  const uint32_t beg = seg_begin[item], end = seg_end[item];
+  const uint32_t beg = seg_begin[rank], end = seg_end[rank];      // (rank-indexed tables)
   if (beg == end) return;
 
   // stream state: the kept-input mask / words / example ids of the current 64-example chunk; the chunk at `next_chunk` is

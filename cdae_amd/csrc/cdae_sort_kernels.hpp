@@ -128,7 +128,8 @@ tile_scatter_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __rest
                     const uint32_t* __restrict__ local_prefix, const uint32_t* __restrict__ block_total,
                     uint32_t* __restrict__ prefix /* [I + 1], written by workgroup 0 */, uint32_t* __restrict__ seg_begin,
                     uint32_t* __restrict__ seg_end, uint32_t* __restrict__ dup_count,
-                    uint64_t* __restrict__ bucketed_val /* item-major, arrival order inside (item, tile) */) {
+                    uint64_t* __restrict__ bucketed_val /* item-major, arrival order inside (item, tile) */,
+                    const uint32_t* __restrict__ rank_of, uint32_t* __restrict__ segr_begin, uint32_t* __restrict__ segr_end) {
   extern __shared__ uint32_t tile_cur[];                                   // [num_items] cursors, then [128] block bases
   uint32_t* block_base = tile_cur + num_items;
   const uint32_t n_blocks = (num_items + 255u) / 256u;                     // <= 128 (TILE_SORT_MAX_ITEMS / 256)
@@ -154,6 +155,7 @@ tile_scatter_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __rest
       prefix[i] = p;
       seg_begin[i] = c ? p : 0u;                                           // items without examples keep (0, 0)
       seg_end[i] = c ? p + c : 0u;
+      if (rank_of) { segr_begin[rank_of[i]] = c ? p : 0u; segr_end[rank_of[i]] = c ? p + c : 0u; }
     }
   }
   if (blockIdx.x == 0) {
