@@ -246,12 +246,12 @@ int join_aux(cdae_hip* h) {
 // writes back and invalidates the caches when it is recorded — measured here as ~14 us of idle main stream per batch around
 // the `released` record and ~3 us at the `ready` wait (profiles/r02_wave_timeline_256.txt: 86 us of kernels in a 100 us step).
 // CDAE_EVENT_SYSTEM_FENCE=1 restores the default.  (The exchange's events in cdae_multi.hip stay system-scope: RCCL peers read.)
-inline unsigned sync_event_flags() {
-  static const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
+inline unsigned sync_event_flags() {      // (the environment is read at every call: per handle, not per process)
+  const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
   return sys ? (unsigned)hipEventDisableTiming : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
 }
 inline unsigned timing_event_flags() {
-  static const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
+  const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
   return sys ? (unsigned)hipEventDefault : (unsigned)hipEventDisableSystemFence;
 }
 
