@@ -182,6 +182,8 @@ struct cdae_hip {
   std::string worker_error;             // valid once worker_failed != 0
   std::mutex prof_mu;                   // spans / event pool are touched by both threads when profiling
   uint32_t gather_halves = 1;           // wavefronts per (unit, item partition) in hidden_gather_kernel (CDAE_GATHER_HALVES = 1 | 2; 2 measured slower)
+  uint32_t encode_users_max = 768;      // batches above this many users take the two-launch encode (a workgroup of 16 wavefronts per user is
+                                        // mostly idle wavefronts; full-output: 512 users -7 % per step with one launch, 1024 +2 %, 2048 +11 %; sampled: equal at 1024, +4 % at 2048); CDAE_ENCODE_USERS_MAX
   bool encode_two_launches = false;     // CDAE_ENCODE_TWO_LAUNCHES: the training encode as encode_partial + encode_finish (developer switch)
   bool debug_skip_prep = false;         // CDAE_DEBUG_SKIP_PREP (timing experiment only: batches reuse stale example lists -> WRONG results)
   bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
@@ -461,7 +463,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
   const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
   const dim3 grid_units((n_units + 3) / 4);
-  if (!explicit_in && !h->encode_two_launches) {
+  if (!explicit_in && !h->encode_two_launches && nb <= h->encode_users_max) {
     // one launch: a workgroup per user (encode_users_kernel)
     DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
                 bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
@@ -592,15 +594,23 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   Prof pr;
 
   CHK(pr.begin(h, F_ENCODE, st));
-  DISPATCH_NI(h->NI, encode_partial_kernel, dim3((n_units + 3) / 4), blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr,
-              n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart,
-              (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user);
-  // bf16 copies D, D^T (rows >= I zero) of this batch: like the input gather above they need the previous batch's row steps
-  // but not its b recurrence, which may still be running on the aux stream — joined here, in front of its first consumer
+  const bool two_launches = h->encode_two_launches || nb > h->encode_users_max;
+  if (two_launches) {
+    DISPATCH_NI(h->NI, encode_partial_kernel, dim3((n_units + 3) / 4), blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr,
+                n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart,
+                (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user);
+  }
+  // bf16 copies D, D^T (rows >= I zero) of this batch: like the input gather they need the previous batch's row steps but not
+  // its b recurrence, which may still be running on the aux stream — joined behind them, in front of its first consumer
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
   CHK(join_aux(h));
-  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  if (two_launches) {
+    DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
+                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  } else {                       // one launch: a workgroup per user (encode_users_kernel)
+    DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
+                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  }
   CHK(pr.end());
 
   CHK(pr.begin(h, F_DECODE, st));
@@ -838,6 +848,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
+  if (const char* ev = std::getenv("CDAE_ENCODE_USERS_MAX")) h->encode_users_max = (uint32_t)std::atoi(ev);
   if (const char* ev = std::getenv("CDAE_GATHER_HALVES")) h->gather_halves = std::atoi(ev) == 2 ? 2u : 1u;
   if (const char* ev = std::getenv("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
