@@ -49,6 +49,32 @@ to_bf16_transpose_kernel(const float* __restrict__ src, uint32_t R, uint32_t C, 
   }
 }
 
+// Two matrices of the same width in one launch (the batch's D and Z copies: a launch each was 2 x 9 us of a 100 us Yelp-shape step):
+// tile rows [0, RpA / 64) belong to A, the rest to B.
+__global__ void __launch_bounds__(256)
+to_bf16_transpose_pair_kernel(const float* __restrict__ srcA, uint32_t RA, uint32_t RpA, __bf16* __restrict__ dstA, __bf16* __restrict__ dstTA,
+                              const float* __restrict__ srcB, uint32_t RB, uint32_t RpB, __bf16* __restrict__ dstB, __bf16* __restrict__ dstTB,
+                              uint32_t C, uint32_t ld_src) {
+  __shared__ float tile[64][65];
+  const bool second = blockIdx.y >= RpA / 64;
+  const float* src = second ? srcB : srcA;
+  const uint32_t R = second ? RB : RA, Rp = second ? RpB : RpA;
+  __bf16* dst = second ? dstB : dstA;
+  __bf16* dstT = second ? dstTB : dstTA;
+  const uint32_t r0 = (second ? blockIdx.y - RpA / 64 : blockIdx.y) * 64, c0 = blockIdx.x * 64;
+  for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const uint32_t r = r0 + i / 64, c = c0 + i % 64;
+    const float v = (r < R && c < C) ? src[(size_t)r * ld_src + c] : 0.f;
+    tile[i / 64][i % 64] = v;
+    if (r < Rp && c < C) dst[(size_t)r * C + c] = (__bf16)v;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const uint32_t c = c0 + i / 64, r = r0 + i % 64;
+    if (r < Rp && c < C) dstT[(size_t)c * Rp + r] = (__bf16)tile[i % 64][i / 64];
+  }
+}
+
 enum { EPI_LOSS = 0, EPI_ATOMIC = 1, EPI_STORE = 2 };
 
 struct GemmEpilogue {

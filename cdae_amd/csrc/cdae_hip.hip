@@ -184,6 +184,7 @@ struct cdae_hip {
   uint32_t gather_halves = 1;           // wavefronts per (unit, item partition) in hidden_gather_kernel (CDAE_GATHER_HALVES = 1 | 2; 2 measured slower)
   uint32_t encode_users_max = 768;      // batches above this many users take the two-launch encode (a workgroup of 16 wavefronts per user is
                                         // mostly idle wavefronts; full-output: 512 users -7 % per step with one launch, 1024 +2 %, 2048 +11 %; sampled: equal at 1024, +4 % at 2048); CDAE_ENCODE_USERS_MAX
+  bool full_separate_copies = false;    // CDAE_FULL_SEPARATE_COPIES: D and Z bf16 copies as two launches (developer switch)
   bool encode_two_launches = false;     // CDAE_ENCODE_TWO_LAUNCHES: the training encode as encode_partial + encode_finish (developer switch)
   bool debug_skip_prep = false;         // CDAE_DEBUG_SKIP_PREP (timing experiment only: batches reuse stale example lists -> WRONG results)
   bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
@@ -601,8 +602,10 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
                 (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user);
   }
   // bf16 copies D, D^T (rows >= I zero) of this batch: like the input gather they need the previous batch's row steps but not
-  // its b recurrence, which may still be running on the aux stream — joined behind them, in front of its first consumer
-  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  // its b recurrence, which may still be running on the aux stream — joined behind them, in front of its first consumer.
+  // Small item spaces: converted together with Z behind the encode instead (one launch less; a launch is ~9 us there)
+  const bool pair_copy = Ip <= 65536 && !h->full_separate_copies;
+  if (!pair_copy) hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
   CHK(join_aux(h));
   if (two_launches) {
     DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
@@ -615,7 +618,11 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 
   CHK(pr.begin(h, F_DECODE, st));
   // bf16 operand copies Z, Z^T (rows >= nb zero)
-  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
+  if (pair_copy)
+    hipLaunchKernelGGL(to_bf16_transpose_pair_kernel, dim3(Kp / 64, Ip / 64 + Bp / 64), blk, 0, st, (const float*)h->dec(), I, Ip, h->d_Db, h->d_DTb,
+                       (const float*)h->d_Z, nb, Bp, h->d_Zb, h->d_ZTb, Kp, Kp);
+  else
+    hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
   const bool fused = Kp <= 256 && !h->full_unfused;
   uint32_t hg_parts = 0, hg_rows = nb;           // slabs of HGpart holding hg and their row count (0: accumulated into HG by atomics)
   if (fused) {
@@ -848,6 +855,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
+  h->full_separate_copies = std::getenv("CDAE_FULL_SEPARATE_COPIES") != nullptr;
   if (const char* ev = std::getenv("CDAE_ENCODE_USERS_MAX")) h->encode_users_max = (uint32_t)std::atoi(ev);
   if (const char* ev = std::getenv("CDAE_GATHER_HALVES")) h->gather_halves = std::atoi(ev) == 2 ? 2u : 1u;
   if (const char* ev = std::getenv("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
