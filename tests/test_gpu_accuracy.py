@@ -14,7 +14,8 @@ dropout masks, negatives; same data) by a standard deviation of 0.0011-0.0024 pe
 the worst of eight stream seeds.  A single-seed comparison therefore cannot resolve 0.002; the mean over seeds can.  The same
 eight streams at batch_users 256 differ from their literal twins by 0.0008-0.0015 (std, paired), with a mean of +0.0019 at
 epoch 1 (the batched schedule is slightly AHEAD after one epoch, 3.5 standard errors) and |mean| <= 0.0004 at epochs 2-5
-(not distinguishable from zero).
+(not distinguishable from zero); a second data set with 24 streams: literal best - worst 0.0073-0.0102, paired mean
++0.0001 / -0.0002 / +0.0002 / +0.0003 / +0.0009.
 
 Stated tolerances (each asserted below; six data/stream seeds):
   * per seed, every epoch: |Recall@10_hip - Recall@10_literal| <= 0.005 — the literal schedule's own best-to-worst spread over
