@@ -1508,7 +1508,9 @@ struct InputGroup {
 // Tried and measured slower (round 2, profiles/r02_main_stream.txt): three groups in a register ring (the round-1 form, 140
 // VGPRs: same time), two alternating groups, and splitting the popular rows over a workgroup's four wavefronts (K quarters, 24
 // examples in flight): the launch is bound by the sum of its serial latencies (dispatch 4 us, prologue 3 round trips, the
-// popular rows' 60-odd dependent AdaGrad steps), not by any one of them.
+// popular rows' 60-odd dependent AdaGrad steps), not by any one of them.  What did help, once the `b` role's registers were out of
+// the way (buffer loads): groups of 12 kept inputs instead of 4 — a popular row then pays 5 round trips instead of 16 (step
+// 0.0943 -> 0.0921 ms at 256 users per batch, 0.1407 -> 0.1354 at 512; 8: 0.0922 / 0.1371).
 template <int NE, int UN, bool ADAGRAD>
 __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t rank, const uint32_t lo,
                                                const uint32_t* __restrict__ item_order,
@@ -1580,7 +1582,7 @@ __device__ __forceinline__ void input_row_role(HyperParams hp, const uint32_t ra
 }
 
 #ifndef CDAE_INPUT_UN
-#define CDAE_INPUT_UN 4
+#define CDAE_INPUT_UN 12
 #endif
 // grid: [bias_blocks: K4b] [the rows, one per wavefront, popular rows first]
 template <int NI>
