@@ -510,7 +510,10 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
     const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
     const uint32_t* row = col + r0;
     const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
-    constexpr int UN = 8;
+#ifndef CDAE_ENCODE_UN
+#define CDAE_ENCODE_UN 8
+#endif
+    constexpr int UN = CDAE_ENCODE_UN;                                  // kept rows in flight per round trip
     for (uint32_t unit = wid; unit < n_units; unit += ENC_WAVES) {
       const uint32_t p_begin = unit * hp.unit_pos, p_end = min(p_begin + hp.unit_pos, n);
       float ua[NI];                                              // the unit's own sum first, as encode_partial_kernel forms it
