@@ -1216,7 +1216,10 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
   if (wave < hot_rows) {
     if (hp.debug_skip & 4u) return;
     const unsigned long long t0 = trace_begin(hp);
-    __builtin_amdgcn_s_setprio(2);
+#ifndef CDAE_HOT_PRIO
+#define CDAE_HOT_PRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
     decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROWS16_LDS_WORDS,
                                            CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
     trace_end(hp, 3, wave, t0);
