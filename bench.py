@@ -169,13 +169,21 @@ def main():
         for k in KEYS:
             acc[k] += getattr(st, k)
 
+    def prefetch_from(i):
+        # the library prepares as many leading batches of the range as its look-ahead is deep (one, or two with the second
+        # prep lane): hand it the next two batches where they are consecutive in one epoch
+        nep, n0, n1 = batch_of(i)
+        mep, m0, m1 = batch_of(i + 1)
+        if mep == nep and m0 == n1:
+            n1 = m1
+        model.prefetch_users(args.seed, nep, n0, n1)
+
     def step(i):
         ep, u0, u1 = batch_of(i)
         # steps queue asynchronously on the library's stream; the next batch is sampled and sorted on the side
         # stream while this one trains (and, with N > 1, while the previous period's deltas are all-reduced)
         model.enqueue_users(args.seed, ep, u0, u1)
-        nep, n0, n1 = batch_of(i + 1)
-        model.prefetch_users(args.seed, nep, n0, n1)
+        prefetch_from(i + 1)
         if exchanging:
             model.exchange_step()
 
@@ -226,8 +234,7 @@ def main():
                 u1 = batch_of(i + c)[2]
                 c += 1
             model.enqueue_users(args.seed, ep, u0, u1)
-            nep, n0, n1 = batch_of(i + c)
-            model.prefetch_users(args.seed, nep, n0, n1)
+            prefetch_from(i + c)
             i += c
 
     run(0, args.warmup)
@@ -243,8 +250,13 @@ def main():
     run(args.warmup, args.steps)
     if exchanging:
         model.exchange_flush()            # the last period's deltas are reduced and merged inside the timed region
+    t_queued = time.perf_counter()
     sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("CDAE_BENCH_PHASES"):      # developer aid: where the host spends the timed region
+        t_a = time.perf_counter(); model.synchronize(); t_b = time.perf_counter(); torch.cuda.synchronize(); t_c = time.perf_counter()
+        print(f"[phases] enqueue {1e6 * (t_queued - t0):.0f} us, wait {1e6 * (elapsed - (t_queued - t0)):.0f} us; on an idle device: "
+              f"model.synchronize {1e6 * (t_b - t_a):.1f} us, torch.cuda.synchronize {1e6 * (t_c - t_b):.1f} us", file=sys.stderr)
     add(model.collect_stats())
     timed = dict(acc)
     if args.profile_every:

@@ -207,9 +207,11 @@ struct cdae_hip {
   uint32_t hsum_eval_cap = 0;
   uint64_t fs_prepped = 0;              // item-sharded training: batches whose example lists have been prepared (buffer set = parity)
 
-  uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q & 1
-  bool pre_valid = false;               // set (seq % NSETS) already holds the prepared batch `pre` (cdae_hip_prefetch_users)
-  uint64_t pre_s0 = 0, pre_seed = 0; uint32_t pre_nb = 0, pre_cidx = 0, pre_epoch = 0;
+  uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q % NSETS
+  // sets (seq + t) % NSETS, t < pre_n, already hold (or have queued) the prepared batches pre[t] (cdae_hip_prefetch_users)
+  struct PreBatch { uint64_t s0, seed; uint32_t nb, cidx, epoch; };
+  PreBatch pre[2] = {};
+  uint32_t pre_n = 0;
   uint64_t acc_users = 0, acc_examples = 0, acc_batches = 0;   // since the last stats collection
   int profiling = 0;                    // 0 off; k >= 1: HIP events around the kernel families of every k-th batch
   uint32_t prof_mask = 0xFFFFFFFFu;     // ... of the families whose bit is set (cdae_hip_set_profiling_families)
@@ -1050,7 +1052,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   }
   h->ex_per_pos = h->mf == 2 ? 2u * h->hp.num_neg : 1u + h->hp.num_neg;
   h->Ecap = emax * h->ex_per_pos;
-  h->seq = 0; h->pre_valid = false;
+  h->seq = 0; h->pre_n = 0;
   // opt-in (CDAE_SORT_COUNTING=1): measured slower than rocPRIM's onesweep beside the training kernels (profiles/r02_*)
   // opt-in (CDAE_SORT_TILE=1).  Measured (profiles/r02_tile_sort.txt): the four launches take 72 us against rocPRIM's ten launches / ~100 us
   // per batch on the prep stream, yet the training step is the same within 1 % at 256 users and 3 % slower at 512 — the prep
@@ -1392,8 +1394,23 @@ int sync_prep(cdae_hip* h) {
   return 0;
 }
 
-bool is_prefetched(const cdae_hip* h, const Batch& b, uint64_t seed, uint32_t epoch) {
-  return h->pre_valid && h->pre_s0 == b.s0 && h->pre_nb == b.nb && h->pre_cidx == b.cidx && h->pre_seed == seed && h->pre_epoch == epoch;
+bool is_prefetched(const cdae_hip* h, size_t t, const Batch& b, uint64_t seed, uint32_t epoch) {
+  if (t >= h->pre_n) return false;
+  const cdae_hip::PreBatch& p = h->pre[t];
+  return p.s0 == b.s0 && p.nb == b.nb && p.cidx == b.cidx && p.seed == seed && p.epoch == epoch;
+}
+// leading batches of `plan` that are already prepared, at most the look-ahead depth
+size_t prefetched_prefix(const cdae_hip* h, const std::vector<Batch>& plan, uint64_t seed, uint32_t epoch) {
+  size_t k = 0;
+  while (k < prep_depth(h) && k < plan.size() && is_prefetched(h, k, plan[k], seed, epoch)) ++k;
+  return k;
+}
+// Prepared batches nobody will train on are dropped.  Their launches may still be in flight, and the batch that takes their
+// set over may be prepared from the other lane: wait for them (a rare path: a caller that prefetches one range and trains another)
+int drop_prefetched(cdae_hip* h, size_t keep) {
+  if (h->pre_n <= keep) return 0;
+  h->pre_n = (uint32_t)keep;
+  return sync_prep(h);
 }
 
 // Enqueue (no host synchronisation) one pass over users [u_begin, u_end): a software pipeline in which the
@@ -1413,9 +1430,17 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
     job_of[t] = h->jobs_submitted;
     return 0;
   };
-  for (size_t t = 0; t < depth && t < plan.size(); ++t)
-    if (t > 0 || !is_prefetched(h, plan[0], seed, epoch)) CHK(prep(t));
-  h->pre_valid = false;
+  const size_t have = prefetched_prefix(h, plan, seed, epoch);
+  // what was prepared beyond this call's batches stays for the next call (one-batch calls with two batches of look-ahead)
+  const bool carry = have == plan.size() && h->pre_n > have;
+  if (carry) {
+    for (uint32_t t = (uint32_t)have; t < h->pre_n; ++t) h->pre[t - have] = h->pre[t];
+    h->pre_n -= (uint32_t)have;
+  } else {
+    CHK(drop_prefetched(h, have));       // (prepared for a range the caller did not come back to)
+    h->pre_n = 0;
+  }
+  for (size_t t = have; t < depth && t < plan.size(); ++t) CHK(prep(t));
   for (size_t t = 0; t < plan.size(); ++t) {
     if (t + depth < plan.size()) CHK(prep(t + depth));
     CHK(await_prep_upto(h, job_of[t]));                          // the set's `ready` record is in the prep stream
@@ -1561,10 +1586,17 @@ int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64
   std::vector<Batch> plan;
   CHK(make_plan(h, u_begin, u_end, plan));
   if (plan.empty()) return 0;
-  if (is_prefetched(h, plan[0], seed, epoch)) return 0;
-  if (!(h->debug_skip_prep && h->seq >= 2 * cdae_hip::NSETS)) CHK(submit_prep(h, set_of(h->seq), plan[0], seed, epoch, prep_lane(h, h->seq), h->seq));
-  h->pre_valid = true;
-  h->pre_s0 = plan[0].s0; h->pre_nb = plan[0].nb; h->pre_cidx = plan[0].cidx; h->pre_seed = seed; h->pre_epoch = epoch;
+  // up to the look-ahead depth: with two prep lanes the second batch is prepared ahead as well
+  const size_t n = std::min(plan.size(), prep_depth(h));
+  const size_t have = prefetched_prefix(h, plan, seed, epoch);
+  if (have >= n) return 0;
+  CHK(drop_prefetched(h, have));
+  for (size_t t = have; t < n; ++t) {
+    const uint64_t q = h->seq + t;
+    if (!(h->debug_skip_prep && q >= 2 * cdae_hip::NSETS)) CHK(submit_prep(h, set_of(q), plan[t], seed, epoch, prep_lane(h, q), q));
+    h->pre[t] = cdae_hip::PreBatch{plan[t].s0, seed, plan[t].nb, plan[t].cidx, epoch};
+    h->pre_n = (uint32_t)t + 1;
+  }
   return 0;
 }
 
@@ -1593,7 +1625,7 @@ int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, ui
   *n_examples = E;
   HIPCHK(hipStreamSynchronize(h->stream));
   CHK(sync_prep(h));
-  h->pre_valid = false;                                   // the set is overwritten: a prefetched batch is gone
+  h->pre_n = 0;                                           // the set is overwritten: a prefetched batch is gone
   const int set = set_of(h->seq);
   const int prof = h->profiling;
   h->profiling = 0;
@@ -1807,7 +1839,7 @@ int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32
     items[n_pos + i] = negative_items[i];
     vals[n_pos + i] = (uint64_t)(n_pos + i) << 32;
   }
-  h->pre_valid = false;
+  h->pre_n = 0;
   HIPCHK(hipStreamSynchronize(h->stream));
   CHK(sync_prep(h));
   const int set = set_of(h->seq);

@@ -146,10 +146,11 @@ int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_
 int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin,
                          uint64_t u_end, cdae_hip_stats* stats);
 /* Asynchronous forms.  enqueue_users = train_users without the final host synchronisation (several calls
- * queue back to back on the library's stream); prefetch_users runs only the sampling + sorting of the first
- * batch of a range on the side stream, so that it overlaps whatever the caller does next (e.g. the RCCL
- * all-reduce of the data-parallel exchange) — a later train/enqueue call for the same (seed, epoch, range)
- * picks the prepared batch up.  collect_stats synchronises and returns the counters (and, with profiling
+ * queue back to back on the library's stream); prefetch_users runs only the sampling + sorting of the leading
+ * batch(es) of a range on the side stream(s) — as many as the library looks ahead: one, or two where the second
+ * prep lane is on — so that it overlaps whatever the caller does next (e.g. the RCCL all-reduce of the
+ * data-parallel exchange); later train/enqueue calls for the same (seed, epoch) starting at the same user
+ * pick the prepared batches up, one-batch calls included.  collect_stats synchronises and returns the counters (and, with profiling
  * on, the HIP-event kernel times) accumulated since the previous train_users / collect_stats. */
 int cdae_hip_enqueue_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end);
 int cdae_hip_prefetch_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end);

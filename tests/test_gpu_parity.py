@@ -371,6 +371,39 @@ def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):
     np.testing.assert_allclose(a.get(0), b.get(0), rtol=5e-6, atol=1e-6)
 
 
+def test_two_batches_of_prefetch_carry_over_and_stale_drops(tiny):
+    """With the second prep lane the library looks two batches ahead, and prefetch_users prepares both leading batches of a
+    range.  Whether the caller then trains them in one call, one batch per call (the second prepared batch carries over), or
+    walks away from them (stale: dropped), the parameters equal those of plain synchronous training of the same batches."""
+    a, _ = make_pair(tiny, K=32, B=40)
+    b, _ = make_pair(tiny, K=32, B=40)
+    U = tiny.num_users
+    a.train_users(seed=5, epoch=0, u_begin=0, u_end=U)
+    a.train_users(seed=5, epoch=1, u_begin=0, u_end=160)
+    a.train_users(seed=5, epoch=2, u_begin=80, u_end=160)
+    # epoch 0: two-batch prefetches consumed by one-batch calls
+    starts = list(range(0, U, 40))
+    b.prefetch_users(5, 0, 0, min(U, 80))
+    for s0 in starts:
+        b.enqueue_users(5, 0, s0, min(U, s0 + 40))
+        if s0 + 40 < U:
+            b.prefetch_users(5, 0, s0 + 40, min(U, s0 + 120))
+    # epoch 1: a two-batch prefetch consumed by one four-batch call
+    b.prefetch_users(5, 1, 0, 80)
+    b.enqueue_users(5, 1, 0, 160)
+    # epoch 2: prepared batches that are never trained (other range, other epoch), then a partial match
+    b.prefetch_users(5, 2, 0, 80)
+    b.prefetch_users(5, 3, 0, 80)
+    b.prefetch_users(5, 2, 80, 160)
+    b.enqueue_users(5, 2, 80, 120)
+    b.prefetch_users(5, 2, 120, 160)          # already carried over: nothing new to prepare
+    b.enqueue_users(5, 2, 120, 160)
+    st = b.collect_stats()
+    assert st.users == U + 160 + 80
+    for which in (0, 1, 4, 5, 6, 7, 8, 9):
+        np.testing.assert_allclose(a.get(which), b.get(which), rtol=5e-6, atol=1e-6)
+
+
 @pytest.fixture(scope="module")
 def ragged(built):
     """Heavy-tailed rows: 1 item, a few, > 128 (several work units), > 2048 (sampler's global-memory path)."""
