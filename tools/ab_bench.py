@@ -39,7 +39,7 @@ def main():
             res[name].append(d["ms_per_step"])
     for name, _ in cfgs:
         v = np.array(res[name])
-        print(f"{name:24s} median {np.median(v):.5f} ms  min {v.min():.5f}  max {v.max():.5f}  ({len(v)} runs)  -> {1e-3 * 256 / np.median(v):.0f}K users/s at 256" if "--batch-users" not in a.args else
+        print(f"{name:24s} median {np.median(v):.5f} ms  min {v.min():.5f}  max {v.max():.5f}  ({len(v)} runs)  -> {256 / np.median(v):.0f}K users/s at 256" if "--batch-users" not in a.args else
               f"{name:24s} median {np.median(v):.5f} ms  min {v.min():.5f}  max {v.max():.5f}  ({len(v)} runs)")
 
 
