@@ -23,7 +23,7 @@ P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG, P_UU, P_UU_
 P_UB, P_UB_AG = 12, 13
 P_COUNT = 14
 
-DEFAULT_BATCH_USERS = 0        # 0 = the library's default (num_users / 160, within [32, 512])
+DEFAULT_BATCH_USERS = 0        # 0 = the library's default (cdae_hip_default_batch_users: num_users / 160, within [32, 256])
 
 
 class _Config(C.Structure):
@@ -57,6 +57,8 @@ EXPORTS = {
     "cdae_hip_destroy": (C.c_int, [C.c_void_p]),
     "cdae_hip_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cdae_hip_row_stride": (C.c_uint32, [C.c_void_p]),
+    "cdae_hip_default_batch_users": (C.c_uint32, [C.c_uint64]),
+    "cdae_hip_batch_users": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_set_user_id_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_set_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
@@ -221,6 +223,11 @@ class CDAE:
 
     def init_params(self, seed: int):
         _chk(self.lib, self.lib.cdae_hip_init_params(self.h, seed))
+
+    @property
+    def batch_users(self) -> int:
+        """users per parameter snapshot the handle is using (the library's choice when the config asked for 0)"""
+        return int(self.lib.cdae_hip_batch_users(self.h))
 
     # ---- parameters --------------------------------------------------------------------------------
     def _shape(self, which):

@@ -174,6 +174,7 @@ struct cdae_hip {
   std::thread worker;
   std::mutex job_mu;
   std::condition_variable job_cv;
+  std::condition_variable issued_cv;    // worker -> caller: jobs_issued advanced (await_prep_upto sleeps here after a short spin)
   std::deque<PrepJob> jobs;
   bool worker_stop = false;
   uint64_t jobs_submitted = 0;          // (caller's thread only)
@@ -931,7 +932,10 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
   c.struct_size = sizeof(c);
   c.num_dim = mc->num_dim; c.num_neg = mc->num_neg; c.num_corruptions = 1;
   c.loss_type = CDAE_LOSS_SQUARE;                          // (validated above; the MF kernels read hp.loss_type, set below)
-  c.using_adagrad = mc->using_adagrad; c.user_factor = 1; c.batch_users = mc->batch_users;
+  c.using_adagrad = mc->using_adagrad; c.user_factor = 1;
+  // default: one user per block = the reference's strictly sequential loop (imf.hpp:71-115, bpr.hpp:56-106).  Larger blocks are a
+  // throughput setting the caller asks for: their accuracy envelope is not certified
+  c.batch_users = mc->batch_users ? mc->batch_users : 1u;
   c.lambda = mc->lambda; c.learn_rate = mc->learn_rate; c.corruption_ratio = 0.; c.beta = mc->beta;
   CHK(cdae_hip_create(&c, device_id, out));
   cdae_hip* h = *out;
@@ -943,6 +947,10 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
 }
 
 uint32_t cdae_hip_row_stride(const cdae_hip_t* h) { return h ? h->Kp : 0; }
+uint32_t cdae_hip_default_batch_users(uint64_t U) {
+  return (uint32_t)std::min<uint64_t>(CDAE_DEFAULT_BATCH_USERS_MAX, std::max<uint64_t>(32, (U / 160) & ~(uint64_t)31));
+}
+uint32_t cdae_hip_batch_users(const cdae_hip_t* h) { return !h || (h->cfg.batch_users == 0 && h->U == 0) ? 0 : h->B; }
 
 int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t offset) {
   if (!h) return fail("null handle");
@@ -976,9 +984,10 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   CHK(quiesce(h));
   CHK(free_interaction_state(h));
   if (h->cfg.batch_users == 0) {
-    // default: ~U/160 users per parameter snapshot, in [32, 512] — 512 of 70 K users is where Recall@10 still stays
-    // within +-0.002 of the sequential reference at every epoch
-    h->B = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(32, (U / 160) & ~(uint64_t)31));
+    // default: ~U/160 users per parameter snapshot, in [32, 256].  256 is the largest size whose Recall@10 shows no systematic
+    // offset against the strictly sequential reference schedule (paired multi-seed study at ML-10M shape, DESIGN.md §2: 384 and
+    // 512 sit 0.001-0.002 low); tests/test_gpu_accuracy.py certifies exactly this value at the BASELINE shapes.
+    h->B = cdae_hip_default_batch_users(U);
   }
   h->U = U; h->I = I; h->hp.num_items = (uint32_t)I;
   {
@@ -1349,7 +1358,12 @@ void prep_worker_main(cdae_hip* h) {
         h->worker_failed.store(1, std::memory_order_release);
       }
     }
-    h->jobs_issued.fetch_add(1, std::memory_order_release);
+    {
+      // (under the mutex so that a caller between its predicate check and its wait cannot miss the wake-up)
+      std::lock_guard<std::mutex> lk(h->job_mu);
+      h->jobs_issued.fetch_add(1, std::memory_order_release);
+    }
+    h->issued_cv.notify_all();
   }
 }
 
@@ -1366,12 +1380,26 @@ int submit_prep(cdae_hip* h, int set, const Batch& bt, uint64_t seed, uint32_t e
 }
 
 // jobs 1..id have been issued (their launches and their `ready` records are in the prep stream)
+// A failed job is reported ONCE, to the call that was waiting for it: the jobs queued behind it were skipped (their example sets were
+// never written), so the queue is drained, whatever was prefetched is forgotten and the flag is cleared — the next call starts
+// clean instead of finding the handle bricked by one transient launch error.
 int await_prep_upto(cdae_hip* h, uint64_t id) {
-  if (h->prep_threaded) {
-    uint32_t spins = 0;
-    while (h->jobs_issued.load(std::memory_order_acquire) < id)
-      if (++spins > 64) std::this_thread::yield();
-    if (h->worker_failed.load(std::memory_order_acquire)) return fail("prep worker: %s", h->worker_error.c_str());
+  if (!h->prep_threaded) return 0;
+  auto wait_for = [&](uint64_t n) {
+    for (uint32_t spins = 0; spins < 4096; ++spins) {        // the worker is normally a few microseconds behind at most
+      if (h->jobs_issued.load(std::memory_order_acquire) >= n) return;
+      __builtin_ia32_pause();
+    }
+    std::unique_lock<std::mutex> lk(h->job_mu);
+    h->issued_cv.wait(lk, [&] { return h->jobs_issued.load(std::memory_order_acquire) >= n; });
+  };
+  wait_for(id);
+  if (h->worker_failed.load(std::memory_order_acquire)) {
+    wait_for(h->jobs_submitted);
+    const std::string msg = h->worker_error;
+    h->pre_n = 0;
+    h->worker_failed.store(0, std::memory_order_release);
+    return fail("prep worker: %s", msg.c_str());
   }
   return 0;
 }

@@ -49,8 +49,9 @@ extern "C" {
 /* 3: cdae_hip_debug_sample_batch (integer-parity test hook), cdae_hip_recommend_user
  * 4: library-owned RCCL communicator + exchange schedule (cdae_hip_comm_*, cdae_hip_exchange_*), cdae_hip_multi_*
  * 5: cdae_hip_create_mf (IMF / BPR handles), CDAE_P_UB / CDAE_P_UB_AG, item-rows layout of cdae_hip_multi_*
- * 6: cdae_hip_set_profiling_families */
-#define CDAE_HIP_ABI_VERSION 6
+ * 6: cdae_hip_set_profiling_families
+ * 7: default batch_users capped at 256 (was 512); cdae_hip_default_batch_users, cdae_hip_batch_users */
+#define CDAE_HIP_ABI_VERSION 7
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -87,7 +88,8 @@ typedef struct cdae_hip_config {
   uint32_t tanh_act;         /* cdae.hpp:30                                                */
   uint32_t batch_users;      /* users whose encode sees the same parameter snapshot; 1 ==  */
                              /* the reference's strictly sequential schedule; 0 -> default */
-                             /* (num_users/160 rounded to 32, within [32, 512])            */
+                             /* (cdae_hip_default_batch_users: num_users/160 rounded down   */
+                             /* to 32, within [32, 256] — the accuracy envelope's bound)    */
   uint32_t full_output;      /* 1: every unrated item is a negative with target 0 (north-star */
                              /* extension; num_neg is ignored): dense decode on the MFMA cores, */
                              /* per-block summed decoder gradient            */
@@ -124,6 +126,16 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t num_users, uint64_t num_it
                               const int64_t* row_ptr, const uint32_t* col_idx);
 
 uint32_t cdae_hip_row_stride(const cdae_hip_t* h);
+
+/* The batch_users a handle created with batch_users = 0 takes for `num_users` users (chosen at cdae_hip_set_interactions):
+ * num_users / 160 rounded down to a multiple of 32, within [32, CDAE_DEFAULT_BATCH_USERS_MAX].  The upper bound is the largest
+ * size for which the driver-run accuracy tests hold the Recall@10 / loss-curve tolerance against the strictly sequential
+ * reference schedule (cdae.hpp:136-146) at the BASELINE shapes; larger values are accepted when asked for explicitly and are
+ * a throughput setting outside that envelope.  cdae_hip_batch_users: the value a handle is using (0 before
+ * cdae_hip_set_interactions when the default was asked for). */
+#define CDAE_DEFAULT_BATCH_USERS_MAX 256u
+uint32_t cdae_hip_default_batch_users(uint64_t num_users);
+uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
 
 /* A data-parallel rank holds only its own users (rows re-based to 0).  The random streams of
  * include/cdae_rng.h are keyed by GLOBAL user id = offset + local row, so a sharded run draws the
@@ -272,7 +284,7 @@ typedef struct cdae_mf_config {
   uint32_t using_adagrad;    /* imf.hpp:22                                               */
   uint32_t using_bias_term;  /* imf.hpp:21                                               */
   uint32_t pairwise;         /* 0: IMF (pointwise instances), 1: BPR (pairs)             */
-  uint32_t batch_users;      /* 0 -> default                                             */
+  uint32_t batch_users;      /* 0 -> 1 (the reference's sequential loop)                 */
   double lambda;             /* imf.hpp:16                                               */
   double learn_rate;         /* imf.hpp:14                                               */
   double beta;               /* imf.hpp:15                                               */

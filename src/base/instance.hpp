@@ -53,39 +53,38 @@ class FeatureGroupInfo {
   FeatureType type_ = SPARSE_BINARY;
 };
 
+// A (user, item, label) record as a VALUE: at most two single-valued feature groups held inline — no heap allocation per
+// rating (the reference's Instance owns three std::vectors, instance.hpp:196-226; at 100 M ratings that is 300 M mallocs).
+// libcf::Data keeps the ratings as columns and hands these out by value from its iterators.
 class Instance {
  public:
+  static const size_t kMaxGroups = 2;
   Instance() = default;
+  Instance(uint32_t g0, uint32_t g1, double label) : label_(label), n_(2) { idx_[0] = g0; idx_[1] = g1; }
   // append a single-valued categorical group (RECSYS loader)
-  void add_feat_group(FeatureGroupInfo& info, const std::string& key) { idx_.push_back(info.get_index(key)); val_.push_back(1.); }
-  void add_feat_group(const std::vector<size_t>& ids) { for (size_t v : ids) { idx_.push_back(v); val_.push_back(1.); } }
+  void add_feat_group(FeatureGroupInfo& info, const std::string& key) { push(info.get_index(key)); }
+  void add_feat_group(const std::vector<size_t>& ids) { for (size_t v : ids) push(v); }
   double label() const { return label_; }
   void set_label(double l) { label_ = l; }
-  size_t size() const { return idx_.size(); }
-  size_t num_feature_groups() const { return idx_.size(); }
+  size_t size() const { return n_; }
+  size_t num_feature_groups() const { return n_; }
   size_t feature_group_size(size_t) const { return 1; }
   size_t get_feature_group_index(size_t fg, size_t /*pos*/) const { return idx_[fg]; }
-  double get_feature_group_value(size_t fg, size_t /*pos*/) const { return val_[fg]; }
-  void write(std::ostream& o) const {
-    io_detail::put<uint64_t>(o, idx_.size());
-    for (size_t k = 0; k < idx_.size(); ++k) io_detail::put<uint64_t>(o, idx_[k]);
-    io_detail::put(o, label_);
-  }
-  void read(std::istream& i) {
-    uint64_t n = 0; io_detail::get(i, n);
-    idx_.resize(n); val_.assign(n, 1.);
-    for (uint64_t k = 0; k < n; ++k) { uint64_t v = 0; io_detail::get(i, v); idx_[k] = v; }
-    io_detail::get(i, label_);
-  }
+  double get_feature_group_value(size_t /*fg*/, size_t /*pos*/) const { return 1.; }
   friend std::ostream& operator<<(std::ostream& o, const Instance& ins) {
     o << ins.label_ << " |";
-    for (size_t k = 0; k < ins.idx_.size(); ++k) o << ' ' << k << ':' << ins.idx_[k];
+    for (size_t k = 0; k < ins.n_; ++k) o << ' ' << k << ':' << ins.idx_[k];
     return o;
   }
  private:
-  std::vector<size_t> idx_;
-  std::vector<double> val_;
+  void push(size_t v) {
+    CHECK_LT(static_cast<size_t>(n_), kMaxGroups) << "this build's Instance holds the two single-valued groups of RECSYS data";
+    CHECK_LT(v, size_t(1) << 32);
+    idx_[n_++] = static_cast<uint32_t>(v);
+  }
   double label_ = 0.;
+  uint32_t idx_[kMaxGroups] = {0, 0};
+  uint32_t n_ = 0;
 };
 
 }  // namespace libcf

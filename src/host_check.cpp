@@ -18,6 +18,7 @@ DEFINE_int32(num_dim, 8, "latent dimensions");
 DEFINE_int32(iters, 2, "epochs");
 DEFINE_string(loss_type, "CE", "SQUARE or CE");
 DEFINE_double(cratio, 0.5, "corruption ratio");
+DEFINE_string(dump_csr, "", "write the train / test rows Data::to_csr produces to <path>.train / <path>.test (int64 rows+1, then uint32 cols)");
 
 int main(int argc, char* argv[]) {
   using namespace libcf;
@@ -56,6 +57,20 @@ int main(int argc, char* argv[]) {
   Data train, test;
   again.random_split_by_feature_group(train, test, 0, 0.2);
   CHECK_EQ(train.size() + test.size(), data.size());
+  if (!FLAGS_dump_csr.empty()) {
+    // the caches the split would write, and the CSR a model's reset() derives from them (tests pin both against numpy)
+    save(train, FLAGS_dump_csr + ".train.bin");
+    save(test, FLAGS_dump_csr + ".test.bin");
+    for (int which = 0; which < 2; ++which) {
+      std::vector<int64_t> row_ptr; std::vector<uint32_t> col;
+      (which ? test : train).to_csr(0, 1, row_ptr, col);
+      std::ofstream out(FLAGS_dump_csr + (which ? ".test" : ".train"), std::ios::binary);
+      const uint64_t rows = row_ptr.size() - 1;
+      out.write(reinterpret_cast<const char*>(&rows), sizeof rows);
+      out.write(reinterpret_cast<const char*>(row_ptr.data()), (std::streamsize)(row_ptr.size() * sizeof(int64_t)));
+      out.write(reinterpret_cast<const char*>(col.data()), (std::streamsize)(col.size() * sizeof(uint32_t)));
+    }
+  }
   {
     Popularity pop;
     Solver<Popularity> solver(pop);

@@ -9,6 +9,7 @@
 #include <utility>
 #include <iomanip>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <unordered_map>
 #include <vector>
@@ -87,30 +88,33 @@ class TOPN_Evaluation : public Evaluation<Model> {
 
   // The reference rebuilds two uid -> {iid -> label} hashtables (validation and train) on EVERY call
   // (evaluation.hpp:118-123) — U + nnz node allocations per epoch.  Here the validation rows are one CSR, built once per
-  // Data object and kept across epochs, and a model that can answer "top-k for the user's own train row" without being
-  // handed the set (recommend_train_row: libcf::CDAE holds the rows it was reset with) is never given one; other models
-  // (Popularity, ...) get the train hashtable as before, also built once.
+  // data set and kept across epochs, and a model that can answer "top-k for the user's own train row" without being handed
+  // the set (recommend_train_row + trained_on: libcf::CDAE / IMF / BPR / Popularity hold the rows they were reset with) is
+  // never given one — but only when `train` IS the data set the model was reset with; evaluated against any other rated set
+  // the model gets that set through recommend(uid, k, set), exactly as the reference passes train_it->second
+  // (evaluation.hpp:145-149).  Caches are keyed by Data::generation() (the identity of the contents, not an address) and
+  // guarded by a mutex, so one Evaluation object may be shared.
   std::string evaluate(Model& model, const Data& validation, const Data& train = Data()) const {
     CHECK_GT(validation.size(), size_t(0));
     const size_t num_users = train.feature_group_total_dimension(0);
     const size_t num_items = train.feature_group_total_dimension(1);
-    const Rows& val = rows_of(validation, val_cache_);
+    std::shared_ptr<const Rows> val_keep = rows_of(validation);
+    const Rows& val = *val_keep;
     size_t n_test_users = 0;
     for (size_t u = 0; u + 1 < val.row_ptr.size(); ++u) n_test_users += val.row_ptr[u + 1] > val.row_ptr[u];
-    const bool self_rows = has_train_row_recommend<Model>::value;
+    const bool self_rows = own_rows(model, train, std::integral_constant<bool, has_train_row_recommend<Model>::value>());
+    std::shared_ptr<const TrainSets> sets;
     if (!self_rows) {
-      if (train_sets_src_ != train.data() || train_sets_n_ != train.size()) {
-        train_sets_ = train.get_feature_pair_label_hashtable(0, 1);
-        train_sets_src_ = train.data(); train_sets_n_ = train.size();
-      }
-      CHECK_EQ(num_users, train_sets_.size());
+      sets = sets_of(train);
+      CHECK_EQ(num_users, sets->size());
     }
     Timer t;
     std::vector<std::vector<double>> per_user(num_users, std::vector<double>(8, 0.));
     model.pre_recommend();                                         // evaluation.hpp:135
     dynamic_parallel_for(0, num_users, [&](size_t uid) {           // recommend() is called concurrently
       if (uid + 1 >= val.row_ptr.size() || val.row_ptr[uid + 1] == val.row_ptr[uid]) return;
-      const std::vector<size_t> rec = recommend_for(model, uid, std::integral_constant<bool, has_train_row_recommend<Model>::value>());
+      const std::vector<size_t> rec = self_rows ? recommend_own(model, uid, std::integral_constant<bool, has_train_row_recommend<Model>::value>())
+                                                : recommend_with(model, uid, *sets);
       for (size_t iid : rec) CHECK_LT(iid, num_items);
       per_user[uid] = evaluate_rec_list(rec, RowView{val.col.data() + val.row_ptr[uid], static_cast<size_t>(val.row_ptr[uid + 1] - val.row_ptr[uid])});
     });
@@ -124,7 +128,8 @@ class TOPN_Evaluation : public Evaluation<Model> {
   }
 
  private:
-  struct Rows { const void* src = nullptr; size_t n = 0; std::vector<int64_t> row_ptr; std::vector<uint32_t> col; };
+  struct Rows { uint64_t generation = 0; std::vector<int64_t> row_ptr; std::vector<uint32_t> col; };
+  typedef std::unordered_map<size_t, std::unordered_map<size_t, double>> TrainSets;
   struct RowView {                                             // a sorted CSR row seen as the `truth` set
     const uint32_t* p; size_t n;
     size_t size() const { return n; }
@@ -132,27 +137,42 @@ class TOPN_Evaluation : public Evaluation<Model> {
   };
   template <class M>
   struct has_train_row_recommend {
-    template <class T> static auto test(int) -> decltype(std::declval<const T&>().recommend_train_row(size_t(0), size_t(0)), std::true_type());
+    template <class T> static auto test(int) -> decltype(std::declval<const T&>().recommend_train_row(size_t(0), size_t(0)),
+                                                         std::declval<const T&>().trained_on(std::declval<const Data&>()), std::true_type());
     template <class> static std::false_type test(...);
     static const bool value = decltype(test<M>(0))::value;
   };
-  std::vector<size_t> recommend_for(Model& model, size_t uid, std::true_type) const { return model.recommend_train_row(uid, 10); }
-  std::vector<size_t> recommend_for(Model& model, size_t uid, std::false_type) const {
-    auto tit = train_sets_.find(uid);
-    CHECK(tit != train_sets_.end());
+  static bool own_rows(const Model& model, const Data& train, std::true_type) { return model.trained_on(train); }
+  static bool own_rows(const Model&, const Data&, std::false_type) { return false; }
+  static std::vector<size_t> recommend_own(Model& model, size_t uid, std::true_type) { return model.recommend_train_row(uid, 10); }
+  static std::vector<size_t> recommend_own(Model&, size_t, std::false_type) { LOG(FATAL) << "unreachable"; return std::vector<size_t>(); }
+  static std::vector<size_t> recommend_with(Model& model, size_t uid, const TrainSets& sets) {
+    auto tit = sets.find(uid);
+    CHECK(tit != sets.end());
     return model.recommend(uid, 10, tit->second);
   }
-  static const Rows& rows_of(const Data& d, Rows& cache) {
-    if (cache.src != d.data() || cache.n != d.size()) {
-      d.to_csr(0, 1, cache.row_ptr, cache.col);
-      cache.src = d.data(); cache.n = d.size();
+  std::shared_ptr<const Rows> rows_of(const Data& d) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!val_cache_ || val_cache_->generation != d.generation()) {
+      auto r = std::make_shared<Rows>();
+      d.to_csr(0, 1, r->row_ptr, r->col);
+      r->generation = d.generation();
+      val_cache_ = r;
     }
-    return cache;
+    return val_cache_;
   }
-  mutable Rows val_cache_;
-  mutable std::unordered_map<size_t, std::unordered_map<size_t, double>> train_sets_;
-  mutable const void* train_sets_src_ = nullptr;
-  mutable size_t train_sets_n_ = 0;
+  std::shared_ptr<const TrainSets> sets_of(const Data& train) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!train_sets_ || train_sets_generation_ != train.generation()) {
+      train_sets_ = std::make_shared<TrainSets>(train.get_feature_pair_label_hashtable(0, 1));
+      train_sets_generation_ = train.generation();
+    }
+    return train_sets_;
+  }
+  mutable std::mutex mu_;
+  mutable std::shared_ptr<const Rows> val_cache_;
+  mutable std::shared_ptr<const TrainSets> train_sets_;
+  mutable uint64_t train_sets_generation_ = 0;
 };
 
 template <class Model>

@@ -103,6 +103,10 @@ class CDAE : public RecsysModelBase {
     std::shared_ptr<Csr> csr = std::make_shared<Csr>();
     data_->to_csr(0, 1, csr->row_ptr, csr->col);           // uid -> sorted {iid}; labels are all 1 (yelp.cpp:66)
     train_csr_ = csr;
+    train_generation_ = data_->generation();
+    // what the device is about to be given, in a form a test can pin against its own derivation of the same rows
+    LOG(INFO) << "CDAE train rows: " << num_users_ << " users x " << num_items_ << " items, " << csr->col.size()
+              << " interactions, csr fnv1a64 " << csr_checksum(*csr);
     seed_ = std::getenv("CDAE_SEED") ? env_u64("CDAE_SEED", 0) : Random::next_u64();
     const std::vector<int> devices = env_devices();
     dev_.reset(); multi_.reset();
@@ -232,6 +236,8 @@ class CDAE : public RecsysModelBase {
     for (size_t i = 0; i < topk; ++i) out[i] = t->ids[uid * topk + i];
     return out;
   }
+  // is `d` the data set this model was reset with?  (Evaluation: recommend_train_row answers for exactly those rows)
+  bool trained_on(const Data& d) const { return train_generation_ != 0 && d.generation() == train_generation_; }
   // the train rows the model was reset with, as CSR (sorted item ids per user)
   const std::vector<int64_t>& train_row_ptr() const { CHECK(train_csr_ != nullptr); return train_csr_->row_ptr; }
   const std::vector<uint32_t>& train_col_idx() const { CHECK(train_csr_ != nullptr); return train_csr_->col; }
@@ -261,6 +267,17 @@ class CDAE : public RecsysModelBase {
     }
     return rec_;
   }
+  // FNV-1a (64 bit) over the little-endian bytes of row_ptr (int64) then col (uint32)
+  static uint64_t csr_checksum(const Csr& c) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto eat = [&h](const void* p, size_t n) {
+      const unsigned char* b = static_cast<const unsigned char*>(p);
+      for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    };
+    eat(c.row_ptr.data(), c.row_ptr.size() * sizeof(int64_t));
+    eat(c.col.data(), c.col.size() * sizeof(uint32_t));
+    return h;
+  }
   bool ready() const { return dev_ != nullptr || multi_ != nullptr; }
   static std::vector<int> env_devices() {                    // CDAE_DEVICES=0,1,2,3
     std::vector<int> out;
@@ -287,6 +304,7 @@ class CDAE : public RecsysModelBase {
   std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
   mutable std::shared_ptr<const Table> rec_;
   std::shared_ptr<const Csr> train_csr_;             // host copy of the train rows (recommend: is the caller's set the train row?)
+  uint64_t train_generation_ = 0;                    // Data::generation() of the set reset() saw
   uint64_t seed_ = 0;
   uint32_t epoch_ = 0;
 };

@@ -4,7 +4,8 @@
 //
 //   method (reference lines)                         -> C ABI
 //   reset (57-69)                                     cdae_hip_create_mf, _set_interactions, _init_params
-//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (CDAE_BATCH_USERS = 1: the reference loop itself)
+//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default: one user per block = the reference loop itself;
+//                                                                                    CDAE_BATCH_USERS > 1: block schedule, throughput setting)
 //   predict_user_item_rating (117-119)                host dot product over parameters fetched once (cdae_hip_get_param)
 //   recommend (RecsysModelBase, 77-104)               cdae_hip_recommend_all in pre_recommend, then table reads
 //   get_user_vecs / get_item_vecs (121-127)           cdae_hip_get_param
@@ -61,14 +62,15 @@ class IMF : public RecsysModelBase {
     cdae_hip_t* raw = nullptr;
     CDAE_HIP_CHECK(cdae_hip_create_mf(&c, static_cast<int>(mf_env_u64("CDAE_DEVICE", 0)), &raw));
     dev_.reset(raw, [](cdae_hip_t* h) { cdae_hip_destroy(h); });
-    std::vector<int64_t> row_ptr;
-    std::vector<uint32_t> col;
-    data_->to_csr(0, 1, row_ptr, col);
-    CDAE_HIP_CHECK(cdae_hip_set_interactions(raw, num_users_, num_items_, row_ptr.data(), col.data()));
+    auto csr = std::make_shared<Csr>();
+    data_->to_csr(0, 1, csr->row_ptr, csr->col);
+    CDAE_HIP_CHECK(cdae_hip_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
+    csr_ = csr;
+    train_generation_ = data_->generation();
     seed_ = std::getenv("CDAE_SEED") ? mf_env_u64("CDAE_SEED", 0) : Random::next_u64();
     CDAE_HIP_CHECK(cdae_hip_init_params(raw, seed_));
     epoch_ = 0;
-    rec_.reset();
+    invalidate();
   }
 
   virtual void train_one_iteration(const Data&) {
@@ -77,17 +79,18 @@ class IMF : public RecsysModelBase {
     CDAE_HIP_CHECK(cdae_hip_train_epoch(dev_.get(), seed_, epoch_++, &st));
     LOG(INFO) << (pairwise_ ? "BPR" : "IMF") << " epoch " << epoch_ << ": " << st.users << " users in " << st.wall_seconds << " s ("
               << static_cast<double>(st.users) / st.wall_seconds << " users/s, " << st.batches << " blocks)";
-    rec_.reset();
+    invalidate();
   }
 
   // imf.hpp:117-119
   double predict_user_item_rating(size_t uid, size_t iid) const {
     CHECK(dev_ != nullptr);
     CHECK_LT(uid, num_users_); CHECK_LT(iid, num_items_);
-    std::vector<float> u(num_users_ * num_dim_), v(num_items_ * num_dim_), ub(num_users_), ib(num_items_);
-    fetch(CDAE_P_WU, u); fetch(CDAE_P_W, v); fetch(CDAE_P_UB, ub); fetch(CDAE_P_BP, ib);
-    double s = ub[uid] + ib[iid];
-    for (size_t k = 0; k < num_dim_; ++k) s += static_cast<double>(u[uid * num_dim_ + k]) * v[iid * num_dim_ + k];
+    // the four parameter arrays come from the device ONCE per training epoch (a loop over (uid, iid) pairs would otherwise move
+    // the whole model over PCIe per call); train_one_iteration / reset drop the copy
+    std::shared_ptr<const HostParams> p = host_params();
+    double s = p->ub[uid] + p->ib[iid];
+    for (size_t k = 0; k < num_dim_; ++k) s += static_cast<double>(p->u[uid * num_dim_ + k]) * p->v[iid * num_dim_ + k];
     return s;
   }
   DMatrix get_user_vecs() { return matrix(CDAE_P_WU, num_users_); }      // imf.hpp:121-123
@@ -100,8 +103,15 @@ class IMF : public RecsysModelBase {
     std::shared_ptr<const Table> t = ensure_table(topk);
     return std::vector<size_t>(t->ids.begin() + uid * topk, t->ids.begin() + (uid + 1) * topk);
   }
-  // (the score does not depend on the rated set beyond its exclusion; Evaluation passes the train row)
-  std::vector<size_t> recommend(size_t uid, size_t topk, const std::unordered_map<size_t, double>&) const { return recommend_train_row(uid, topk); }
+  bool trained_on(const Data& d) const { return train_generation_ != 0 && d.generation() == train_generation_; }
+  // RecsysModelBase::recommend(uid, topk, rated) excludes exactly `rated` (recsys_model_base.hpp:77-104).  When that is the user's
+  // own train row — what Evaluation passes — the GPU table answers; any other set takes the reference's generic scan + heap over
+  // predict_user_item_rating (host copy of the parameters, fetched once per epoch).
+  std::vector<size_t> recommend(size_t uid, size_t topk, const std::unordered_map<size_t, double>& rated) const {
+    CHECK_LT(uid, num_users_);
+    if (is_train_row(uid, rated)) return recommend_train_row(uid, topk);
+    return RecsysModelBase::recommend(uid, topk, rated);
+  }
 
  protected:
   void configure(const IMFConfig& mcfg, bool pairwise, const char* name) {
@@ -114,6 +124,30 @@ class IMF : public RecsysModelBase {
               << "}, {Penalty: " << penalty_->penalty_type() << "}\n"
               << "\t{Dim: " << num_dim_ << "}, {BiasTerm: " << using_bias_term_ << "}, {Using AdaGrad: " << using_adagrad_
               << "}, {Num Negative: " << num_neg_ << "}";
+  }
+  struct Csr { std::vector<int64_t> row_ptr; std::vector<uint32_t> col; };
+  struct HostParams { std::vector<float> u, v, ub, ib; };
+  bool is_train_row(size_t uid, const std::unordered_map<size_t, double>& rated) const {
+    if (!csr_) return false;
+    const int64_t a = csr_->row_ptr[uid], b = csr_->row_ptr[uid + 1];
+    if (static_cast<size_t>(b - a) != rated.size()) return false;
+    for (int64_t p = a; p < b; ++p) if (!rated.count(csr_->col[p])) return false;
+    return true;
+  }
+  std::shared_ptr<const HostParams> host_params() const {
+    std::lock_guard<std::mutex> lk(*mu_);
+    if (!host_) {
+      auto p = std::make_shared<HostParams>();
+      p->u.resize(num_users_ * num_dim_); p->v.resize(num_items_ * num_dim_); p->ub.resize(num_users_); p->ib.resize(num_items_);
+      fetch(CDAE_P_WU, p->u); fetch(CDAE_P_W, p->v); fetch(CDAE_P_UB, p->ub); fetch(CDAE_P_BP, p->ib);
+      host_ = p;
+    }
+    return host_;
+  }
+  void invalidate() {
+    std::lock_guard<std::mutex> lk(*mu_);
+    rec_.reset();
+    host_.reset();
   }
   struct Table { size_t topk; std::vector<uint32_t> ids; };
   std::shared_ptr<const Table> ensure_table(size_t topk) const {
@@ -148,6 +182,9 @@ class IMF : public RecsysModelBase {
   std::shared_ptr<cdae_hip_t> dev_;                  // shared by copies: Solver copies the model (solver.hpp:17)
   std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
   mutable std::shared_ptr<const Table> rec_;
+  mutable std::shared_ptr<const HostParams> host_;   // parameters on the host for predict_user_item_rating; dropped when they change
+  std::shared_ptr<const Csr> csr_;                   // the train rows the handle was reset with
+  uint64_t train_generation_ = 0;
   uint64_t seed_ = 0;
   uint32_t epoch_ = 0;
 };

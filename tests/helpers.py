@@ -43,3 +43,57 @@ def max_param_err(model, o):
         if err > worst:
             worst, name = err, which
     return worst, name
+
+
+# ---- the host layer's own binary cache (src/base/data.hpp Data::write; src/base/io/file.hpp save) -------------------------------
+def read_data_cache(path):
+    """-> dict(user_names, item_names, users, items, labels) from a cache written by libcf::save(Data) of this repository's
+    host layer: magic, columnar tag, the two first-seen dictionaries, then the columns."""
+    import struct
+    buf = open(path, "rb").read()
+    off = 0
+
+    def u64():
+        nonlocal off
+        v = struct.unpack_from("<Q", buf, off)[0]
+        off += 8
+        return v
+    assert u64() == 0x3145414443464C43, "not a cache of this build"          # "CLFCDAE1"
+    assert u64() == 0x324C4F4345414443, "not the columnar format"            # "CDAECOL2"
+    assert u64() == 2
+    names = []
+    for _ in range(2):
+        u64(); u64()                         # feature type, dense length
+        n = u64()
+        grp = []
+        for _ in range(n):
+            ln = u64()
+            grp.append(buf[off:off + ln].decode())
+            off += ln
+        names.append(grp)
+    n, uniform = u64(), u64()
+    uniform_label = struct.unpack_from("<d", buf, off)[0]
+    off += 8
+    users = np.frombuffer(buf, np.uint32, n, off); off += 4 * n
+    items = np.frombuffer(buf, np.uint32, n, off); off += 4 * n
+    labels = np.full(n, uniform_label) if uniform else np.frombuffer(buf, np.float64, n, off)
+    off += 0 if uniform else 8 * n
+    assert off == len(buf)
+    return dict(user_names=names[0], item_names=names[1], users=users, items=items, labels=labels)
+
+
+def csr_of(users, items, num_users):
+    """uid -> sorted unique item ids (what Data::to_csr / the reference's uid -> {iid -> label} table hold)"""
+    key = np.unique(users.astype(np.int64) << 32 | items.astype(np.int64))
+    ptr = np.zeros(num_users + 1, np.int64)
+    np.add.at(ptr, (key >> 32) + 1, 1)
+    return np.cumsum(ptr), (key & 0xFFFFFFFF).astype(np.uint32)
+
+
+def fnv1a64(*arrays):
+    """FNV-1a over the little-endian bytes of the arrays, as src/model/recsys/cdae.hpp logs for the rows it hands to the device"""
+    h = 0xcbf29ce484222325
+    for a in arrays:
+        for b in np.ascontiguousarray(a).tobytes():
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h

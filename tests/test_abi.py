@@ -29,12 +29,26 @@ def test_header_symbols_are_all_exported_and_bound(built):
 
 def test_abi_version_and_config_layout(built):
     lib = cdae_amd.load_library()
-    assert lib.cdae_hip_abi_version() == 6
+    assert lib.cdae_hip_abi_version() == 7
     hdr = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
-    assert "#define CDAE_HIP_ABI_VERSION 6" in hdr
+    assert "#define CDAE_HIP_ABI_VERSION 7" in hdr
     # 14 uint32 + 4 double, naturally aligned
     assert ctypes.sizeof(binding._Config) == 14 * 4 + 4 * 8
     assert ctypes.sizeof(binding.Stats) == 8 * 11
+
+
+def test_default_batch_users_is_the_certified_one(built):
+    """The drop-in default (batch_users = 0 in cdae_hip_config, what src/model/recsys/cdae.hpp passes without CDAE_BATCH_USERS)
+    must be the value the accuracy tests certify: tests/test_gpu_accuracy.py trains at bench.DEFAULT_BATCH_USERS."""
+    import bench
+    lib = cdae_amd.load_library()
+    hdr = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
+    cap = int(re.search(r"#define CDAE_DEFAULT_BATCH_USERS_MAX (\d+)u", hdr).group(1))
+    assert cap == bench.DEFAULT_BATCH_USERS == 256
+    assert lib.cdae_hip_default_batch_users(70_000) == bench.DEFAULT_BATCH_USERS          # ML-10M shape (BASELINE configs[2])
+    assert lib.cdae_hip_default_batch_users(480_000) == bench.DEFAULT_BATCH_USERS         # Netflix shape (configs[3])
+    assert lib.cdae_hip_default_batch_users(10_000) == 32 and lib.cdae_hip_default_batch_users(17) == 32
+    assert max(lib.cdae_hip_default_batch_users(u) for u in (1, 5_000, 40_000, 41_000, 10**7, 2**30 - 1)) <= cap
 
 
 def test_no_cpu_fallback_without_a_device(built):

@@ -20,13 +20,17 @@ epoch 1 (the batched schedule is slightly AHEAD after one epoch, 3.5 standard er
 Stated tolerances (each asserted below; six data/stream seeds):
   * per seed, every epoch: |Recall@10_hip - Recall@10_literal| <= 0.005 — the literal schedule's own best-to-worst spread over
     stream seeds; anything larger is not seed noise
-  * MEAN over the seeds of the signed difference: |mean| <= 0.002 (the north star's figure) at the final epoch and at every
-    epoch from the second on, <= 0.003 at epoch 1 (the measured head start).  Measured on the six fixtures: +0.0010 / -0.0007 /
-    -0.0008 / -0.0009 / -0.0012 per epoch, standard error of a six-seed mean ~0.0006
-  * reported train loss within 3 % of the literal run's at every epoch, and the curve has the same shape: the
-    epoch-to-epoch change agrees in sign wherever the literal curve moves by more than 0.5 %
+  * MEAN over the seeds of the signed difference: |mean| <= 0.0015 at EVERY epoch — inside the north star's 0.002 and about 2.5
+    standard errors of a six-seed mean (~0.0006).  Measured on the six fixtures: +0.0010 / -0.0007 / -0.0008 / -0.0009 / -0.0012.
+    The north star's "+-0.002 of reference" is therefore certified as a MEAN-OVER-SEEDS statement; a single run can differ by
+    up to the reference's own seed noise (first bullet)
+  * reported train loss: the batched schedule reads systematically LOW (-1.6 ... -2.6 % at 256 users per batch, every seed and
+    epoch); asserted as a band around that known offset, |loss/literal - 1 + 0.021| <= 0.008, so neither a drift back towards 0
+    nor a further 1 % of offset passes unnoticed; and the curve has the same shape: the epoch-to-epoch change agrees in sign
+    wherever the literal curve moves by more than 0.5 %
   * `batch_users` = 1 IS the reference schedule: one full-size epoch reproduces the fixture's Recall@10 to 1e-4 and its loss
     to 2e-4 relative (fp32 device arithmetic against the fp64 oracle over 70 000 sequential users)
+Round-3: the mean bound went 0.002 / 0.003 (epoch 1) -> 0.0015 everywhere and the loss bound from +-3 % to the band above (review).
 Round-2 history: with three seeds the per-seed bound was 0.002 final / 0.003 per epoch and all three passed; three more seeds
 (42, 99, 314159) gave |d| up to 0.0046 (seed 99, epoch 1) and 0.0037 (seed 314159, final) — which is what prompted measuring
 the reference's own noise above.  Batch sizes: the sweep in DESIGN.md §2 (tools/accuracy_envelope.py) is flat in the batch
@@ -49,9 +53,12 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RECALL_TOL_SEED = 0.005           # per seed and epoch: the literal schedule's own spread over stream seeds
-RECALL_TOL_MEAN = 0.002           # mean over seeds, final epoch and every epoch >= 2: the north star's figure
-RECALL_TOL_MEAN_FIRST = 0.003     # mean over seeds, epoch 1
-LOSS_REL_TOL = 0.03
+RECALL_TOL_MEAN = 0.0015          # mean over the six seeds, every epoch: inside the north star's 0.002, ~2.5 standard errors (0.0006)
+# Train loss: the 256-user schedule reads 1.6-2.6 % LOW at every seed and epoch (the hidden layer of a batch is evaluated against
+# the batch-start snapshot) — a known, systematic schedule offset, not a tolerance to hide drift in: the bound is a band
+# AROUND it (round 2 measured -0.0264 ... -0.0160 over 3 seeds x 5 epochs), not 3 % either way.
+LOSS_SCHEDULE_OFFSET = -0.021
+LOSS_TOL_AROUND_OFFSET = 0.008
 HYPER = dict(num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01)
 
 FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "ml10m_k200_ce_literal_seed*.npz")))
@@ -95,7 +102,7 @@ def test_there_are_at_least_six_seeds():
 def test_recall_and_loss_curve_at_bench_batch_users(built, path):
     rec, ref_rec, loss, ref_loss = curves_of(path)
     assert np.abs(rec - ref_rec).max() <= RECALL_TOL_SEED, (path, rec - ref_rec)
-    assert np.abs(loss / ref_loss - 1.0).max() <= LOSS_REL_TOL, (path, loss / ref_loss - 1.0)
+    assert np.abs(loss / ref_loss - 1.0 - LOSS_SCHEDULE_OFFSET).max() <= LOSS_TOL_AROUND_OFFSET, (path, loss / ref_loss - 1.0)
     moves = np.abs(np.diff(ref_loss)) > 0.005 * ref_loss[:-1]
     assert (np.sign(np.diff(loss))[moves] == np.sign(np.diff(ref_loss))[moves]).all()
 
@@ -106,9 +113,7 @@ def test_mean_recall_difference_over_the_seeds(built):
     mean = d.mean(axis=0)
     print(f"\n{len(FIXTURES)} seeds: mean signed dRecall@10 per epoch {np.round(mean, 5)}, std {np.round(d.std(axis=0, ddof=1), 5)}, "
           f"max |d| {np.round(np.abs(d).max(axis=0), 5)}")
-    assert abs(mean[-1]) <= RECALL_TOL_MEAN, mean
-    assert np.abs(mean[1:]).max() <= RECALL_TOL_MEAN, mean
-    assert abs(mean[0]) <= RECALL_TOL_MEAN_FIRST, mean
+    assert np.abs(mean).max() <= RECALL_TOL_MEAN, mean
 
 
 def test_batch_users_one_is_the_reference_schedule_at_full_size(built):

@@ -1,0 +1,100 @@
+"""-m gpu: BASELINE configs[3] — Netflix-shape synthetic (480 000 users x 17 700 items, ~80 M train interactions), K=200,
+negative-sampling=5, CE — on ONE GPU (the 8-GPU form of the config is the driver's to run; what one GPU can certify is the
+path itself at this shape: > 2^32 / 12 examples per epoch, 64-bit row pointers, 1 875 batches per epoch, 384 MB of Wu).
+
+  * integer work bit-exact on 256-user windows (masks, negatives, item-major order, segments, duplicate flags) against the
+    oracle's draws — get_corrputed_input cdae.hpp:361-371, sample_negative_item recsys_model_base.hpp:46-57
+  * `batch_users` = 1 on the leading users against the LITERAL restatement (cdae.hpp:136-146, 198-358), parameters <= 2e-4 of range
+  * the committed literal fixtures (tests/golden/netflix_k200_ce_literal_seed*.npz: CPU oracle, strictly sequential, fp64, every
+    user trained, Recall@10 over the first `eval_users` users) against the HIP path at the LIBRARY DEFAULT batch_users — the
+    handle is created with batch_users = 0, exactly as src/model/recsys/cdae.hpp does without CDAE_BATCH_USERS
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import cdae_amd
+from cdae_amd import synth
+import oracle as orc
+from oracle import binding as ob
+from test_gpu_integer import check_batch, make
+from test_gpu_accuracy import HYPER, RECALL_TOL_SEED, LOSS_SCHEDULE_OFFSET, LOSS_TOL_AROUND_OFFSET
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netflix_k200_ce_literal_seed*.npz")))
+_data = {}
+
+
+def netflix(seed):
+    if seed not in _data:
+        _data.clear()                     # one 100 M-interaction data set in memory at a time
+        _data[seed] = synth.generate_shape("netflix", seed=seed)
+    return _data[seed]
+
+
+def test_netflix_shape_integer_work_bit_exact(built):
+    d = netflix(20141119)
+    assert d.num_users == 480_000 and d.num_items == 17_700 and d.nnz_train > 70_000_000
+    model, o = make(d, K=8, B=256)
+    dups = 0
+    for ep, u0 in ((0, 0), (2, 256 * 911), (1, d.num_users - 256)):
+        dups += check_batch(model, o, d, 20141119, ep, u0, 256)
+    assert dups > 0
+    model.close()
+
+
+def test_netflix_shape_batch_users_one_is_the_literal_schedule(built):
+    d = netflix(20141119)
+    n = 1500
+    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=200, lt=cdae_amd.CROSS_ENTROPY, batch_users=1, **HYPER))
+    m.reset(d, seed=5)
+    o = orc.Oracle(orc.OracleConfig(num_dim=200, loss_type=ob.LOSS_CE, **HYPER), d.num_users, d.num_items, d.train_ptr, d.train_col)
+    for which in (cdae_amd.P_W, cdae_amd.P_W_AG, cdae_amd.P_B, cdae_amd.P_B_AG, cdae_amd.P_BP, cdae_amd.P_BP_AG):
+        o.set(which, m.get(which).astype(np.float64))
+    wu0 = m.get(cdae_amd.P_WU)
+    o.set(ob.P_WU, wu0.astype(np.float64))
+    o.set(ob.P_WU_AG, m.get(cdae_amd.P_WU_AG).astype(np.float64))
+    st = m.train_users(9, 0, 0, n)
+    assert st.users == n and st.batches == n
+    o.train_literal(9, 0, 0, n)
+    for which, rows in ((cdae_amd.P_W, d.num_items), (cdae_amd.P_W_AG, d.num_items), (cdae_amd.P_BP, 0), (cdae_amd.P_B, 0), (cdae_amd.P_WU, n)):
+        got, ref = m.get(which).astype(np.float64), o.get(which)
+        ref = ref.reshape(got.shape)
+        if which == cdae_amd.P_WU:
+            got, ref = got[:n], ref[:n]
+        err = np.abs(got - ref).max() / (1e-3 + np.abs(ref).max())
+        assert err <= 2e-4, (which, err)
+    m.close()
+
+
+def test_there_is_a_netflix_fixture():
+    assert len(FIXTURES) >= 1, "tests/golden/make_literal_curves.py --shape netflix --eval-users 60000"
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_netflix_literal_fixture_at_the_library_default_batch_users(built, path):
+    f = np.load(path, allow_pickle=True)
+    seed, K, ne = int(f["seed"]), int(f["num_dim"]), int(f["eval_users"])
+    assert str(f["shape"]) == "netflix" and K == 200 and str(f["loss"]) == "CE"
+    d = netflix(seed)
+    assert d.nnz_train == int(f["nnz_train"]), "the synthetic generator changed: regenerate the fixtures"
+    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=0, **HYPER))
+    m.reset(d, seed=seed)
+    import bench
+    assert m.batch_users == bench.DEFAULT_BATCH_USERS == 256
+    rec, loss = [], []
+    for ep in range(len(f["recall10"])):
+        st = m.train_one_iteration(seed, ep)
+        assert st.users == d.num_users and st.batches == -(-d.num_users // 256)
+        loss.append(m.current_loss(seed, ep))
+        rec.append(orc.eval_topn(m.recommend_all(10, 0, ne), d.test_ptr[:ne + 1], d.test_col[:d.test_ptr[ne]])[5])
+    m.close()
+    rec, loss = np.array(rec), np.array(loss)
+    print(f"\nnetflix seed {seed}: recall@10 hip {np.round(rec, 5)} literal {np.round(f['recall10'], 5)} d {np.round(rec - f['recall10'], 5)}; "
+          f"loss hip/literal - 1 {np.round(loss / f['train_loss'] - 1, 4)}")
+    assert np.abs(rec - f["recall10"]).max() <= RECALL_TOL_SEED
+    assert np.abs(loss / f["train_loss"] - 1.0 - LOSS_SCHEDULE_OFFSET).max() <= LOSS_TOL_AROUND_OFFSET

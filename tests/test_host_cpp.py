@@ -77,6 +77,104 @@ def test_reference_yelp_app_builds_unmodified_and_runs_config1_plumbing(host_bin
     assert run([yelp, "--task=train"], tmp_path)[0] != 0
 
 
+def test_text_ingest_split_and_csr_are_pinned(host_bins, tmp_path):
+    """SURVEY.md §8(f) rank 2, the data path in front of cdae_hip_set_interactions, against an independent numpy derivation:
+      * text -> columns: ids in FIRST-SEEN order (instance-inl.hpp:22-37), one (user, item, 1) triple per line, file order
+      * per-user split: floor(0.2 n) of every user's ratings to test, the rest to train, nothing lost or invented
+        (data-inl.hpp:249-261)
+      * Data::to_csr == sorted unique items per user of exactly the cached train / test ratings (data-inl.hpp:414-429)."""
+    from helpers import read_data_cache, csr_of
+    write_ratings(tmp_path / "ratings.txt")
+    rc, out = run([os.path.join(host_bins, "host_check"), f"--input_file={tmp_path / 'ratings.txt'}", f"--dump_csr={tmp_path / 'csr'}"], tmp_path)
+    assert rc == 0, out
+    # ---- text -> columns
+    users, items, uid, iid = [], [], {}, {}
+    for line in open(tmp_path / "ratings.txt").read().splitlines()[1:]:
+        u, i = line.split()
+        users.append(uid.setdefault(u, len(uid)))
+        items.append(iid.setdefault(i, len(iid)))
+    whole = read_data_cache(tmp_path / "ratings.txt.bin")
+    assert whole["user_names"] == list(uid) and whole["item_names"] == list(iid)
+    np.testing.assert_array_equal(whole["users"], np.array(users, np.uint32))
+    np.testing.assert_array_equal(whole["items"], np.array(items, np.uint32))
+    assert (whole["labels"] == 1.0).all()
+    # ---- split
+    tr, te = read_data_cache(tmp_path / "csr.train.bin"), read_data_cache(tmp_path / "csr.test.bin")
+    U, I = len(uid), len(iid)
+    pair = lambda d: np.sort(d["users"].astype(np.int64) << 32 | d["items"].astype(np.int64))
+    np.testing.assert_array_equal(np.sort(np.r_[pair(tr), pair(te)]), pair(whole))
+    n_all, n_te = np.bincount(whole["users"], minlength=U), np.bincount(te["users"], minlength=U)
+    np.testing.assert_array_equal(n_te, np.floor(0.2 * n_all).astype(np.int64))
+    # ---- CSR
+    for name, d in (("train", tr), ("test", te)):
+        raw = open(tmp_path / f"csr.{name}", "rb").read()
+        rows = int(np.frombuffer(raw, np.uint64, 1)[0])
+        ptr = np.frombuffer(raw, np.int64, rows + 1, 8)
+        col = np.frombuffer(raw, np.uint32, int(ptr[-1]), 8 + 8 * (rows + 1))
+        eptr, ecol = csr_of(d["users"], d["items"], U)
+        assert rows == U and col.max() < I
+        np.testing.assert_array_equal(ptr, eptr)
+        np.testing.assert_array_equal(col, ecol)
+
+
+def _app_tables(yelp, tmp_path, flags, env):
+    rc, out = run([yelp, "--task=test", "--method=CDAE"] + flags, tmp_path, env=env)
+    assert rc == 0, out[-3000:]
+    rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)][2:]           # after the two Popularity rows
+    assert len(rows) == 51
+    loss = np.array([float(r.split("|")[2]) for r in rows])
+    topn = np.array([[float(x) for x in r.split("|")[3:11]] for r in rows])
+    m = re.search(r"(\d+) interactions, csr fnv1a64 (\d+)", out)
+    return loss, topn, int(m.group(1)), int(m.group(2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch_users", [1, 64])
+def test_reference_yelp_app_table_matches_the_oracle_on_the_same_rows(host_bins, tmp_path, batch_users):
+    """Boundary-level parity (solver-inl.hpp:51-69): the UNMODIFIED yelp app's `Train Loss` and TOPN columns, iteration by
+    iteration, against the CPU oracle run on the rows the app itself split (its train / test caches) with the same CDAE_SEED.
+    batch_users = 1: the oracle's LITERAL schedule (cdae.hpp:136-358); 64: its block schedule.  The CSR handed to the device is
+    pinned through the checksum the host class logs."""
+    from helpers import read_data_cache, csr_of, fnv1a64
+    import oracle as orc
+    from oracle import binding as ob
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    seed, K = 11, 50
+    loss, topn, nnz, checksum = _app_tables(yelp, tmp_path, [f"--num_dim={K}", "--loss_type=CE", "--cratio=0.4", "--scaled=true", "--beta=1"],
+                                            {"CDAE_SEED": str(seed), "CDAE_BATCH_USERS": str(batch_users)})
+    tr, te = read_data_cache(tmp_path / "yelp.train.bin"), read_data_cache(tmp_path / "yelp.test.bin")
+    U, I = len(tr["user_names"]), len(tr["item_names"])
+    ptr, col = csr_of(tr["users"], tr["items"], U)
+    tptr, tcol = csr_of(te["users"], te["items"], U)
+    assert nnz == col.size and checksum == fnv1a64(ptr, col)              # the rows the device trained on are these rows
+    o = orc.Oracle(orc.OracleConfig(num_dim=K, loss_type=ob.LOSS_CE, corruption_ratio=0.4, scaled=True, beta=1.0, learn_rate=0.1,
+                                    lambda_=0.01, num_neg=5, num_corruptions=1), U, I, ptr, col)
+    o.init_params(seed)
+    exp_loss, exp_topn = [0.0], [orc.eval_topn(o.recommend(10), tptr, tcol)]
+    for ep in range(50):
+        if batch_users == 1:
+            o.train_literal(seed, ep)
+        else:
+            o.train_batched(seed, ep, batch_users)
+        exp_loss.append(o.data_loss(seed, ep + 1) + o.penalty_loss())    # the host class reports the loss with the NEXT epoch's masks
+        exp_topn.append(orc.eval_topn(o.recommend(10), tptr, tcol))
+    exp_loss, exp_topn = np.array(exp_loss), np.array(exp_topn)
+    rel = np.abs(loss[1:] / exp_loss[1:] - 1)
+    d_top = np.abs(topn - exp_topn)
+    print(f"\nbatch_users {batch_users}: max rel loss diff, iterations 1-10 {rel[:10].max():.2e}, 1-50 {rel.max():.2e}; "
+          f"max |d| of the TOPN columns {d_top.max(axis=0).round(5)}; rows with identical R@10: {(d_top[:, 5] < 6e-6).sum()}/51")
+    assert loss[0] == 0.0
+    assert rel[:10].max() <= 2e-4 and rel.max() <= 2e-3
+    # one hit more or less on one of 300 users moves R@10 by ~0.0007 (fp32 device scores vs fp64 near ties); allow two
+    assert d_top[0].max() <= 6e-6                                         # untrained model: same initial parameters, same lists
+    assert d_top[:, 5].max() <= 0.0015 and d_top[:11, 5].max() <= 0.0008
+
+
 @pytest.mark.gpu
 def test_solver_cdae_trains_on_gpu_through_host_layer(host_bins, tmp_path):
     write_ratings(tmp_path / "ratings.txt")
