@@ -156,6 +156,18 @@ def _load():
     lib.oracle_train_users_batched.argtypes = [vp, u64, u32, u64, u64, u64]
     lib.oracle_train_users_full.argtypes = [vp, u64, u32, u64, u64, u64]
     lib.oracle_step_user.argtypes = [vp, u64, vp, u64, vp, u64, vp, vp, vp, vp]
+    lib.oracle_ref_seed.argtypes = [vp, u64, u32]
+    lib.oracle_ref_set_insertion_order.argtypes = [vp, vp]
+    lib.oracle_ref_init_params.argtypes = [vp]
+    lib.oracle_train_users_reference_sequenced.argtypes = [vp, u64, u64]
+    lib.oracle_ref_draw_user.argtypes = [vp, u64, vp, vp, vp, vp]
+    lib.oracle_step_user_seq.argtypes = [vp, u64, vp, u64, vp, u64, vp, u64]
+    lib.oracle_ref_rand.restype = u32
+    lib.oracle_ref_rand.argtypes = [vp]
+    lib.oracle_ref_mt.restype = u64
+    lib.oracle_ref_mt.argtypes = [vp]
+    lib.oracle_ref_uniform.restype = dbl
+    lib.oracle_ref_uniform.argtypes = [vp]
     lib.oracle_draw_inputs.argtypes = [vp, u64, u32, u64, u32, u32, vp, vp]
     lib.oracle_draw_negatives.argtypes = [vp, u64, u32, u64, u32, vp]
     lib.oracle_encode.argtypes = [vp, u64, u32, C.c_int, vp, u64, vp]
@@ -242,6 +254,42 @@ class Oracle:
     def train_full(self, seed: int, epoch: int, batch_users: int, u0: int = 0, u1: int | None = None):
         """Full-output decode (every unrated item is a negative once), block-summed gradients."""
         self.lib.oracle_train_users_full(self.h, seed, epoch, u0, self.U if u1 is None else u1, batch_users)
+
+    # ---- reference-sequenced mode: the reference's own generators in the reference's own order (cdae_oracle.cpp GlibcRand) ----
+    def ref_seed(self, mt_seed: int, rand_seed: int = 1):
+        """Random::seed(mt_seed) (random.hpp:29-31) and srand(rand_seed) — the reference never calls srand, i.e. 1"""
+        self.lib.oracle_ref_seed(self.h, mt_seed, rand_seed)
+
+    def ref_set_insertion_order(self, items=None):
+        a = None if items is None else np.ascontiguousarray(items, dtype=np.uint32)
+        self.lib.oracle_ref_set_insertion_order(self.h, None if a is None else _p(a))
+
+    def ref_init_params(self):
+        self.lib.oracle_ref_init_params(self.h)
+
+    def train_reference_sequenced(self, u0: int = 0, u1: int | None = None):
+        self.lib.oracle_train_users_reference_sequenced(self.h, u0, self.U if u1 is None else u1)
+
+    def ref_draw_user(self, uid: int):
+        """(train items in the reference's visiting order, kept inputs in theirs, negatives) of the next user-corruption"""
+        n = int(self.row_ptr[uid + 1] - self.row_ptr[uid])
+        pos, inp, neg = np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n * self.cfg.num_neg, np.uint32)
+        n_in = C.c_uint64()
+        self.lib.oracle_ref_draw_user(self.h, uid, _p(pos), _p(inp), C.byref(n_in), _p(neg))
+        return pos, inp[:n_in.value].copy(), neg
+
+    def step_user_seq(self, uid: int, pos_seq, in_seq, neg_items):
+        p, i, n = (np.ascontiguousarray(a, dtype=np.uint32) for a in (pos_seq, in_seq, neg_items))
+        self.lib.oracle_step_user_seq(self.h, uid, _p(p), p.size, _p(i), i.size, _p(n), n.size)
+
+    def ref_rand(self) -> int:
+        return int(self.lib.oracle_ref_rand(self.h))
+
+    def ref_mt(self) -> int:
+        return int(self.lib.oracle_ref_mt(self.h))
+
+    def ref_uniform(self) -> float:
+        return float(self.lib.oracle_ref_uniform(self.h))
 
     def step_user(self, uid: int, in_items, neg_items):
         i = np.ascontiguousarray(in_items, dtype=np.uint32)

@@ -23,7 +23,10 @@
  *              B = 1 the two schedules are the same algorithm (tests assert agreement to 1e-12; only
  *              the summation order of the hidden gradient differs).
  * Randomness: include/cdae_rng.h counter streams (the reference's global mt19937_64 / rand() are
- * order-dependent and cannot be shared with a parallel implementation; see that header).
+ * order-dependent and cannot be shared with a parallel implementation; see that header).  The literal
+ * schedule can ALSO be driven with the reference's own generators in the reference's own order
+ * (oracle_ref_*: rand() from srand(1), std::mt19937_64, std::unordered_map iteration order), for a reader
+ * who can build the reference and wants to compare a run of it draw for draw.
  */
 #include <algorithm>
 #include <cmath>
@@ -31,6 +34,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <random>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -151,8 +156,15 @@ struct Oracle {
   // Optional taps (z, y per output, g per output, hg) for the known-answer fixtures.
   void train_user_literal(size_t uid, const uint32_t* in, size_t n_in, const uint32_t* neg,
                           size_t n_neg, double* tap_z, double* tap_y, double* tap_g, double* tap_hg) {
-    const uint32_t* pos = &col[row_ptr[uid]];
-    size_t n_pos = row_ptr[uid + 1] - row_ptr[uid];
+    train_user_seq(uid, &col[row_ptr[uid]], row_ptr[uid + 1] - row_ptr[uid], in, n_in, neg, n_neg, tap_z, tap_y, tap_g, tap_hg);
+  }
+  // The same step with the two container orders made explicit: `pos` = the order `for (auto& p : output_set)` visits the
+  // user's train items (cdae.hpp:225), `in` = the order `for (auto& p : input_set)` visits the kept inputs (:333 and the
+  // encode's :377).  train_user_literal passes both ascending (CSR order); the reference-sequenced mode below passes the
+  // iteration orders of the reference's std::unordered_map containers.  The orders only change rounding (every row is touched
+  // once per loop), but they decide WHICH item a dropout draw belongs to.
+  void train_user_seq(size_t uid, const uint32_t* pos, size_t n_pos, const uint32_t* in, size_t n_in, const uint32_t* neg,
+                      size_t n_neg, double* tap_z, double* tap_y, double* tap_g, double* tap_hg) {
     double sc = scale();
     std::vector<double> z(K), d(K), hg(K, 0.), grad(K);
     hidden(uid, in, n_in, sc, z.data());                                     // :207
@@ -160,8 +172,17 @@ struct Oracle {
     if (tap_z) std::memcpy(tap_z, z.data(), K * sizeof(double));
     std::vector<double> defer_g(n_pos, 0.);                                  // input_gradient, :222
     std::vector<char> is_in(n_pos, 0);
-    { size_t t = 0;                                                          // input_set.count(iid), :249
-      for (size_t p = 0; p < n_pos; ++p) { while (t < n_in && in[t] < pos[p]) ++t; is_in[p] = (t < n_in && in[t] == pos[p]); } }
+    std::vector<size_t> pos_of_in(n_in, 0);                                  // position in `pos` of every kept input
+    {                                                                        // input_set.count(iid), :249
+      std::vector<std::pair<uint32_t, size_t>> by_item(n_pos);
+      for (size_t p = 0; p < n_pos; ++p) by_item[p] = std::make_pair(pos[p], p);
+      std::sort(by_item.begin(), by_item.end());
+      for (size_t t = 0; t < n_in; ++t) {
+        auto it = std::lower_bound(by_item.begin(), by_item.end(), std::make_pair(in[t], (size_t)0));
+        pos_of_in[t] = it->second;                                           // (a kept input is one of the user's train items)
+        is_in[it->second] = 1;
+      }
+    }
     std::vector<double>& D = c.asymmetric ? V : W;
     std::vector<double>& D_ag = c.asymmetric ? V_ag : W_ag;
     for (size_t p = 0; p < n_pos; ++p) {                                     // :225-260
@@ -204,8 +225,8 @@ struct Oracle {
       uu_grad.resize(K);
       for (size_t k = 0; k < K; ++k) uu_grad[k] = Uu[uid * K + k] * c.lambda;
     }
-    for (size_t p = 0; p < n_pos; ++p) {                                     // :333-349 (input rows, CSR order)
-      if (!is_in[p]) continue;
+    for (size_t t = 0; t < n_in; ++t) {                                      // :333-349 (input rows, in `in` order)
+      const size_t p = pos_of_in[t];
       size_t jid = pos[p];
       double* row = &W[jid * K];
       for (size_t k = 0; k < K; ++k) {
@@ -232,6 +253,86 @@ struct Oracle {
         draw_negatives(seed, epoch, uid, ci, neg);                           // :217-220
         train_user_literal(uid, in.data(), in.size(), neg.data(), neg.size(), nullptr, nullptr, nullptr, nullptr);
       }
+  }
+
+  // ---- reference-SEQUENCED randomness (SURVEY.md §7 step 2 "glibc mode") -------------------------------------------
+  // The reference draws from two process-global generators: C rand() — never seeded, i.e. srand(1) — for Eigen's
+  // DMatrix::Random in reset() (cdae.hpp:112-113,116,120) and for sample_negative_item (recsys_model_base.hpp:46-57:
+  // `rand() % num_items_` until unrated), and libcf::Random::rng, a std::mt19937_64 (random.hpp:14,82), for the dropout
+  // masks (`Random::uniform() > corruption_ratio`, cdae.hpp:361-371; random.hpp:34-37: std::uniform_real_distribution<>).
+  // This mode consumes both in exactly the reference's order, through the reference's own containers
+  // (std::unordered_map<size_t,double> built by insertion as data-inl.hpp:414-429 builds it, so its iteration order — which
+  // item a draw belongs to — is the reference's when both are compiled against the same libstdc++), so that a reader who CAN
+  // build the reference (Eigen, Boost, glog, gflags) can line a run of it up with this oracle draw for draw.
+  // rand() is restated (glibc stdlib/random_r.c, TYPE_3: r[i] = r[i-3] + r[i-31], output >> 1) instead of called, so that the
+  // oracle neither depends on nor disturbs the process-global state; tests/test_oracle.py pins the restatement against this
+  // platform's rand().  Assumed, not verifiable here (no Eigen): DenseBase::Random() = -1 + 2 * rand() / RAND_MAX per
+  // coefficient (Eigen 3.x internal::random<double>), coefficients visited in storage order (row-major, mat.hpp:12).
+  struct GlibcRand {
+    uint32_t ring[31];
+    int f = 3, b = 0;
+    void seed(uint32_t s) {
+      if (s == 0) s = 1;
+      int32_t w[31];
+      w[0] = (int32_t)s;
+      for (int i = 1; i < 31; ++i) {                       // Schrage form of 16807 * w mod (2^31 - 1)
+        const int32_t hi = w[i - 1] / 127773, lo = w[i - 1] % 127773;
+        int32_t v = 16807 * lo - 2836 * hi;
+        if (v < 0) v += 2147483647;
+        w[i] = v;
+      }
+      for (int i = 0; i < 31; ++i) ring[i] = (uint32_t)w[i];
+      f = 3; b = 0;
+      for (int i = 0; i < 310; ++i) next();                // glibc discards 10 * degree outputs
+    }
+    uint32_t next() {
+      ring[f] += ring[b];
+      const uint32_t out = ring[f] >> 1;
+      if (++f == 31) f = 0;
+      if (++b == 31) b = 0;
+      return out;
+    }
+  };
+  GlibcRand ref_rand;
+  std::mt19937_64 ref_mt;
+  std::vector<uint32_t> ref_insertion;      // per user (row_ptr layout) its items in data order; empty: ascending
+  void ref_seed(uint64_t mt_seed, uint32_t rand_seed) { ref_mt.seed(mt_seed); ref_rand.seed(rand_seed); }
+  double ref_uniform() { std::uniform_real_distribution<> dist(0., 1.); return dist(ref_mt); }     // random.hpp:34-37
+  void ref_item_set(size_t uid, std::unordered_map<size_t, double>& m) const {                      // data-inl.hpp:420-426
+    const uint32_t* items = ref_insertion.empty() ? &col[row_ptr[uid]] : &ref_insertion[row_ptr[uid]];
+    const size_t n = row_ptr[uid + 1] - row_ptr[uid];
+    std::unordered_map<size_t, double> tmp;
+    for (size_t p = 0; p < n; ++p) tmp.insert(std::make_pair((size_t)items[p], 1.));
+    m = std::move(tmp);
+  }
+  // one user-corruption's draws, in the reference's order: the mask first (train_one_iteration, cdae.hpp:142), then the
+  // negatives (train_one_user_corruption, :217-220)
+  void ref_draw_user(const std::unordered_map<size_t, double>& item_set, std::vector<uint32_t>& pos_seq,
+                     std::vector<uint32_t>& in_seq, std::vector<uint32_t>& neg) {
+    std::unordered_map<size_t, double> rets;                                                        // cdae.hpp:363-370
+    rets.reserve((size_t)(item_set.size() * (1. - c.corruption_ratio)));
+    for (auto& p : item_set) if (ref_uniform() > c.corruption_ratio) rets.insert(p);
+    pos_seq.clear(); in_seq.clear();
+    for (auto& p : item_set) pos_seq.push_back((uint32_t)p.first);
+    for (auto& p : rets) in_seq.push_back((uint32_t)p.first);
+    neg.resize(item_set.size() * c.num_neg);                                                        // :217
+    for (size_t i = 0; i < neg.size(); ++i) {                                                       // recsys_model_base.hpp:46-57
+      size_t it;
+      do { it = (size_t)ref_rand.next() % I; } while (item_set.count(it));
+      neg[i] = (uint32_t)it;
+    }
+  }
+  void train_users_reference_sequenced(size_t u0, size_t u1) {
+    std::unordered_map<size_t, double> item_set;
+    std::vector<uint32_t> pos_seq, in_seq, neg;
+    for (size_t uid = u0; uid < u1; ++uid) {                                                        // cdae.hpp:137
+      ref_item_set(uid, item_set);
+      for (uint32_t ci = 0; ci < c.num_corruptions; ++ci) {                                         // :141
+        ref_draw_user(item_set, pos_seq, in_seq, neg);
+        train_user_seq(uid, pos_seq.data(), pos_seq.size(), in_seq.data(), in_seq.size(), neg.data(), neg.size(),
+                       nullptr, nullptr, nullptr, nullptr);
+      }
+    }
   }
 
   // ---- the HIP path's schedule (see file header) ----
@@ -561,6 +662,44 @@ void oracle_init_params(void* h, uint64_t seed) {
   if (o->c.linear_function) { o->Uu.assign(o->U * K, 1.); o->Uu_ag.assign(o->U * K, 0.0001); }   // :130-133
   else { o->Uu.clear(); o->Uu_ag.clear(); }
 }
+
+// ---- reference-sequenced mode (see Oracle::GlibcRand) ----
+void oracle_ref_seed(void* h, uint64_t mt_seed, uint32_t rand_seed) { ((Oracle*)h)->ref_seed(mt_seed, rand_seed); }
+// the items of every user in DATA order (what decides the reference's hashtable iteration order); NULL = ascending
+void oracle_ref_set_insertion_order(void* h, const uint32_t* items) {
+  Oracle* o = (Oracle*)h;
+  if (items) o->ref_insertion.assign(items, items + o->col.size()); else o->ref_insertion.clear();
+}
+// reset() with Eigen's Random = rand(): W, [V], [Wu] in that order (cdae.hpp:113,116,120), row-major
+void oracle_ref_init_params(void* h) {
+  Oracle* o = (Oracle*)h;
+  oracle_init_params(h, 0);                                                  // sizes, accumulators, biases
+  const double init_scale = 4. * std::sqrt(6. / (double)(o->I + o->K));      // :112
+  auto fill = [&](std::vector<double>& m) {
+    for (double& v : m) v = (-1. + 2. * (double)o->ref_rand.next() / 2147483647.) * init_scale;
+  };
+  fill(o->W);
+  if (o->c.asymmetric) fill(o->V);
+  if (o->c.user_factor) fill(o->Wu);
+}
+void oracle_train_users_reference_sequenced(void* h, uint64_t u0, uint64_t u1) { ((Oracle*)h)->train_users_reference_sequenced(u0, u1); }
+// advance the generators by one user-corruption and return what the step would have used (tests): capacities n_u, n_u, n_u * num_neg
+void oracle_ref_draw_user(void* h, uint64_t uid, uint32_t* pos_seq, uint32_t* in_seq, uint64_t* n_in, uint32_t* neg) {
+  Oracle* o = (Oracle*)h;
+  std::unordered_map<size_t, double> item_set;
+  std::vector<uint32_t> p, i, n;
+  o->ref_item_set(uid, item_set);
+  o->ref_draw_user(item_set, p, i, n);
+  std::copy(p.begin(), p.end(), pos_seq); std::copy(i.begin(), i.end(), in_seq); std::copy(n.begin(), n.end(), neg);
+  *n_in = i.size();
+}
+void oracle_step_user_seq(void* h, uint64_t uid, const uint32_t* pos, uint64_t n_pos, const uint32_t* in, uint64_t n_in,
+                          const uint32_t* neg, uint64_t n_neg) {
+  ((Oracle*)h)->train_user_seq(uid, pos, n_pos, in, n_in, neg, n_neg, nullptr, nullptr, nullptr, nullptr);
+}
+uint32_t oracle_ref_rand(void* h) { return ((Oracle*)h)->ref_rand.next(); }
+uint64_t oracle_ref_mt(void* h) { return ((Oracle*)h)->ref_mt(); }
+double oracle_ref_uniform(void* h) { return ((Oracle*)h)->ref_uniform(); }
 
 size_t oracle_param_size(void* h, uint32_t which) { auto* p = param((Oracle*)h, which); return p ? p->size() : 0; }
 int oracle_get_param(void* h, uint32_t which, double* out, size_t n) {

@@ -18,6 +18,7 @@ DEFINE_int32(num_dim, 8, "latent dimensions");
 DEFINE_int32(iters, 2, "epochs");
 DEFINE_string(loss_type, "CE", "SQUARE or CE");
 DEFINE_double(cratio, 0.5, "corruption ratio");
+DEFINE_string(csr_only, "", "load this Data cache, time Data::to_csr (what a model's reset() derives for the device) and exit");
 DEFINE_string(dump_csr, "", "write the train / test rows Data::to_csr produces to <path>.train / <path>.test (int64 rows+1, then uint32 cols)");
 
 int main(int argc, char* argv[]) {
@@ -38,6 +39,18 @@ int main(int argc, char* argv[]) {
   CHECK(r[2] > 0.199 && r[2] < 0.201) << r[2];
   CHECK(r[5] > 0.666 && r[5] < 0.667) << r[5];
 
+  if (!FLAGS_csr_only.empty()) {                  // tools/ingest_bench.py: the host part of reset() at scale
+    Timer t_load;
+    Data d;
+    load(FLAGS_csr_only, d);
+    const double load_s = t_load.elapsed();
+    Timer t_csr;
+    std::vector<int64_t> row_ptr; std::vector<uint32_t> col;
+    d.to_csr(0, 1, row_ptr, col);
+    LOG(INFO) << "csr_only: " << d.size() << " ratings, " << row_ptr.size() - 1 << " rows, " << col.size() << " unique; load "
+              << load_s << " s, to_csr " << t_csr.elapsed() << " s";
+    return 0;
+  }
   if (FLAGS_input_file.empty()) { LOG(INFO) << "host layer OK (no input file given)"; return 0; }
 
   auto parser = [&](const std::string& line) {
