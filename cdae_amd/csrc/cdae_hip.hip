@@ -207,6 +207,17 @@ struct cdae_hip {
   float* d_Hsum = nullptr; float* d_hsum_eval = nullptr; uint32_t* d_iota_eval = nullptr; float* d_rec_score = nullptr; size_t rec_score_cap = 0;
   uint32_t hsum_eval_cap = 0;
   uint64_t fs_prepped = 0;              // item-sharded training: batches whose example lists have been prepared (buffer set = parity)
+  // item shard: users [own_u0, own_u1) keep their private rows (Wu, Wu_ag, Uu, Uu_ag) HERE, table row 0 = user own_u0 (SURVEY.md
+  // §8(e): the user node is sharded by user; the rows of a batch's users reach the other shards through the input-sum all-reduce)
+  uint64_t own_u0 = 0, own_u1 = ~0ull;
+  uint64_t wu_rows() const { return item_shard ? std::min<uint64_t>(own_u1, U) - std::min<uint64_t>(own_u0, U) : U; }
+  // item shard, SAMPLED decode: the WHOLE train rows with global item ids — negatives are drawn from all I_global items and
+  // rejected against the whole row, the example list keeps the single-GPU layout (work units over the whole rows)
+  const int64_t* g_row_ptr_src = nullptr; const uint32_t* g_col_src = nullptr;   // (set_item_shard_global -> the next set_interactions)
+  std::vector<int64_t> h_grow_ptr;
+  std::vector<uint32_t> h_gunit_ptr;
+  int64_t* d_grow_ptr = nullptr; uint32_t* d_gcol = nullptr; uint32_t* d_gunit_ptr = nullptr; uint32_t* d_gunit_user = nullptr;
+  bool shard_sampled() const { return item_shard && !cfg.full_output; }
 
   uint64_t seq = 0;                     // batches enqueued so far; batch q uses example-buffer set q % NSETS
   // sets (seq + t) % NSETS, t < pre_n, already hold (or have queued) the prepared batches pre[t] (cdae_hip_prefetch_users)
@@ -352,7 +363,8 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
-                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of};
+                   (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
+                   (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -374,6 +386,8 @@ template <class T> int dev_alloc(T** p, size_t n) {
 struct Batch { uint64_t s0; uint32_t nb; uint32_t cidx; uint64_t E; };
 
 inline uint32_t units_of(const cdae_hip* h, const Batch& b) { return h->h_unit_ptr[b.s0 + b.nb] - h->h_unit_ptr[b.s0]; }
+// item shard, sampled decode: units over the WHOLE rows (sample_kernel, hidden_gather_kernel)
+inline uint32_t gunits_of(const cdae_hip* h, const Batch& b) { return h->h_gunit_ptr[b.s0 + b.nb] - h->h_gunit_ptr[b.s0]; }
 
 // K1 + sort on the prep stream into example-buffer set `b`
 // lane 1: the second prep stream with the second half of the sort workspace (two batches are prepared side by side)
@@ -386,7 +400,8 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   Prof pr;
   HIPCHK(hipStreamWaitEvent(st, x.released, 0));               // the batch that last used this set is done with it
   CHK(pr.begin(h, F_SAMPLE, st, prof_q));
-  const uint32_t n_units = units_of(h, bt);
+  const bool shs = h->shard_sampled();
+  const uint32_t n_units = shs ? gunits_of(h, bt) : units_of(h, bt);
   if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
     HIPCHK(hipMemsetAsync(x.seg, 0, 4 * (size_t)I * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), st));
@@ -394,6 +409,12 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
     hipLaunchKernelGGL(mf_sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->mf == 2 ? 1u : 0u, h->d_row_ptr, h->d_col,
                        h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, seed, epoch, x.item, x.val, x.key16, x.seg, 2u * I, x.dup_count,
                        x.dup_of_ex, h->d_unit_user);
+  } else if (shs) {
+    // item shard, sampled decode: the single-GPU example list of the batch from the WHOLE rows, other shards' examples VOID
+    hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_grow_ptr, h->d_gcol,
+                       h->d_gunit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
+                       x.seg, 4u * I, x.dup_count, x.dup_of_ex, h->d_gunit_user,
+                       (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)h->item0, I, (uint32_t)h->I_global);
   } else
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
@@ -426,13 +447,13 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint16_t>, seg_grid, dim3(256), 0, st, x.sorted_key16, x.sorted_val, (uint32_t)bt.E,
                        x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes,
-                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I);
+                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, shs ? I : 0xFFFFFFFFu);
   } else {
     HIPCHK(rocprim::radix_sort_pairs(sort_tmp, h->sort_tmp_bytes, x.item, x.sorted_item, x.val, x.sorted_val,
                                      (size_t)bt.E, 0u, (unsigned)h->sort_bits, st));
     hipLaunchKernelGGL(segment_kernel<uint32_t>, seg_grid, dim3(256), 0, st, x.sorted_item, x.sorted_val, (uint32_t)bt.E,
                        x.seg, x.seg + I, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex, h->dup_stripes,
-                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I);
+                       (const uint32_t*)h->d_rank_of, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, shs ? I : 0xFFFFFFFFu);
   }
   CHK(pr.end());
   if (h->cfg.full_output && h->d_bits_train) {
@@ -448,40 +469,14 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   return 0;
 }
 
-// K2..K5 on the main stream from example-buffer set `b`.
-// explicit_in != nullptr: single user whose example list (already sorted into set b) and input set come from the caller
-int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch,
-                  const uint32_t* explicit_in = nullptr, uint32_t n_explicit = 0) {
+// K3 on the main stream: the decode of example-buffer set `x` over this handle's item rows (shared by the single-handle step and
+// the sampled item-shard step)
+int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x) {
   using namespace cdae;
-  cdae_hip::ExBuf& x = h->ex[b];
   hipStream_t st = h->stream;
-  const uint32_t I = (uint32_t)h->I, nb = bt.nb;
-  const uint64_t s0 = bt.s0;
+  const uint32_t I = (uint32_t)h->I;
   const dim3 blk(256);
-  const dim3 grid_users((nb + 3) / 4), grid_rows((I + 3) / 4);
-  Prof pr;
-
-  h->hp.trace_odd = (uint32_t)(h->seq & 1);
-  CHK(pr.begin(h, F_ENCODE, st));
-  // explicit mode: one user, one unit (the caller's lists need not follow the num_neg proportion)
-  const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
-  const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
-  const dim3 grid_units((n_units + 3) / 4);
-  if (!explicit_in && !h->encode_two_launches && nb <= h->encode_users_max) {
-    // one launch: a workgroup per user (encode_users_kernel)
-    DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
-                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
-  } else {
-    DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
-                (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
-                explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
-    DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
-  }
-  CHK(pr.end());
-
-  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
-  CHK(pr.begin(h, F_DECODE, st));
+  const dim3 grid_rows((I + 3) / 4);
 #define DECODE_TAIL h->d_item_order, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, x.sorted_val, h->d_Z, h->dec(), h->dec_ag(), \
                     h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_HG, h->d_G, h->d_D0, h->d_touched, x.dup_of_pos, h->d_dup_corr
 #define DECODE_ARGS h->hp, DECODE_TAIL
@@ -532,6 +527,46 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
 #undef DECODE_LA
 #undef DECODE_NI
 #undef DECODE_ARGS
+#undef DECODE_TAIL
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// K2..K5 on the main stream from example-buffer set `b`.
+// explicit_in != nullptr: single user whose example list (already sorted into set b) and input set come from the caller
+int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch,
+                  const uint32_t* explicit_in = nullptr, uint32_t n_explicit = 0) {
+  using namespace cdae;
+  cdae_hip::ExBuf& x = h->ex[b];
+  hipStream_t st = h->stream;
+  const uint32_t I = (uint32_t)h->I, nb = bt.nb;
+  const uint64_t s0 = bt.s0;
+  const dim3 blk(256);
+  const dim3 grid_users((nb + 3) / 4), grid_rows((I + 3) / 4);
+  Prof pr;
+
+  h->hp.trace_odd = (uint32_t)(h->seq & 1);
+  CHK(pr.begin(h, F_ENCODE, st));
+  // explicit mode: one user, one unit (the caller's lists need not follow the num_neg proportion)
+  const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
+  const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
+  const dim3 grid_units((n_units + 3) / 4);
+  if (!explicit_in && !h->encode_two_launches && nb <= h->encode_users_max) {
+    // one launch: a workgroup per user (encode_users_kernel)
+    DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
+                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  } else {
+    DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
+                (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
+                explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
+    DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
+                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  }
+  CHK(pr.end());
+
+  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  CHK(pr.begin(h, F_DECODE, st));
+  CHK(launch_decode(h, x));
   CHK(pr.end());
 
   CHK(pr.begin(h, F_HIDDEN, st));
@@ -767,6 +802,7 @@ int compute_batch_mf(cdae_hip* h, int b, const Batch& bt) {
 int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, int mode, uint32_t stream_id,
                  uint32_t cidx, uint64_t seed, uint32_t epoch, uint32_t n_units_list = 0, float* z_out = nullptr,
                  float* hpart = nullptr, uint32_t hpart_cap = 0) {
+  if (h->item_shard) return fail("an item shard encodes in phases under the multi-shard handle (its rows and its users' private rows are partial)");
   const uint32_t n_units = d_uids ? n_units_list : h->h_unit_ptr[u0 + nb] - h->h_unit_ptr[u0];
   const uint32_t* uptr = d_uids ? h->d_uptr_tmp : h->d_unit_ptr + u0;
   if (!hpart) { hpart = h->d_Hpart; hpart_cap = h->unit_cap; }
@@ -783,6 +819,10 @@ int encode_chunk(cdae_hip* h, const uint32_t* d_uids, uint64_t u0, uint32_t nb, 
 // Evaluation workspace (data_loss, recommend): z rows and encode partial sums for up to EVAL_CHUNK users per launch — the
 // training workspace holds only batch_users of them, far too few wavefronts to fill the chip.
 constexpr uint32_t EVAL_CHUNK = 32768;
+// item shard: blocks of [users x Kp] floats in the input-sum all-reduce buffer: the input sums, then — the user node being sharded by
+// user — the batch's Wu rows (user_factor) and Uu rows (linear_function) contributed by their owner
+constexpr uint32_t SHARD_BLOCKS = 3;
+inline uint32_t shard_blocks_of(const cdae_hip* h) { return 1u + (h->cfg.user_factor ? 1u : 0u) + (h->cfg.linear_function ? 1u : 0u); }
 int ensure_eval_ws(cdae_hip* h, uint32_t users, uint32_t units) {
   if (h->eval_cap < users) {
     if (h->d_zeval) HIPCHK(hipFree(h->d_zeval));
@@ -803,13 +843,14 @@ int copy_param_out(cdae_hip* h, uint32_t which, float* host, size_t count) {
   float* d = h->P(which);
   if (!d) return count == 0 ? 0 : fail("parameter %u is not allocated in this configuration", which);
   const bool vec = (which == CDAE_P_BP || which == CDAE_P_BP_AG || which == CDAE_P_UB || which == CDAE_P_UB_AG);
-  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
+  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? (size_t)h->wu_rows() : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
   if (vec) {
     const size_t want = (which == CDAE_P_UB || which == CDAE_P_UB_AG) ? h->U : h->I;
     if (count != want) return fail("parameter %u has %llu elements, got %zu", which, (unsigned long long)want, count);
     HIPCHK(hipMemcpyAsync(host, d, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   } else {
     if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
+    if (rows == 0) return 0;
     HIPCHK(hipMemcpy2DAsync(host, h->K * sizeof(float), d, h->Kp * sizeof(float), h->K * sizeof(float), rows,
                             hipMemcpyDeviceToHost, h->stream));
   }
@@ -894,6 +935,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hp.linear = cfg->linear; hp.tanh_act = cfg->tanh_act; hp.linear_function = cfg->linear_function;
   hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
   hp.uid_offset = 0; hp.num_items = 0; hp.K = h->K; hp.Kp = h->Kp;
+  hp.own_u0 = 0; hp.own_u1 = ~0ull;
   if (std::getenv("CDAE_WAVE_TRACE")) {      // developer aid (tools/wave_trace.py): the last training batch's wavefront timeline
     if (hipMalloc((void**)&hp.trace, 4 * cdae::TRACE_CAP * sizeof(unsigned long long)) != hipSuccess) hp.trace = nullptr;
     if (hp.trace) (void)hipMemset(hp.trace, 0, 4 * cdae::TRACE_CAP * sizeof(unsigned long long));
@@ -960,7 +1002,8 @@ int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t offset) {
 
 int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64_t* row_ptr, const uint32_t* col) {
   if (!h || !row_ptr || (!col && U && row_ptr[U])) return fail("null argument");
-  if (h->item_shard && !h->cfg.full_output) return fail("the item-sharded layout exists for the full-output decode only");
+  if (h->shard_sampled() && (!h->g_row_ptr_src || !h->g_col_src)) return fail("an item shard of the sampled decode needs the whole rows (set_item_shard_global)");
+  if (h->shard_sampled() && h->mf) return fail("the item-sharded layout is CDAE's");
   if (U == 0 || I == 0) return fail("empty interaction matrix (%llu users, %llu items)", (unsigned long long)U, (unsigned long long)I);
   if (I >= (1ull << 30) || U >= (1ull << 30)) return fail("at most 2^30 users and items");
   if (row_ptr[0] != 0) return fail("row_ptr[0] must be 0");
@@ -990,6 +1033,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     h->B = cdae_hip_default_batch_users(U);
   }
   h->U = U; h->I = I; h->hp.num_items = (uint32_t)I;
+  if (h->item_shard) {
+    if (h->own_u1 == ~0ull) { h->own_u0 = 0; h->own_u1 = U; }
+    if (h->own_u0 > h->own_u1 || h->own_u1 > U) return fail("owned user range [%llu, %llu) outside the %llu users", (unsigned long long)h->own_u0, (unsigned long long)h->own_u1, (unsigned long long)U);
+    h->hp.own_u0 = h->own_u0; h->hp.own_u1 = h->own_u1;
+  }
   {
     // Work-unit size of the user-parallel kernels (sample, encode, hidden gather, data_loss: one wavefront per unit).  Those
     // launches are latency-bound per wavefront — a unit's rows are gathered a few at a time — so a batch should offer the chip
@@ -1041,15 +1089,16 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   h->n_shared = o;
   CHK(dev_alloc(&h->d_shared, h->n_shared));
   HIPCHK(hipMemset(h->d_shared, 0, h->n_shared * sizeof(float)));
-  h->cnt[CDAE_P_WU] = h->cnt[CDAE_P_WU_AG] = (size_t)U * h->Kp;
-  CHK(dev_alloc(&h->d_Wu, (size_t)U * h->Kp));
-  CHK(dev_alloc(&h->d_Wu_ag, (size_t)U * h->Kp));
-  HIPCHK(hipMemset(h->d_Wu, 0, (size_t)U * h->Kp * sizeof(float)));
-  HIPCHK(hipMemset(h->d_Wu_ag, 0, (size_t)U * h->Kp * sizeof(float)));
+  const size_t WR = (size_t)h->wu_rows();                   // private rows held here: every user, or an item shard's own user range
+  h->cnt[CDAE_P_WU] = h->cnt[CDAE_P_WU_AG] = WR * h->Kp;
+  CHK(dev_alloc(&h->d_Wu, WR * h->Kp));
+  CHK(dev_alloc(&h->d_Wu_ag, WR * h->Kp));
+  HIPCHK(hipMemset(h->d_Wu, 0, std::max<size_t>(WR * h->Kp, 1) * sizeof(float)));
+  HIPCHK(hipMemset(h->d_Wu_ag, 0, std::max<size_t>(WR * h->Kp, 1) * sizeof(float)));
   if (h->cfg.linear_function) {
-    h->cnt[CDAE_P_UU] = h->cnt[CDAE_P_UU_AG] = (size_t)U * h->Kp;
-    CHK(dev_alloc(&h->d_Uu, (size_t)U * h->Kp));
-    CHK(dev_alloc(&h->d_Uu_ag, (size_t)U * h->Kp));
+    h->cnt[CDAE_P_UU] = h->cnt[CDAE_P_UU_AG] = WR * h->Kp;
+    CHK(dev_alloc(&h->d_Uu, WR * h->Kp));
+    CHK(dev_alloc(&h->d_Uu_ag, WR * h->Kp));
   }
 
   // batch workspace sized for the largest batch of B consecutive users
@@ -1061,12 +1110,39 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   }
   h->ex_per_pos = h->mf == 2 ? 2u * h->hp.num_neg : 1u + h->hp.num_neg;
   h->Ecap = emax * h->ex_per_pos;
+  h->h_grow_ptr.clear(); h->h_gunit_ptr.clear();
+  if (h->shard_sampled()) {
+    // the example list of a batch is the single-GPU one (every position of the WHOLE rows, every negative draw), entries of other
+    // shards' rows VOID: capacity, units and offsets come from the whole rows
+    const int64_t* grp = h->g_row_ptr_src;
+    const uint32_t* gcl = h->g_col_src;
+    h->g_row_ptr_src = nullptr; h->g_col_src = nullptr;
+    if (grp[0] != 0) return fail("whole-row row_ptr[0] must be 0");
+    h->h_grow_ptr.assign(grp, grp + U + 1);
+    uint64_t gmax = 0;
+    for (uint64_t s0 = 0; s0 < U; ++s0) gmax = std::max<uint64_t>(gmax, (uint64_t)(grp[std::min<uint64_t>(U, s0 + B)] - grp[s0]));
+    h->Ecap = gmax * h->ex_per_pos;
+    const size_t gnnz = (size_t)grp[U];
+    CHK(dev_alloc(&h->d_grow_ptr, U + 1)); CHK(dev_alloc(&h->d_gcol, gnnz));
+    HIPCHK(hipMemcpy(h->d_grow_ptr, grp, (U + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_gcol, gcl, gnnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->h_gunit_ptr.assign(U + 1, 0u);
+    for (uint64_t u = 0; u < U; ++u)
+      h->h_gunit_ptr[u + 1] = h->h_gunit_ptr[u] + (uint32_t)((grp[u + 1] - grp[u] + h->hp.unit_pos - 1) / h->hp.unit_pos);
+    CHK(dev_alloc(&h->d_gunit_ptr, U + 1));
+    HIPCHK(hipMemcpy(h->d_gunit_ptr, h->h_gunit_ptr.data(), (U + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<uint32_t> guser(h->h_gunit_ptr[U]);
+    for (uint64_t u = 0; u < U; ++u)
+      for (uint32_t g = h->h_gunit_ptr[u]; g < h->h_gunit_ptr[u + 1]; ++g) guser[g] = (uint32_t)u;
+    CHK(dev_alloc(&h->d_gunit_user, std::max<size_t>(guser.size(), 1)));
+    HIPCHK(hipMemcpy(h->d_gunit_user, guser.data(), guser.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   h->seq = 0; h->pre_n = 0;
   // opt-in (CDAE_SORT_COUNTING=1): measured slower than rocPRIM's onesweep beside the training kernels (profiles/r02_*)
   // opt-in (CDAE_SORT_TILE=1).  Measured (profiles/r02_tile_sort.txt): the four launches take 72 us against rocPRIM's ten launches / ~100 us
   // per batch on the prep stream, yet the training step is the same within 1 % at 256 users and 3 % slower at 512 — the prep
   // stream runs beside the training kernels, and what counts there is how much it disturbs them, not its own length
-  h->counting_sort = I <= cdae::TILE_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_TILE") != nullptr;
+  h->counting_sort = I <= cdae::TILE_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_TILE") != nullptr && !h->shard_sampled();
   h->h_unit_ptr.assign(U + 1, 0u);
   for (uint64_t u = 0; u < U; ++u)
     h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + h->hp.unit_pos - 1) / h->hp.unit_pos);
@@ -1084,6 +1160,9 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     for (uint32_t i = 0; i < B; ++i) top += per[i];
     h->unit_cap = (uint32_t)std::max<uint64_t>(h->unit_cap, top);
   }
+  if (h->shard_sampled())                                   // hidden_gather's partial rows are per unit of the WHOLE rows
+    for (uint64_t s0 = 0; s0 < U; ++s0)
+      h->unit_cap = std::max(h->unit_cap, h->h_gunit_ptr[std::min<uint64_t>(U, s0 + B)] - h->h_gunit_ptr[s0]);
   CHK(dev_alloc(&h->d_unit_ptr, U + 1));
   HIPCHK(hipMemcpy(h->d_unit_ptr, h->h_unit_ptr.data(), (U + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
   {
@@ -1112,7 +1191,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       CHK(dev_alloc(&b.rank, (size_t)I)); CHK(dev_alloc(&b.bucketed, h->Ecap));
       CHK(dev_alloc(&b.tile_hist, (size_t)((h->Ecap + cdae::TILE_EX - 1) / cdae::TILE_EX + 1) * I));
       CHK(dev_alloc(&b.block_total, 128));
-    } else if (I <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }
+    } else if (I + (h->shard_sampled() ? 1u : 0u) <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }   // (a sampled item shard sorts one more key: VOID = I)
     if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, sync_event_flags())); HIPCHK(hipEventCreateWithFlags(&b.released, sync_event_flags())); }
     HIPCHK(hipEventRecord(b.released, h->stream));
   }
@@ -1137,7 +1216,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     HIPCHK(hipMemset(h->d_ub, 0, (size_t)U * sizeof(float)));
   }
   h->sort_bits = 1;
-  while ((1ull << h->sort_bits) < I) h->sort_bits++;
+  while ((1ull << h->sort_bits) < I + (h->shard_sampled() ? 1u : 0u)) h->sort_bits++;
   h->sort_tmp_bytes = 0;
   HIPCHK(rocprim::radix_sort_pairs(nullptr, h->sort_tmp_bytes, h->ex[0].item, h->ex[0].sorted_item, h->ex[0].val,
                                    h->ex[0].sorted_val, (size_t)std::max<uint64_t>(h->Ecap, 1), 0u, (unsigned)h->sort_bits, h->stream));
@@ -1160,11 +1239,6 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
     CHK(dev_alloc(&h->d_dD, (size_t)h->Ip * h->Kp));
     {
-      std::vector<uint32_t> iota((size_t)std::max<uint32_t>(B, h->item_shard ? EVAL_CHUNK : 0u) + 1);
-      std::iota(iota.begin(), iota.end(), 0u);
-      CHK(dev_alloc(&h->d_iota, iota.size()));
-      HIPCHK(hipMemcpy(h->d_iota, iota.data(), iota.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      if (h->item_shard) CHK(dev_alloc(&h->d_Hsum, (size_t)B * h->Kp));
       h->bits_stride = (size_t)B * ((I + 31) / 32);
       CHK(dev_alloc(&h->d_bits_train, cdae_hip::NSETS * h->bits_stride));     // one per example-buffer set
       // item slices of the fused decode: slices x Bp/128 workgroups ~ one per CU (measured best at B = 2048: 16 slices; every
@@ -1173,6 +1247,14 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>({32u, tiles, (256u + ublocks - 1) / ublocks}));
       if (const char* ev = std::getenv("CDAE_FULL_SLICES")) h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)std::atoi(ev)));
     }
+  }
+  if (h->cfg.full_output || h->item_shard) {
+    std::vector<uint32_t> iota((size_t)std::max<uint32_t>(B, h->item_shard ? EVAL_CHUNK : 0u) + 1);
+    std::iota(iota.begin(), iota.end(), 0u);
+    CHK(dev_alloc(&h->d_iota, iota.size()));
+    HIPCHK(hipMemcpy(h->d_iota, iota.data(), iota.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // item shard: [input sums | gathered Wu rows | gathered Uu rows] of a batch, one all-reduce buffer
+    if (h->item_shard) CHK(dev_alloc(&h->d_Hsum, (size_t)SHARD_BLOCKS * B * h->Kp));
   }
   {
     size_t rows = 8 * (size_t)h->gather_halves * h->unit_cap;
@@ -1189,14 +1271,14 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   // weights 0, accumulators 1e-4 (cdae.hpp:114,...), accumulator pad lanes 1: a well-defined state even
   // before init_params / set_param (a zero accumulator pad would make beta == 0 divide 0 by 0)
   auto fillm = [&](float* M, size_t rows, uint32_t K, uint32_t Kp, float v, float pad) {
-    if (M) hipLaunchKernelGGL(cdae::fill_matrix_kernel, dim3((uint32_t)((rows * Kp + 255) / 256)), dim3(256), 0, h->stream, M, rows,
-                              K, Kp, v, pad);
+    if (M && rows) hipLaunchKernelGGL(cdae::fill_matrix_kernel, dim3((uint32_t)((rows * Kp + 255) / 256)), dim3(256), 0, h->stream, M, rows,
+                                      K, Kp, v, pad);
   };
   fillm(h->P(CDAE_P_W_AG), I, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_V_AG), I, h->K, h->Kp, 1e-4f, 1.f);
-  fillm(h->d_Wu_ag, U, h->K, h->Kp, 1e-4f, 1.f);
-  fillm(h->d_Uu, U, h->K, h->Kp, 1.f, 0.f);                 // cdae.hpp:131-132
-  fillm(h->d_Uu_ag, U, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->d_Wu_ag, WR, h->K, h->Kp, 1e-4f, 1.f);
+  fillm(h->d_Uu, WR, h->K, h->Kp, 1.f, 0.f);                // cdae.hpp:131-132
+  fillm(h->d_Uu_ag, WR, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f, 1.f);
   fillm(h->P(CDAE_P_BP_AG), I, 1, 1, 1e-4f, 1.f);
   fillm(h->d_ub_ag, U, 1, 1, 1e-4f, 1.f);
@@ -1234,13 +1316,15 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
   }
   init(h->P(CDAE_P_W), h->I, CDAE_P_W, h->item0); fill(h->P(CDAE_P_W_AG), h->I, h->K, h->Kp, 1e-4f);     // :113-114
   if (h->cfg.asymmetric) { init(h->P(CDAE_P_V), h->I, CDAE_P_V, h->item0); fill(h->P(CDAE_P_V_AG), h->I, h->K, h->Kp, 1e-4f); }   // :115-118
-  if (h->cfg.user_factor) { init(h->d_Wu, h->U, CDAE_P_WU, h->uid_offset); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }   // :119-122
-  else { fill(h->d_Wu, h->U, h->K, h->Kp, 0.f); fill(h->d_Wu_ag, h->U, h->K, h->Kp, 1e-4f); }
+  const size_t WR = (size_t)h->wu_rows();                   // (an item shard: its own user range, rows keyed by global user id)
+  const uint64_t wu_row0 = h->uid_offset + (h->item_shard ? h->own_u0 : 0);
+  if (h->cfg.user_factor && WR) { init(h->d_Wu, WR, CDAE_P_WU, wu_row0); fill(h->d_Wu_ag, WR, h->K, h->Kp, 1e-4f); }   // :119-122
+  else if (WR) { fill(h->d_Wu, WR, h->K, h->Kp, 0.f); fill(h->d_Wu_ag, WR, h->K, h->Kp, 1e-4f); }
   fill(h->P(CDAE_P_B), 1, h->K, h->Kp, 0.f); fill(h->P(CDAE_P_B_AG), 1, h->K, h->Kp, 1e-4f);    // :123-124
   fill(h->P(CDAE_P_BP), h->I, 1, 1, 0.f); fill(h->P(CDAE_P_BP_AG), h->I, 1, 1, 1e-4f);          // :125-126
-  if (h->cfg.linear_function) {                                                                 // :130-133
-    hipLaunchKernelGGL(fill_matrix_kernel, blocks(h->U * h->Kp), dim3(256), 0, h->stream, h->d_Uu, h->U, h->K, h->Kp, 1.f, 0.f);
-    fill(h->d_Uu_ag, h->U, h->K, h->Kp, 1e-4f);
+  if (h->cfg.linear_function && WR) {                                                           // :130-133
+    hipLaunchKernelGGL(fill_matrix_kernel, blocks(WR * h->Kp), dim3(256), 0, h->stream, h->d_Uu, WR, h->K, h->Kp, 1.f, 0.f);
+    fill(h->d_Uu_ag, WR, h->K, h->Kp, 1e-4f);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1260,8 +1344,9 @@ int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t 
     HIPCHK(hipMemcpy(d, host, count * sizeof(float), hipMemcpyHostToDevice));
     return 0;
   }
-  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? h->U : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
+  const size_t rows = (which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG) ? (size_t)h->wu_rows() : ((which == CDAE_P_B || which == CDAE_P_B_AG) ? 1 : h->I);
   if (count != rows * h->K) return fail("parameter %u has %zu elements, got %zu", which, rows * h->K, count);
+  if (rows == 0) return 0;
   const bool is_acc = (which & 1u) != 0u;                 // odd ids are the *_AG accumulators: pad lanes stay 1
   hipLaunchKernelGGL(cdae::fill_matrix_kernel, dim3((uint32_t)((rows * h->Kp + 255) / 256)), dim3(256), 0, h->stream, d, rows,
                      h->K, h->Kp, 0.f, is_acc ? 1.f : 0.f);
@@ -2042,10 +2127,22 @@ int private_penalty(cdae_hip_t* h, double* out) {
 // ---- item-sharded layout: phases of a full-output batch and of the evaluation passes (cdae_internal.hpp) ---------------
 int set_item_shard(cdae_hip_t* h, uint64_t item0, uint64_t num_items_global) {
   if (!h) return fail("null handle");
-  if (!h->cfg.full_output) return fail("the item-sharded layout exists for the full-output decode only");
+  if (h->mf) return fail("the item-sharded layout is CDAE's");
   h->item_shard = true; h->item0 = item0; h->I_global = num_items_global;
   return 0;
 }
+int set_item_shard_owner(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end) {
+  if (!h || !h->item_shard) return fail("set_item_shard must be called first");
+  if (u_begin > u_end) return fail("bad owned user range");
+  h->own_u0 = u_begin; h->own_u1 = u_end;
+  return 0;
+}
+int set_item_shard_global(cdae_hip_t* h, const int64_t* row_ptr, const uint32_t* col) {
+  if (!h || !h->item_shard) return fail("set_item_shard must be called first");
+  h->g_row_ptr_src = row_ptr; h->g_col_src = col;
+  return 0;
+}
+uint32_t shard_blocks(const cdae_hip_t* h) { return shard_blocks_of(h); }
 int set_item_shard_positions(cdae_hip_t* h, const uint32_t* len_and_first /* [2 U] */) {
   if (!h || !h->d_shared || !h->item_shard || !len_and_first) return fail("set_item_shard and set_interactions must be called first");
   HIPCHK(hipSetDevice(h->device));
@@ -2059,10 +2156,29 @@ float* hg_buf(cdae_hip_t* h) { return h->d_HG; }
 float* ev_hsum_buf(cdae_hip_t* h) { return h->d_hsum_eval; }
 uint32_t eval_chunk() { return EVAL_CHUNK; }
 
+// blocks 1.. of the input-sum all-reduce buffer `buf` ([blocks][n][Kp]): the Wu / Uu rows of users [u0, u0 + n) this shard owns
+// (zeros for everybody else's): after the all-reduce(sum) every shard holds the owners' rows, bit for bit
+static int stage_own_rows(cdae_hip* h, uint64_t u0, uint32_t n, float* buf) {
+  uint32_t blk = 1;
+  if (h->cfg.user_factor)
+    DISPATCH_NI(h->NI, cdae::own_rows_stage_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->hp, (const float*)h->d_Wu, u0, n,
+                buf + (size_t)(blk++) * n * h->Kp);
+  if (h->cfg.linear_function)
+    DISPATCH_NI(h->NI, cdae::own_rows_stage_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->hp, (const float*)h->d_Uu, u0, n,
+                buf + (size_t)(blk++) * n * h->Kp);
+  return 0;
+}
+// the gathered rows inside an all-reduced buffer (nullptr when the configuration has none)
+static const float* gathered_wu(const cdae_hip* h, const float* buf, uint32_t n) { return h->cfg.user_factor ? buf + (size_t)n * h->Kp : nullptr; }
+static const float* gathered_uu(const cdae_hip* h, const float* buf, uint32_t n) {
+  return h->cfg.linear_function ? buf + (size_t)(h->cfg.user_factor ? 2 : 1) * n * h->Kp : nullptr;
+}
+
 static int fs_batch(cdae_hip* h, uint64_t s0, uint32_t nb, uint32_t cidx, Batch* bt) {
   if (!h->d_shared || !h->item_shard) return fail("not an item-sharded handle with data");
   if (nb == 0 || s0 + nb > h->U || nb > std::min<uint64_t>(h->B, h->U)) return fail("bad batch [%llu, +%u)", (unsigned long long)s0, nb);
-  const uint64_t E = (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]);
+  const uint64_t E = h->shard_sampled() ? (uint64_t)(h->h_grow_ptr[s0 + nb] - h->h_grow_ptr[s0]) * h->ex_per_pos
+                                        : (uint64_t)(h->h_row_ptr[s0 + nb] - h->h_row_ptr[s0]);
   if (E > h->Ecap) return fail("batch has %llu examples, capacity %llu", (unsigned long long)E, (unsigned long long)h->Ecap);
   *bt = Batch{s0, nb, cidx, E};
   return 0;
@@ -2089,6 +2205,7 @@ int fs_phase0(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_
                 h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Hpart,
                 (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user, (const uint32_t*)h->d_gpos);
   DISPATCH_NI(h->NI, cdae::unit_sum_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, nb, h->d_Hsum);
+  CHK(stage_own_rows(h, s0, nb, h->d_Hsum));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2103,11 +2220,30 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
   hipStream_t st = h->stream;
   const uint32_t I = (uint32_t)h->I, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
   const dim3 blk(256), grid_users((nb + 3) / 4);
+  // the batch's Wu / Uu rows arrived with the all-reduced input sums (stage_own_rows): encode_finish reads them by slot (uids = iota)
+  const float* wu_b = gathered_wu(h, h->d_Hsum, nb);
+  const float* uu_b = gathered_uu(h, h->d_Hsum, nb);
+  if (!h->cfg.full_output) {
+    // ---- sampled decode over the local item rows: the single-GPU step's kernels on this shard's rows / examples ----
+    DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, wu_b, h->P(CDAE_P_B),
+                (const uint32_t*)h->d_iota, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, uu_b, h->d_Ssum);
+    HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+    CHK(launch_decode(h, x));
+    // local hidden gradient: the user's examples on THIS shard's rows (the others are VOID), partial rows per unit of the whole rows
+    const uint32_t n_gunits = gunits_of(h, bt), halves = h->gather_halves;
+    const uint32_t* guptr = h->d_gunit_ptr + s0;
+    if (n_gunits)
+      DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_gunits + 3) / 4)), blk, 0, st, h->hp, h->d_grow_ptr, guptr, n_gunits, s0, nb,
+                  x.item, h->d_G, h->d_D0, h->d_HGpart, 0u, x.dup_of_ex, h->d_dup_corr, (const uint32_t*)h->d_gunit_user, halves);
+    DISPATCH_NI(h->NI, hg_raw_kernel, grid_users, blk, 0, st, h->hp, guptr, n_gunits, nb, h->d_HGpart, 8u * halves, h->d_HG);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
   CHK(join_aux(h));
   // z from the ALL-REDUCED input sums: encode_finish with one "unit" per user (identity prefix)
-  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, h->d_Wu, h->P(CDAE_P_B),
-              (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+  DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, wu_b, h->P(CDAE_P_B),
+              (const uint32_t*)h->d_iota, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, uu_b, h->d_Ssum);
   hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   uint32_t parts = 0, rows = nb;
@@ -2159,11 +2295,27 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
   hipStream_t st = h->stream;
   const uint32_t I = (uint32_t)h->I, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
   const dim3 blk(256), grid_users((nb + 3) / 4);
+  const float* uu_b = gathered_uu(h, h->d_Hsum, nb);
+  if (!h->cfg.full_output) {
+    // ---- sampled decode: delta from the all-reduced hg, the Wu / Uu steps of the users this shard owns, then the local input rows
+    // and (replicated, identical everywhere) the b recurrence — the tail of the single-GPU step ----
+    DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
+                h->d_HG, h->d_Wu, h->d_Wu_ag, 0u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, uu_b);
+    const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
+    DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I,
+                x.sorted_val, h->d_Z, h->d_HG, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), CDAE_TOUCHED_ARG, nb, h->P(CDAE_P_B),
+                h->P(CDAE_P_B_AG), h->delta_rows());
+    HIPCHK(hipEventRecord(x.released, st));
+    HIPCHK(hipGetLastError());
+    h->seq++;
+    h->acc_examples += bt.E; h->acc_batches++; h->acc_users += nb;
+    return 0;
+  }
   HIPCHK(hipEventRecord(h->ev_fork, st));
   HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-  // d_HG holds the all-reduced hg: delta, the Wu steps (replicated: every shard steps its copy identically), then the b recurrence
+  // d_HG holds the all-reduced hg: delta, the Wu steps of the users this shard owns, then the b recurrence (replicated)
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
-              h->d_HG, h->d_Wu, h->d_Wu_ag, 0u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
+              h->d_HG, h->d_Wu, h->d_Wu_ag, 0u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, uu_b);
   HIPCHK(hipEventRecord(h->ev_delta, h->aux));
   hipLaunchKernelGGL(hidden_bias_kernel, dim3((Kp + 255u) / 256u), blk, 0, h->aux, h->hp, nb, h->d_HG, h->P(CDAE_P_B), h->P(CDAE_P_B_AG));
   HIPCHK(hipEventRecord(h->ev_join, h->aux));
@@ -2199,7 +2351,7 @@ int ev_phase0(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, 
   if (h->hsum_eval_cap < nu) {
     if (h->d_hsum_eval) HIPCHK(hipFree(h->d_hsum_eval));
     h->d_hsum_eval = nullptr; h->hsum_eval_cap = 0;
-    CHK(dev_alloc(&h->d_hsum_eval, (size_t)nu * h->Kp));
+    CHK(dev_alloc(&h->d_hsum_eval, (size_t)SHARD_BLOCKS * nu * h->Kp));
     h->hsum_eval_cap = nu;
   }
   const uint32_t* uptr = h->d_unit_ptr + u0;
@@ -2208,6 +2360,7 @@ int ev_phase0(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, 
                 h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, u0, nu, mode, mode ? CDAE_STREAM_LOSS_CORRUPT : CDAE_STREAM_CORRUPT, cidx,
                 seed, epoch, h->d_hpart_eval, (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user, (const uint32_t*)h->d_gpos);
   DISPATCH_NI(h->NI, cdae::unit_sum_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_hpart_eval, uptr, nu, h->d_hsum_eval);
+  CHK(stage_own_rows(h, u0, nu, h->d_hsum_eval));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2215,8 +2368,8 @@ int ev_phase0(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, 
 int ev_finish(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode) {
   HIPCHK(hipSetDevice(h->device));
   DISPATCH_NI(h->NI, cdae::encode_finish_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_hsum_eval, (const uint32_t*)h->d_iota,
-              h->d_Wu, h->P(CDAE_P_B), (const uint32_t*)nullptr, u0, nu, mode, h->d_zeval, (float*)nullptr, (float*)nullptr, h->d_Uu,
-              (float*)nullptr);
+              gathered_wu(h, h->d_hsum_eval, nu), h->P(CDAE_P_B), (const uint32_t*)h->d_iota, u0, nu, mode, h->d_zeval, (float*)nullptr,
+              (float*)nullptr, gathered_uu(h, h->d_hsum_eval, nu), (float*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }

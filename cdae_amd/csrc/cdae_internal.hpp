@@ -38,11 +38,18 @@ void*& exchange_slot(cdae_hip_t* h);
 void set_exchange_deleter(cdae_hip_t* h, void (*deleter)(void*));
 
 
-// ---- item-sharded layout (full-output decode) --------------------------------------------------------------
-// A shard is a complete handle over item rows [item0, item0 + I_local) and ALL users (Wu, b replicated and stepped
-// identically everywhere).  Two per-user sums cross shards in every batch — the input sum of the encode and the hidden
-// gradient — so a batch runs in three phases with an all-reduce(sum) of [n_users x row_stride] floats after the first two.
+// ---- item-sharded layout: full-output decode and, since round 3, the sampled decode ------------------------
+// A shard is a complete handle over item rows [item0, item0 + I_local) and ALL users; b is replicated and stepped identically
+// everywhere; the user node (Wu, Uu) is sharded by user range — the owner contributes a batch's rows to the first all-reduce.
+// Two per-user sums cross shards in every batch — the input sum of the encode and the hidden gradient — so a batch runs in
+// three phases with an all-reduce(sum) of [n_users x row_stride] floats (x shard_blocks for the first) after the first two.
 int set_item_shard(cdae_hip_t* h, uint64_t item0, uint64_t num_items_global);      // before set_interactions
+// users [u_begin, u_end) keep their private rows (Wu, Wu_ag, Uu, Uu_ag) on this shard (before set_interactions; default: all)
+int set_item_shard_owner(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end);
+// sampled decode: the WHOLE train rows (global item ids) — read by the NEXT set_interactions call only, not kept by pointer
+int set_item_shard_global(cdae_hip_t* h, const int64_t* row_ptr, const uint32_t* col);
+// [users x row_stride] blocks in the input-sum all-reduce buffers (hsum_buf, ev_hsum_buf): the sums, then the gathered Wu / Uu rows
+uint32_t shard_blocks(const cdae_hip_t* h);
 // per user: (length of the WHOLE train row, position of the first local item in it) — the dropout stream is indexed by position
 // in the whole row, so a shard must know where its slice sits (after set_interactions)
 int set_item_shard_positions(cdae_hip_t* h, const uint32_t* len_and_first /* [2 U] */);

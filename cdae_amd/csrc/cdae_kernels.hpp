@@ -54,6 +54,9 @@ struct HyperParams {
   unsigned long long* trace; // CDAE_WAVE_TRACE (developer aid, tools/wave_trace.py): per-wavefront {tag, start, end, extra} records, or nullptr
   uint32_t trace_odd;        // (wave trace) 1 on batches with an odd sequence number
   uint32_t debug_skip;       // CDAE_DEBUG_SKIP_ROLES (timing experiments only, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows
+  // users whose private rows (Wu, Wu_ag, Uu, Uu_ag) THIS handle holds, table row 0 = user own_u0.  Everything except an item
+  // shard owns every user ([0, 2^64)); an item shard owns a contiguous range (the user node is sharded by user)
+  uint64_t own_u0, own_u1;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -222,7 +225,13 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
               const uint32_t* __restrict__ unit_user /* global unit -> user id */,
               uint32_t* __restrict__ /* unused (round-2 global-atomic counting sort) */,
-              const uint32_t* __restrict__ gpos /* item shard: [2 U] (length of the user's WHOLE row, position of the first local item in it); else nullptr */) {
+              const uint32_t* __restrict__ gpos /* item shard: [2 U] (length of the user's WHOLE row, position of the first local item in it); else nullptr */,
+              // Item shard of the SAMPLED decode: row_ptr / col are the WHOLE rows with global item ids (negatives are rejected
+              // against the whole row and drawn from all `draw_items` items, exactly as on one GPU), the example list keeps the
+              // single-GPU layout and numbering, and an example whose item lies outside [shard_item0, shard_item0 + shard_items)
+              // is VOID: item = key = shard_items (one past the last local row) — it sorts behind every local row, segment_kernel
+              // and hidden_gather_kernel skip it.  shard_items = 0: not a shard (ids pass through).
+              uint32_t shard_item0 = 0, uint32_t shard_items = 0, uint32_t draw_items = 0) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
@@ -251,11 +260,14 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   for (uint32_t p = p0 + lane; p < p1; p += WAVE) {
     const int keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n_rng + p_rng0 + p), hp.keep_thr);
     const uint64_t e = base + p;
-    ex_item[e] = row[p];
-    if (ex_key16) ex_key16[e] = (uint16_t)row[p];
+    uint32_t it = row[p];
+    if (shard_items) it = it - shard_item0 < shard_items ? it - shard_item0 : shard_items;
+    ex_item[e] = it;
+    if (ex_key16) ex_key16[e] = (uint16_t)it;
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
   }
+  const uint32_t n_items = draw_items ? draw_items : hp.num_items;
   // the wavefront's own LDS writes are visible to it once they are issued in order (no cross-wave sharing)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -268,16 +280,17 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
       bool found = false;
       cand = 0;
       for (uint32_t t = 0; t < CDAE_NEG_MAX_TRY && !found; ++t) {
-        cand = cdae_item_from_draw(cdae_rng_draw(key_n, draw * CDAE_NEG_MAX_TRY + t), hp.num_items);
+        cand = cdae_item_from_draw(cdae_rng_draw(key_n, draw * CDAE_NEG_MAX_TRY + t), n_items);
         found = !lds_row_contains(lrow, n, cand);
       }
-      for (uint32_t t = 0; t < hp.num_items && !found; ++t) {
-        cand = cand + 1u == hp.num_items ? 0u : cand + 1u;
+      for (uint32_t t = 0; t < n_items && !found; ++t) {
+        cand = cand + 1u == n_items ? 0u : cand + 1u;
         found = !lds_row_contains(lrow, n, cand);
       }
     } else {
-      cand = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, hp.num_items);
+      cand = cdae_sample_negative(key_n, (uint64_t)cidx * m + i, row, n, n_items);
     }
+    if (shard_items) cand = cand - shard_item0 < shard_items ? cand - shard_item0 : shard_items;
     ex_item[e] = cand;
     if (ex_key16) ex_key16[e] = (uint16_t)cand;
     dup_of_ex[e] = DUP_NONE;
@@ -300,7 +313,8 @@ segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint3
                uint32_t stripes /* 1..DUP_STRIPES counters in use */,
                const uint32_t* __restrict__ rank_of /* item -> popularity rank, or nullptr */,
                uint32_t* __restrict__ segr_begin /* the same table indexed by RANK (decode / input rows read it beside item_order[rank]: */,
-               uint32_t* __restrict__ segr_end /* one dependent round trip less at the head of every row) */) {
+               uint32_t* __restrict__ segr_end /* one dependent round trip less at the head of every row) */,
+               uint32_t void_key = 0xFFFFFFFFu /* item shard: examples of other shards' rows (sorted last); no segment, no duplicate marks */) {
   __shared__ uint32_t blk_count, blk_base;
   if (threadIdx.x == 0) blk_count = 0u;
   __syncthreads();
@@ -311,6 +325,7 @@ segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint3
     const uint32_t p = p0 + i * blockDim.x;
     if (p >= n_ex) break;
     const uint32_t it = sorted_item[p];
+    if (it == void_key) continue;
     const bool first = p == 0 || sorted_item[p - 1] != it, last = p + 1 == n_ex || sorted_item[p + 1] != it;
     if (first) { seg_begin[it] = p; if (rank_of) segr_begin[rank_of[it]] = p; }
     if (last) { seg_end[it] = p + 1; if (rank_of) segr_end[rank_of[it]] = p + 1; }
@@ -1301,7 +1316,7 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   load_chunk(c_begin, my_item, my_g, my_di);
   for (uint32_t c0 = c_begin; c0 < c_end; c0 += WAVE) {
     if (c0 + WAVE < c_end) load_chunk(c0 + WAVE, nx_item, nx_g, nx_di);
-    const bool mine = my_item != 0xFFFFFFFFu && (my_item & 7u) == part;
+    const bool mine = my_item < hp.num_items && (my_item & 7u) == part;      // (fillers are 0xFFFFFFFF, an item shard's VOID examples num_items)
     unsigned long long mask = __ballot(mine);
     // duplicate negatives (rare): add decode's correction rows, in example order
     unsigned long long dmask = __ballot(mine && my_di != DUP_NONE);
@@ -1364,21 +1379,24 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
                      float* __restrict__ Wu, float* __restrict__ Wu_ag,
                      uint32_t n_parts /* slabs of HGpart [n_parts][n_units][Kp] to add to HG (0: HG already holds hg) */,
                      float* __restrict__ Uu, float* __restrict__ Uu_ag, const float* __restrict__ Ssum,
-                     float* __restrict__ DELTA_ROWS /* linear_function only: Uu[u] (.) delta_u for the input rows */) {
+                     float* __restrict__ DELTA_ROWS /* linear_function only: Uu[u] (.) delta_u for the input rows */,
+                     const float* __restrict__ Uu_batch = nullptr /* item shard: the batch's gathered Uu rows [nb][Kp] (a user this
+                                                                     shard does not own still needs Uu[u] (.) delta for its input rows) */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const unsigned long long t0 = trace_begin(hp);
   const uint64_t uid = u0 + slot;
+  const bool own = uid >= hp.own_u0 && uid < hp.own_u1;          // wave-uniform: the private rows of this user live here
   const uint32_t lo = lane * NI;
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
   vload<NI>(hg, HG + o);
   // everything the tail needs is requested up front, beside the partial rows (it was two more round trips behind them)
-  const size_t ou = (size_t)uid * hp.Kp + lo;
+  const size_t ou = (size_t)(own ? uid - hp.own_u0 : 0) * hp.Kp + lo;
   float p[NI], pa[NI];
   vload<NI>(dz, Dz + o);
-  if (hp.user_factor) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
+  if (hp.user_factor && own) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
   const uint32_t ub = n_parts ? uptr[slot] - uptr[0] : 0u, ue = n_parts ? uptr[slot + 1] - uptr[0] : 0u;
   // fixed order (unit-major, then partition): deterministic.  Eight partitions (the training path): two units' 16 partial
   // rows are in flight per trip (a user has 2-3 units at ML-10M shape; the second unit is clamped and added as 0 past the end)
@@ -1427,13 +1445,20 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
 #pragma unroll
   for (int i = 0; i < NI; ++i) delta[i] = hg[i] * dz[i];
   vstore<NI>(HG + o, delta);
-  if (hp.user_factor) {
+  if (hp.user_factor && own) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) ada_step(hp, p[i], pa[i], fmaf(hp.lambda, p[i], delta[i]));
     vstore<NI>(Wu + ou, p);
     vstore<NI>(Wu_ag + ou, pa);
   }
-  if (hp.linear_function) {
+  if (hp.linear_function && !own) {
+    // another shard's user: only the input rows' delta, with the gathered Uu[u] (bit-equal to the owner's row before its step)
+    float uu[NI], dr[NI];
+    vload<NI>(uu, Uu_batch + o);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dr[i] = uu[i] * delta[i];
+    vstore<NI>(DELTA_ROWS + o, dr);
+  } else if (hp.linear_function) {
     // The input rows take Uu[u] (.) delta (cdae.hpp:339) with Uu[u] from BEFORE its own step (:351-357 comes last).
     // Uu_grad = lambda Uu[u] + sum_k delta (.) W[k] (cdae.hpp:295-299, 340 — no input scale there): the kept rows have
     // not moved since the encode inside one user's step, so the sum is delta (.) Ssum with the encode's own row sum.
@@ -1826,6 +1851,48 @@ slab_sum_kernel(HyperParams hp, const float* __restrict__ HGpart, uint32_t n_par
     for (int i = 0; i < NI; ++i) acc[i] += part[i];
   }
   vstore<NI>(HG + (size_t)slot * hp.Kp + lo, acc);
+}
+
+// Item shard, user node sharded by user: the private rows of a batch's users reach every shard through the SAME
+// all-reduce(sum) that carries the input sums — the owner contributes the row, everybody else zeros, and x + 0 + ... + 0 is exact,
+// so the gathered rows are the owner's bits.  out[slot] = table[uid - own_u0] if this handle owns user u0 + slot, else 0.
+template <int NI>
+__global__ void __launch_bounds__(256)
+own_rows_stage_kernel(HyperParams hp, const float* __restrict__ table, uint64_t u0, uint32_t nb, float* __restrict__ out) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint64_t uid = u0 + slot;
+  const uint32_t lo = lane * NI;
+  float v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) v[i] = 0.f;
+  if (uid >= hp.own_u0 && uid < hp.own_u1) vload<NI>(v, table + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
+  vstore<NI>(out + (size_t)slot * hp.Kp + lo, v);
+}
+// Item shard, sampled decode: the RAW local hidden gradient of every user of the batch — HG (decode's overflow corrections) plus
+// hidden_gather_kernel's partial rows, added in exactly hidden_finish_kernel's order (unit-major, then partition), so that with one
+// shard the all-reduced sum is the single-GPU hg bit for bit.  delta is formed after the all-reduce (hidden_finish, n_parts = 0).
+template <int NI>
+__global__ void __launch_bounds__(256)
+hg_raw_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_units, uint32_t nb, const float* __restrict__ HGpart,
+              uint32_t n_parts, float* __restrict__ HG) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint32_t lo = lane * NI;
+  const size_t o = (size_t)slot * hp.Kp + lo;
+  float hg[NI];
+  vload<NI>(hg, HG + o);
+  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  for (uint32_t u = ub; u < ue; ++u)
+    for (uint32_t x = 0; x < n_parts; ++x) {
+      float part[NI];
+      vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) hg[i] += part[i];
+    }
+  vstore<NI>(HG + o, hg);
 }
 
 // data-parallel exchange helpers (no reference counterpart; DESIGN.md "Multi-GPU")

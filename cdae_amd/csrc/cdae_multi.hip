@@ -401,7 +401,7 @@ int all_reduce_bufs(cdae_hip_multi* m, const std::vector<float*>& bufs, size_t n
 // one epoch of the item-sharded layout: every batch of users runs on EVERY shard (each over its item rows) in three phases
 int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end) {
   const size_t S = m->shard.size();
-  const uint32_t Kp = cdae_internal::row_stride(m->shard[0]);
+  const uint32_t Kp = cdae_internal::row_stride(m->shard[0]), blocks = cdae_internal::shard_blocks(m->shard[0]);
   struct Bt { uint64_t s0; uint32_t nb, c; };
   std::vector<Bt> plan;
   for (uint64_t s0 = u_begin; s0 < u_end; s0 += m->B)
@@ -413,7 +413,7 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
   for (size_t t = 0; t < plan.size(); ++t) {
     const Bt& b = plan[t];
     for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_phase0(h, seed, epoch, b.s0, b.nb, b.c));
-    CHK(all_reduce_bufs(m, hs, (size_t)b.nb * Kp));                       // input sums over ALL item rows
+    CHK(all_reduce_bufs(m, hs, (size_t)b.nb * Kp * blocks));              // input sums over ALL item rows (+ the owners' Wu / Uu rows of the batch)
     if (t + 1 < plan.size())                                             // the next batch's example lists: prep streams, beside the decode
       for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[t + 1].s0, plan[t + 1].nb, plan[t + 1].c));
     for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_phase1(h, b.s0, b.nb));
@@ -433,7 +433,7 @@ int item_encode_chunk(cdae_hip_multi* m, uint64_t u0, uint32_t nu, int mode, uin
     CHK(cdae_internal::ev_phase0(m->shard[s], u0, nu, mode, cidx, seed, epoch));
     bufs[s] = cdae_internal::ev_hsum_buf(m->shard[s]);
   }
-  CHK(all_reduce_bufs(m, bufs, (size_t)nu * Kp));
+  CHK(all_reduce_bufs(m, bufs, (size_t)nu * Kp * cdae_internal::shard_blocks(m->shard[0])));
   for (cdae_hip_t* h : m->shard) CHK(cdae_internal::ev_finish(h, u0, nu, mode));
   return 0;
 }
@@ -494,7 +494,6 @@ int cdae_hip_multi_shard(cdae_hip_multi_t* m, int shard, cdae_hip_t** handle, ui
 int cdae_hip_multi_set_layout(cdae_hip_multi_t* m, uint32_t layout) {
   CHK(check_multi(m, false));
   if (layout > CDAE_LAYOUT_ITEM_ROWS) return fail("unknown layout %u", layout);
-  if (layout == CDAE_LAYOUT_ITEM_ROWS && !m->cfg.full_output) return fail("CDAE_LAYOUT_ITEM_ROWS exists for the full-output decode only");
   if (m->U) return fail("set the layout before cdae_hip_multi_set_interactions");
   m->layout = layout;
   return 0;
@@ -520,6 +519,14 @@ static int set_interactions_item_rows(cdae_hip_multi* m, uint64_t U, uint64_t I,
     m->icut[s] = i;
   }
   m->icut[S] = I;
+  // the user node (Wu, Uu) is sharded by USER: contiguous user ranges balanced by interactions; a shard may own no user
+  m->cut.assign(S + 1, 0);
+  for (size_t s = 1; s < S; ++s) {
+    const int64_t want = (int64_t)(((__int128)nnz * (int64_t)s + (int64_t)S - 1) / (int64_t)S);
+    uint64_t u = (uint64_t)(std::lower_bound(row_ptr, row_ptr + U + 1, want) - row_ptr);
+    m->cut[s] = std::min<uint64_t>(std::max<uint64_t>(u, m->cut[s - 1]), U);
+  }
+  m->cut[S] = U;
   std::vector<int64_t> rp(U + 1);
   std::vector<uint32_t> lc, pos(2 * U);
   for (size_t s = 0; s < S; ++s) {
@@ -537,12 +544,12 @@ static int set_interactions_item_rows(cdae_hip_multi* m, uint64_t U, uint64_t I,
       pos[2 * u] = (uint32_t)(b - a); pos[2 * u + 1] = (uint32_t)(lo - a);
     }
     CHK(cdae_internal::set_item_shard(m->shard[s], i0, I));
+    CHK(cdae_internal::set_item_shard_owner(m->shard[s], m->cut[s], m->cut[s + 1]));
+    if (!m->cfg.full_output) CHK(cdae_internal::set_item_shard_global(m->shard[s], row_ptr, col));   // sampled decode: negatives against the whole rows
     static const uint32_t none = 0;
     CHK(cdae_hip_set_interactions(m->shard[s], U, i1 - i0, rp.data(), lc.empty() ? &none : lc.data()));
     CHK(cdae_internal::set_item_shard_positions(m->shard[s], pos.data()));
   }
-  m->cut.assign(S + 1, 0);
-  m->cut[S] = U;                                           // (user ranges are not used in this layout)
   m->U = U; m->I = I;
   m->B = cdae_internal::batch_users(m->shard[0]);
   std::vector<Exchange*> xs(S, nullptr);
@@ -633,7 +640,8 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
         cdae_hip_stats st;
         CHK(cdae_hip_collect_stats(m->shard[s], &st));
         if (s == 0) { stats->users = st.users; stats->batches = st.batches; }     // every shard sees every user
-        stats->examples += st.examples;
+        // full output: a shard lists its own positives; sampled: every shard walks the whole list (other shards' examples VOID)
+        if (m->cfg.full_output || s == 0) stats->examples += st.examples;
       }
       stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
@@ -697,8 +705,8 @@ int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out) {
   double total = 0, v = 0;
   if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
     for (cdae_hip_t* h : m->shard) { CHK(cdae_internal::item_rows_penalty(h, &v)); total += v; }     // every shard's own rows
-    CHK(cdae_internal::hidden_bias_penalty(m->shard[0], &v)); total += v;                             // b and Wu are replicated: once
-    CHK(cdae_internal::private_penalty(m->shard[0], &v)); total += v;
+    CHK(cdae_internal::hidden_bias_penalty(m->shard[0], &v)); total += v;                             // b is replicated: once
+    for (cdae_hip_t* h : m->shard) { CHK(cdae_internal::private_penalty(h, &v)); total += v; }        // Wu: every shard's own users
     *out = total;
     return 0;
   }
@@ -756,8 +764,15 @@ static bool is_item_rows(uint32_t which) {
 
 int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, size_t count) {
   CHK(check_multi(m, true));
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS && is_private(which)) {                                 // user node: sharded by user range
+    const size_t K = m->cfg.num_dim;
+    if (count != m->U * K) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->U * K), count);
+    for (size_t s = 0; s < m->shard.size(); ++s)
+      CHK(cdae_hip_get_param(m->shard[s], which, host + m->cut[s] * K, (m->cut[s + 1] - m->cut[s]) * K));
+    return 0;
+  }
   if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
-    if (!is_item_rows(which)) return cdae_hip_get_param(m->shard[0], which, host, count);          // replicated
+    if (!is_item_rows(which)) return cdae_hip_get_param(m->shard[0], which, host, count);          // replicated (b)
     const size_t w = (which == CDAE_P_BP || which == CDAE_P_BP_AG) ? 1 : m->cfg.num_dim;
     if (count != m->I * w) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->I * w), count);
     for (size_t s = 0; s < m->shard.size(); ++s)
@@ -774,6 +789,13 @@ int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, s
 
 int cdae_hip_multi_set_param(cdae_hip_multi_t* m, uint32_t which, const float* host, size_t count) {
   CHK(check_multi(m, true));
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS && is_private(which)) {
+    const size_t K = m->cfg.num_dim;
+    if (count != m->U * K) return fail("parameter %u has %zu elements, got %zu", which, (size_t)(m->U * K), count);
+    for (size_t s = 0; s < m->shard.size(); ++s)
+      CHK(cdae_hip_set_param(m->shard[s], which, host + m->cut[s] * K, (m->cut[s + 1] - m->cut[s]) * K));
+    return 0;
+  }
   if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
     if (!is_item_rows(which)) { for (cdae_hip_t* h : m->shard) CHK(cdae_hip_set_param(h, which, host, count)); return 0; }
     const size_t w = (which == CDAE_P_BP || which == CDAE_P_BP_AG) ? 1 : m->cfg.num_dim;

@@ -133,6 +133,44 @@ def test_batch_users_one_is_the_reference_schedule_at_full_size(built):
     assert abs(loss / f["train_loss"][0] - 1.0) <= 2e-4     # fp32 sum of 8 M positive-example losses (tests/test_gpu_parity.py: same bound)
 
 
+# ---- the multi-GPU schedule with an accuracy claim: sampled decode in the item-rows layout ------------------
+# It is the single-GPU schedule over item shards (per-row chains sequential over the GLOBAL batch, two all-reduced per-user sums),
+# so it must hold the SAME bounds as the single handle; run here as four logical shards of the one GPU a test box has.
+_shard_curves = {}
+
+
+def shard_curves_of(path, shards=4):
+    if path not in _shard_curves:
+        f = np.load(path, allow_pickle=True)
+        seed, K = int(f["seed"]), int(f["num_dim"])
+        d = synth.generate_shape("ml10m", seed=seed)
+        B = bench_default_batch_users()
+        m = cdae_amd.MultiCDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, **HYPER), devices=[0] * shards, item_rows=True)
+        m.reset(d, seed=seed)
+        rec, loss = [], []
+        for ep in range(len(f["recall10"])):
+            m.train_one_iteration(seed, ep)
+            loss.append(m.current_loss(seed, ep))
+            rec.append(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5])
+        m.close()
+        _shard_curves[path] = (np.array(rec), np.asarray(f["recall10"]), np.array(loss), np.asarray(f["train_loss"]))
+    return _shard_curves[path]
+
+
+def test_item_rows_sampled_layout_holds_the_accuracy_bounds_at_ml10m_shape(built):
+    d = np.array([shard_curves_of(p)[0] - shard_curves_of(p)[1] for p in FIXTURES])
+    lo = np.array([shard_curves_of(p)[2] / shard_curves_of(p)[3] - 1.0 for p in FIXTURES])
+    single = np.array([curves_of(p)[0] for p in FIXTURES])
+    sharded = np.array([shard_curves_of(p)[0] for p in FIXTURES])
+    print(f"\n4 item shards, {len(FIXTURES)} seeds: mean signed dRecall@10 per epoch {np.round(d.mean(axis=0), 5)}, max |d| {np.round(np.abs(d).max(axis=0), 5)}; "
+          f"loss offset {np.round(lo.min(), 4)} ... {np.round(lo.max(), 4)}; max |Recall@10 sharded - single GPU| {np.abs(sharded - single).max():.5f}")
+    assert np.abs(d).max() <= RECALL_TOL_SEED
+    assert np.abs(d.mean(axis=0)).max() <= RECALL_TOL_MEAN
+    assert np.abs(lo - LOSS_SCHEDULE_OFFSET).max() <= LOSS_TOL_AROUND_OFFSET
+    # and it is the SAME trajectory as the single GPU's up to fp32 association of two sums: Recall@10 moves by a few users' lists at most
+    assert np.abs(sharded - single).max() <= 5e-4
+
+
 # ---- BASELINE configs[1]: Yelp-shape K=50 FULL-OUTPUT decode (bf16 MFMA), CE ---------------------------------------
 # The reference has no full-output training; the expected curve is the oracle's block schedule
 # (Oracle.train_full: every unrated item a negative with target 0, per-block summed decoder gradient, fp64) at the same

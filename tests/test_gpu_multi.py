@@ -27,7 +27,7 @@ def small(built):
 
 
 def cfg_of(K=24, B=32, **kw):
-    return cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, **{**HYPER, **kw})
+    return cdae_amd.CDAEConfig(num_dim=K, batch_users=B, **{"lt": cdae_amd.CROSS_ENTROPY, **HYPER, **kw})
 
 
 def emulate(d, cfg, cuts, init_seed, seed, epochs, period):
@@ -250,6 +250,115 @@ def test_item_rows_layout_tracks_the_oracle_block_schedule(built):
         assert np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()) < 2e-2
 
 
-def test_item_rows_layout_needs_full_output(built):
-    with pytest.raises(cdae_amd.CDAEError):
-        cdae_amd.MultiCDAE(cfg_of(), devices=[0, 0], item_rows=True)
+# ---- the SAMPLED decode in the item-rows layout: the single-GPU schedule itself, over item shards (round 3) ------------------
+PRIVATE = [cdae_amd.P_WU, cdae_amd.P_WU_AG]
+
+
+def _all_params(m, extra=()):
+    return {w: m.get(w) for w in SHARED + PRIVATE + list(extra)}
+
+
+@pytest.mark.parametrize("K,B,kw", [(24, 48, {}), (200, 64, {}), (24, 300, dict(num_corruptions=2)), (40, 37, dict(asymmetric=True)),
+                                    (24, 48, dict(linear_function=True)), (24, 48, dict(user_factor=False)), (300, 16, {})])
+def test_item_rows_sampled_with_one_shard_is_the_single_handle_bit_for_bit(built, K, B, kw):
+    """One item shard runs the three phases (input sums -> z, decode + local hidden gradient, hidden-layer + input-row steps) on
+    ALL rows: the same kernels on the same lists, every sum in the same order — so it IS the single handle, bit for bit.  What
+    the phases add is only where the two per-user sums would cross shards."""
+    d = synth.generate_shape("tiny", seed=5)
+    cfg = cfg_of(K=K, B=B, **kw)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(d, seed=11)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0], item_rows=True)
+    mm.reset(d, seed=11)
+    extra = ([cdae_amd.P_V, cdae_amd.P_V_AG] if kw.get("asymmetric") else []) + ([cdae_amd.P_UU, cdae_amd.P_UU_AG] if kw.get("linear_function") else [])
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+        ref = one.train_one_iteration(3, ep)
+        assert (st.users, st.batches, st.examples) == (ref.users, ref.batches, ref.examples)
+    a, b = _all_params(mm, extra), _all_params(one, extra)
+    for w in a:
+        np.testing.assert_array_equal(a[w], b[w], err_msg=f"parameter {w}")
+    assert mm.current_loss(5, 0) == one.current_loss(5, 0)
+
+
+@pytest.mark.parametrize("K,B,shards,kw", [(24, 48, 2, {}), (24, 300, 3, {}), (200, 64, 4, {}), (300, 32, 2, {}), (24, 48, 3, dict(asymmetric=True)),
+                                           (24, 48, 2, dict(linear_function=True)), (24, 64, 5, dict(lt=cdae_amd.SQUARE, beta=1.0))])
+def test_item_rows_sampled_layout_is_the_single_gpu_schedule(built, K, B, shards, kw):
+    """N item shards: every shard samples the batch's WHOLE example list (negatives rejected against the whole rows) and keeps the
+    examples of its rows; per-row chains are untouched; only the two cross-shard sums (input sums, hidden gradient) are associated
+    differently in fp32.  Parameters after two epochs within 1e-4 of their range of the single handle's (measured ~1e-6), same
+    reported loss, same top-10; the user node is sharded by user range and reassembles to the single handle's Wu."""
+    d = synth.generate_shape("tiny", seed=5)
+    cfg = cfg_of(K=K, B=B, **kw)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(d, seed=11)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards, item_rows=True)
+    mm.reset(d, seed=11)
+    cuts = mm.shards()
+    assert cuts[0][0] == 0 and cuts[-1][1] == d.num_items and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    extra = ([cdae_amd.P_V, cdae_amd.P_V_AG] if kw.get("asymmetric") else []) + ([cdae_amd.P_UU, cdae_amd.P_UU_AG] if kw.get("linear_function") else [])
+    for w, v in _all_params(mm, extra).items():                  # rows initialised by GLOBAL item / user id
+        np.testing.assert_array_equal(v, one.get(w))
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+        ref = one.train_one_iteration(3, ep)
+        assert (st.users, st.batches, st.examples) == (ref.users, ref.batches, ref.examples)
+    errs = {w: _param_range_err(v, one.get(w)) for w, v in _all_params(mm, extra).items()}
+    print(f"\nsampled item-rows layout, {shards} shards vs single handle:", {k: float(f"{v:.2e}") for k, v in errs.items()})
+    assert max(errs.values()) < 1e-4, errs
+    for w in SHARED + PRIVATE + extra:                           # loss / top-10 of the SAME parameters
+        mm.set(w, one.get(w))
+        np.testing.assert_array_equal(mm.get(w), one.get(w))
+    la, lb = mm.current_loss(5, 0), one.current_loss(5, 0)
+    assert abs(la - lb) <= 2e-5 * abs(lb), (la, lb)
+    rec_m, rec_o = mm.recommend_all(10), one.recommend_all(10)
+    assert (rec_m == rec_o).all(axis=1).mean() > 0.97
+    for u in range(d.num_users):
+        rated = d.train_col[d.train_ptr[u]:d.train_ptr[u + 1]]
+        assert len(set(rec_m[u].tolist())) == 10 and not np.intersect1d(rec_m[u], rated).size
+
+
+def test_item_rows_sampled_layout_tracks_the_oracle_block_schedule(built):
+    import oracle as orc
+    from oracle import binding as ob
+    d = synth.generate_shape("tiny", seed=5)
+    K, B = 24, 48
+    cfg = cfg_of(K=K, B=B)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0, 0, 0], item_rows=True)
+    mm.reset(d, seed=11)
+    o = orc.Oracle(orc.OracleConfig(num_dim=K, loss_type=ob.LOSS_CE, **HYPER), d.num_users, d.num_items, d.train_ptr, d.train_col)
+    o.init_params(11)
+    for which in SHARED + PRIVATE:
+        o.set(which, mm.get(which).astype(np.float64))
+    for ep in range(2):
+        mm.train_one_iteration(4, ep)
+        o.train_batched(4, ep, B)
+    for which in SHARED + PRIVATE:
+        ref = o.get(which)
+        err = np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max())
+        assert err < 2e-4, (which, err)
+
+
+def test_item_rows_layout_shards_the_user_node_by_user(built):
+    """Wu / Wu_ag live on the shard that owns the user (contiguous user ranges balanced by interactions), not on
+    every shard: the shard handles' own tables add up to the user count, and a shard's table is exactly its range of the global Wu."""
+    import ctypes as C
+    d = synth.generate_shape("tiny", seed=5)
+    cfg = cfg_of(K=24, B=48)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * 4, item_rows=True)
+    mm.reset(d, seed=11)
+    mm.train_one_iteration(3, 0)
+    wu = mm.get(cdae_amd.P_WU)
+    lib, rows, at = mm.lib, [], 0
+    for s in range(4):
+        h = C.c_void_p()
+        assert lib.cdae_hip_multi_shard(mm.h, s, C.byref(h), None, None) == 0
+        p, n = C.c_void_p(), C.c_size_t()
+        assert lib.cdae_hip_param_device_ptr(h, cdae_amd.P_WU, C.byref(p), C.byref(n)) == 0
+        r = n.value // lib.cdae_hip_row_stride(h)
+        out = np.empty((r, 24), np.float32)
+        assert lib.cdae_hip_get_param(h, cdae_amd.P_WU, out.ctypes.data, out.size) == 0
+        np.testing.assert_array_equal(out, wu[at:at + r])
+        rows.append(r)
+        at += r
+    assert sum(rows) == d.num_users and max(rows) < d.num_users and min(rows) > 0
