@@ -83,11 +83,15 @@ def main():
                          "ONE data set of the named shape, users sharded over the ranks by interactions (BASELINE configs[3]: "
                          "--shape netflix --scaling strong).  Either way the ranks exchange shared-parameter deltas, which is "
                          "OUTSIDE the single-GPU accuracy envelope (DESIGN.md §7): the N > 1 value is a throughput figure")
-    ap.add_argument("--layout", choices=["users", "item-rows"], default="users",
-                    help="item-rows (with --full-output): the GPUs cut the ITEM rows of W / b' and of the three decode products instead of "
-                         "the users (BASELINE configs[4]: --full-output --shape cfg5_items --num-dim 512 --layout item-rows); exact "
-                         "single-GPU schedule, two [batch x K] all-reduces per batch.  One process drives all N GPUs through "
-                         "cdae_hip_multi_* (rank 0 when launched by torch.distributed.run; the other ranks only keep the barriers)")
+    ap.add_argument("--layout", choices=["users", "item-rows"], default=None,
+                    help="How N > 1 GPUs divide the model.  item-rows (the DEFAULT for N > 1): the GPUs cut the ITEM rows of W / b' and the "
+                         "decode over them, every GPU sees every user, the user node is sharded by user; two [batch x K] all-reduces per "
+                         "batch; it is the single-GPU schedule EXACTLY, so the N > 1 number carries the single-GPU accuracy claim "
+                         "(tests/test_gpu_accuracy.py::test_item_rows_sampled_layout_holds_the_accuracy_bounds_at_ml10m_shape).  One "
+                         "process drives all N GPUs through cdae_hip_multi_* (rank 0 when launched by torch.distributed.run; the other "
+                         "ranks only keep the barriers).  With --full-output it is BASELINE configs[4]'s layout (--shape cfg5_items "
+                         "--num-dim 512).  users: user shards + exchange of shared-parameter deltas (one process per GPU, library-owned "
+                         "RCCL): scales in throughput but is OUTSIDE the accuracy envelope (DESIGN.md §7) — a throughput figure only")
     ap.add_argument("--logical-shards", type=int, default=0, help="--layout item-rows on ONE GPU: this many logical shards of cuda:0 "
                     "(the all-reduce is a sum kernel) — measures the cost of the phase structure without a second GPU")
     ap.add_argument("--share-device", action="store_true", help="all ranks use cuda:0 (functional test of the N > 1 path on one GPU; "
@@ -115,6 +119,8 @@ def main():
     from cdae_amd import synth
     from cdae_amd.distributed import shard_bounds
 
+    if args.layout is None:
+        args.layout = "item-rows" if (world > 1 or args.logical_shards) else "users"
     if args.layout == "item-rows":
         return bench_item_rows(args, rank, world)
     if args.scaling == "strong" and world > 1:
@@ -374,12 +380,12 @@ def main():
 
 
 def bench_item_rows(args, rank, world):
-    """--layout item-rows: ONE process (rank 0) drives all N GPUs through cdae_hip_multi_* with CDAE_LAYOUT_ITEM_ROWS."""
+    """--layout item-rows: ONE process (rank 0) drives all N GPUs through cdae_hip_multi_* with CDAE_LAYOUT_ITEM_ROWS — the sampled
+    decode (BASELINE configs[2] / [3] on N GPUs, the default for N > 1) or, with --full-output, the bf16 matrix-core decode
+    (configs[4]).  One data set, strong scaling; a step = one batch of `batch_users` users through all three phases on every GPU."""
     import torch
     import cdae_amd
     from cdae_amd import synth
-    if not args.full_output:
-        raise SystemExit("--layout item-rows is a layout of the full-output decode: add --full-output")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -393,43 +399,72 @@ def bench_item_rows(args, rank, world):
     data = synth.generate_shape(args.shape, seed=args.seed)
     K, B = args.num_dim, min(args.batch_users, data.num_users)
     cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True,
-                              learn_rate=0.1, beta=1.0, lambda_=0.01, using_adagrad=True, user_factor=True, batch_users=B, full_output=True)
+                              learn_rate=0.1, beta=1.0, lambda_=0.01, using_adagrad=True, user_factor=True, batch_users=B,
+                              full_output=args.full_output)
     model = cdae_amd.MultiCDAE(cfg, devices=devices, item_rows=True)
     model.reset(data, seed=args.seed)
     n_batches = (data.num_users + B - 1) // B
+    RUN = 1 if args.full_output else 16  # sampled decode: a step is ~0.1 ms, so batches are handed over in runs (one host sync per run)
 
-    def step(i):
-        b = i % n_batches
-        return model.train_users(args.seed, i // n_batches, b * B, min(data.num_users, (b + 1) * B))      # synchronises at its end
+    def run(first, count):
+        """batches first .. first + count - 1 (cycling through the data set, epoch = pass number); returns users trained"""
+        users, i, end = 0, first, first + count
+        while i < end:
+            b = i % n_batches
+            n = min(RUN, end - i, n_batches - b)
+            users += model.train_users(args.seed, i // n_batches, b * B, min(data.num_users, (b + n) * B)).users
+            i += n
+        return users
 
-    for i in range(args.warmup):
-        step(i)
+    run(0, args.warmup)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    users = 0
-    for i in range(args.warmup, args.warmup + args.steps):
-        users += step(i).users
+    users = run(args.warmup, args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     n_gpus = len(set(devices))
-    MFMA_PEAK_TFLOPS = 2500.0
-    flops_step = 6.0 * K * data.num_items * B
-    achieved = flops_step * args.steps / elapsed / 1e12 / n_gpus          # per GPU, whole step (not the decode family alone)
-    out = {"metric": f"users/sec (whole node) K={K} {args.shape}-shape full-output, item-rows layout",
+    Kp = 64 * (1 if K <= 64 else 2 if K <= 128 else 4 if K <= 256 else 8)
+    par = f"item-rows x{len(devices)}" + (" (logical shards of one GPU)" if args.logical_shards else "")
+    if args.full_output:
+        MFMA_PEAK_TFLOPS = 2500.0
+        flops_step = 6.0 * K * data.num_items * B
+        achieved = flops_step * args.steps / elapsed / 1e12 / n_gpus          # per GPU, whole step (not the decode family alone)
+        metric = f"users/sec (whole node) K={K} {args.shape}-shape full-output, item-rows layout"
+        work = "FULL-OUTPUT decode, CE loss, AdaGrad, q=0.5 scaled"
+        accuracy = "the single-GPU full-output schedule exactly (tests/test_gpu_multi.py: parameters within 5e-3 of range of the single handle)"
+        roofline = {"bound": "mfma", "kernel": "whole step per GPU (three bf16 products over the local item rows + row steps + replicated hidden layer)",
+                    "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None}
+    else:
+        ex_per_batch = data.nnz_train * 6.0 / n_batches
+        comp = compulsory_decode_bytes(K, Kp, data.num_items, ex_per_batch, B) / n_gpus      # every GPU moves its share of the rows once
+        achieved = comp / (elapsed / args.steps) / 1e9
+        metric = ("users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity" if (args.shape == "ml10m" and K == 200)
+                  else f"users/sec (whole node) K={K} {args.shape}-shape")
+        work = "num_neg=5, CE loss, AdaGrad, q=0.5 scaled"
+        accuracy = ("the single-GPU schedule exactly: per-row chains sequential over the GLOBAL batch, two all-reduced per-user sums "
+                    "(tests/test_gpu_multi.py: one shard == the single handle bit for bit; tests/test_gpu_accuracy.py: four shards hold "
+                    "the single-GPU Recall@10 / loss bounds at ML-10M shape)" if B <= DEFAULT_BATCH_USERS
+                    else "the single-GPU schedule exactly, at a batch_users ABOVE the accuracy envelope (throughput only)")
+        roofline = {"bound": "hbm", "kernel": "whole step per GPU (the decode launch is not timed on its own in this layout)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac_definition": "this GPU's share of the decode's compulsory bytes / WHOLE step time / HBM peak — a lower bound of the "
+                                       "decode kernel's own fraction; the step is bound by two latency-bound all-reduces and the longest row "
+                                       "chain, not by bandwidth (DESIGN.md §7b cost model)"}
+    out = {"metric": metric,
            "value": users / elapsed, "unit": "users/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "bf16", "data": "synthetic",
+           "dtype": "bf16" if args.full_output else "f32", "data": "synthetic",
            "config": {"workload": f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} (ONE data set, item rows cut over the GPUs), "
-                                  f"nnz_train={data.nnz_train}, K={K}, FULL-OUTPUT decode, CE loss, AdaGrad, q=0.5 scaled",
-                      "batch_users": B, "global_batch": B, "parallelism": f"item-rows x{len(devices)}" + (" (logical shards of one GPU)" if args.logical_shards else ""),
-                      "exchange": "two all-reduces of [batch_users x row_stride] fp32 per batch (input sums, hidden gradient); no parameter crosses GPUs",
-                      "accuracy": "the single-GPU full-output schedule exactly (tests/test_gpu_multi.py: parameters within 5e-3 of range of the single handle)"},
-           "roofline": {"bound": "mfma", "kernel": "whole step per GPU (three bf16 products over the local item rows + row steps + replicated hidden layer)",
-                        "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None}}
+                                  f"nnz_train={data.nnz_train}, K={K}, {work}",
+                      "batch_users": B, "global_batch": B, "parallelism": par,
+                      "exchange": "two all-reduces per batch: [batch_users x row_stride] fp32 input sums (+ the owners' Wu rows) and hidden "
+                                  "gradient; no item-row parameter crosses GPUs, the user node is sharded by user",
+                      "accuracy": accuracy},
+           "roofline": roofline}
     model.close()
     if dist is not None:
         dist.destroy_process_group()

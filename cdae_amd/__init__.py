@@ -1,8 +1,8 @@
 """cdae_amd — MI355X-native CDAE training hot path (HIP kernels behind a C ABI) and its host mirror.
 
 Layout: csrc/ (gfx950 kernels + C ABI, built into lib/libcdae_hip.so), binding.py (ctypes + the
-libcf::CDAE-shaped host class), synth.py (BASELINE-shaped synthetic data), distributed.py (one process
-per GPU, RCCL all-reduce of the shared-parameter deltas).
+libcf::CDAE-shaped host classes CDAE / MultiCDAE / MF), synth.py (BASELINE-shaped synthetic data), distributed.py (shard bounds
+and device-buffer views for hosts of the library's multi-GPU layouts; the exchange itself lives in csrc/cdae_multi.hip).
 """
 from .binding import (CDAE, MultiCDAE, MF, MFConfig, comm_unique_id, CDAEConfig, HINGE, LOG, P_UB, P_UB_AG, CDAEError, CROSS_ENTROPY, SQUARE, LOGISTIC, Stats,  # noqa: F401
                       load_library, LIB_PATH, EXPORTS, P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG,

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/cdae_rng.h"
+#include "cdae_exchange_algebra.h"
 
 namespace cdae {
 
@@ -1387,7 +1388,7 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
   if (slot >= nb) return;
   const unsigned long long t0 = trace_begin(hp);
   const uint64_t uid = u0 + slot;
-  const bool own = uid >= hp.own_u0 && uid < hp.own_u1;          // wave-uniform: the private rows of this user live here
+  const bool own = cdae_xa::owns_user(uid, hp.own_u0, hp.own_u1);   // wave-uniform: the private rows of this user live here
   const uint32_t lo = lane * NI;
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
@@ -1867,7 +1868,10 @@ own_rows_stage_kernel(HyperParams hp, const float* __restrict__ table, uint64_t 
   float v[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) v[i] = 0.f;
-  if (uid >= hp.own_u0 && uid < hp.own_u1) vload<NI>(v, table + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
+  const bool own = cdae_xa::owns_user(uid, hp.own_u0, hp.own_u1);          // wave-uniform
+  if (own) vload<NI>(v, table + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) v[i] = cdae_xa::own_row_contribution(own, v[i]);
   vstore<NI>(out + (size_t)slot * hp.Kp + lo, v);
 }
 // Item shard, sampled decode: the RAW local hidden gradient of every user of the batch — HG (decode's overflow corrections) plus
@@ -1937,22 +1941,12 @@ apply_delta_kernel(float* __restrict__ cur, const float* __restrict__ base, cons
 // cur += recv - send: algebraically the same, but each replica rounded differently and the copies drifted by ulps.)
 // send / recv are COMPACT: the matrices' pad columns (56 of 256 at K = 200) are neither staged nor all-reduced — row r of a
 // matrix occupies Kc = round_up(K, 4) floats there — followed by the block's tail [b' | b'_ag | b | b_ag] as it is.
-enum { DELTA_STAGE = 0, DELTA_MERGE = 1, DELTA_MERGE_STAGE = 2 };
+enum { DELTA_STAGE = cdae_xa::STAGE, DELTA_MERGE = cdae_xa::MERGE, DELTA_MERGE_STAGE = cdae_xa::MERGE_STAGE };
 
+// (the algebra itself lives in cdae_exchange_algebra.h, shared with the CPU slice the two-rank gloo test drives)
 template <int MODE>
 __device__ __forceinline__ void delta_pipe_elem(float& c, float& A, float& snap, float& s, float& r) {
-  if (MODE == DELTA_STAGE) {
-    const float d = c - A;
-    s = d; r = d; snap = c;
-  } else if (MODE == DELTA_MERGE) {
-    A += r;
-    c = A + (c - snap);
-  } else {
-    A += r;
-    c = A + (c - snap);
-    const float d = c - A;
-    s = d; r = d; snap = c;
-  }
+  cdae_xa::pipe_elem<MODE>(c, A, snap, s, r);
 }
 
 template <int MODE>

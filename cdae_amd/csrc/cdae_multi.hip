@@ -24,6 +24,7 @@
 #include <thread>
 #include <vector>
 
+#include "cdae_exchange_algebra.h"
 #include "cdae_internal.hpp"
 
 using cdae_internal::fail;
@@ -409,6 +410,38 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
   if (plan.empty()) return 0;
   std::vector<float*> hs(S), hg(S);
   for (size_t s = 0; s < S; ++s) { hs[s] = cdae_internal::hsum_buf(m->shard[s]); hg[s] = cdae_internal::hg_buf(m->shard[s]); }
+  if (S > 1 && !m->single_device) {
+    // one shard per GPU: one host thread per shard, like the user-sharded layout (a batch is ~15 launches per shard; from one
+    // thread the HOST would pace N GPUs).  Every thread issues the same sequence — phases on its shard's main stream, the two
+    // all-reduces on its own communicator of the ncclCommInitAll group — so the collectives pair up without a group call.
+    std::vector<int> rc(S, 0);
+    std::vector<std::string> err(S);
+    std::vector<std::thread> th;
+    auto run = [&](size_t s) -> int {
+      cdae_hip_t* h = m->shard[s];
+      HIPCHK(hipSetDevice(m->devices[s]));
+      hipStream_t st = cdae_internal::main_stream(h);
+      CHK(cdae_internal::fs_prep(h, seed, epoch, plan[0].s0, plan[0].nb, plan[0].c));
+      for (size_t t = 0; t < plan.size(); ++t) {
+        const Bt& b = plan[t];
+        CHK(cdae_internal::fs_phase0(h, seed, epoch, b.s0, b.nb, b.c));
+        NCCLCHK(ncclAllReduce(hs[s], hs[s], (size_t)b.nb * Kp * blocks, ncclFloat32, ncclSum, m->comms[s], st));
+        if (t + 1 < plan.size()) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[t + 1].s0, plan[t + 1].nb, plan[t + 1].c));
+        CHK(cdae_internal::fs_phase1(h, b.s0, b.nb));
+        NCCLCHK(ncclAllReduce(hg[s], hg[s], (size_t)b.nb * Kp, ncclFloat32, ncclSum, m->comms[s], st));
+        CHK(cdae_internal::fs_phase2(h, b.s0, b.nb));
+      }
+      return cdae_hip_synchronize(h);
+    };
+    for (size_t s = 0; s < S; ++s)
+      th.emplace_back([&, s] {
+        rc[s] = run(s);
+        if (rc[s]) err[s] = cdae_hip_last_error();
+      });
+    for (std::thread& t : th) t.join();
+    for (size_t s = 0; s < S; ++s) if (rc[s]) return fail("item shard %zu: %s", s, err[s].c_str());
+    return 0;
+  }
   for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[0].s0, plan[0].nb, plan[0].c));
   for (size_t t = 0; t < plan.size(); ++t) {
     const Bt& b = plan[t];
@@ -511,22 +544,13 @@ static int set_interactions_item_rows(cdae_hip_multi* m, uint64_t U, uint64_t I,
   }
   for (uint64_t i = 0; i < I; ++i) cnt[i + 1] += cnt[i];
   m->icut.assign(S + 1, 0);
-  for (size_t s = 1; s < S; ++s) {
-    const uint64_t want = (uint64_t)(((__int128)nnz * (int64_t)s + (int64_t)S - 1) / (int64_t)S);
-    uint64_t i = (uint64_t)(std::lower_bound(cnt.begin(), cnt.end(), want) - cnt.begin());
-    i = std::max<uint64_t>(i, m->icut[s - 1] + 1);
-    i = std::min<uint64_t>(i, I - (S - s));
-    m->icut[s] = i;
+  {
+    std::vector<int64_t> pre(cnt.begin(), cnt.end());
+    cdae_xa::balanced_cuts(pre.data(), I, S, true, m->icut.data());
   }
-  m->icut[S] = I;
   // the user node (Wu, Uu) is sharded by USER: contiguous user ranges balanced by interactions; a shard may own no user
   m->cut.assign(S + 1, 0);
-  for (size_t s = 1; s < S; ++s) {
-    const int64_t want = (int64_t)(((__int128)nnz * (int64_t)s + (int64_t)S - 1) / (int64_t)S);
-    uint64_t u = (uint64_t)(std::lower_bound(row_ptr, row_ptr + U + 1, want) - row_ptr);
-    m->cut[s] = std::min<uint64_t>(std::max<uint64_t>(u, m->cut[s - 1]), U);
-  }
-  m->cut[S] = U;
+  cdae_xa::balanced_cuts(row_ptr, U, S, false, m->cut.data());
   std::vector<int64_t> rp(U + 1);
   std::vector<uint32_t> lc, pos(2 * U);
   for (size_t s = 0; s < S; ++s) {
@@ -569,15 +593,7 @@ int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t U, uint64_t I,
   if (U < S) return fail("%llu users cannot be split into %zu shards", (unsigned long long)U, S);
   // contiguous user ranges balanced by interactions; every shard gets at least one user
   m->cut.assign(S + 1, 0);
-  const int64_t nnz = row_ptr[U];
-  for (size_t s = 1; s < S; ++s) {
-    const int64_t want = (int64_t)(((__int128)nnz * (int64_t)s + (int64_t)S - 1) / (int64_t)S);    // first user whose prefix reaches s/S of the interactions
-    uint64_t u = (uint64_t)(std::lower_bound(row_ptr, row_ptr + U + 1, want) - row_ptr);
-    u = std::max<uint64_t>(u, m->cut[s - 1] + 1);
-    u = std::min<uint64_t>(u, U - (S - s));
-    m->cut[s] = u;
-  }
-  m->cut[S] = U;
+  cdae_xa::balanced_cuts(row_ptr, U, S, true, m->cut.data());   // first user whose prefix reaches s/S of the interactions
   std::vector<int64_t> rp;
   for (size_t s = 0; s < S; ++s) {
     const uint64_t a = m->cut[s], b = m->cut[s + 1];

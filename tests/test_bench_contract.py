@@ -72,3 +72,17 @@ def test_item_rows_layout_line(built):
         assert k in d, k
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["bound"] == "mfma"
     assert "item-rows x3" in d["config"]["parallelism"]
+
+
+def test_sampled_item_rows_line_is_the_default_layout_beyond_one_gpu(built):
+    """What `--gpus N` (N > 1) runs by default — the sampled decode in the item-rows layout, the multi-GPU schedule that carries the
+    single-GPU accuracy claim — exercised on one GPU as logical shards (--logical-shards selects the layout like world > 1 does)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shape", "small", "--steps", "20", "--warmup", "3", "--batch-users", "128",
+                          "--num-dim", "32", "--logical-shards", "4", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    for k, t in REQUIRED.items():
+        assert k in d, k
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["dtype"] == "f32"
+    assert d["roofline"]["bound"] == "hbm" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    assert "item-rows x4" in d["config"]["parallelism"] and "single-GPU schedule exactly" in d["config"]["accuracy"]

@@ -1,11 +1,21 @@
-"""CPU, world_size 2 over gloo: the data-parallel exchange protocol of cdae_amd/distributed.py.
+"""CPU, world_size 2 over gloo: the arithmetic of the SHIPPED multi-GPU layouts, run by two real ranks.
 
-Each rank trains its own user shard with the oracle (test infrastructure standing in for the GPU
-kernels), exchanges shared-parameter deltas through HostDeltaExchange, and the result must equal a
-single-process emulation of the same protocol.  Also checks shard_bounds and combine_reference.
+tests/native/exchange_cpu.cpp compiles cdae_amd/csrc/cdae_exchange_algebra.h — the header the device kernels
+(delta_pipe_kernel, own_rows_stage_kernel) and cdae_multi.hip compile — into a small CPU library; two gloo ranks drive it with
+torch.distributed collectives in the place RCCL takes on the GPUs:
+
+  * user-sharded layout, pipelined shared-parameter exchange (cdae_multi.hip boundary_stage / boundary_reduce): STAGE, all-reduce
+    the staged deltas, MERGE — synchronous and pipelined schedules; replicas' agreed state A bit-identical across ranks at every
+    boundary, parameters bit-identical after the flush, equal to a one-process restatement of the same schedule;
+  * item-rows layout (item_epoch): every rank holds an item range and a user range; per batch all-reduce(sum) of
+    [input sums | owners' Wu rows], then of the hidden gradient: the gathered private rows are the owner's bits, the two sums equal
+    the whole-matrix sums up to fp32 association, rows never leave their owner;
+  * the balanced contiguous cuts both layouts shard by.
 """
+import ctypes as C
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -17,149 +27,107 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from cdae_amd import synth  # noqa: E402
-from cdae_amd.distributed import (HostDeltaExchange, HostPipelinedDeltaExchange, combine_reference,  # noqa: E402
-                                  shard_bounds, RULE_SUM, RULE_TOUCH_MEAN)
+from cdae_amd.distributed import shard_bounds  # noqa: E402
 
-SHARED = [0, 1, 8, 9, 6, 7]     # W, W_ag, bp, bp_ag, b, b_ag — the library's shared-block order (tied mode)
-K, B, STEPS = 8, 16, 3
+STAGE, MERGE, MERGE_STAGE = 0, 1, 2
 
 
-def _make_oracle(data):
-    import oracle as orc
-    from oracle import binding as ob
-    o = orc.Oracle(orc.OracleConfig(num_dim=K, loss_type=ob.LOSS_CE, beta=1.0), data.num_users, data.num_items,
-                   data.train_ptr, data.train_col)
-    o.init_params(5)
-    return o
+def build_slice():
+    src = os.path.join(ROOT, "tests", "native", "exchange_cpu.cpp")
+    hdr = os.path.join(ROOT, "cdae_amd", "csrc", "cdae_exchange_algebra.h")
+    out = os.path.join(ROOT, "build", "libcdae_exchange_cpu.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out])
+    return out
 
 
-def _get_shared(o):
-    return torch.from_numpy(np.concatenate([o.get(w) for w in SHARED]))
+def load_slice():
+    lib = C.CDLL(build_slice())
+    fp, vp = C.POINTER(C.c_float), C.c_void_p
+    lib.xa_pipe.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_size_t]
+    lib.xa_stage_own_rows.argtypes = [fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, fp]
+    lib.xa_balanced_cuts.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp]
+    return lib
 
 
-def _set_shared(o, t):
-    a, off = t.numpy(), 0
-    for w in SHARED:
-        n = o.get(w).size
-        o.set(w, a[off:off + n])
-        off += n
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def _run_rank(rank, world, port, rule, out_dir):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    data = synth.generate_shape("tiny", seed=5)
-    u0, u1 = shard_bounds(data.num_users, world, rank, data.train_ptr)
-    o = _make_oracle(data)
-    I = data.num_items
-    state = {"before": None}
+class Replica:
+    """One rank's copy of a shared block under the pipelined exchange (what cdae_hip_delta_stage / _merge keep per handle)."""
 
-    def touched():
-        d = (_get_shared(o) - state["before"]).numpy()
-        return torch.from_numpy(((np.abs(d[:I * K].reshape(I, K)).sum(1) + np.abs(d[2 * I * K:2 * I * K + I])) > 0).astype(np.float64))
+    def __init__(self, lib, init):
+        self.lib = lib
+        self.cur = init.copy()
+        self.base = init.copy()                        # cdae_hip_delta_begin: A = current
+        self.snap = np.zeros_like(init)
+        self.send = np.zeros_like(init)
+        self.recv = np.zeros_like(init)
 
-    ex = HostDeltaExchange(lambda: _get_shared(o), lambda t: _set_shared(o, t), touched, dist, world,
-                           n_matrix=2 * I * K, Kp=K, num_items=I, rule=rule)
-    for step in range(STEPS):
-        ex.begin()
-        state["before"] = _get_shared(o)
-        s0 = u0 + step * B
-        o.train_batched(9, 0, B, s0, min(u1, s0 + B))
-        ex.finish()
-    np.save(os.path.join(out_dir, f"shared_{rank}.npy"), _get_shared(o).numpy())
-    np.save(os.path.join(out_dir, f"wu_{rank}.npy"), o.get(4))
-    dist.destroy_process_group()
+    def apply(self, mode):
+        self.lib.xa_pipe(mode, fptr(self.cur), fptr(self.base), fptr(self.snap), fptr(self.send), fptr(self.recv), self.cur.size)
 
 
-def _emulate(world, rule):
-    data = synth.generate_shape("tiny", seed=5)
-    I = data.num_items
-    reps = [_make_oracle(data) for _ in range(world)]
-    bounds = [shard_bounds(data.num_users, world, r, data.train_ptr) for r in range(world)]
-    for step in range(STEPS):
-        base = _get_shared(reps[0])
-        deltas, touches = [], []
-        for r, o in enumerate(reps):
-            u0, u1 = bounds[r]
-            s0 = u0 + step * B
-            o.train_batched(9, 0, B, s0, min(u1, s0 + B))
-            d = _get_shared(o) - base
-            deltas.append(d)
-            dn = d.numpy()
-            touches.append(torch.from_numpy(((np.abs(dn[:I * K].reshape(I, K)).sum(1) + np.abs(dn[2 * I * K:2 * I * K + I])) > 0).astype(np.float64)))
-        new = combine_reference(base, sum(deltas), sum(touches), 2 * I * K, K, I, world, rule)
-        for o in reps:
-            _set_shared(o, new)
-    return _get_shared(reps[0]).numpy(), [o.get(4) for o in reps], bounds
+def local_training(cur, rank, step):
+    """stand-in for a shard's training step: a deterministic, rank- and step-dependent fp32 update of part of the block"""
+    rng = np.random.default_rng(1000 * rank + step)
+    idx = rng.choice(cur.size, cur.size // 3, replace=False)
+    cur[idx] += (rng.standard_normal(idx.size) * 0.05).astype(np.float32)
 
 
-def _run_rank_pipelined(rank, world, port, period, out_dir):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    data = synth.generate_shape("tiny", seed=5)
-    u0, u1 = shard_bounds(data.num_users, world, rank, data.train_ptr)
-    o = _make_oracle(data)
-    ex = HostPipelinedDeltaExchange(lambda: _get_shared(o), lambda t: _set_shared(o, t), dist, world, period=period)
-    for step in range(PIPE_STEPS):
-        s0 = u0 + step * B
-        o.train_batched(9, 0, B, s0, min(u1, s0 + B))
-        ex.after_batch()
-    ex.flush()
-    np.save(os.path.join(out_dir, f"shared_{rank}.npy"), _get_shared(o).numpy())
-    dist.destroy_process_group()
-
-
-PIPE_STEPS = 5
-
-
-def _emulate_pipelined(world, period):
-    """Single-process restatement: rank r trains from its own replica; at every boundary the previous period's peer
-    deltas are merged, then this period's own deltas are staged (they reach the peers one period later)."""
-    data = synth.generate_shape("tiny", seed=5)
-    reps = [_make_oracle(data) for _ in range(world)]
-    bounds = [shard_bounds(data.num_users, world, r, data.train_ptr) for r in range(world)]
-    base = [_get_shared(o) for o in reps]
-    in_flight = None                                  # per-rank deltas staged at the previous boundary
+def run_schedule(lib, init, world, period, steps, all_reduce, rank=None, on_boundary=None):
+    """cdae_multi.hip step_single / flush_single for one rank (rank given) or, with rank None, for every rank in lockstep with a
+    plain sum standing in for the collective (the one-process restatement)."""
+    ranks = [rank] if rank is not None else list(range(world))
+    reps = {r: Replica(lib, init) for r in ranks}
+    for rep in reps.values():
+        rep.apply(STAGE)                               # begin_if_needed: stages a zero delta
+    pending = False
 
     def boundary(start_next):
-        nonlocal in_flight
-        if in_flight is not None:
-            total = sum(in_flight)
-            for r, o in enumerate(reps):
-                peers = total - in_flight[r]
-                _set_shared(o, _get_shared(o) + peers)
-                base[r] = base[r] + peers
-            in_flight = None
+        nonlocal pending
+        for rep in reps.values():
+            rep.apply(MERGE_STAGE if pending and start_next else MERGE if pending else STAGE) if (pending or start_next) else None
+        pending = False
         if start_next:
-            in_flight = []
-            for r, o in enumerate(reps):
-                cur = _get_shared(o)
-                in_flight.append(cur - base[r])
-                base[r] = cur.clone()
+            all_reduce(reps)
+            pending = True
+        if on_boundary:
+            on_boundary(reps)
 
-    for step in range(PIPE_STEPS):
-        for r, o in enumerate(reps):
-            u0, u1 = bounds[r]
-            s0 = u0 + step * B
-            o.train_batched(9, 0, B, s0, min(u1, s0 + B))
-        if (step + 1) % period == 0:
+    for t in range(steps):
+        for r, rep in reps.items():
+            local_training(rep.cur, r, t)
+        if period == 0:
+            boundary(True); boundary(False)
+        elif (t + 1) % period == 0:
             boundary(True)
-    boundary(True)
-    boundary(False)
-    return [_get_shared(o).numpy() for o in reps]
+    if period != 0 or pending:
+        boundary(True); boundary(False)
+    return reps
 
 
-@pytest.mark.parametrize("period", [1, 2])
-def test_two_rank_gloo_pipelined_exchange(built, tmp_path, period):
-    world = 2
-    mp.spawn(_run_rank_pipelined, args=(world, _free_port(), period, str(tmp_path)), nprocs=world, join=True)
-    got = [np.load(tmp_path / f"shared_{r}.npy") for r in range(world)]
-    ref = _emulate_pipelined(world, period)
-    np.testing.assert_allclose(got[0], got[1], rtol=1e-12, atol=1e-14)     # replicas converge after flush()
-    for r in range(world):
-        np.testing.assert_allclose(got[r], ref[r], rtol=1e-12, atol=1e-14)
+def _rank_pipelined(rank, world, port, period, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = load_slice()
+    init = np.random.default_rng(7).standard_normal(4099).astype(np.float32)
+    agreed = []
+
+    def all_reduce(reps):
+        t = torch.from_numpy(reps[rank].recv)          # in place, like ncclAllReduce(recv, recv, ...)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def on_boundary(reps):
+        agreed.append(reps[rank].base.copy())
+
+    reps = run_schedule(lib, init, world, period, steps, all_reduce, rank=rank, on_boundary=on_boundary)
+    np.save(os.path.join(out_dir, f"cur_{rank}.npy"), reps[rank].cur)
+    np.save(os.path.join(out_dir, f"agreed_{rank}.npy"), np.stack(agreed))
+    dist.destroy_process_group()
 
 
 def _free_port():
@@ -170,47 +138,104 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("rule", [RULE_SUM, RULE_TOUCH_MEAN])
-def test_two_rank_gloo_exchange_matches_emulation(built, tmp_path, rule):
+@pytest.mark.parametrize("period", [0, 1, 3])
+def test_two_rank_gloo_pipelined_exchange_runs_the_shipped_algebra(tmp_path, period):
+    world, steps = 2, 7
+    mp.spawn(_rank_pipelined, args=(world, _free_port(), period, steps, str(tmp_path)), nprocs=world, join=True)
+    cur = [np.load(tmp_path / f"cur_{r}.npy") for r in range(world)]
+    agreed = [np.load(tmp_path / f"agreed_{r}.npy") for r in range(world)]
+    np.testing.assert_array_equal(agreed[0], agreed[1])          # A: the same bits on every rank at every boundary
+    np.testing.assert_array_equal(cur[0], cur[1])                # after the flush the replicas are bit-identical ...
+    np.testing.assert_array_equal(cur[0], agreed[0][-1])         # ... and equal to the agreed state
+    # one-process restatement of the same schedule: gloo's two-rank sum is a + b in either order, so bit-equal
+    lib = load_slice()
+    init = np.random.default_rng(7).standard_normal(4099).astype(np.float32)
+
+    def local_sum(reps):
+        total = reps[0].recv + reps[1].recv
+        for rep in reps.values():
+            rep.recv[:] = total
+
+    ref = run_schedule(lib, init, world, period, steps, local_sum)
+    for r in range(world):
+        np.testing.assert_array_equal(cur[r], ref[r].cur)
+    # and the exchange really carried the peers' progress: the result differs from either rank training alone
+    alone = init.copy()
+    for t in range(steps):
+        local_training(alone, 0, t)
+    assert np.abs(cur[0] - alone).max() > 1e-3
+
+
+def _rank_item_rows(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = load_slice()
+    d = synth.generate_shape("tiny", seed=5)
+    U, I, K = d.num_users, d.num_items, 8
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((I, K)).astype(np.float32)           # every rank draws the same matrices, keeps its slices
+    Wu = rng.standard_normal((U, K)).astype(np.float32)
+    G = rng.standard_normal((U, I)).astype(np.float32)
+    cnt = np.r_[0, np.cumsum(np.bincount(d.train_col, minlength=I))].astype(np.int64)
+    icut, ucut = np.zeros(world + 1, np.uint64), np.zeros(world + 1, np.uint64)
+    lib.xa_balanced_cuts(cnt.ctypes.data, I, world, 1, icut.ctypes.data)
+    lib.xa_balanced_cuts(d.train_ptr.ctypes.data, U, world, 0, ucut.ctypes.data)
+    i0, i1, u0, u1 = int(icut[rank]), int(icut[rank + 1]), int(ucut[rank]), int(ucut[rank + 1])
+    W_loc, Wu_loc = W[i0:i1].copy(), Wu[u0:u1].copy()            # item rows and private user rows THIS rank holds
+    s0, nb = 120, 64                                             # a batch that straddles the two ranks' user ranges
+    # phase 0: local input sums over the local item rows + the owners' Wu rows, one all-reduce
+    buf = np.zeros((2, nb, K), np.float32)
+    for s in range(nb):
+        row = d.train_col[d.train_ptr[s0 + s]:d.train_ptr[s0 + s + 1]]
+        loc = row[(row >= i0) & (row < i1)] - i0
+        buf[0, s] = W_loc[loc].sum(axis=0, dtype=np.float32)
+    lib.xa_stage_own_rows(fptr(Wu_loc), u0, u1, s0, nb, K, fptr(buf[1]))
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    # phase 1: local hidden gradient over the local item rows, second all-reduce
+    hg = (G[s0:s0 + nb, i0:i1] @ W_loc).astype(np.float32)
+    dist.all_reduce(torch.from_numpy(hg), op=dist.ReduceOp.SUM)
+    np.savez(os.path.join(out_dir, f"rank_{rank}.npz"), sums=buf[0], wu=buf[1], hg=hg, icut=icut, ucut=ucut)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_item_rows_phases(tmp_path):
     world = 2
-    mp.spawn(_run_rank, args=(world, _free_port(), rule, str(tmp_path)), nprocs=world, join=True)
-    ref_shared, ref_wu, bounds = _emulate(world, rule)
-    got = [np.load(tmp_path / f"shared_{r}.npy") for r in range(world)]
-    np.testing.assert_array_equal(got[0], got[1])                 # replicas stay identical
-    np.testing.assert_allclose(got[0], ref_shared, rtol=1e-13, atol=1e-15)
-    for r in range(world):                                        # the user node never leaves its rank
-        u0, u1 = bounds[r]
-        wu = np.load(tmp_path / f"wu_{r}.npy").reshape(-1, K)
-        np.testing.assert_allclose(wu[u0:u1], ref_wu[r].reshape(-1, K)[u0:u1], rtol=1e-13)
-        other = np.ones(wu.shape[0], bool); other[u0:u1] = False
-        init = _make_oracle(synth.generate_shape("tiny", seed=5)).get(4).reshape(-1, K)
-        np.testing.assert_array_equal(wu[other], init[other])
+    mp.spawn(_rank_item_rows, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"rank_{r}.npz") for r in range(world)]
+    d = synth.generate_shape("tiny", seed=5)
+    U, I, K = d.num_users, d.num_items, 8
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((I, K)).astype(np.float32)
+    Wu = rng.standard_normal((U, K)).astype(np.float32)
+    G = rng.standard_normal((U, I)).astype(np.float32)
+    s0, nb = 120, 64
+    for k in ("sums", "wu", "hg", "icut", "ucut"):
+        np.testing.assert_array_equal(got[0][k], got[1][k])       # every rank ends a phase with the same buffers
+    icut, ucut = got[0]["icut"], got[0]["ucut"]
+    assert icut[0] == 0 and icut[-1] == I and 0 < icut[1] < I and ucut[0] == 0 and ucut[-1] == U
+    assert ucut[0] <= s0 < ucut[1] < s0 + nb                       # the batch did straddle both owners
+    np.testing.assert_array_equal(got[0]["wu"], Wu[s0:s0 + nb])    # gathered private rows: the owners' bits
+    whole = np.stack([W[d.train_col[d.train_ptr[u]:d.train_ptr[u + 1]]].sum(axis=0, dtype=np.float64) for u in range(s0, s0 + nb)])
+    np.testing.assert_allclose(got[0]["sums"], whole, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got[0]["hg"], G[s0:s0 + nb].astype(np.float64) @ W.astype(np.float64), rtol=0, atol=2e-4)
 
 
-def test_shard_bounds_cover_and_balance():
+def test_balanced_cuts_cover_balance_and_match_shard_bounds():
+    lib = load_slice()
     d = synth.generate_shape("tiny", seed=5)
     for world in (1, 2, 3, 8):
-        cuts = [shard_bounds(d.num_users, world, r, d.train_ptr) for r in range(world)]
-        assert cuts[0][0] == 0 and cuts[-1][1] == d.num_users
-        assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
-        nnz = [d.train_ptr[b] - d.train_ptr[a] for a, b in cuts]
+        cuts = np.zeros(world + 1, np.uint64)
+        lib.xa_balanced_cuts(d.train_ptr.ctypes.data, d.num_users, world, 1, cuts.ctypes.data)
+        assert cuts[0] == 0 and cuts[-1] == d.num_users and (np.diff(cuts.astype(np.int64)) >= 1).all()
+        nnz = [int(d.train_ptr[int(b)] - d.train_ptr[int(a)]) for a, b in zip(cuts[:-1], cuts[1:])]
         assert max(nnz) - min(nnz) <= np.diff(d.train_ptr).max() * 2
+        assert [shard_bounds(d.num_users, world, r, d.train_ptr) for r in range(world)] == [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
         even = [shard_bounds(d.num_users, world, r) for r in range(world)]
         assert even[0][0] == 0 and even[-1][1] == d.num_users
-
-
-def test_combine_reference_rules():
-    I, Kp = 5, 4
-    n_matrix = 2 * I * Kp
-    n = n_matrix + 2 * I + 2 * Kp
-    base = torch.arange(n, dtype=torch.float64)
-    summed = torch.ones(n, dtype=torch.float64) * 6
-    touch = torch.tensor([0., 1., 2., 3., 6.], dtype=torch.float64)
-    out = combine_reference(base, summed, touch, n_matrix, Kp, I, 3, RULE_SUM)
-    assert torch.equal(out, base + 6)
-    out = combine_reference(base, summed, touch, n_matrix, Kp, I, 3, RULE_TOUCH_MEAN) - base
-    w = 6 / torch.clamp(touch, min=1)
-    assert torch.allclose(out[:I * Kp].reshape(I, Kp), w[:, None].expand(I, Kp))
-    assert torch.allclose(out[I * Kp:n_matrix].reshape(I, Kp), w[:, None].expand(I, Kp))
-    assert torch.allclose(out[n_matrix:n_matrix + I], w) and torch.allclose(out[n_matrix + I:n_matrix + 2 * I], w)
-    assert torch.allclose(out[-2 * Kp:], torch.full((2 * Kp,), 2.0, dtype=torch.float64))
+    # ranges that may be empty (item-rows layout: user ownership), more ranges than rows with weight
+    pre = np.array([0, 0, 0, 10, 10, 10], np.int64)
+    cuts = np.zeros(5, np.uint64)
+    lib.xa_balanced_cuts(pre.ctypes.data, 5, 4, 0, cuts.ctypes.data)
+    assert cuts[0] == 0 and cuts[-1] == 5 and (np.diff(cuts.astype(np.int64)) >= 0).all()

@@ -168,22 +168,23 @@ def test_errors_are_reported_not_swallowed(tiny):
 
 
 @pytest.mark.parametrize("rule", [0, 1])
-def test_delta_exchange_kernel_matches_torch_restatement(tiny, rule):
-    """World of one process emulating two identical ranks: the all-reduced buffer is 2 x this rank's."""
+def test_delta_exchange_kernel_matches_numpy_restatement(tiny, rule):
+    """cdae_hip_delta_begin / _compute / _apply with a hand-made "all-reduce": one process emulating two identical ranks (the
+    all-reduced buffer is 2 x this rank's).  rule 0: sum; rule 1: item rows divided by the ranks that touched them, b by the world."""
     import torch
-    from cdae_amd.distributed import DeltaExchange, combine_reference
+    from cdae_amd.distributed import wrap_device_floats
     model, _ = make_pair(tiny, K=20, B=64)
-    ex = DeltaExchange(model, None, 1, rule)
     shared_ids = (0, 1, 8, 9, 6, 7)
-    ex.begin()
+    model.delta_begin()
+    buf = wrap_device_floats(*model.delta_device_ptr())
+    stream = torch.cuda.ExternalStream(model.stream_handle(), device=buf.device)     # the stream the library's delta calls run on
     before = {w: model.get(w).astype(np.float64) for w in shared_ids}
     model.train_users(seed=2, epoch=0, u_begin=0, u_end=64)
     after = {w: model.get(w).astype(np.float64) for w in shared_ids}
     model.delta_compute()
-    model.synchronize()                                # the delta calls are stream-ordered on the library's stream
-    assert ex.buf.is_cuda and ex.buf.numel() == model.delta_device_ptr()[1]
-    with torch.cuda.stream(ex.stream):                 # the stream the real all-reduce is enqueued on
-        ex.buf.mul_(2.0)                               # "all-reduce" of two identical ranks
+    model.synchronize()
+    with torch.cuda.stream(stream):
+        buf.mul_(2.0)                                  # "all-reduce" of two identical ranks
     model.delta_apply(2, rule)
     touched = (np.abs(after[1] - before[1]).sum(1) + np.abs(after[9] - before[9])) > 0
     for w in shared_ids:
@@ -267,10 +268,15 @@ def test_pipelined_exchange_kernels(tiny, K):
     own staged delta (so the row pads stay zero, as with real peers); the peer part must land on the live parameters one
     period late while the rank's own later steps are kept, and must never be re-sent."""
     import torch
-    from cdae_amd.distributed import PipelinedDeltaExchange
+    from cdae_amd.distributed import wrap_device_floats
     model, _ = make_pair(tiny, K=K, B=64)
     shared_ids = (0, 1, 8, 9, 6, 7)
-    ex = PipelinedDeltaExchange(model, None, 1, period=1)
+
+    class ex:                                            # the receive buffer of the library's exchange, on the library's stream
+        pass
+    model.delta_begin(); model.delta_stage(); model.synchronize()
+    ex.recv = wrap_device_floats(*model.delta_recv_device_ptr())
+    ex.stream = torch.cuda.ExternalStream(model.stream_handle(), device=ex.recv.device)
 
     def snap():
         return {w: model.get(w).astype(np.float64) for w in shared_ids}
@@ -309,42 +315,6 @@ def test_pipelined_exchange_kernels(tiny, K):
     for w in shared_ids:
         np.testing.assert_allclose(model.get(w).astype(np.float64), x4[w] - 0.5 * (x2[w] - x1[w]), rtol=1e-6, atol=5e-6)
     assert close(staged_sum(), sum(float((x4[w] - x3[w]).sum()) for w in shared_ids))
-
-
-def test_pipelined_exchange_over_rccl_single_rank(tiny):
-    """The real collective path with a one-rank RCCL group: async all_reduce on the wrapped library stream, stream-level
-    wait, merge.  With one rank the sum is the rank's own delta, so training must be unaffected by the exchange."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    if not dist.is_nccl_available():
-        pytest.skip("no RCCL in this torch build")
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        from cdae_amd.distributed import PipelinedDeltaExchange
-        a, _ = make_pair(tiny, K=24, B=32)
-        b, _ = make_pair(tiny, K=24, B=32)
-        ex = PipelinedDeltaExchange(a, dist, 1, period=1 << 30)
-        for i in range(2):                                 # bench.py's start-up: a few batches without exchange, flush,
-            a.enqueue_users(3, 0, 32 * i, 32 * (i + 1))    # then the period is chosen from a timed all-reduce
-            ex.after_batch()
-            b.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
-        ex.flush()
-        period, t_ar = ex.choose_period(step_seconds=1e-4)
-        assert 1 <= period <= 8 and t_ar > 0 and ex.period == period
-        ex.period = 2
-        for i in range(2, 7):
-            a.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
-            ex.after_batch()
-            b.enqueue_users(3, 0, 32 * i, 32 * (i + 1))
-        ex.flush()
-        a.synchronize(); b.synchronize()
-        torch.cuda.synchronize()
-        for which in (0, 1, 6, 7, 8, 9):
-            np.testing.assert_allclose(a.get(which), b.get(which), rtol=2e-6, atol=2e-6)
-    finally:
-        dist.destroy_process_group()
 
 
 def test_async_enqueue_and_prefetch_equal_synchronous_training(tiny):

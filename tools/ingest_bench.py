@@ -27,15 +27,34 @@ from cdae_amd import synth  # noqa: E402
 
 
 def timed(cmd, cwd, ok=(0,)):
-    """wall seconds, peak RSS (GiB) of THIS child (wait4's rusage), combined output"""
+    """wall seconds, peak RSS (GiB) of THIS child — /proc/<pid>/status VmHWM, polled: wait4's ru_maxrss also counts the pages the
+    child shared with this Python process between fork and exec — and its combined output"""
+    import tempfile
+    import threading
     t0 = time.perf_counter()
-    p = subprocess.Popen(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    log = p.stdout.read()
-    _, status, ru = os.wait4(p.pid, 0)
-    dt = time.perf_counter() - t0
-    rc = os.waitstatus_to_exitcode(status) if hasattr(os, "waitstatus_to_exitcode") else (status >> 8)
-    assert rc in ok, log[-2000:]
-    return dt, ru.ru_maxrss / 2**20, log
+    with tempfile.TemporaryFile(mode="w+") as logf:
+        p = subprocess.Popen(cmd, cwd=cwd, stdout=logf, stderr=subprocess.STDOUT, text=True)
+        peak = [0]
+
+        def poll():
+            while p.poll() is None:
+                try:
+                    for line in open(f"/proc/{p.pid}/status"):
+                        if line.startswith("VmHWM:"):
+                            peak[0] = max(peak[0], int(line.split()[1]))
+                except OSError:
+                    pass
+                time.sleep(0.05)
+        th = threading.Thread(target=poll)
+        th.start()
+        rc = p.wait()
+        th.join()
+        dt = time.perf_counter() - t0
+        logf.seek(0)
+        log = logf.read()
+    rc = rc if rc >= 0 else 256 + rc
+    assert (rc & 0xFF) in ok, log[-2000:]
+    return dt, peak[0] / 2**20, log
 
 
 def main():
@@ -44,22 +63,27 @@ def main():
     ap.add_argument("--dir", default="/tmp/ingest")
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ap.add_argument("--seed", type=int, default=20141119)
+    ap.add_argument("--reuse-text", action="store_true", help="the ratings file of an earlier run is still in --dir")
     args = ap.parse_args()
     os.makedirs(args.dir, exist_ok=True)
     txt = os.path.join(args.dir, "yelp_10core.txt")
     t0 = time.perf_counter()
-    d = synth.generate_shape(args.shape, seed=args.seed)
-    users = np.r_[np.repeat(np.arange(d.num_users, dtype=np.uint32), np.diff(d.train_ptr)),
-                  np.repeat(np.arange(d.num_users, dtype=np.uint32), np.diff(d.test_ptr))]
-    items = np.r_[d.train_col, d.test_col]
-    order = np.random.default_rng(1).permutation(users.size)
-    import pandas as pd
-    df = pd.DataFrame({"user": users[order], "item": items[order]})
-    df["user"] = "u" + df["user"].astype(str)
-    df["item"] = "i" + df["item"].astype(str)
-    df.to_csv(txt, sep=" ", index=False)
-    n = int(users.size)
-    del df, users, items, order, d
+    if args.reuse_text and os.path.exists(txt):
+        with open(txt, "rb") as f:
+            n = sum(buf.count(b"\n") for buf in iter(lambda: f.read(1 << 24), b"")) - 1
+    else:
+        d = synth.generate_shape(args.shape, seed=args.seed)
+        users = np.r_[np.repeat(np.arange(d.num_users, dtype=np.uint32), np.diff(d.train_ptr)),
+                      np.repeat(np.arange(d.num_users, dtype=np.uint32), np.diff(d.test_ptr))]
+        items = np.r_[d.train_col, d.test_col]
+        order = np.random.default_rng(1).permutation(users.size)
+        import pandas as pd
+        df = pd.DataFrame({"user": users[order], "item": items[order]})
+        df["user"] = "u" + df["user"].astype(str)
+        df["item"] = "i" + df["item"].astype(str)
+        df.to_csv(txt, sep=" ", index=False)
+        n = int(users.size)
+        del df, users, items, order, d
     gen_s = time.perf_counter() - t0
     yelp, check = os.path.join(ROOT, "build", "yelp"), os.path.join(ROOT, "build", "host_check")
     out = {"shape": args.shape, "ratings": n, "text_bytes": os.path.getsize(txt), "generate_s": round(gen_s, 1), "threads": args.threads}
