@@ -20,9 +20,10 @@
 // 0,1,2,3: Solver<CDAE>::train runs data-parallel over these GPUs through cdae_hip_multi_* — users sharded, shared
 // parameters exchanged by RCCL inside the library; a repeated id, e.g. 0,0, makes logical shards of one GPU),
 // CDAE_EXCHANGE_EVERY (0 = synchronous exchange at every step, the default; k = pipelined every k steps),
-// CDAE_LAYOUT=item_rows (with CDAE_FULL_OUTPUT=1: the shards cut the ITEM rows instead of the users — the exact single-GPU
-// full-output schedule, two small all-reduces per batch, no accuracy cost; BASELINE configs[4]'s layout).
-// The data-parallel schedule is NOT inside the accuracy envelope of the single-GPU one.
+// CDAE_LAYOUT=item_rows (the shards cut the ITEM rows instead of the users, every shard sees every user, the user node is sharded by
+// user: the exact single-GPU schedule — sampled decode, or with CDAE_FULL_OUTPUT=1 the full-output one, BASELINE configs[4]'s
+// layout — two small all-reduces per batch, no accuracy cost).
+// The default user-sharded delta exchange is NOT inside the accuracy envelope of the single-GPU schedule.
 #ifndef CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 #define CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 
@@ -115,12 +116,13 @@ class CDAE : public RecsysModelBase {
       CDAE_HIP_CHECK(cdae_hip_multi_create(&c, static_cast<int>(devices.size()), devices.data(), &raw));
       multi_.reset(raw, [](cdae_hip_multi_t* m) { cdae_hip_multi_destroy(m); });
       CDAE_HIP_CHECK(cdae_hip_multi_set_exchange(raw, static_cast<int>(env_u64("CDAE_EXCHANGE_EVERY", 0))));
-      const char* layout = std::getenv("CDAE_LAYOUT");      // "item_rows": the shards cut the item rows (full-output decode only; exact)
+      const char* layout = std::getenv("CDAE_LAYOUT");      // "item_rows": the shards cut the item rows (exact single-GPU schedule)
       item_rows_ = layout && std::string(layout) == "item_rows";
       if (item_rows_) CDAE_HIP_CHECK(cdae_hip_multi_set_layout(raw, CDAE_LAYOUT_ITEM_ROWS));
       CDAE_HIP_CHECK(cdae_hip_multi_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
       CDAE_HIP_CHECK(cdae_hip_multi_init_params(raw, seed_));
-      LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES), exchange every " << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
+      if (item_rows_) LOG(INFO) << "CDAE: " << devices.size() << " item-row shards (CDAE_DEVICES, CDAE_LAYOUT=item_rows): the single-GPU schedule over item shards";
+      else LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES), exchange every " << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
     } else {
       cdae_hip_t* raw = nullptr;
       CDAE_HIP_CHECK(cdae_hip_create(&c, devices.empty() ? static_cast<int>(env_u64("CDAE_DEVICE", 0)) : devices[0], &raw));

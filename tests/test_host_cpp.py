@@ -299,6 +299,30 @@ def test_reference_yelp_app_trains_full_output_in_the_item_rows_layout(host_bins
 
 
 @pytest.mark.gpu
+def test_reference_yelp_app_trains_the_sampled_decode_in_the_item_rows_layout(host_bins, tmp_path):
+    """CDAE_LAYOUT=item_rows + CDAE_DEVICES without CDAE_FULL_OUTPUT: the unmodified yelp app on the multi-GPU schedule that carries
+    the single-GPU accuracy claim (sampled decode over item shards; logical shards of GPU 0 here).  It is the single-GPU schedule,
+    so its `Train Loss` / TOPN table is the single-GPU run's."""
+    yelp = os.path.join(host_bins, "yelp")
+    if not os.path.exists(yelp):
+        pytest.skip("no build/yelp (reference sources were not present at build time)")
+    write_ratings(tmp_path / "yelp_10core.txt")
+    for task in ("prepare", "split"):
+        assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
+    tables = []
+    for env in ({}, {"CDAE_DEVICES": "0,0,0,0", "CDAE_LAYOUT": "item_rows"}):
+        rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.5", "--scaled=true",
+                       "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "64", **env})
+        assert rc == 0, out[-3000:]
+        rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
+        assert len(rows) == 2 + 51
+        tables.append(np.array([[float(x) for x in r.split("|")[2:10]] for r in rows[2:]]))
+    loss_a, loss_b = tables[0][1:, 0], tables[1][1:, 0]
+    assert np.abs(loss_b / loss_a - 1).max() < 2e-4                # the same schedule up to fp32 association of two sums
+    assert np.abs(tables[1][:, 6] - tables[0][:, 6]).max() < 0.003  # Recall@10 column (300 users: one hit on one user = 0.0007)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("method,loss", [("MF", "SQUARE"), ("MF", "CE"), ("BPR", "LOG"), ("BPR", "HINGE")])
 def test_reference_yelp_app_trains_the_sibling_models_on_gpu(host_bins, tmp_path, method, loss):
     """--method=MF (libcf::IMF) and --method=BPR through the unmodified yelp app (yelp.cpp:122-165): both run on the GPU behind
