@@ -317,12 +317,14 @@ int cdae_hip_exchange_time_all_reduce(cdae_hip_t* h, int repeats, double* second
 typedef struct cdae_hip_multi cdae_hip_multi_t;
 /* How the shards divide the model (set before _set_interactions):
  *   CDAE_LAYOUT_USERS      (default) user shards + exchange of shared-parameter deltas, as described above.
- *   CDAE_LAYOUT_ITEM_ROWS  full_output only (BASELINE configs[4]: 1 M items x K=512, whose dense delta would be 2 GB): every shard
- *       owns a contiguous range of ITEM rows — W / W_ag / (V / V_ag) / b' and the three products of the decode over them — and
- *       sees every user; Wu and b are replicated and stepped identically everywhere.  Per batch two all-reduces of
- *       [batch_users x row_stride] floats cross the shards (the input sums of the encode, the hidden gradient); no parameter
- *       ever does.  The schedule is the single-GPU full-output schedule EXACTLY (same steps, same order; only the two sums are
- *       associated differently), so this layout has no accuracy cost.  _shard() reports item ranges in this layout. */
+ *   CDAE_LAYOUT_ITEM_ROWS  every shard owns a contiguous range of ITEM rows — W / W_ag / (V / V_ag) / b' and the decode over them —
+ *       and sees every user; b is replicated and stepped identically everywhere; the user node (Wu, Uu) is sharded by contiguous
+ *       USER ranges (the owner's rows of a batch ride the first all-reduce).  Per batch two all-reduces of [batch_users x row_stride]
+ *       floats cross the shards (the input sums of the encode, the hidden gradient); no item-row parameter ever does.  The schedule
+ *       is the single-GPU schedule EXACTLY (same steps, same order; only the two sums are associated differently), so this layout
+ *       has no accuracy cost — for the sampled decode (every shard samples the batch's whole example list against the whole rows and
+ *       keeps the examples of its rows; one shard is the single handle bit for bit) and for the full-output decode (BASELINE
+ *       configs[4]: 1 M items x K=512, whose dense delta would be 2 GB).  _shard() reports item ranges in this layout. */
 #define CDAE_LAYOUT_USERS 0u
 #define CDAE_LAYOUT_ITEM_ROWS 1u
 int cdae_hip_multi_set_layout(cdae_hip_multi_t* m, uint32_t layout);
