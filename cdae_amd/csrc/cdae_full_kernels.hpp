@@ -733,6 +733,23 @@ hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA,
   else hidden_bias_role<false>(hp, k, nb, DELTA, b, b_ag);
 }
 
+// bf16 images of a decoder row that has just been stepped, written by the kernel that holds it in registers (round 3: the separate
+// fp32 -> bf16 conversion pass over the whole matrix was 27 us of a 196 us ML-10M-shape step): Db[item][k] — the lane's NI
+// elements are contiguous — and DTb[k][item], one 2-byte store per element (10.6 K rows x 256 columns per block: the L2 merges them;
+// NOT used for item spaces >= 32768, where a million rows x 512 scattered 2-byte stores would cost more than the pass they replace).
+template <int NI>
+__device__ __forceinline__ void store_row_bf16(const float (&w)[NI], uint32_t item, uint32_t lo, uint32_t Kp, uint32_t Ip,
+                                               __bf16* __restrict__ Db, __bf16* __restrict__ DTb) {
+  __bf16 hb[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) hb[i] = (__bf16)w[i];
+  __bf16* drow = Db + (size_t)item * Kp + lo;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) drow[i] = hb[i];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) DTb[(size_t)(lo + i) * Ip + item] = hb[i];
+}
+
 // Row steps of the full-output schedule (+ the hidden-bias recurrence as the leading workgroups, like K5):
 //   b'[j]: grad = sum_u G[u][j] + lambda b'[j]                                 cdae.hpp:230-237, summed over the block
 //   tied : W[j]: grad = dD[j] + scale * sum_{u: j kept} delta_u + lambda W[j]     cdae.hpp:252-257 + 337-348 merged
@@ -745,7 +762,8 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
                  const float* __restrict__ dD, const __bf16* __restrict__ GT, uint32_t ldgt, uint32_t nb,
                  float* __restrict__ W, float* __restrict__ W_ag, float* __restrict__ V, float* __restrict__ V_ag,
                  float* __restrict__ bp, float* __restrict__ bp_ag, float* __restrict__ b, float* __restrict__ b_ag,
-                 uint32_t* __restrict__ touched) {
+                 uint32_t* __restrict__ touched,
+                 __bf16* __restrict__ Db = nullptr /* [Ip][Kp] */, __bf16* __restrict__ DTb = nullptr /* [Kp][Ip] */, uint32_t Ip = 0) {
   const uint32_t bias_blocks = b ? (hp.Kp + blockDim.x - 1) / blockDim.x : 0u;   // b == nullptr: the recurrence runs in hidden_bias_kernel
   if (blockIdx.x < bias_blocks) {
     if (hp.adagrad) hidden_bias_role<true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
@@ -822,6 +840,7 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
     for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
     vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
     vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+    if (Db) store_row_bf16<NI>(w, item, lo, hp.Kp, Ip, Db, DTb);
   } else {
     float w[NI], a[NI];
     vload<NI>(w, V + (size_t)item * hp.Kp + lo);
@@ -830,6 +849,7 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
     for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.lambda, w[i], dd[i]));
     vstore<NI>(V + (size_t)item * hp.Kp + lo, w);
     vstore<NI>(V_ag + (size_t)item * hp.Kp + lo, a);
+    if (Db) store_row_bf16<NI>(w, item, lo, hp.Kp, Ip, Db, DTb);
     if (has_in) {
       vload<NI>(w, W + (size_t)item * hp.Kp + lo);
       vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);

@@ -153,6 +153,13 @@ struct cdae_hip {
   uint32_t* d_bits_train = nullptr;     // [NSETS][B x ceil(I/32)] rated-item bitmap of the batch (targets of the fused full-output decode), per example-buffer set
   size_t bits_stride = 0;
   uint32_t full_slices = 1;
+  // Full-output path, item spaces below 32768 (full_rows_kernel): the row step writes the bf16 images of every decoder row it
+  // has just stepped and the encode writes those of z, so a steady-state batch needs no conversion launch.  db_valid: d_Db / d_DTb
+  // hold the CURRENT decoder (cleared by everything else that writes parameters); zb_rows: rows of d_Zb / columns of d_ZTb that may
+  // be non-zero (the encode only writes the batch's users: a shorter batch takes the zero-filling conversion kernel once)
+  bool db_valid = false;
+  uint32_t zb_rows = 0xFFFFFFFFu;
+  bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
   bool join_pending = false;            // full-output path: the aux stream's b recurrence of the last batch has not been joined yet
@@ -373,6 +380,7 @@ int free_interaction_state(cdae_hip* h) {
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   h->rec_cap = 0; h->score_cap = 0; h->rec_score_cap = 0; h->hsum_eval_cap = 0;
+  h->db_valid = false; h->zb_rows = 0xFFFFFFFFu;
   h->eval_cap = 0; h->eval_unit_cap = 0; h->bits_cap = 0;
   return 0;
 }
@@ -642,25 +650,34 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // bf16 copies D, D^T (rows >= I zero) of this batch: like the input gather they need the previous batch's row steps but not
   // its b recurrence, which may still be running on the aux stream — joined behind them, in front of its first consumer.
   // Small item spaces: converted together with Z behind the encode instead (one launch less; a launch is ~9 us there)
-  const bool pair_copy = Ip <= 65536 && !h->full_separate_copies;
-  if (!pair_copy) hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  // Round 3: for item spaces below 32768 the row step (full_rows_kernel) leaves the bf16 images of the decoder behind and the
+  // encode writes those of z: no conversion launch in the steady state.  D is converted here only when something else wrote the
+  // parameters (init, set_param, an exchange), Z only when the batch is shorter than the rows the images may hold.
+  const bool rows_write_images = h->fused_images && I < 32768u;
+  const bool need_d = !(rows_write_images && h->db_valid);
+  const bool z_in_encode = h->fused_images && h->zb_rows == nb;
+  const bool pair_copy = Ip <= 65536 && !h->full_separate_copies && need_d && !z_in_encode;
+  if (need_d && !pair_copy) hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
   CHK(join_aux(h));
+  __bf16* zb = z_in_encode ? h->d_Zb : nullptr;
+  __bf16* ztb = z_in_encode ? h->d_ZTb : nullptr;
   if (two_launches) {
     DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum, zb, ztb, Bp);
   } else {                       // one launch: a workgroup per user (encode_users_kernel)
     DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
-                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum, zb, ztb, Bp);
   }
   CHK(pr.end());
 
   CHK(pr.begin(h, F_DECODE, st));
-  // bf16 operand copies Z, Z^T (rows >= nb zero)
+  // bf16 operand copies Z, Z^T (rows >= nb zero) where the encode did not write them
   if (pair_copy)
     hipLaunchKernelGGL(to_bf16_transpose_pair_kernel, dim3(Kp / 64, Ip / 64 + Bp / 64), blk, 0, st, (const float*)h->dec(), I, Ip, h->d_Db, h->d_DTb,
                        (const float*)h->d_Z, nb, Bp, h->d_Zb, h->d_ZTb, Kp, Kp);
-  else
+  else if (!z_in_encode)
     hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Bp / 64), blk, 0, st, h->d_Z, nb, Kp, Kp, Bp, h->d_Zb, h->d_ZTb);
+  h->zb_rows = nb;
   const bool fused = Kp <= 256 && !h->full_unfused;
   uint32_t hg_parts = 0, hg_rows = nb;           // slabs of HGpart holding hg and their row count (0: accumulated into HG by atomics)
   if (fused) {
@@ -756,7 +773,9 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   else
     DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
-                h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
+                h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched,
+                rows_write_images ? h->d_Db : (__bf16*)nullptr, rows_write_images ? h->d_DTb : (__bf16*)nullptr, Ip);
+  h->db_valid = rows_write_images;                             // every decoder row was stepped and imaged by this launch
   h->join_pending = true;                                      // the aux stream (b recurrence) is joined by its next consumer: join_aux
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
@@ -900,6 +919,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
   h->full_separate_copies = std::getenv("CDAE_FULL_SEPARATE_COPIES") != nullptr;
+  h->fused_images = !h->full_separate_copies;
   if (const char* ev = std::getenv("CDAE_ENCODE_USERS_MAX")) h->encode_users_max = (uint32_t)std::atoi(ev);
   if (const char* ev = std::getenv("CDAE_GATHER_HALVES")) h->gather_halves = std::atoi(ev) == 2 ? 2u : 1u;
   if (const char* ev = std::getenv("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
@@ -1288,6 +1308,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
 }
 
 int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
+  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
@@ -1332,6 +1353,7 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
 }
 
 int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t count) {
+  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (which >= CDAE_P_COUNT || !host) return fail("bad argument");
   HIPCHK(hipSetDevice(h->device));
@@ -1922,6 +1944,7 @@ int cdae_hip_recommend_user(cdae_hip_t* h, uint64_t uid, const uint32_t* rated_i
 
 int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32_t* input_items, size_t n_in,
                                        const uint32_t* negative_items, size_t n_neg) {
+  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (uid >= h->U) return fail("user id %llu out of range", (unsigned long long)uid);
   if (h->cfg.full_output) return fail("train_one_user_corruption takes an explicit negative list; it is not available in full_output mode");
@@ -2023,6 +2046,7 @@ int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_fl
 }
 
 int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
+  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_delta) return fail("delta_begin must be called first");
   if (world_size == 0) return fail("world_size must be >= 1");
   if (rule > CDAE_DELTA_TOUCH_MEAN) return fail("unknown delta rule %u", rule);
@@ -2055,6 +2079,7 @@ int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* cou
 }
 
 int cdae_hip_delta_merge(cdae_hip_t* h) {
+  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
@@ -2062,6 +2087,7 @@ int cdae_hip_delta_merge(cdae_hip_t* h) {
 }
 
 int cdae_hip_delta_merge_stage(cdae_hip_t* h) {
+  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));

@@ -356,6 +356,22 @@ segment_kernel(const KeyT* __restrict__ sorted_item, uint64_t* sorted_val, uint3
   }
 }
 
+// Full-output path (round 3): the encode writes the bf16 operand images of z itself — Zb[slot][k] (the lane's NI elements are
+// contiguous) and ZTb[k][slot] — instead of a conversion launch behind it.  Rows >= the batch's users stay zero (host: zb_rows).
+typedef __bf16 BF16_T;
+template <int NI>
+__device__ __forceinline__ void store_z_bf16(const float (&z)[NI], uint32_t slot, uint32_t lo, uint32_t Kp, uint32_t Bp,
+                                             BF16_T* __restrict__ Zb, BF16_T* __restrict__ ZTb) {
+  BF16_T hb[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) hb[i] = (BF16_T)z[i];
+  BF16_T* zrow = Zb + (size_t)slot * Kp + lo;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) zrow[i] = hb[i];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) ZTb[(size_t)(lo + i) * Bp + slot] = hb[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2  encode: z_u = act(scale * sum_{i in In(u)} W[i] + b + Wu[u])   (get_hidden_values, cdae.hpp:373-416)
 // Two launches: encode_partial_kernel — one wavefront per unit sums the kept rows of its <= 128 positives
@@ -434,7 +450,9 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
                      uint64_t u0, uint32_t nb, int mode, float* __restrict__ Z, float* __restrict__ Dz,
                      float* __restrict__ HGzero /* training: the batch's duplicate-correction rows start at 0 */,
                      const float* __restrict__ Uu /* linear_function only */,
-                     float* __restrict__ Ssum /* linear_function training: the unscaled input sums, for the Uu step */) {
+                     float* __restrict__ Ssum /* linear_function training: the unscaled input sums, for the Uu step */,
+                     BF16_T* __restrict__ Zb = nullptr /* full-output path: bf16 images of z, [Bp][Kp] and (ZTb) [Kp][Bp], written here */,
+                     BF16_T* __restrict__ ZTb = nullptr, uint32_t Bp = 0) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -481,6 +499,7 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
     dz[i] = live ? act_deriv(hp, zz) : 0.f;
   }
   vstore<NI>(Z + (size_t)slot * hp.Kp + lo, z);
+  if (Zb) store_z_bf16<NI>(z, slot, lo, hp.Kp, Bp, Zb, ZTb);
   if (Dz) vstore<NI>(Dz + (size_t)slot * hp.Kp + lo, dz);
   if (HGzero) {
 #pragma unroll
@@ -504,7 +523,8 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
                     const float* __restrict__ W, const uint32_t* __restrict__ uptr, uint64_t u0, uint32_t nb,
                     uint32_t cidx, uint64_t seed, uint32_t epoch, const float* __restrict__ Wu, const float* __restrict__ b,
                     float* __restrict__ Z, float* __restrict__ Dz, float* __restrict__ HGzero,
-                    const float* __restrict__ Uu /* linear_function only */, float* __restrict__ Ssum /* linear_function only */) {
+                    const float* __restrict__ Uu /* linear_function only */, float* __restrict__ Ssum /* linear_function only */,
+                    BF16_T* __restrict__ Zb = nullptr, BF16_T* __restrict__ ZTb = nullptr, uint32_t Bp = 0 /* as encode_finish_kernel */) {
   __shared__ float part[ENC_WAVES][64 * NI];
   const uint32_t slot = blockIdx.x, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const unsigned long long t0 = trace_begin(hp);
@@ -594,6 +614,7 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
     dz[i] = live ? act_deriv(hp, zz) : 0.f;
   }
   vstore<NI>(Z + (size_t)slot * hp.Kp + lo, z);
+  if (Zb) store_z_bf16<NI>(z, slot, lo, hp.Kp, Bp, Zb, ZTb);
   vstore<NI>(Dz + (size_t)slot * hp.Kp + lo, dz);
 #pragma unroll
   for (int i = 0; i < NI; ++i) z[i] = 0.f;
