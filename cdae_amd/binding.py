@@ -59,6 +59,7 @@ EXPORTS = {
     "cdae_hip_row_stride": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_default_batch_users": (C.c_uint32, [C.c_uint64]),
     "cdae_hip_batch_users": (C.c_uint32, [C.c_void_p]),
+    "cdae_hip_user_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_user_id_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_set_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
@@ -223,6 +224,12 @@ class CDAE:
 
     def init_params(self, seed: int):
         _chk(self.lib, self.lib.cdae_hip_init_params(self.h, seed))
+
+    def user_order(self) -> np.ndarray:
+        """out[position] = user id of the handle's training order (the identity except for IMF / BPR block schedules)"""
+        out = np.empty(self.num_users, dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_user_order(self.h, out.ctypes.data, out.size))
+        return out
 
     @property
     def batch_users(self) -> int:

@@ -50,7 +50,8 @@ extern "C" {
  * 4: library-owned RCCL communicator + exchange schedule (cdae_hip_comm_*, cdae_hip_exchange_*), cdae_hip_multi_*
  * 5: cdae_hip_create_mf (IMF / BPR handles), CDAE_P_UB / CDAE_P_UB_AG, item-rows layout of cdae_hip_multi_*
  * 6: cdae_hip_set_profiling_families
- * 7: default batch_users capped at 256 (was 512); cdae_hip_default_batch_users, cdae_hip_batch_users */
+ * 7: default batch_users capped at 256 (was 512); cdae_hip_default_batch_users, cdae_hip_batch_users; cdae_hip_user_order (IMF / BPR
+ *    block schedules train in activity-grouped order; their default is one user per block) */
 #define CDAE_HIP_ABI_VERSION 7
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
@@ -276,6 +277,14 @@ int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous perio
  * concurrently against the block-start item rows; 1 == the reference's strictly sequential loop.  data_loss / penalty_loss are
  * 0 for these models, as in the reference (ModelBase defaults, model_base.hpp:36-45); cdae_hip_encode, the explicit-input step
  * and the full-output decode do not apply. */
+/* Training order.  A CDAE handle, and an IMF / BPR handle with one user per block, visit the users in id order like the reference.
+ * An IMF / BPR handle with batch_users > 1 (the block schedule: a throughput setting) trains them in ACTIVITY-GROUPED order — users
+ * sorted by train-row length, cut into blocks of batch_users, the blocks visited in a fixed pseudo-random order — because a block
+ * lasts as long as its most active user's serial chain.  cdae_hip_user_order returns that order: out[position] = user id
+ * (count = num_users; the identity for every other handle).  The random streams, cdae_hip_train_users' range and
+ * cdae_hip_debug_sample_batch's window are in POSITIONS; get / set_param and recommend_all are by user id as everywhere. */
+int cdae_hip_user_order(cdae_hip_t* h, uint32_t* out, size_t count);
+
 typedef struct cdae_mf_config {
   uint32_t struct_size;      /* sizeof(cdae_mf_config)                                   */
   uint32_t num_dim;          /* IMFConfig::num_dim          imf.hpp:19                   */
@@ -284,7 +293,8 @@ typedef struct cdae_mf_config {
   uint32_t using_adagrad;    /* imf.hpp:22                                               */
   uint32_t using_bias_term;  /* imf.hpp:21                                               */
   uint32_t pairwise;         /* 0: IMF (pointwise instances), 1: BPR (pairs)             */
-  uint32_t batch_users;      /* 0 -> 1 (the reference's sequential loop)                 */
+  uint32_t batch_users;      /* 0 -> 1 (the reference's sequential loop); > 1: block     */
+                             /* schedule in activity-grouped order (cdae_hip_user_order) */
   double lambda;             /* imf.hpp:16                                               */
   double learn_rate;         /* imf.hpp:14                                               */
   double beta;               /* imf.hpp:15                                               */
