@@ -168,11 +168,11 @@ def test_entry_points_that_do_not_apply_fail_loudly(tiny):
 def test_block_schedule_orders_users_by_activity_and_round_trips_parameters(built):
     """batch_users > 1: blocks of users with similar train-row lengths (a block lasts as long as its most active user's chain), the
     blocks in a fixed pseudo-random order; get / set_param stay by user id."""
-    d = synth.generate(1200, 500, 60_000, seed=9)
+    d = synth.generate(1280, 500, 64_000, seed=9)
     m = cdae_amd.MF(cdae_amd.MFConfig(num_dim=16, batch_users=64))
     m.reset(d, seed=3)
     order = m.user_order()
-    n = np.diff(d.train_ptr)[order].reshape(-1, 64)[:-1]       # (the last block may be short)
+    n = np.diff(d.train_ptr)[order].reshape(-1, 64)            # 20 full blocks
     assert (n.max(axis=1) - n.min(axis=1)).max() <= np.diff(d.train_ptr).max() // 4            # similar lengths inside a block
     firsts = n[:, 0]
     assert not (np.diff(firsts) <= 0).all() and not (np.diff(firsts) >= 0).all()                # heavy and light blocks interleave
