@@ -318,6 +318,48 @@ def test_item_rows_sampled_layout_is_the_single_gpu_schedule(built, K, B, shards
         assert len(set(rec_m[u].tolist())) == 10 and not np.intersect1d(rec_m[u], rated).size
 
 
+@pytest.mark.parametrize("K,B,shards,kw", [(1, 1, 3, {}), (64, 7, 2, dict(num_neg=1)), (130, 1000, 8, {}), (24, 50, 3, dict(corruption_ratio=0.0, scaled=False)),
+                                           (24, 50, 4, dict(corruption_ratio=1.0, scaled=False)), (33, 299, 6, dict(num_corruptions=3, tanh=True)),
+                                           (16, 64, 2, dict(using_adagrad=False, learn_rate=0.02)), (20, 33, 3, dict(linear=True, user_factor=False))])
+def test_item_rows_sampled_layout_edge_shapes(built, K, B, shards, kw):
+    """one user per batch over three shards, a batch larger than the data set, shards of a handful of rows, no / total corruption,
+    several corruptions, SGD, linear hidden layer: always the single handle's trajectory"""
+    d = synth.generate_shape("tiny", seed=5)
+    cfg = cfg_of(K=K, B=B, **kw)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(d, seed=2)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards, item_rows=True)
+    mm.reset(d, seed=2)
+    for ep in range(2):
+        st = mm.train_one_iteration(9, ep)
+        ref = one.train_one_iteration(9, ep)
+        assert (st.users, st.batches, st.examples) == (ref.users, ref.batches, ref.examples)
+    errs = {w: _param_range_err(v, one.get(w)) for w, v in _all_params(mm).items() if v.size}
+    assert max(errs.values()) < 1e-4, errs
+    assert abs(mm.current_loss(5, 0) - one.current_loss(5, 0)) <= 2e-5 * abs(one.current_loss(5, 0))
+
+
+def test_item_rows_sampled_with_a_user_who_rated_almost_everything_and_shards_without_examples(built):
+    """the sampler's fallback walk (a user who rated all but 3 items) lands on the same negatives in every shard; a shard none of
+    whose rows a batch touches only runs its per-batch clears"""
+    rng = np.random.default_rng(3)
+    I = 400
+    rows = [np.sort(rng.choice(I, n, replace=False)).astype(np.uint32) for n in (I - 3, 30, 17, 2, 120, 5)]
+    rows += [np.sort(rng.choice(40, 6, replace=False)).astype(np.uint32) for _ in range(20)]      # users who only know the first 40 items
+    ptr = np.r_[0, np.cumsum([r.size for r in rows])].astype(np.int64)
+    d = synth.Interactions(len(rows), I, ptr, np.concatenate(rows), np.zeros(len(rows) + 1, np.int64), np.empty(0, np.uint32))
+    cfg = cfg_of(K=12, B=4, num_neg=2)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(d, seed=2)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * 5, item_rows=True)
+    mm.reset(d, seed=2)
+    for ep in range(2):
+        mm.train_one_iteration(4, ep)
+        one.train_one_iteration(4, ep)
+    errs = {w: _param_range_err(v, one.get(w)) for w, v in _all_params(mm).items()}
+    assert max(errs.values()) < 1e-4, errs
+
+
 def test_item_rows_sampled_layout_tracks_the_oracle_block_schedule(built):
     import oracle as orc
     from oracle import binding as ob
