@@ -501,6 +501,171 @@ gemm_nt_bf16_lds3_kernel(const __bf16* __restrict__ A, const __bf16* __restrict_
   }
 }
 
+// Wide form (round 3; M % 256 == 0 and N % 256 == 0: every product of the K > 256 path at BASELINE configs[4]): 512 threads own a
+// 256 x 256 tile — eight wavefronts as 4 (M) x 2 (N), 64 x 128 each, 2 x 4 MFMA tiles — so a staged byte feeds 128 flop instead of
+// 85.  All three products were bound by the global -> LDS fill rate, not by the matrix cores: their time is linear in the block size
+// and their rate is the tile's flop per staged byte (profiles/r03_full_cfg5_block_sweep.txt).  A stage is 64 KiB (A slice 256 x 64
+// bf16, then B slice 256 x 64), two stages: one slice in flight across each barrier — a step now carries 2048 SIMD cycles of MFMA per
+// CU, twice the 256 x 128 kernel's, which is what the third stage bought there.  Same LDS image, swizzle and fragment reads as the
+// kernels above (6 ds_read_b128 per 8 MFMAs instead of 4 per 4).  EPI_LOSS leaves through a [256][256] bf16 image, once per
+// orientation, like the narrower kernels.
+constexpr int GEMMW_STAGE_BYTES = (256 + 256) * GEMM_BK * 2;      // 64 KiB
+constexpr uint32_t GEMMW_TS = 528;                                // epilogue image: 256 bf16 per row + 16 B (bank spread)
+constexpr size_t gemmw_lds_bytes() { return 256 * (size_t)GEMMW_TS > 2 * (size_t)GEMMW_STAGE_BYTES ? 256 * (size_t)GEMMW_TS : 2 * (size_t)GEMMW_STAGE_BYTES; }
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+gemm_nt_bf16_ldsw_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
+                         uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep, GemmGrid gg) {
+  extern __shared__ __attribute__((aligned(1024))) char smemw[];
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;      // wid 0..7
+  uint32_t mt, nt, zt;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, in = gg.inner();
+    const uint32_t t = j % in, o = (j / in) * 8u + xcd;
+    if (o >= gg.outer()) return;
+    if (gg.mode == 0) { mt = t; nt = o; zt = 0; }
+    else if (gg.mode == 1) { nt = t; mt = o; zt = 0; }
+    else { mt = t / gg.Nt; nt = t % gg.Nt; zt = o; }
+  }
+  const uint32_t m_tile = mt * 256u, n_tile = nt * 256u;
+  const uint32_t wm = (wid >> 1) * 64u, wn = (wid & 1u) * 128u;
+  const uint32_t m_base = m_tile + wm, n_base = n_tile + wn;
+  const uint32_t k_begin = zt * k_per_split;
+  const uint32_t k_end = min(Kd, k_begin + k_per_split);
+  const uint32_t n_steps = (k_end - k_begin) / GEMM_BK;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: a stage is 64 DMA instructions of 1 KiB (8 rows each): 32 of A then 32 of B; wavefront w issues 4w..4w+3 of each
+  const uint32_t st_row = lane >> 3, st_slot = lane & 7u;
+  const __bf16* a_src[4];
+  const __bf16* b_src[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t r = (wid * 4u + q) * 8u + st_row;
+    a_src[q] = A + (size_t)(m_tile + r) * lda + 8u * (st_slot ^ ((r >> 1) & 7u));
+    b_src[q] = Bm + (size_t)min(n_tile + r, N - 1u) * ldb + 8u * (st_slot ^ ((r >> 1) & 7u));
+  }
+  auto stage = [&](uint32_t step, uint32_t slot) {
+    char* base = smemw + slot * GEMMW_STAGE_BYTES;
+    const uint32_t k = k_begin + step * GEMM_BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[q] + k),
+                                       (__attribute__((address_space(3))) void*)(base + (wid * 4u + q) * 1024u), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[q] + k),
+                                       (__attribute__((address_space(3))) void*)(base + 256 * 128 + (wid * 4u + q) * 1024u), 16, 0, 0);
+  };
+  const uint32_t f_row = lane & 31u, f_half = lane >> 5;
+  uint32_t a_off[2], a_sw[2], b_off[4], b_sw[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint32_t ra = wm + i * 32u + f_row;
+    a_off[i] = ra * 128u; a_sw[i] = (ra >> 1) & 7u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t rb = wn + j * 32u + f_row;
+    b_off[j] = 256u * 128u + rb * 128u; b_sw[j] = (rb >> 1) & 7u;
+  }
+
+  stage(0, 0);
+  uint32_t slot = 0;
+  for (uint32_t step = 0; step < n_steps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wavefront's DMAs of slice `step` have landed
+    __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; the other stage (slice step-1) is free
+    if (step + 1 < n_steps) stage(step + 1u, slot ^ 1u);
+    const char* base = smemw + slot * GEMMW_STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < GEMM_BK / 16; ++s) {
+      const uint32_t c = 2u * s + f_half;
+      bf16x8 fa[2], fb[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    slot ^= 1u;
+  }
+  __syncthreads();                                                         // every wavefront is done with the stages
+  const uint32_t half = lane >> 5, col = lane & 31u;
+  if constexpr (EPI == EPI_LOSS) {
+    // [256 m][256 n] image -> G rows; then [256 n][256 m] -> G^T rows: whole 512-byte rows leave as 16-byte pieces
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t n = n_base + j * 32 + col;
+      const float bias = n < ep.cols_live ? ep.bp[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t ml = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, nl = wn + j * 32 + col;
+          float g = 0.f;
+          if (m_tile + ml < ep.rows_live && n < ep.cols_live) g = loss_grad(ep.loss_type, acc[i][j][r] + bias, 0.f);
+          acc[i][j][r] = g;                                                // (kept for the second orientation)
+          *reinterpret_cast<__bf16*>(smemw + ml * GEMMW_TS + nl * 2u) = (__bf16)g;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smemw + row * GEMMW_TS + c16 * 16u);
+      *reinterpret_cast<bf16x8*>(ep.G + (size_t)(m_tile + row) * ep.ldg + n_tile + c16 * 8u) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t nl = wn + j * 32 + col, m0 = wm + i * 32 + 8 * q + 4 * half;
+          const bf16x4 v = {(__bf16)acc[i][j][4 * q], (__bf16)acc[i][j][4 * q + 1], (__bf16)acc[i][j][4 * q + 2], (__bf16)acc[i][j][4 * q + 3]};
+          *reinterpret_cast<bf16x4*>(smemw + nl * GEMMW_TS + m0 * 2u) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smemw + row * GEMMW_TS + c16 * 16u);
+      if (n_tile + row < N) *reinterpret_cast<bf16x8*>(ep.GT + (size_t)(n_tile + row) * ep.ldgt + m_tile + c16 * 8u) = v;
+    }
+  } else {
+    if (m_base >= M) return;
+    float* C = ep.Cout;
+    if constexpr (EPI == EPI_STORE) C += (size_t)zt * ep.split_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t n = n_base + j * 32 + col;
+        if (n >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if constexpr (EPI == EPI_ATOMIC) {
+            if (m < ep.rows_live) unsafeAtomicAdd(C + (size_t)m * ep.ldc + n, acc[i][j][r]);
+          } else {
+            C[(size_t)m * ep.ldc + n] = acc[i][j][r];
+          }
+        }
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused forward + loss' + hidden gradient (replaces GEMM 1, the positive fix-up and GEMM 2 when Kp <= 256):
 // a workgroup owns 128 users (wavefront w: 32 of them) and one slice of the item dimension, and walks the slice in tiles

@@ -198,6 +198,8 @@ struct cdae_hip {
   bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
   bool tile_attr_set = false;           // dynamic LDS above 64 KiB allowed for the two tile kernels (per handle: the attribute is per device)
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
+  bool gemmw_attr_set[8] = {false, false, false, false, false, false, false, false};   // ... of the 256 x 256-tile kernel
+  bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
 
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr; float* d_snap = nullptr;   // agreed state, staged delta, all-reduced delta, parameters at the last stage
@@ -611,6 +613,17 @@ int launch_gemm_lds(cdae_hip* h, hipStream_t st, const __bf16* A, const __bf16* 
                     uint32_t ldb, uint32_t kps, const cdae::GemmEpilogue& ep, uint32_t splits, uint32_t mode) {
   using namespace cdae;
   const uint32_t Nt = (N + 127) / 128;
+  if (M % 256 == 0 && N % 256 == 0 && !h->gemm_two_stage && !h->gemm_narrow) {
+    // 256 x 256 tiles (round 3): 128 flop per byte staged into LDS instead of 85
+    if (!h->gemmw_attr_set[EPI]) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_bf16_ldsw_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemmw_lds_bytes()));
+      h->gemmw_attr_set[EPI] = true;
+    }
+    const GemmGrid gg{M / 256, N / 256, splits, mode};
+    hipLaunchKernelGGL((gemm_nt_bf16_ldsw_kernel<EPI>), dim3(gg.workgroups()), dim3(512), gemmw_lds_bytes(), st, A, Bm, M, N, Kd, lda, ldb,
+                       kps, ep, gg);
+    return 0;
+  }
   if (M % 256 == 0 && !h->gemm_two_stage) {
     if (!h->gemm3_attr_set[EPI]) {     // per handle: the attribute belongs to the (function, device) pair
       HIPCHK(hipFuncSetAttribute((const void*)gemm_nt_bf16_lds3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm3s_lds_bytes()));
@@ -924,6 +937,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->full_unfused = std::getenv("CDAE_FULL_UNFUSED") != nullptr;
   h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
   h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
+  h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;

@@ -598,3 +598,27 @@ def test_recommend_with_a_rated_set_that_is_not_the_train_row(small):
         np.testing.assert_array_equal(model.recommend_user(uid, row, 10), model.recommend_all(10, uid, uid + 1)[0])
     with pytest.raises(cdae_amd.CDAEError):
         model.recommend_user(0, [1, 1, 2], 10)
+
+
+def test_wide_gemm_tiles_change_no_bit(built, monkeypatch):
+    """K > 256 full-output path: the 256 x 256-tile kernel (round 3; all three products when rows and columns are multiples of 256)
+    against the 256 x 128 / 128 x 128 ones (CDAE_GEMM_NARROW=1).  Every output element is the same sum over k in the same order
+    (64-wide slices, four MFMA steps each), whatever the tile: identical G, identical slabs, identical parameters."""
+    d = synth.generate(600, 33_000, 36_000, seed=6, min_items=20)
+    cfg = cdae_amd.CDAEConfig(num_dim=300, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=256, full_output=True)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=4)
+        m.train_one_iteration(4, 0)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        loss = m.current_loss(4, 0)
+        m.close()
+        return out, loss
+
+    wide, loss_w = run()
+    monkeypatch.setenv("CDAE_GEMM_NARROW", "1")
+    narrow, loss_n = run()
+    for w in wide:
+        assert np.array_equal(wide[w], narrow[w]), w
+    assert loss_w == loss_n and np.isfinite(loss_w)
