@@ -31,6 +31,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // fp32 [R x C] (row stride ld_src) -> bf16 [Rp x C] with rows >= R zero, and its transpose [C x Rp].
 // 64 x 64 tiles through LDS so that both images are written in coalesced runs.
+template <typename SrcT>
+__device__ __forceinline__ void to_bf16_transpose_body(const SrcT* __restrict__ src, uint32_t R, uint32_t C, uint32_t ld_src, uint32_t Rp,
+                                                       __bf16* __restrict__ dst /* nullptr: only the transposed image */, __bf16* __restrict__ dstT) {
+  __shared__ float tile[64][65];
+  const uint32_t r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const uint32_t r = r0 + i / 64, c = c0 + i % 64;
+    const float v = (r < R && c < C) ? (float)src[(size_t)r * ld_src + c] : 0.f;
+    tile[i / 64][i % 64] = v;
+    if (dst && r < Rp && c < C) dst[(size_t)r * C + c] = (__bf16)v;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const uint32_t c = c0 + i / 64, r = r0 + i % 64;
+    if (r < Rp && c < C) dstT[(size_t)c * Rp + r] = (__bf16)tile[i % 64][i / 64];
+  }
+}
+// D^T image from the row-major bf16 image the row step has just written (item spaces >= 32768: full_rows_wave_kernel writes Db, the
+// 2-byte scattered stores of D^T would not pay there): half the traffic of converting from the fp32 matrix
+__global__ void __launch_bounds__(256)
+bf16_transpose_kernel(const __bf16* __restrict__ src, uint32_t R, uint32_t C, uint32_t Rp, __bf16* __restrict__ dstT) {
+  to_bf16_transpose_body<__bf16>(src, R, C, C, Rp, nullptr, dstT);
+}
 __global__ void __launch_bounds__(256)
 to_bf16_transpose_kernel(const float* __restrict__ src, uint32_t R, uint32_t C, uint32_t ld_src, uint32_t Rp,
                          __bf16* __restrict__ dst, __bf16* __restrict__ dstT) {
@@ -915,6 +938,13 @@ __device__ __forceinline__ void store_row_bf16(const float (&w)[NI], uint32_t it
   for (int i = 0; i < NI; ++i) DTb[(size_t)(lo + i) * Ip + item] = hb[i];
 }
 
+template <int NI>
+__device__ __forceinline__ void store_row_only_bf16(const float (&w)[NI], uint32_t item, uint32_t lo, uint32_t Kp, __bf16* __restrict__ Db) {
+  __bf16* drow = Db + (size_t)item * Kp + lo;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) drow[i] = (__bf16)w[i];
+}
+
 // Row steps of the full-output schedule (+ the hidden-bias recurrence as the leading workgroups, like K5):
 //   b'[j]: grad = sum_u G[u][j] + lambda b'[j]                                 cdae.hpp:230-237, summed over the block
 //   tied : W[j]: grad = dD[j] + scale * sum_{u: j kept} delta_u + lambda W[j]     cdae.hpp:252-257 + 337-348 merged
@@ -1036,7 +1066,8 @@ full_rows_wave_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, co
                       const uint64_t* __restrict__ sorted_val, const float* __restrict__ DELTA,
                       const float* __restrict__ dD, const __bf16* __restrict__ GT, uint32_t ldgt, uint32_t nb,
                       float* __restrict__ W, float* __restrict__ W_ag, float* __restrict__ V, float* __restrict__ V_ag,
-                      float* __restrict__ bp, float* __restrict__ bp_ag, uint32_t* __restrict__ touched) {
+                      float* __restrict__ bp, float* __restrict__ bp_ag, uint32_t* __restrict__ touched,
+                      __bf16* __restrict__ Db = nullptr /* [Ip][Kp]: the stepped decoder row's bf16 image (one 2 NI-byte store per lane) */) {
   const uint32_t item = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (item >= hp.num_items) return;
@@ -1095,11 +1126,13 @@ full_rows_wave_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, co
     for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
     vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
     vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+    if (Db) store_row_only_bf16<NI>(w, item, lo, hp.Kp, Db);
   } else {
 #pragma unroll
     for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.lambda, w[i], dd[i]));
     vstore<NI>(V + (size_t)item * hp.Kp + lo, w);
     vstore<NI>(V_ag + (size_t)item * hp.Kp + lo, a);
+    if (Db) store_row_only_bf16<NI>(w, item, lo, hp.Kp, Db);
     if (has_in) {
       vload<NI>(w, W + (size_t)item * hp.Kp + lo);
       vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);

@@ -158,6 +158,7 @@ struct cdae_hip {
   // hold the CURRENT decoder (cleared by everything else that writes parameters); zb_rows: rows of d_Zb / columns of d_ZTb that may
   // be non-zero (the encode only writes the batch's users: a shorter batch takes the zero-filling conversion kernel once)
   bool db_valid = false;
+  bool db_rows_valid = false;           // item spaces >= 32768: d_Db (only) holds the current decoder — the batch starts with a bf16 -> bf16 transposition
   uint32_t zb_rows = 0xFFFFFFFFu;
   bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
@@ -388,7 +389,7 @@ int free_interaction_state(cdae_hip* h) {
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   h->rec_cap = 0; h->score_cap = 0; h->rec_score_cap = 0; h->hsum_eval_cap = 0;
-  h->db_valid = false; h->zb_rows = 0xFFFFFFFFu;
+  h->db_valid = false; h->db_rows_valid = false; h->zb_rows = 0xFFFFFFFFu;
   h->eval_cap = 0; h->eval_unit_cap = 0; h->bits_cap = 0;
   return 0;
 }
@@ -673,7 +674,10 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // encode writes those of z: no conversion launch in the steady state.  D is converted here only when something else wrote the
   // parameters (init, set_param, an exchange), Z only when the batch is shorter than the rows the images may hold.
   const bool rows_write_images = h->fused_images && I < 32768u;
-  const bool need_d = !(rows_write_images && h->db_valid);
+  const bool rows_write_db = h->fused_images && I >= 32768u;             // full_rows_wave_kernel: the row-major image only
+  const bool need_d = !(rows_write_images && h->db_valid) && !(rows_write_db && h->db_rows_valid);
+  if (rows_write_db && h->db_rows_valid)                                  // D^T from the bf16 rows the row step left (2 GB instead of 4 at 1 M x 512)
+    hipLaunchKernelGGL(bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, (const __bf16*)h->d_Db, I, Kp, Ip, h->d_DTb);
   const bool z_in_encode = h->fused_images && h->zb_rows == nb;
   const bool pair_copy = Ip <= 65536 && !h->full_separate_copies && need_d && !z_in_encode;
   if (need_d && !pair_copy) hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
@@ -788,13 +792,14 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   if (I >= 32768u)     // rows are plentiful and mostly without kept inputs: one wavefront per row
     DISPATCH_NI(h->NI, full_rows_wave_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
-                h->P(CDAE_P_BP_AG), h->d_touched);
+                h->P(CDAE_P_BP_AG), h->d_touched, rows_write_db ? h->d_Db : (__bf16*)nullptr);
   else
     DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched,
                 rows_write_images ? h->d_Db : (__bf16*)nullptr, rows_write_images ? h->d_DTb : (__bf16*)nullptr, Ip);
   h->db_valid = rows_write_images;                             // every decoder row was stepped and imaged by this launch
+  h->db_rows_valid = rows_write_db;
   h->join_pending = true;                                      // the aux stream (b recurrence) is joined by its next consumer: join_aux
   CHK(pr.end());
   HIPCHK(hipEventRecord(x.released, st));
@@ -1365,7 +1370,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
 }
 
 int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
-  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
+  if (h) h->db_valid = h->db_rows_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
@@ -1410,7 +1415,7 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed) {
 }
 
 int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t count) {
-  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
+  if (h) h->db_valid = h->db_rows_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (which >= CDAE_P_COUNT || !host) return fail("bad argument");
   std::vector<float> by_pos;
@@ -2027,7 +2032,7 @@ int cdae_hip_recommend_user(cdae_hip_t* h, uint64_t uid, const uint32_t* rated_i
 
 int cdae_hip_train_one_user_corruption(cdae_hip_t* h, uint64_t uid, const uint32_t* input_items, size_t n_in,
                                        const uint32_t* negative_items, size_t n_neg) {
-  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
+  if (h) h->db_valid = h->db_rows_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_shared) return fail("set_interactions must be called first");
   if (uid >= h->U) return fail("user id %llu out of range", (unsigned long long)uid);
   if (h->cfg.full_output) return fail("train_one_user_corruption takes an explicit negative list; it is not available in full_output mode");
@@ -2129,7 +2134,7 @@ int cdae_hip_delta_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_fl
 }
 
 int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
-  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
+  if (h) h->db_valid = h->db_rows_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_delta) return fail("delta_begin must be called first");
   if (world_size == 0) return fail("world_size must be >= 1");
   if (rule > CDAE_DELTA_TOUCH_MEAN) return fail("unknown delta rule %u", rule);
@@ -2162,7 +2167,7 @@ int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* cou
 }
 
 int cdae_hip_delta_merge(cdae_hip_t* h) {
-  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
+  if (h) h->db_valid = h->db_rows_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
@@ -2170,7 +2175,7 @@ int cdae_hip_delta_merge(cdae_hip_t* h) {
 }
 
 int cdae_hip_delta_merge_stage(cdae_hip_t* h) {
-  if (h) h->db_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
+  if (h) h->db_valid = h->db_rows_valid = false;      // the bf16 images of the decoder no longer match it (full-output path, compute_batch_full)
   if (!h || !h->d_recv) return fail("delta_stage must be called first");
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
