@@ -52,7 +52,29 @@ __device__ __forceinline__ void to_bf16_transpose_body(const SrcT* __restrict__ 
 // 2-byte scattered stores of D^T would not pay there): half the traffic of converting from the fp32 matrix
 __global__ void __launch_bounds__(256)
 bf16_transpose_kernel(const __bf16* __restrict__ src, uint32_t R, uint32_t C, uint32_t Rp, __bf16* __restrict__ dstT) {
-  to_bf16_transpose_body<__bf16>(src, R, C, C, Rp, nullptr, dstT);
+  // 64 x 64 tile, 16-byte global accesses both ways (a 2-byte-per-thread form ran at a fifth of the HBM rate); LDS rows of 66
+  // elements: the 2-byte column reads of the write pass walk 33 banks
+  __shared__ uint16_t tile[64][66];
+  const uint32_t r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const uint16_t* s16 = reinterpret_cast<const uint16_t*>(src);
+  uint16_t* d16 = reinterpret_cast<uint16_t*>(dstT);
+#pragma unroll
+  for (uint32_t pass = 0; pass < 2; ++pass) {
+    const uint32_t rl = threadIdx.x / 8 + 32 * pass, c8 = (threadIdx.x % 8) * 8, r = r0 + rl;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < R) v = *reinterpret_cast<const uint4*>(s16 + (size_t)r * C + c0 + c8);          // C is a multiple of 64: in bounds, aligned
+    uint32_t* t32 = reinterpret_cast<uint32_t*>(&tile[rl][c8]);
+    t32[0] = v.x; t32[1] = v.y; t32[2] = v.z; t32[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t pass = 0; pass < 2; ++pass) {
+    const uint32_t cl = threadIdx.x / 8 + 32 * pass, i8 = (threadIdx.x % 8) * 8;
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[i8 + 2 * j][cl] | ((uint32_t)tile[i8 + 2 * j + 1][cl] << 16);
+    if (r0 + i8 < Rp) *reinterpret_cast<uint4*>(d16 + (size_t)(c0 + cl) * Rp + r0 + i8) = make_uint4(w[0], w[1], w[2], w[3]);   // Rp % 64 == 0
+  }
 }
 __global__ void __launch_bounds__(256)
 to_bf16_transpose_kernel(const float* __restrict__ src, uint32_t R, uint32_t C, uint32_t ld_src, uint32_t Rp,
