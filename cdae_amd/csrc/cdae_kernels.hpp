@@ -93,6 +93,7 @@ __device__ __forceinline__ void vload(float (&d)[NI], const float* __restrict__ 
     }
   }
 }
+typedef float cdae_f4v __attribute__((ext_vector_type(4)));
 template <int NI>
 __device__ __forceinline__ void vstore(float* __restrict__ p, const float (&d)[NI]) {
   if constexpr (NI == 1) {
@@ -101,8 +102,14 @@ __device__ __forceinline__ void vstore(float* __restrict__ p, const float (&d)[N
     *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
   } else {
 #pragma unroll
-    for (int q = 0; q < NI / 4; ++q)
+    for (int q = 0; q < NI / 4; ++q) {
+#ifdef CDAE_NT_STORES        // experiment (profiles/r03_nt_stores.txt): streaming stores, so that less is dirty in the L2s when the launch ends
+      const cdae_f4v v = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+      __builtin_nontemporal_store(v, reinterpret_cast<cdae_f4v*>(p) + q);
+#else
       reinterpret_cast<float4*>(p)[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+#endif
+    }
   }
 }
 
@@ -1037,8 +1044,14 @@ __device__ __forceinline__ void row16_load(float (&r)[4 * NV + NT], const float*
 template <int NV, int NT>
 __device__ __forceinline__ void row16_store(float* __restrict__ base, const float (&r)[4 * NV + NT], uint32_t l) {
 #pragma unroll
-  for (int v = 0; v < NV; ++v)
+  for (int v = 0; v < NV; ++v) {
+#ifdef CDAE_NT_STORES
+    const cdae_f4v q = {r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]};
+    __builtin_nontemporal_store(q, reinterpret_cast<cdae_f4v*>(base + 64 * v + 4 * l));
+#else
     *reinterpret_cast<float4*>(base + 64 * v + 4 * l) = make_float4(r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]);
+#endif
+  }
 #pragma unroll
   for (int i = 0; i < NT; ++i) base[64 * NV + l + 16 * i] = r[4 * NV + i];
 }
