@@ -460,7 +460,7 @@ class MultiCDAE:
     envelope).  exchange_every: 0 = synchronous exchange of the shared-parameter deltas at every step, k >= 1 = pipelined."""
 
     def __init__(self, mcfg: CDAEConfig, devices, exchange_every: int = 0, item_rows: bool = False):
-        """item_rows=True: CDAE_LAYOUT_ITEM_ROWS — the shards cut the item rows (full_output only; exact single-GPU schedule)."""
+        """item_rows=True: CDAE_LAYOUT_ITEM_ROWS — the shards cut the item rows (exact single-GPU schedule, sampled or full-output decode; the user node sharded by user)."""
         self.lib = load_library()
         self.cfg = mcfg
         c = _Config(C.sizeof(_Config), mcfg.num_dim, mcfg.num_neg, mcfg.num_corruptions, mcfg.lt,
