@@ -44,12 +44,16 @@ def main():
     ap.add_argument("--loss", default="CE", choices=["CE", "SQUARE"])
     ap.add_argument("--full-output-batch", type=int, default=0,
                     help="> 0: the full-output block schedule (Oracle.train_full) with this many users per block instead of the literal one")
+    ap.add_argument("--data-seed", type=int, default=None,
+                    help="seed of the synthetic DATA SET when it should differ from --seed (which then only keys the random streams: initial "
+                         "values, dropout masks, negatives) — several stream seeds on one data set cost the GPU test one data generation")
     ap.add_argument("--eval-users", type=int, default=0,
                     help="> 0: Recall@10 over the first N users only (the fp64 top-10 of 480 000 x 17 700 x 200 is ~20 min of one core "
                          "per epoch; training and the reported loss always cover every user)")
     args = ap.parse_args()
 
-    d = synth.generate_shape(args.shape, seed=args.seed)
+    data_seed = args.seed if args.data_seed is None else args.data_seed
+    d = synth.generate_shape(args.shape, seed=data_seed)
     lt = ob.LOSS_CE if args.loss == "CE" else ob.LOSS_SQUARE
     o = orc.Oracle(orc.OracleConfig(num_dim=args.num_dim, loss_type=lt, **HYPER), d.num_users, d.num_items, d.train_ptr, d.train_col)
     o.init_params(args.seed)
@@ -80,8 +84,8 @@ def main():
                   Wu_rows=o.get(ob.P_WU).reshape(d.num_users, K)[probe_users], b=o.get(ob.P_B),
                   W_absmax=np.abs(o.get(ob.P_W)).max(), Wu_absmax=np.abs(o.get(ob.P_WU)).max(), bp_absmax=np.abs(o.get(ob.P_BP)).max())
     tag = f"full{args.full_output_batch}" if args.full_output_batch else "literal"
-    name = f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_{tag}_seed{args.seed}.npz"
-    np.savez(os.path.join(OUT, name), shape=args.shape, seed=args.seed, num_dim=args.num_dim, loss=args.loss,
+    name = f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_{tag}_seed{args.seed}" + ("" if args.data_seed is None else f"_data{data_seed}") + ".npz"
+    np.savez(os.path.join(OUT, name), shape=args.shape, seed=args.seed, data_seed=data_seed, num_dim=args.num_dim, loss=args.loss,
              full_output_batch=args.full_output_batch, hyper=np.array(sorted(HYPER.items()), dtype=object).astype(str),
              recall10=np.array(rec10), train_loss=np.array(loss), data_loss=np.array(data_loss), topn=np.array(metrics),
              train_seconds=np.array(secs), nnz_train=d.nnz_train, eval_users=ne, **probes)

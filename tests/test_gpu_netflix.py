@@ -75,26 +75,54 @@ def test_there_is_a_netflix_fixture():
     assert len(FIXTURES) >= 1, "tests/golden/make_literal_curves.py --shape netflix --eval-users 60000"
 
 
+def data_seed_of(path):
+    f = np.load(path, allow_pickle=True)
+    return int(f["data_seed"]) if "data_seed" in f.files else int(f["seed"])
+
+
+FIXTURES.sort(key=lambda p: (data_seed_of(p) != 20141119, data_seed_of(p), p))   # one data set = one generation; the first tests' set first
+_curves = {}
+
+
+def curves_of(path):
+    if path not in _curves:
+        f = np.load(path, allow_pickle=True)
+        seed, K, ne = int(f["seed"]), int(f["num_dim"]), int(f["eval_users"])
+        assert str(f["shape"]) == "netflix" and K == 200 and str(f["loss"]) == "CE"
+        d = netflix(data_seed_of(path))
+        assert d.nnz_train == int(f["nnz_train"]), "the synthetic generator changed: regenerate the fixtures"
+        m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=0, **HYPER))
+        m.reset(d, seed=seed)
+        import bench
+        assert m.batch_users == bench.DEFAULT_BATCH_USERS == 256
+        rec, loss = [], []
+        for ep in range(len(f["recall10"])):
+            st = m.train_one_iteration(seed, ep)
+            assert st.users == d.num_users and st.batches == -(-d.num_users // 256)
+            loss.append(m.current_loss(seed, ep))
+            rec.append(orc.eval_topn(m.recommend_all(10, 0, ne), d.test_ptr[:ne + 1], d.test_col[:d.test_ptr[ne]])[5])
+        m.close()
+        rec, loss = np.array(rec), np.array(loss)
+        print(f"\nnetflix data seed {data_seed_of(path)} stream seed {seed}: recall@10 hip {np.round(rec, 5)} literal {np.round(f['recall10'], 5)} "
+              f"d {np.round(rec - f['recall10'], 5)}; loss hip/literal - 1 {np.round(loss / f['train_loss'] - 1, 4)}")
+        _curves[path] = (rec, np.asarray(f["recall10"]), loss, np.asarray(f["train_loss"]))
+    return _curves[path]
+
+
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
 def test_netflix_literal_fixture_at_the_library_default_batch_users(built, path):
-    f = np.load(path, allow_pickle=True)
-    seed, K, ne = int(f["seed"]), int(f["num_dim"]), int(f["eval_users"])
-    assert str(f["shape"]) == "netflix" and K == 200 and str(f["loss"]) == "CE"
-    d = netflix(seed)
-    assert d.nnz_train == int(f["nnz_train"]), "the synthetic generator changed: regenerate the fixtures"
-    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=0, **HYPER))
-    m.reset(d, seed=seed)
-    import bench
-    assert m.batch_users == bench.DEFAULT_BATCH_USERS == 256
-    rec, loss = [], []
-    for ep in range(len(f["recall10"])):
-        st = m.train_one_iteration(seed, ep)
-        assert st.users == d.num_users and st.batches == -(-d.num_users // 256)
-        loss.append(m.current_loss(seed, ep))
-        rec.append(orc.eval_topn(m.recommend_all(10, 0, ne), d.test_ptr[:ne + 1], d.test_col[:d.test_ptr[ne]])[5])
-    m.close()
-    rec, loss = np.array(rec), np.array(loss)
-    print(f"\nnetflix seed {seed}: recall@10 hip {np.round(rec, 5)} literal {np.round(f['recall10'], 5)} d {np.round(rec - f['recall10'], 5)}; "
-          f"loss hip/literal - 1 {np.round(loss / f['train_loss'] - 1, 4)}")
-    assert np.abs(rec - f["recall10"]).max() <= RECALL_TOL_SEED
-    assert np.abs(loss / f["train_loss"] - 1.0 - LOSS_SCHEDULE_OFFSET).max() <= LOSS_TOL_AROUND_OFFSET
+    rec, ref_rec, loss, ref_loss = curves_of(path)
+    assert np.abs(rec - ref_rec).max() <= RECALL_TOL_SEED
+    assert np.abs(loss / ref_loss - 1.0 - LOSS_SCHEDULE_OFFSET).max() <= LOSS_TOL_AROUND_OFFSET
+
+
+def test_netflix_mean_recall_difference_over_the_seeds(built):
+    """the mean-over-seeds statement of tests/test_gpu_accuracy.py at Netflix shape, once there are enough fixtures to carry it
+    (stream seeds on one data set count: what is averaged out is the schedule's sensitivity to the random streams)"""
+    if len(FIXTURES) < 4:
+        pytest.skip(f"{len(FIXTURES)} Netflix-shape fixtures: a mean over fewer than four seeds does not resolve 0.0015")
+    d = np.array([curves_of(p)[0] - curves_of(p)[1] for p in FIXTURES])
+    mean = d.mean(axis=0)
+    print(f"\n{len(FIXTURES)} Netflix-shape seeds: mean signed dRecall@10 per epoch {np.round(mean, 5)}, std {np.round(d.std(axis=0, ddof=1), 5)}")
+    from test_gpu_accuracy import RECALL_TOL_MEAN
+    assert np.abs(mean).max() <= RECALL_TOL_MEAN, mean
