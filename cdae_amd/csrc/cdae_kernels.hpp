@@ -149,8 +149,11 @@ __device__ __forceinline__ float act_deriv(const HyperParams& hp, float z) {
   return hp.linear ? 1.f : (hp.tanh_act ? 1.f - z * z : z - z * z);
 }
 // one coordinate of every `if (using_adagrad_) {...} p -= lr*grad` block (e.g. cdae.hpp:252-257)
-__device__ __forceinline__ void ada_step(const HyperParams& hp, float& p, float& acc, float grad) {
-  if (hp.adagrad) {
+// ADA at compile time: a loop that steps several independent elements per iteration (the IMF / BPR kernels) keeps their
+// sqrt -> rcp chains interleaved only when no branch sits between them
+template <bool ADA>
+__device__ __forceinline__ void ada_step_t(const HyperParams& hp, float& p, float& acc, float grad) {
+  if (ADA) {
     acc = fmaf(grad, grad, acc);
     // -lr * grad is formed beside the sqrt -> rcp chain, so the parameter is one fma behind the rcp (every step of a row's or
     // of b's recurrence is this chain: six dependent instructions instead of seven)
@@ -158,6 +161,9 @@ __device__ __forceinline__ void ada_step(const HyperParams& hp, float& p, float&
   } else {
     p = fmaf(-hp.lr, grad, p);
   }
+}
+__device__ __forceinline__ void ada_step(const HyperParams& hp, float& p, float& acc, float grad) {
+  if (hp.adagrad) ada_step_t<true>(hp, p, acc, grad); else ada_step_t<false>(hp, p, acc, grad);
 }
 
 // Wavefront all-reduce on the VALU's DPP lanes (no LDS crossbar): quad swaps, row mirrors, then the two

@@ -18,6 +18,8 @@
 
 #include "cdae_kernels.hpp"
 
+#include <type_traits>
+
 namespace cdae {
 
 // loss.hpp gradients of every loss the two models accept (yelp.cpp:122-165): SQUARE 0, LOGISTIC 1, LOG 2, HINGE 3, CROSS_ENTROPY 5
@@ -97,7 +99,8 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
                const uint32_t* __restrict__ ex_item, float* __restrict__ UV, float* __restrict__ UV_ag, float* __restrict__ UB,
                float* __restrict__ UB_ag, float* __restrict__ IV, float* __restrict__ IV_ag, float* __restrict__ IB,
                float* __restrict__ IB_ag, float* __restrict__ UVpre /* [instances][Kp] */, float* __restrict__ G /* [instances] */) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  // wave-uniform by construction; said so, everything derived from it (row bounds, counts, loop control) stays scalar
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const uint64_t uid = u0 + slot;
@@ -109,39 +112,58 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   const uint32_t lo = lane * NI;
   const float lam2 = hp.lambda;                      // the host stores 2 * lambda here (imf.hpp:92-95 regularise with 2 lambda)
   const float neg_label = mf_negative_label(hp.loss_type);
+  // the whole loop twice, AdaGrad or plain SGD fixed at compile time (see ada_step_t)
+  auto run = [&](auto ada_tag) __attribute__((always_inline)) {
+  constexpr bool ADA = decltype(ada_tag)::value;
   float uv[NI], ua[NI];
   vload<NI>(uv, UV + (size_t)uid * hp.Kp + lo);
   vload<NI>(ua, UV_ag + (size_t)uid * hp.Kp + lo);
   float ub = UB[uid], uba = UB_ag[uid];
-  constexpr int PF = 4;                              // item rows in flight
-  // this lane's item id(s) of the current chunk of 64 instances
-  uint32_t ci = 0, cj = 0;
-  auto load_ids = [&](uint32_t c0) {
+  // item rows of the NEXT group of PF instances travel while the current group is stepped (IN_PLACE: rows move under the loop,
+  // nothing is fetched ahead).  Two register sets and a copy at the group boundary: the ring-of-slots form (fetch x + PF into
+  // slot x % PF) made the compiler wait for every load in flight at each instance, the one just issued included.
+  constexpr int PF = IN_PLACE ? 1 : (PAIR || NI > 4) ? 8 : 16;
+  // this lane's item id(s) of the current chunk of 64 instances and, when the item side does not move under this kernel, their
+  // biases (one gather per chunk instead of one dependent scalar load per instance)
+  uint32_t ci = 0, cj = 0, ni = 0, nj = 0;
+  float cib = 0.f, cjb = 0.f;
+  auto load_ids = [&](uint32_t c0, uint32_t& a, uint32_t& b) {
     const uint32_t t = c0 + lane;
+    a = 0; b = 0;
     if (t < n_inst) {
-      if (PAIR) { ci = ex_item[2u * (inst0 + t)]; cj = ex_item[2u * (inst0 + t) + 1u]; }
-      else ci = ex_item[inst0 + t];
+      if (PAIR) { a = ex_item[2u * (inst0 + t)]; b = ex_item[2u * (inst0 + t) + 1u]; }
+      else a = ex_item[inst0 + t];
     }
   };
+  load_ids(0, ni, nj);
   for (uint32_t c0 = 0; c0 < n_inst; c0 += WAVE) {
-    load_ids(c0);
+    ci = ni; cj = nj;
+    if (c0 + WAVE < n_inst) load_ids(c0 + WAVE, ni, nj);     // the next chunk's ids travel while this one is stepped
+    if (!IN_PLACE) { cib = IB[ci]; if (PAIR) cjb = IB[cj]; }
     const uint32_t cnt = min((uint32_t)WAVE, n_inst - c0);
-    float ri[PF][NI], rj[PF][NI];
-    auto fetch = [&](int s, uint32_t idx) {            // rows of chunk instance idx into ring slot s (IN_PLACE: rows move, no prefetch)
+    float ri[PF][NI], rj[PF][NI], qi[PF][NI], qj[PF][NI];
+    auto fetch = [&](float (&di)[NI], float (&dj)[NI], uint32_t idx) {      // rows of chunk instance idx
       const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, idx);
-      if (IN_PLACE) vload_coherent<NI>(ri[s], IV + (size_t)it * hp.Kp + lo); else vload<NI>(ri[s], IV + (size_t)it * hp.Kp + lo);
+      if (IN_PLACE) vload_coherent<NI>(di, IV + (size_t)it * hp.Kp + lo); else vload<NI>(di, IV + (size_t)it * hp.Kp + lo);
       if (PAIR) {
         const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)cj, idx);
-        if (IN_PLACE) vload_coherent<NI>(rj[s], IV + (size_t)jt * hp.Kp + lo); else vload<NI>(rj[s], IV + (size_t)jt * hp.Kp + lo);
+        if (IN_PLACE) vload_coherent<NI>(dj, IV + (size_t)jt * hp.Kp + lo); else vload<NI>(dj, IV + (size_t)jt * hp.Kp + lo);
       }
     };
-    if (!IN_PLACE)
-      for (int s = 0; s < PF; ++s) if ((uint32_t)s < cnt) fetch(s, (uint32_t)s);
-    for (uint32_t x = 0; x < cnt; ++x) {
-      const int s = (int)(x % PF);
+    auto fetch_group = [&](uint32_t g0) {              // past the end of the chunk: the last row again (in bounds, never used)
+#pragma unroll
+      for (int s = 0; s < PF; ++s) fetch(qi[s], qj[s], min(g0 + (uint32_t)s, cnt - 1u));
+    };
+    auto take_group = [&]() {
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { ri[s][i] = qi[s][i]; if (PAIR) rj[s][i] = qj[s][i]; }
+    };
+    auto step = [&](int s, uint32_t x) __attribute__((always_inline)) {   // instance x of the chunk, its rows in register set s
       const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, x);
       const uint32_t jt = PAIR ? (uint32_t)__builtin_amdgcn_readlane((int)cj, x) : 0u;
-      if (IN_PLACE) fetch(s, x);
+      if (IN_PLACE) fetch(ri[s], rj[s], x);
       float d[NI];                                   // the item-side vector of the user step: iv[i] (IMF) or iv[i] - iv[j] (BPR)
 #pragma unroll
       for (int i = 0; i < NI; ++i) d[i] = PAIR ? ri[s][i] - rj[s][i] : ri[s][i];
@@ -150,9 +172,11 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
       for (int i = 0; i < NI; ++i) dot = fmaf(uv[i], d[i], dot);
       float pred = wave_sum(dot);
       float truth;
-      const float ibi = IN_PLACE ? __hip_atomic_load(IB + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : IB[it];
+      const float ibi = IN_PLACE ? __hip_atomic_load(IB + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cib), x));
       if (PAIR) {                                                                  // bpr.hpp:73-76 (ub cancels in the difference)
-        pred += ibi - (IN_PLACE ? __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : IB[jt]);
+        pred += ibi - (IN_PLACE ? __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cjb), x)));
         truth = 1.f;
       } else {                                                                     // imf.hpp:117-119, 80-84
         pred += ub + ibi;
@@ -168,35 +192,56 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
         float w[NI], a[NI];
         vload_coherent<NI>(a, IV_ag + (size_t)it * hp.Kp + lo);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { w[i] = ri[s][i]; ada_step(hp, w[i], a[i], fmaf(g, uv[i], lam2 * w[i])); }
+        for (int i = 0; i < NI; ++i) { w[i] = ri[s][i]; ada_step_t<ADA>(hp, w[i], a[i], fmaf(g, uv[i], lam2 * w[i])); }
         vstore<NI>(IV + (size_t)it * hp.Kp + lo, w);
         vstore<NI>(IV_ag + (size_t)it * hp.Kp + lo, a);
         if (bias_term && lane == 0) {
           float b = ibi, ba = __hip_atomic_load(IB_ag + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ada_step(hp, b, ba, fmaf(lam2, b, g)); IB[it] = b; IB_ag[it] = ba;
+          ada_step_t<ADA>(hp, b, ba, fmaf(lam2, b, g)); IB[it] = b; IB_ag[it] = ba;
         }
         if (PAIR) {
           vload_coherent<NI>(a, IV_ag + (size_t)jt * hp.Kp + lo);
 #pragma unroll
-          for (int i = 0; i < NI; ++i) { w[i] = rj[s][i]; ada_step(hp, w[i], a[i], fmaf(-g, uv[i], lam2 * w[i])); }
+          for (int i = 0; i < NI; ++i) { w[i] = rj[s][i]; ada_step_t<ADA>(hp, w[i], a[i], fmaf(-g, uv[i], lam2 * w[i])); }
           vstore<NI>(IV + (size_t)jt * hp.Kp + lo, w);
           vstore<NI>(IV_ag + (size_t)jt * hp.Kp + lo, a);
           if (bias_term && lane == 0) {
             float b = __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ba = __hip_atomic_load(IB_ag + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ada_step(hp, b, ba, fmaf(lam2, b, -g)); IB[jt] = b; IB_ag[jt] = ba;
+            ada_step_t<ADA>(hp, b, ba, fmaf(lam2, b, -g)); IB[jt] = b; IB_ag[jt] = ba;
           }
         }
         __builtin_amdgcn_s_waitcnt(WAIT_VM0);          // the next instance may hit the same row (duplicate negative): stores first
       }
-      if (!PAIR && bias_term) ada_step(hp, ub, uba, fmaf(lam2, ub, g));            // imf.hpp:97-101, 108-111 (BPR never steps ub)
+      if (!PAIR && bias_term) ada_step_t<ADA>(hp, ub, uba, fmaf(lam2, ub, g));            // imf.hpp:97-101, 108-111 (BPR never steps ub)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) ada_step(hp, uv[i], ua[i], fmaf(g, d[i], lam2 * uv[i]));
-      if (!IN_PLACE && x + PF < cnt) fetch(s, x + PF);
+      for (int i = 0; i < NI; ++i) ada_step_t<ADA>(hp, uv[i], ua[i], fmaf(g, d[i], lam2 * uv[i]));
+    };
+    if (IN_PLACE) {
+      for (uint32_t x = 0; x < cnt; ++x) step(0, x);
+    } else {
+      // a full group with a successor: fetch the successor, step the group, take the successor -- one straight path, so the wait
+      // before the take is a count of the stores issued since (not "everything")
+      fetch_group(0);
+      take_group();
+      uint32_t x0 = 0;
+      for (; x0 + PF < cnt; x0 += PF) {
+        fetch_group(x0 + PF);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) step(s, x0 + (uint32_t)s);
+        take_group();
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        if (x0 + (uint32_t)s >= cnt) break;
+        step(s, x0 + (uint32_t)s);
+      }
     }
   }
   vstore<NI>(UV + (size_t)uid * hp.Kp + lo, uv);
   vstore<NI>(UV_ag + (size_t)uid * hp.Kp + lo, ua);
   if (lane == 0) { UB[uid] = ub; UB_ag[uid] = uba; }
+  };
+  if (hp.adagrad) run(std::true_type{}); else run(std::false_type{});
 }
 
 // phase I: one wavefront per item row, contributions in (user, instance) order
@@ -206,7 +251,7 @@ mf_item_kernel(HyperParams hp, uint32_t bias_term, const uint32_t* __restrict__ 
                const uint32_t* __restrict__ seg_end, const uint64_t* __restrict__ sorted_val, const float* __restrict__ UVpre,
                const float* __restrict__ G, float* __restrict__ IV, float* __restrict__ IV_ag, float* __restrict__ IB,
                float* __restrict__ IB_ag) {
-  const uint32_t rank = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const uint32_t item = item_order[rank];
@@ -214,32 +259,48 @@ mf_item_kernel(HyperParams hp, uint32_t bias_term, const uint32_t* __restrict__ 
   if (beg == end) return;
   const uint32_t lo = lane * NI;
   const float lam2 = hp.lambda;
+  auto run = [&](auto ada_tag) __attribute__((always_inline)) {
+  constexpr bool ADA = decltype(ada_tag)::value;
   float w[NI], a[NI];
   vload<NI>(w, IV + (size_t)item * hp.Kp + lo);
   vload<NI>(a, IV_ag + (size_t)item * hp.Kp + lo);
   float b = IB[item], ba = IB_ag[item];
-  constexpr int PF = 4;
+  constexpr int PF = NI > 4 ? 8 : 16;                  // contributions per group; the next group's rows travel under this one's steps
   for (uint32_t c0 = beg; c0 < end; c0 += WAVE) {
     const uint32_t cnt = min((uint32_t)WAVE, end - c0);
     const uint64_t v = c0 + lane < end ? sorted_val[c0 + lane] : 0ull;
     const uint32_t inst = (uint32_t)(v >> 32);
     float gl = c0 + lane < end ? G[inst] : 0.f;
     if ((uint32_t)v & TARGET_BIT) gl = -gl;                                        // the negative item of a pair (bpr.hpp:80, 83)
-    float up[PF][NI];
-    for (int s = 0; s < PF; ++s)
-      if ((uint32_t)s < cnt) vload<NI>(up[s], UVpre + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)inst, s) * hp.Kp + lo);
-    for (uint32_t x = 0; x < cnt; ++x) {
-      const int s = (int)(x % PF);
-      const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), x));
-      if (bias_term) ada_step(hp, b, ba, fmaf(lam2, b, g));                        // imf.hpp:93, 98-100, 110
+    float up[PF][NI], uq[PF][NI];
+    auto fetch_group = [&](uint32_t g0) {              // past the end: the last contribution again (never used)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(g, up[s][i], lam2 * w[i]));   // imf.hpp:95, 103-106, 114
-      if (x + PF < cnt) vload<NI>(up[s], UVpre + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)inst, x + PF) * hp.Kp + lo);
+      for (int s = 0; s < PF; ++s)
+        vload<NI>(uq[s], UVpre + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)inst, min(g0 + (uint32_t)s, cnt - 1u)) * hp.Kp + lo);
+    };
+    fetch_group(0);
+    for (uint32_t x0 = 0; x0 < cnt; x0 += PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) up[s][i] = uq[s][i];
+      if (x0 + PF < cnt) fetch_group(x0 + PF);
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        const uint32_t x = x0 + (uint32_t)s;
+        if (x >= cnt) break;
+        const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), x));
+        if (bias_term) ada_step_t<ADA>(hp, b, ba, fmaf(lam2, b, g));                      // imf.hpp:93, 98-100, 110
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ada_step_t<ADA>(hp, w[i], a[i], fmaf(g, up[s][i], lam2 * w[i]));   // imf.hpp:95, 103-106, 114
+      }
     }
   }
   vstore<NI>(IV + (size_t)item * hp.Kp + lo, w);
   vstore<NI>(IV_ag + (size_t)item * hp.Kp + lo, a);
   if (lane == 0) { IB[item] = b; IB_ag[item] = ba; }
+  };
+  if (hp.adagrad) run(std::true_type{}); else run(std::false_type{});
 }
 
 }  // namespace cdae
