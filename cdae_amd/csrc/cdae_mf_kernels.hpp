@@ -112,9 +112,12 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   const uint32_t lo = lane * NI;
   const float lam2 = hp.lambda;                      // the host stores 2 * lambda here (imf.hpp:92-95 regularise with 2 lambda)
   const float neg_label = mf_negative_label(hp.loss_type);
-  // the whole loop twice, AdaGrad or plain SGD fixed at compile time (see ada_step_t)
-  auto run = [&](auto ada_tag) __attribute__((always_inline)) {
+  // the whole loop several times over: AdaGrad or plain SGD fixed at compile time (see ada_step_t), and so is the loss for the two
+  // the models default to (LT < 0: the run-time switch).  A lone wavefront per user issues one instruction every ~5 cycles whatever
+  // its kind, so the instance chain is its instruction count: the switch and its branches were a seventh of it.
+  auto run = [&](auto ada_tag, auto lt_tag) __attribute__((always_inline)) {
   constexpr bool ADA = decltype(ada_tag)::value;
+  constexpr int LT = decltype(lt_tag)::value;
   float uv[NI], ua[NI];
   vload<NI>(uv, UV + (size_t)uid * hp.Kp + lo);
   vload<NI>(ua, UV_ag + (size_t)uid * hp.Kp + lo);
@@ -141,6 +144,10 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
     if (c0 + WAVE < n_inst) load_ids(c0 + WAVE, ni, nj);     // the next chunk's ids travel while this one is stepped
     if (!IN_PLACE) { cib = IB[ci]; if (PAIR) cjb = IB[cj]; }
     const uint32_t cnt = min((uint32_t)WAVE, n_inst - c0);
+    // per lane: the label of chunk instance `lane` (imf.hpp:80-84: a positive, then its negatives), and the slot its loss
+    // gradient is parked in until the chunk's 64 go out in one store
+    const float tl = PAIR ? 1.f : ((c0 + lane) % per == 0u) ? 1.f : neg_label;
+    float gl = 0.f;
     float ri[PF][NI], rj[PF][NI], qi[PF][NI], qj[PF][NI];
     auto fetch = [&](float (&di)[NI], float (&dj)[NI], uint32_t idx) {      // rows of chunk instance idx
       const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, idx);
@@ -180,13 +187,13 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
         truth = 1.f;
       } else {                                                                     // imf.hpp:117-119, 80-84
         pred += ub + ibi;
-        truth = ((c0 + x) % per == 0u) ? 1.f : neg_label;
+        truth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl), x));
       }
-      const float g = mf_loss_grad(hp.loss_type, pred, truth);
+      const float g = mf_loss_grad(LT < 0 ? hp.loss_type : (uint32_t)LT, pred, truth);
       const uint64_t inst = inst0 + c0 + x;
       if (!IN_PLACE) {
         vstore<NI>(UVpre + (size_t)inst * hp.Kp + lo, uv);
-        if (lane == 0) G[inst] = g;
+        gl = lane == x ? g : gl;
       } else {
         // the reference loop: item row(s) stepped at once with the user vector from BEFORE its own step (imf.hpp:94-114)
         float w[NI], a[NI];
@@ -235,13 +242,23 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
         if (x0 + (uint32_t)s >= cnt) break;
         step(s, x0 + (uint32_t)s);
       }
+      if (lane < cnt) G[inst0 + c0 + lane] = gl;
     }
   }
   vstore<NI>(UV + (size_t)uid * hp.Kp + lo, uv);
   vstore<NI>(UV_ag + (size_t)uid * hp.Kp + lo, ua);
   if (lane == 0) { UB[uid] = ub; UB_ag[uid] = uba; }
   };
-  if (hp.adagrad) run(std::true_type{}); else run(std::false_type{});
+  using any_loss = std::integral_constant<int, -1>;
+  if (IN_PLACE) {                                      // the literal loop (blocks of one user): not a speed path
+    if (hp.adagrad) run(std::true_type{}, any_loss{}); else run(std::false_type{}, any_loss{});
+  } else if (hp.adagrad) {
+    if (hp.loss_type == 0u) run(std::true_type{}, std::integral_constant<int, 0>{});
+    else if (hp.loss_type == 2u) run(std::true_type{}, std::integral_constant<int, 2>{});
+    else run(std::true_type{}, any_loss{});
+  } else {
+    run(std::false_type{}, any_loss{});
+  }
 }
 
 // phase I: one wavefront per item row, contributions in (user, instance) order
