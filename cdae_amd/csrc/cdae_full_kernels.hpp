@@ -1167,4 +1167,303 @@ full_rows_wave_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, co
   if (lane == 0 && touched) touched[item] = 1u;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K > 256, item spaces >= 32768 (BASELINE configs[4]): GEMM 3 and the row step in ONE launch.
+//
+// The separate launches moved dD twice (2 GB written by GEMM 3, 2 GB read by the row step at 1 M items x K = 512), the row step
+// read the G^T row of every item a second time for the b' gradient (2 GB) — 13 GB for a step whose own operands are 10 GB.
+// Here a 256-thread workgroup owns 128 items x all 512 k of  dD^T[k][item] = sum_u Z^T[k][u] G^T[item][u]  (contraction over
+// the block's users) and keeps it in the accumulators (wavefront w: k in [128 w, 128 w + 128) x 128 items = 4 x 4 tiles of
+// v_mfma_f32_32x32x16_bf16, 256 registers; one wavefront per SIMD), then steps its rows from there: the C layout of the MFMA
+// puts FOUR CONSECUTIVE k of one item into a lane, so D / D_ag are read and written as 16-byte pieces of the item's row and
+// the row-major bf16 image as 8-byte pieces; pairs of lanes cover 32 contiguous bytes and the four pieces of a lane a whole
+// 128-byte line.  The b' gradient (the row sum of G^T) is summed from the operand slices that pass through LDS anyway.
+//   contraction: slices of 32 users, three 40 KiB LDS stages (512 Z^T rows + 128 G^T rows of 64 bytes; slot c of row r holds
+//   source chunk c ^ ((r >> 2) & 3): the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots), two slices in flight
+//   across every raw barrier, counted vmcnt (10 DMA instructions per wavefront and slice);
+//   epilogue: eight stages of (32 items x 64 k) per wavefront, the next stage's 16 row pieces requested before the current
+//   stage's 64 AdaGrad steps (16 KiB in flight per wavefront: the epilogue is HBM-bound, 10 bytes per parameter).
+// Every dD element is the same sum over users in the same order as gemm_nt_bf16_ldsw_kernel's and the row step is
+// full_rows_wave_kernel's expression, so D / D_ag / W come out bit-identical to the separate launches; b' differs in the
+// order its gradient is summed (test_fused_rows_kernel_matches_separate_launches).
+constexpr int FR_ITEMS = 128, FR_BK = 32;
+// KH: workgroups per item tile.  1: 256 threads, all 512 k (40 KiB stages).  2: 128 threads and 256 k each (24 KiB stages, the G^T
+// tile staged by both) — two workgroups per CU, so that one's HBM-bound row steps run beside the other's contraction.
+template <int KH> constexpr int fr_stage_bytes() { return (512 / KH + FR_ITEMS) * FR_BK * 2; }
+template <int KH> constexpr size_t fused_rows_lds_bytes() { return 3 * (size_t)fr_stage_bytes<KH>(); }
+
+struct FusedRowsCtx {
+  float* P0; float* P0a; float* dD;
+  __bf16* Db; __bf16* DTb;
+  uint32_t in_mask;     // bit ib: this lane's item of block ib has a kept input (stepped by full_rows_inputs_kernel from dD)
+  uint32_t Ip, tile_row /* tile0 + (lane & 31) */, kl /* 128 wid + 4 (lane >> 5) */;
+};
+// piece t of a stage: 4 floats at row offset 64 (ST & 1) + 32 (t >> 2) + 8 (t & 3) from column kl
+template <int ST>
+__device__ __forceinline__ void fr_load_stage(const HyperParams& hp, const FusedRowsCtx& cx, float4 (&wv)[8], float4 (&av)[8]) {
+  const uint32_t row = min(cx.tile_row + (uint32_t)(ST >> 1) * 32u, hp.num_items - 1u);
+  const size_t ro = (size_t)row * 512u + cx.kl + (uint32_t)(ST & 1) * 64u;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    wv[t] = *reinterpret_cast<const float4*>(cx.P0 + ro + (t >> 2) * 32 + (t & 3) * 8);
+    av[t] = *reinterpret_cast<const float4*>(cx.P0a + ro + (t >> 2) * 32 + (t & 3) * 8);
+  }
+}
+template <int ST, bool ADA, bool DT>
+__device__ __forceinline__ void fr_rows_stage(const HyperParams& hp, const FusedRowsCtx& cx, const f32x16 (&acc)[4][4],
+                                              const float4 (&wv)[8], const float4 (&av)[8]) {
+  constexpr int ib = ST >> 1, kp = ST & 1;
+  const uint32_t item = cx.tile_row + (uint32_t)ib * 32u;
+  const bool live = item < hp.num_items, deferred = (cx.in_mask >> ib) & 1u;
+  const size_t ro = (size_t)min(item, hp.num_items - 1u) * 512u + cx.kl + (uint32_t)kp * 64u;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int kb = 2 * kp + (t >> 2), q4 = t & 3;
+    const uint32_t po = (t >> 2) * 32 + (t & 3) * 8;
+    float w4[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w}, a4[4] = {av[t].x, av[t].y, av[t].z, av[t].w};
+    float dd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)       // the products stay in the accumulation registers until their piece is stepped (left to itself hipcc 7.2
+                                      // moves all 256 to VGPRs behind the loop and spills them)
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dd[e]) : "a"(acc[kb][ib][4 * q4 + e]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ada_step_t<ADA>(hp, w4[e], a4[e], fmaf(hp.lambda, w4[e], dd[e]));
+    if (live && deferred) {
+      *reinterpret_cast<float4*>(cx.dD + ro + po) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    } else if (live) {
+      *reinterpret_cast<float4*>(cx.P0 + ro + po) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+      *reinterpret_cast<float4*>(cx.P0a + ro + po) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+      const bf16x4 hb = {(__bf16)w4[0], (__bf16)w4[1], (__bf16)w4[2], (__bf16)w4[3]};
+      *reinterpret_cast<bf16x4*>(cx.Db + ro + po) = hb;
+      if (DT) {
+        const uint32_t k0 = cx.kl + (uint32_t)kp * 64u + po;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cx.DTb[(size_t)(k0 + e) * cx.Ip + item] = hb[e];
+      }
+    }
+  }
+}
+
+template <bool ADA, bool DT, int KH>
+__global__ void __launch_bounds__(256 / KH)
+gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][ldz] */, const __bf16* __restrict__ GT /* [Ip][ldgt] */,
+                        uint32_t ldz, uint32_t ldgt, uint32_t nb,
+                        const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                        const uint64_t* __restrict__ sorted_val, float* __restrict__ dD /* [Ip][512]: rows with a kept input only */,
+                        float* __restrict__ W, float* __restrict__ W_ag,
+                        float* __restrict__ bp, float* __restrict__ bp_ag, uint32_t* __restrict__ touched,
+                        __bf16* __restrict__ Db /* [Ip][512] */, __bf16* __restrict__ DTb /* [512][Ip] (DT) */, uint32_t Ip) {
+  extern __shared__ __attribute__((aligned(1024))) char smemf[];
+  constexpr uint32_t KP = 512;
+  constexpr uint32_t NW = 4 / KH, ZROWS = 512 / KH, GQ = 8 / NW;              // wavefronts, staged Z^T rows, G^T DMA instructions per wavefront
+  constexpr uint32_t STAGE = (uint32_t)fr_stage_bytes<KH>();
+  const uint32_t lane = threadIdx.x % WAVE, wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // 0 .. NW-1
+  uint32_t tile, kh;
+  if (KH == 1) { tile = blockIdx.x; kh = 0; }
+  else { tile = (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u); kh = (blockIdx.x >> 3) & 1u; }   // both halves of a tile on ONE XCD (ids go round-robin over the 8): G^T from HBM once
+  const uint32_t tile0 = tile * FR_ITEMS;
+  if (tile0 >= Ip) return;
+  const uint32_t kw = kh * NW + wid;                                       // this wavefront's k block of 128: [128 kw, 128 kw + 128)
+  const uint32_t n_steps = (hp.debug_skip & 32u) ? 0u : (nb + FR_BK - 1) / FR_BK;     // columns >= nb of Z^T and G^T are zero (debug_skip: timing experiments only)
+  f32x16 acc[4][4];                                                        // [k block][item block]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: a slice is ZROWS / 16 + 8 DMA instructions of 1 KiB (16 rows of 64 bytes); a wavefront issues the 8 of its own Z^T rows and GQ of G^T
+  const uint32_t st_row = lane >> 2, st_src = 8u * ((lane & 3u) ^ ((lane >> 4) & 3u));
+  const __bf16* z_src[8];
+  const __bf16* g_src[GQ];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) z_src[q] = ZT + (size_t)(kw * 128u + q * 16u + st_row) * ldz + st_src;
+#pragma unroll
+  for (int q = 0; q < (int)GQ; ++q) g_src[q] = GT + (size_t)min(tile0 + (wid * GQ + q) * 16u + st_row, Ip - 1u) * ldgt + st_src;
+  auto stage = [&](uint32_t step, uint32_t slot) {
+    char* base = smemf + slot * STAGE;
+    const uint32_t k = step * FR_BK;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(z_src[q] + k),
+                                       (__attribute__((address_space(3))) void*)(base + (wid * 8u + q) * 1024u), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < (int)GQ; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_src[q] + k),
+                                       (__attribute__((address_space(3))) void*)(base + ZROWS * 64u + (wid * GQ + q) * 1024u), 16, 0, 0);
+  };
+  const uint32_t f_row = lane & 31u, f_half = lane >> 5, f_sw = (f_row >> 2) & 3u;
+  const uint32_t a_off = (wid * 128u + f_row) * 64u;                       // + 32 rows per k block
+  const uint32_t b_off = ZROWS * 64u + f_row * 64u;                        // + 32 rows per item block
+  const uint32_t gblk = kh * NW + wid;                                     // the item block whose b' gradient this wavefront sums (KH = 2: blocks 2 kh, 2 kh + 1)
+  float gs = 0.f;                                                          // this lane's share of sum_u G^T[item][u], item = tile0 + 32 gblk + f_row
+
+  // the first two stages of row pieces are requested now and land under the contraction
+  FusedRowsCtx cx;
+  cx.P0 = W; cx.P0a = W_ag; cx.dD = dD; cx.Db = Db; cx.DTb = DTb; cx.Ip = Ip; cx.in_mask = 0;
+  cx.tile_row = tile0 + f_row; cx.kl = kw * 128u + 4u * f_half;
+  float4 w0[8], a0[8], w1[8], a1[8];
+  stage(0, 0);
+  if (n_steps > 1) stage(1, 1);
+  // Tied weights: a row that some user of the block kept as an input takes ONE step with dD + the summed input gradient
+  // (cdae.hpp:252-257 and 337-348 merged).  Those rows (a few per cent at this item count) are not stepped here: their dD pieces
+  // go to memory and full_rows_inputs_kernel steps them behind this launch.  Found while the first slices are in flight.
+  uint32_t in_mask = 0;                                                    // bit j: item tile0 + 32 j + f_row has a kept input
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t item = tile0 + (uint32_t)j * 32u + f_row;
+    const uint32_t beg = item < hp.num_items ? seg_begin[item] : 0u, end = item < hp.num_items ? seg_end[item] : 0u;
+    uint32_t any = 0;
+    for (uint32_t q = beg; q < end; ++q) any |= (uint32_t)sorted_val[q] >> 31;
+    in_mask |= any << j;
+  }
+  fr_load_stage<0>(hp, cx, w0, a0);
+  fr_load_stage<1>(hp, cx, w1, a1);
+  uint32_t slot = 0;
+  for (uint32_t step = 0; step < n_steps; ++step) {
+    if (step + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (KH == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // (8 + GQ: the DMA instructions of the slice still in flight)
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint32_t nslot = slot == 0 ? 2u : slot - 1u;
+    if (step + 2 < n_steps) stage(step + 2u, nslot);
+    const char* base = smemf + slot * STAGE;
+#pragma unroll
+    for (int s = 0; s < FR_BK / 16; ++s) {
+      const uint32_t c16 = ((2u * s + f_half) ^ f_sw) << 4;
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048u + c16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048u + c16);
+      {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 u = *reinterpret_cast<const u32x4*>(base + b_off + gblk * 2048u + c16);      // G^T piece of this wavefront's b' rows
+#pragma unroll
+        for (int d = 0; d < 4; ++d) gs += __builtin_bit_cast(float, u[d] << 16) + __builtin_bit_cast(float, u[d] & 0xFFFF0000u);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0u : slot + 1u;
+  }
+
+  __builtin_amdgcn_s_waitcnt(WAIT_VM0);      // (nothing is in flight here; said through the builtin so that hipcc's own wait insertion counts from a known state below)
+  // b'[item] of the 32 items this wavefront summed
+  gs += __shfl_xor(gs, 32);
+  {
+    const uint32_t item = tile0 + gblk * 32u + f_row;
+    if (f_half == 0 && item < hp.num_items) {
+      float p = bp[item], pa = bp_ag[item];
+      ada_step_t<ADA>(hp, p, pa, fmaf(hp.lambda, p, gs));
+      bp[item] = p; bp_ag[item] = pa;
+      if (touched) touched[item] = 1u;
+    }
+  }
+
+  if (hp.debug_skip & 16u) {                                               // (timing experiments only: contraction without the row steps)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[i][j][0])); t += v; }
+    if (t == 123.456f) bp[0] = 0.f;
+    return;
+  }
+  // row steps: stage = (item block ib, k-block pair kp); lane: item = tile0 + 32 ib + f_row, pieces k = 128 kw + 32 kb + 8 q + 4 f_half.
+  // The epilogue is HBM-bound (10 bytes per parameter) and only four wavefronts live on the CU, so what counts is the bytes in
+  // flight: four row-piece buffers, filled as the accumulators of finished stages free their registers — one stage ahead at first,
+  // two, then three (stages 0 and 1 were requested in front of the contraction).
+  cx.in_mask = in_mask;
+#define FR_SB() __builtin_amdgcn_sched_barrier(0)
+  float4 w2[8], a2[8], w3[8], a3[8];
+  fr_rows_stage<0, ADA, DT>(hp, cx, acc, w0, a0); FR_SB();
+  fr_load_stage<2>(hp, cx, w0, a0); FR_SB();
+  fr_rows_stage<1, ADA, DT>(hp, cx, acc, w1, a1); FR_SB();
+  fr_load_stage<3>(hp, cx, w1, a1); fr_load_stage<4>(hp, cx, w2, a2); FR_SB();
+  fr_rows_stage<2, ADA, DT>(hp, cx, acc, w0, a0); FR_SB();
+  fr_load_stage<5>(hp, cx, w0, a0); FR_SB();
+  fr_rows_stage<3, ADA, DT>(hp, cx, acc, w1, a1); FR_SB();
+  fr_load_stage<6>(hp, cx, w1, a1); fr_load_stage<7>(hp, cx, w3, a3); FR_SB();
+  fr_rows_stage<4, ADA, DT>(hp, cx, acc, w2, a2); FR_SB();
+  fr_rows_stage<5, ADA, DT>(hp, cx, acc, w0, a0); FR_SB();
+  fr_rows_stage<6, ADA, DT>(hp, cx, acc, w1, a1); FR_SB();
+  fr_rows_stage<7, ADA, DT>(hp, cx, acc, w3, a3);
+#undef FR_SB
+}
+
+// Behind gemm3_rows_fused_kernel (tied weights): the rows some user of the block kept as an input — dD from the fused launch, the
+// summed delta rows added as full_rows_wave_kernel adds them, one step.  b' of these rows was stepped by the fused launch.
+template <int NI>
+__global__ void __launch_bounds__(256)
+full_rows_inputs_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                        const uint64_t* __restrict__ sorted_val, const float* __restrict__ DELTA, const float* __restrict__ dD,
+                        float* __restrict__ W, float* __restrict__ W_ag, __bf16* __restrict__ Db, __bf16* __restrict__ DTb, uint32_t Ip) {
+  // a wavefront looks at 64 items, one per lane (nearly all have no positive at all in the block), then steps the few with a kept
+  // input one after the other with all its lanes
+  const uint32_t item0 = (blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE) * WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (item0 >= hp.num_items) return;
+  uint32_t my_beg = 0, my_end = 0;
+  bool mine = false;
+  if (item0 + lane < hp.num_items) {
+    my_beg = seg_begin[item0 + lane]; my_end = seg_end[item0 + lane];
+    for (uint32_t q = my_beg; q < my_end; ++q) mine = mine || ((uint32_t)sorted_val[q] & INPUT_BIT) != 0u;
+  }
+  unsigned long long todo = __ballot(mine);
+  const uint32_t lo = lane * NI;
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const uint32_t item = item0 + (uint32_t)src;
+    const uint32_t beg = (uint32_t)__builtin_amdgcn_readlane((int)my_beg, src), end = (uint32_t)__builtin_amdgcn_readlane((int)my_end, src);
+    float dd[NI], w[NI], a[NI], din[NI];
+    vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);
+    vload<NI>(w, W + (size_t)item * hp.Kp + lo);
+    vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) din[i] = 0.f;
+    constexpr int UN = 8;
+    for (uint32_t p0 = beg; p0 < end; p0 += WAVE) {
+      const uint32_t q = p0 + lane;
+      const uint32_t word = q < end ? (uint32_t)sorted_val[q] : 0u;
+      unsigned long long mask = __ballot((word & INPUT_BIT) != 0u);
+      while (mask) {
+        float v[UN][NI];
+#pragma unroll
+        for (int t = 0; t < UN; ++t) {
+          if (mask) {
+            const int s2 = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)word, s2) & SLOT_MASK;
+            vload<NI>(v[t], DELTA + (size_t)slot * hp.Kp + lo);
+          } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[t][i] = 0.f;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < UN; ++t)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) din[i] += v[t][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
+    vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
+    vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
+    if (Db) {
+      store_row_only_bf16<NI>(w, item, lo, hp.Kp, Db);
+      if (DTb) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) DTb[(size_t)(lo + i) * Ip + item] = (__bf16)w[i];
+      }
+    }
+  }
+}
+
 }  // namespace cdae

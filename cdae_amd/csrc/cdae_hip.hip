@@ -201,6 +201,10 @@ struct cdae_hip {
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
   bool gemmw_attr_set[8] = {false, false, false, false, false, false, false, false};   // ... of the 256 x 256-tile kernel
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
+  bool rows_separate = false;           // CDAE_FULL_ROWS_SEPARATE: GEMM 3 and the row step as two launches where gemm3_rows_fused_kernel would run (A/B switch)
+  bool rows_fused_dt = false;           // CDAE_FULL_ROWS_DT: the fused row step writes D^T itself (2-byte stores: slower than bf16_transpose_kernel's pass, measured; A/B switch)
+  bool fused_rows_attr_set[2][2][2] = {};   // dynamic-LDS attribute of gemm3_rows_fused_kernel<ADA, DT, KH> set on this handle's device
+  int rows_fused_kh = 2;                // CDAE_FULL_ROWS_KH: workgroups per item tile of the fused row step (1 | 2)
 
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr; float* d_snap = nullptr;   // agreed state, staged delta, all-reduced delta, parameters at the last stage
@@ -647,6 +651,37 @@ uint32_t gemm2_k_per_split(const cdae_hip* h) {
   return (((h->Ip + want - 1) / want + 63) / 64) * 64;
 }
 
+// GEMM 3 + row step in one launch (gemm3_rows_fused_kernel): Kp = 512 over item spaces >= 32768, i.e. BASELINE configs[4]'s path
+bool rows_fused_path(const cdae_hip* h) {
+  return h->Kp == 512 && h->I >= 32768 && h->Ip % cdae::FR_ITEMS == 0 && !h->cfg.asymmetric && h->fused_images && !h->gemm_direct && !h->rows_separate;
+}
+int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uint32_t nb, __bf16* Db, __bf16* DTb) {
+  using namespace cdae;
+  const uint32_t I = (uint32_t)h->I;
+#define FR_LAUNCH(ADA_, DT_, KH_)                                                                                                         \
+  do {                                                                                                                                    \
+    if (!h->fused_rows_attr_set[ADA_][DT_][KH_ - 1]) {                                                                                    \
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3_rows_fused_kernel<ADA_, DT_, KH_>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                 (int)fused_rows_lds_bytes<KH_>()));                                                                      \
+      h->fused_rows_attr_set[ADA_][DT_][KH_ - 1] = true;                                                                                  \
+    }                                                                                                                                     \
+    const uint32_t tiles = h->Ip / FR_ITEMS, grid = KH_ == 1 ? tiles : 16u * ((tiles + 7u) / 8u);                                         \
+    hipLaunchKernelGGL((gemm3_rows_fused_kernel<ADA_, DT_, KH_>), dim3(grid), dim3(256 / KH_), fused_rows_lds_bytes<KH_>(), st, h->hp,    \
+                       (const __bf16*)h->d_ZTb, (const __bf16*)h->d_GTb, h->Bp, h->Bp, nb, (const uint32_t*)x.seg,                        \
+                       (const uint32_t*)(x.seg + I), (const uint64_t*)x.sorted_val, h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG),           \
+                       h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_touched, Db, DTb, h->Ip);                                                \
+  } while (0)
+#define FR_LAUNCH2(ADA_, DT_) do { if (h->rows_fused_kh == 1) FR_LAUNCH(ADA_, DT_, 1); else FR_LAUNCH(ADA_, DT_, 2); } while (0)
+  if (h->cfg.using_adagrad) { if (DTb) FR_LAUNCH2(true, true); else FR_LAUNCH2(true, false); }
+  else { if (DTb) FR_LAUNCH2(false, true); else FR_LAUNCH2(false, false); }
+#undef FR_LAUNCH2
+#undef FR_LAUNCH
+  // the rows kept as inputs (tied weights: one step with dD + the summed input gradient)
+  DISPATCH_NI(h->NI, full_rows_inputs_kernel, dim3((I + 255) / 256), dim3(256), 0, st, h->hp, (const uint32_t*)x.seg, (const uint32_t*)(x.seg + I),
+              (const uint64_t*)x.sorted_val, (const float*)h->delta_rows(), (const float*)h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), Db, DTb, h->Ip);
+  return 0;
+}
+
 // Full-output decode of one batch (MFMA path, cdae_full_kernels.hpp).  The example list holds the positives only.
 int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
   using namespace cdae;
@@ -673,8 +708,9 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // Round 3: for item spaces below 32768 the row step (full_rows_kernel) leaves the bf16 images of the decoder behind and the
   // encode writes those of z: no conversion launch in the steady state.  D is converted here only when something else wrote the
   // parameters (init, set_param, an exchange), Z only when the batch is shorter than the rows the images may hold.
-  const bool rows_write_images = h->fused_images && I < 32768u;
-  const bool rows_write_db = h->fused_images && I >= 32768u;             // full_rows_wave_kernel: the row-major image only
+  const bool rows_fused = rows_fused_path(h);                             // GEMM 3 + row step in one launch (Kp = 512, >= 32768 items)
+  const bool rows_write_images = h->fused_images && (I < 32768u || (rows_fused && h->rows_fused_dt));
+  const bool rows_write_db = h->fused_images && I >= 32768u && !rows_write_images;   // full_rows_wave_kernel: the row-major image only
   const bool need_d = !(rows_write_images && h->db_valid) && !(rows_write_db && h->db_rows_valid);
   if (rows_write_db && h->db_rows_valid)                                  // D^T from the bf16 rows the row step left (2 GB instead of 4 at 1 M x 512)
     hipLaunchKernelGGL(bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, (const __bf16*)h->d_Db, I, Kp, Ip, h->d_DTb);
@@ -779,7 +815,9 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     e3.Cout = h->d_dD; e3.ldc = Kp;
     // 64-row workgroups (two wavefronts): 2 x Ip/64 of them spread over all CUs, 128-row ones would occupy only 166 at ML-10M shape
     // (developer switch CDAE_GEMM_DIRECT; the default is the LDS-staged kernel: 73 -> 31 us at ML-10M shape, 2048 users)
-    if (h->gemm_direct)
+    if (rows_fused)
+      ;                                                          // (the product stays in the accumulators of the row-step launch below)
+    else if (h->gemm_direct)
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
                          Bp, Bp, Bp, Bp, e3);
     else
@@ -789,7 +827,9 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
   CHK(pr.begin(h, F_INPUT, st));
-  if (I >= 32768u)     // rows are plentiful and mostly without kept inputs: one wavefront per row
+  if (rows_fused)      // dD = G^T Z and the row steps from its accumulators (gemm3_rows_fused_kernel)
+    CHK(launch_rows_fused(h, st, x, nb, h->d_Db, rows_write_images ? h->d_DTb : (__bf16*)nullptr));
+  else if (I >= 32768u)     // rows are plentiful and mostly without kept inputs: one wavefront per row
     DISPATCH_NI(h->NI, full_rows_wave_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), h->d_touched, rows_write_db ? h->d_Db : (__bf16*)nullptr);
@@ -943,6 +983,9 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
   h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
   h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
+  h->rows_separate = std::getenv("CDAE_FULL_ROWS_SEPARATE") != nullptr;
+  h->rows_fused_dt = std::getenv("CDAE_FULL_ROWS_DT") != nullptr;
+  if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;

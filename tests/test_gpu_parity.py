@@ -622,3 +622,76 @@ def test_wide_gemm_tiles_change_no_bit(built, monkeypatch):
     for w in wide:
         assert np.array_equal(wide[w], narrow[w]), w
     assert loss_w == loss_n and np.isfinite(loss_w)
+
+
+@pytest.mark.parametrize("adagrad", [True, False])
+def test_fused_rows_kernel_matches_separate_launches(built, monkeypatch, adagrad):
+    """K > 256 over >= 32768 items (BASELINE configs[4]'s path): GEMM 3 and the row step in one launch (gemm3_rows_fused_kernel: dD
+    stays in the accumulators; the rows some user kept as an input are stepped from their dD pieces by full_rows_inputs_kernel)
+    against the two separate launches (CDAE_FULL_ROWS_SEPARATE=1).  One block: every dD element is the same sum over the users in
+    the same order and the row step is the same expression, so W / W_ag are IDENTICAL, rows with kept inputs included; b' sums its
+    gradient (the row of G^T) in another order.  Then a whole epoch of three blocks, where b' feeds the next block's forward
+    product: close.  CDAE_FULL_ROWS_DT=1 (D^T written by the fused launch instead of the transposer) and CDAE_FULL_ROWS_KH=1 (one
+    workgroup per item tile instead of two) must not change a bit against the default."""
+    d = synth.generate(600, 33_000, 36_000, seed=6, min_items=20)
+
+    def run(batch_users):
+        cfg = cdae_amd.CDAEConfig(num_dim=300, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=batch_users, full_output=True,
+                                  using_adagrad=adagrad, learn_rate=0.1 if adagrad else 0.01)
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=4)
+        m.train_one_iteration(4, 0)
+        m.train_one_iteration(4, 1)          # second epoch: the forward product reads the bf16 images the first one's row steps left
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        loss = m.current_loss(4, 0)
+        m.close()
+        return out, loss
+
+    fused1, loss_f1 = run(640)               # one block per epoch
+    fused3, loss_f3 = run(256)
+    monkeypatch.setenv("CDAE_FULL_ROWS_DT", "1")
+    nodt3, loss_n3 = run(256)
+    monkeypatch.delenv("CDAE_FULL_ROWS_DT")
+    monkeypatch.setenv("CDAE_FULL_ROWS_KH", "1")
+    kh1, loss_k1 = run(256)
+    monkeypatch.delenv("CDAE_FULL_ROWS_KH")
+    monkeypatch.setenv("CDAE_FULL_ROWS_SEPARATE", "1")
+    sep1, loss_s1 = run(640)
+    sep3, loss_s3 = run(256)
+    for w in fused3:
+        assert np.array_equal(fused3[w], nodt3[w]), w
+        assert np.array_equal(fused3[w], kh1[w]), w
+    assert abs(loss_f3 - loss_n3) <= 1e-12 * abs(loss_f3) and abs(loss_f3 - loss_k1) <= 1e-12 * abs(loss_f3)
+    # the kept-input rows really are exercised: some rows moved by more than the no-input step could explain
+    for w in fused1:
+        scale = np.abs(sep1[w]).max() + 1e-30
+        err = np.abs(fused1[w] - sep1[w]).max() / scale
+        assert err <= 2e-5, (w, err)
+        err3 = np.abs(fused3[w] - sep3[w]).max() / (np.abs(sep3[w]).max() + 1e-30)
+        assert err3 <= 2e-4, (w, err3)
+    assert abs(loss_f1 - loss_s1) <= 1e-5 * abs(loss_s1) and abs(loss_f3 - loss_s3) <= 1e-4 * abs(loss_s3)
+
+
+def test_fused_rows_first_block_is_bit_identical(built, monkeypatch):
+    """One block from fresh parameters: the decoder rows and their accumulators out of the fused launch are bit-identical to the
+    separate launches' (b' differs only in the order its gradient is summed: 1e-6)."""
+    d = synth.generate(500, 33_000, 30_000, seed=9, min_items=20)
+    cfg = cdae_amd.CDAEConfig(num_dim=300, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=512, full_output=True)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=3)
+        w_init = m.get(0)
+        m.train_one_iteration(4, 0)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        m.close()
+        return out, w_init
+
+    fused, w_init = run()
+    monkeypatch.setenv("CDAE_FULL_ROWS_SEPARATE", "1")
+    sep, _ = run()
+    for w in (0, 1, 4, 5, 6, 7):
+        assert np.array_equal(fused[w], sep[w]), w
+    for w in (8, 9):
+        np.testing.assert_allclose(fused[w], sep[w], rtol=2e-6, atol=1e-9)
+    assert np.abs(fused[0] - w_init).max() > 0      # (the rows moved at all)
