@@ -924,11 +924,13 @@ full_decode_fused_kernel(HyperParams hp, const __bf16* __restrict__ Zb /* [Bp x 
 // c = 1 (cross-entropy: sigmoid(y) - t) or 2 (square: -2 (t - y)), so the batch's positives are patched in place.
 __global__ void __launch_bounds__(256)
 full_positive_fixup_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __restrict__ ex_val, uint32_t n_ex,
-                           float c, __bf16* __restrict__ G, uint32_t ldg, __bf16* __restrict__ GT, uint32_t ldgt) {
+                           float c, __bf16* __restrict__ G, uint32_t ldg, __bf16* __restrict__ GT, uint32_t ldgt,
+                           uint8_t* __restrict__ has_in = nullptr /* [I]: marks the items some user of the block kept as an input (gemm3_rows_fused_kernel) */) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_ex) return;
   const uint32_t item = ex_item[e];
   const uint32_t slot = (uint32_t)ex_val[e] & SLOT_MASK;
+  if (has_in && ((uint32_t)ex_val[e] & INPUT_BIT)) has_in[item] = 1;
   const float g = (float)G[(size_t)slot * ldg + item] - c;
   G[(size_t)slot * ldg + item] = (__bf16)g;
   GT[(size_t)item * ldgt + slot] = (__bf16)g;
@@ -1193,67 +1195,88 @@ constexpr int FR_ITEMS = 128, FR_BK = 32;
 template <int KH> constexpr int fr_stage_bytes() { return (512 / KH + FR_ITEMS) * FR_BK * 2; }
 template <int KH> constexpr size_t fused_rows_lds_bytes() { return 3 * (size_t)fr_stage_bytes<KH>(); }
 
+// Epilogue of gemm3_rows_fused_kernel.  The C layout of the MFMA gives a lane 4 consecutive k of ONE item and its 32 lanes 32
+// different items: stepping the rows from there means 32-byte pieces of 32 rows per memory instruction (measured: 4.0 TB/s over
+// the epilogue's 9 GB, against 5.2 TB/s for full_rows_wave_kernel's whole rows).  So a quarter of the tile at a time — 32 items x
+// the workgroup's k span — goes through LDS (row stride KS * 4 + 16 bytes: the 8 lanes of a ds_write_b128 group hit 8 distinct
+// 16-byte bank groups) and comes back ROW-MAJOR: a wavefront then steps whole rows, 16 bytes per lane, every access a
+// contiguous 1 KiB (the workgroup's k span of one row is 1 KiB at KH = 2, 2 KiB at KH = 1).
 struct FusedRowsCtx {
   float* P0; float* P0a; float* dD;
-  __bf16* Db; __bf16* DTb;
-  uint32_t in_mask;     // bit ib: this lane's item of block ib has a kept input (stepped by full_rows_inputs_kernel from dD)
-  uint32_t Ip, tile_row /* tile0 + (lane & 31) */, kl /* 128 wid + 4 (lane >> 5) */;
+  __bf16* Db;
+  char* lds;
+  uint32_t in_mask;     // lane l (and l + 32): bit c set if item tile0 + 32 c + l has a kept input (stepped by full_rows_inputs_kernel from dD)
+  uint32_t tile0, kbase /* first k of the workgroup */, wid, lane, num_items;
 };
-// piece t of a stage: 4 floats at row offset 64 (ST & 1) + 32 (t >> 2) + 8 (t & 3) from column kl
-template <int ST>
-__device__ __forceinline__ void fr_load_stage(const HyperParams& hp, const FusedRowsCtx& cx, float4 (&wv)[8], float4 (&av)[8]) {
-  const uint32_t row = min(cx.tile_row + (uint32_t)(ST >> 1) * 32u, hp.num_items - 1u);
-  const size_t ro = (size_t)row * 512u + cx.kl + (uint32_t)(ST & 1) * 64u;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    wv[t] = *reinterpret_cast<const float4*>(cx.P0 + ro + (t >> 2) * 32 + (t & 3) * 8);
-    av[t] = *reinterpret_cast<const float4*>(cx.P0a + ro + (t >> 2) * 32 + (t & 3) * 8);
-  }
+// piece p (0..15) of a quarter, wavefront wid: which row of the quarter and which 4 floats of the workgroup's k span this lane holds
+template <int KH>
+__device__ __forceinline__ void fr_piece(const FusedRowsCtx& cx, int p, uint32_t& item_local, uint32_t& col) {
+  if (KH == 2) { item_local = cx.wid * 16u + (uint32_t)p; col = cx.lane * 4u; }
+  else { item_local = cx.wid * 8u + (uint32_t)(p >> 1); col = (uint32_t)(p & 1) * 256u + cx.lane * 4u; }
 }
-template <int ST, bool ADA, bool DT>
-__device__ __forceinline__ void fr_rows_stage(const HyperParams& hp, const FusedRowsCtx& cx, const f32x16 (&acc)[4][4],
-                                              const float4 (&wv)[8], const float4 (&av)[8]) {
-  constexpr int ib = ST >> 1, kp = ST & 1;
-  const uint32_t item = cx.tile_row + (uint32_t)ib * 32u;
-  const bool live = item < hp.num_items, deferred = (cx.in_mask >> ib) & 1u;
-  const size_t ro = (size_t)min(item, hp.num_items - 1u) * 512u + cx.kl + (uint32_t)kp * 64u;
+template <int C, int KH>
+__device__ __forceinline__ void fr_load_piece(const FusedRowsCtx& cx, int p, float4& wv, float4& av) {
+  uint32_t il, col;
+  fr_piece<KH>(cx, p, il, col);
+  const uint32_t row = min(cx.tile0 + (uint32_t)C * 32u + il, cx.num_items - 1u);
+  const size_t o = (size_t)row * 512u + cx.kbase + col;
+  wv = *reinterpret_cast<const float4*>(cx.P0 + o);
+  av = *reinterpret_cast<const float4*>(cx.P0a + o);
+}
+template <int C, bool ADA, int KH>
+__device__ __forceinline__ void fr_quarter(const HyperParams& hp, const FusedRowsCtx& cx, const f32x16 (&acc)[4][4], float4 (&wq)[16], float4 (&aq)[16]) {
+  constexpr uint32_t KS = 512u / KH, RS = KS * 4u + 16u;
+  __builtin_amdgcn_s_barrier();                                // the contraction's last slice / the previous quarter has been read by every wavefront
+  {
+    const uint32_t f_row = cx.lane & 31u, f_half = cx.lane >> 5;
+    char* wp = cx.lds + f_row * RS + (cx.wid * 128u + 4u * f_half) * 4u;
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int kb = 2 * kp + (t >> 2), q4 = t & 3;
-    const uint32_t po = (t >> 2) * 32 + (t & 3) * 8;
-    float w4[4] = {wv[t].x, wv[t].y, wv[t].z, wv[t].w}, a4[4] = {av[t].x, av[t].y, av[t].z, av[t].w};
-    float dd[4];
+    for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)       // the products stay in the accumulation registers until their piece is stepped (left to itself hipcc 7.2
-                                      // moves all 256 to VGPRs behind the loop and spills them)
-      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dd[e]) : "a"(acc[kb][ib][4 * q4 + e]));
+      for (int q = 0; q < 4; ++q) {
+        float d[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ada_step_t<ADA>(hp, w4[e], a4[e], fmaf(hp.lambda, w4[e], dd[e]));
-    if (live && deferred) {
-      *reinterpret_cast<float4*>(cx.dD + ro + po) = make_float4(dd[0], dd[1], dd[2], dd[3]);
-    } else if (live) {
-      *reinterpret_cast<float4*>(cx.P0 + ro + po) = make_float4(w4[0], w4[1], w4[2], w4[3]);
-      *reinterpret_cast<float4*>(cx.P0a + ro + po) = make_float4(a4[0], a4[1], a4[2], a4[3]);
-      const bf16x4 hb = {(__bf16)w4[0], (__bf16)w4[1], (__bf16)w4[2], (__bf16)w4[3]};
-      *reinterpret_cast<bf16x4*>(cx.Db + ro + po) = hb;
-      if (DT) {
-        const uint32_t k0 = cx.kl + (uint32_t)kp * 64u + po;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cx.DTb[(size_t)(k0 + e) * cx.Ip + item] = hb[e];
+        for (int e = 0; e < 4; ++e)     // the products stay in the accumulation registers until their quarter leaves (left to itself hipcc 7.2 moves
+                                        // all 256 to VGPRs behind the loop and spills them)
+          asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d[e]) : "a"(acc[kb][C][4 * q + e]));
+        *reinterpret_cast<float4*>(wp + (kb * 32 + q * 8) * 4) = make_float4(d[0], d[1], d[2], d[3]);
       }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wavefront's LDS writes are done (NOT __syncthreads(): its vmcnt(0) would drain the row requests in flight)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    uint32_t il, col;
+    fr_piece<KH>(cx, p, il, col);
+    const uint32_t item = cx.tile0 + (uint32_t)C * 32u + il;                                   // wave-uniform
+    const bool live = item < cx.num_items;
+    const bool deferred = ((uint32_t)__builtin_amdgcn_readlane((int)cx.in_mask, (int)il) >> C) & 1u;
+    const float4 dv = *reinterpret_cast<const float4*>(cx.lds + il * RS + col * 4u);
+    const size_t o = (size_t)min(item, cx.num_items - 1u) * 512u + cx.kbase + col;
+    float w4[4] = {wq[p].x, wq[p].y, wq[p].z, wq[p].w}, a4[4] = {aq[p].x, aq[p].y, aq[p].z, aq[p].w};
+    const float d4[4] = {dv.x, dv.y, dv.z, dv.w};
+    if (C < 3) fr_load_piece<(C < 3 ? C + 1 : 3), KH>(cx, p, wq[p], aq[p]);                   // the same piece of the next quarter, into the registers just read
+    if (live && deferred) {
+      *reinterpret_cast<float4*>(cx.dD + o) = dv;
+    } else if (live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ada_step_t<ADA>(hp, w4[e], a4[e], fmaf(hp.lambda, w4[e], d4[e]));
+      *reinterpret_cast<float4*>(cx.P0 + o) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+      *reinterpret_cast<float4*>(cx.P0a + o) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+      const bf16x4 hb = {(__bf16)w4[0], (__bf16)w4[1], (__bf16)w4[2], (__bf16)w4[3]};
+      *reinterpret_cast<bf16x4*>(cx.Db + o) = hb;
     }
   }
 }
 
-template <bool ADA, bool DT, int KH>
+template <bool ADA, int KH>
 __global__ void __launch_bounds__(256 / KH)
 gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][ldz] */, const __bf16* __restrict__ GT /* [Ip][ldgt] */,
-                        uint32_t ldz, uint32_t ldgt, uint32_t nb,
-                        const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
-                        const uint64_t* __restrict__ sorted_val, float* __restrict__ dD /* [Ip][512]: rows with a kept input only */,
+                        uint32_t ldz, uint32_t ldgt, uint32_t nb, const uint8_t* __restrict__ has_in /* [I], full_positive_fixup_kernel */,
+                        float* __restrict__ dD /* [Ip][512]: rows with a kept input only */,
                         float* __restrict__ W, float* __restrict__ W_ag,
                         float* __restrict__ bp, float* __restrict__ bp_ag, uint32_t* __restrict__ touched,
-                        __bf16* __restrict__ Db /* [Ip][512] */, __bf16* __restrict__ DTb /* [512][Ip] (DT) */, uint32_t Ip) {
+                        __bf16* __restrict__ Db /* [Ip][512] */, uint32_t Ip) {
   extern __shared__ __attribute__((aligned(1024))) char smemf[];
   constexpr uint32_t KP = 512;
   constexpr uint32_t NW = 4 / KH, ZROWS = 512 / KH, GQ = 8 / NW;              // wavefronts, staged Z^T rows, G^T DMA instructions per wavefront
@@ -1300,11 +1323,11 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
   const uint32_t gblk = kh * NW + wid;                                     // the item block whose b' gradient this wavefront sums (KH = 2: blocks 2 kh, 2 kh + 1)
   float gs = 0.f;                                                          // this lane's share of sum_u G^T[item][u], item = tile0 + 32 gblk + f_row
 
-  // the first two stages of row pieces are requested now and land under the contraction
+  // the first quarter's row pieces are requested in front of the contraction and land under it
   FusedRowsCtx cx;
-  cx.P0 = W; cx.P0a = W_ag; cx.dD = dD; cx.Db = Db; cx.DTb = DTb; cx.Ip = Ip; cx.in_mask = 0;
-  cx.tile_row = tile0 + f_row; cx.kl = kw * 128u + 4u * f_half;
-  float4 w0[8], a0[8], w1[8], a1[8];
+  cx.P0 = W; cx.P0a = W_ag; cx.dD = dD; cx.Db = Db; cx.lds = smemf; cx.in_mask = 0;
+  cx.tile0 = tile0; cx.kbase = kh * (512u / KH); cx.wid = wid; cx.lane = lane; cx.num_items = hp.num_items;
+  float4 wq[16], aq[16];
   stage(0, 0);
   if (n_steps > 1) stage(1, 1);
   // Tied weights: a row that some user of the block kept as an input takes ONE step with dD + the summed input gradient
@@ -1314,13 +1337,10 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t item = tile0 + (uint32_t)j * 32u + f_row;
-    const uint32_t beg = item < hp.num_items ? seg_begin[item] : 0u, end = item < hp.num_items ? seg_end[item] : 0u;
-    uint32_t any = 0;
-    for (uint32_t q = beg; q < end; ++q) any |= (uint32_t)sorted_val[q] >> 31;
-    in_mask |= any << j;
+    in_mask |= (item < hp.num_items ? (uint32_t)has_in[item] : 0u) << j;
   }
-  fr_load_stage<0>(hp, cx, w0, a0);
-  fr_load_stage<1>(hp, cx, w1, a1);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) fr_load_piece<0, KH>(cx, p, wq[p], aq[p]);
   uint32_t slot = 0;
   for (uint32_t step = 0; step < n_steps; ++step) {
     if (step + 1 >= n_steps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1374,52 +1394,39 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
     if (t == 123.456f) bp[0] = 0.f;
     return;
   }
-  // row steps: stage = (item block ib, k-block pair kp); lane: item = tile0 + 32 ib + f_row, pieces k = 128 kw + 32 kb + 8 q + 4 f_half.
-  // The epilogue is HBM-bound (10 bytes per parameter) and only four wavefronts live on the CU, so what counts is the bytes in
-  // flight: four row-piece buffers, filled as the accumulators of finished stages free their registers — one stage ahead at first,
-  // two, then three (stages 0 and 1 were requested in front of the contraction).
+  // row steps, a quarter of the tile (32 items) at a time through LDS (fr_quarter)
   cx.in_mask = in_mask;
-#define FR_SB() __builtin_amdgcn_sched_barrier(0)
-  float4 w2[8], a2[8], w3[8], a3[8];
-  fr_rows_stage<0, ADA, DT>(hp, cx, acc, w0, a0); FR_SB();
-  fr_load_stage<2>(hp, cx, w0, a0); FR_SB();
-  fr_rows_stage<1, ADA, DT>(hp, cx, acc, w1, a1); FR_SB();
-  fr_load_stage<3>(hp, cx, w1, a1); fr_load_stage<4>(hp, cx, w2, a2); FR_SB();
-  fr_rows_stage<2, ADA, DT>(hp, cx, acc, w0, a0); FR_SB();
-  fr_load_stage<5>(hp, cx, w0, a0); FR_SB();
-  fr_rows_stage<3, ADA, DT>(hp, cx, acc, w1, a1); FR_SB();
-  fr_load_stage<6>(hp, cx, w1, a1); fr_load_stage<7>(hp, cx, w3, a3); FR_SB();
-  fr_rows_stage<4, ADA, DT>(hp, cx, acc, w2, a2); FR_SB();
-  fr_rows_stage<5, ADA, DT>(hp, cx, acc, w0, a0); FR_SB();
-  fr_rows_stage<6, ADA, DT>(hp, cx, acc, w1, a1); FR_SB();
-  fr_rows_stage<7, ADA, DT>(hp, cx, acc, w3, a3);
-#undef FR_SB
+  fr_quarter<0, ADA, KH>(hp, cx, acc, wq, aq);
+  fr_quarter<1, ADA, KH>(hp, cx, acc, wq, aq);
+  fr_quarter<2, ADA, KH>(hp, cx, acc, wq, aq);
+  fr_quarter<3, ADA, KH>(hp, cx, acc, wq, aq);
 }
 
 // Behind gemm3_rows_fused_kernel (tied weights): the rows some user of the block kept as an input — dD from the fused launch, the
 // summed delta rows added as full_rows_wave_kernel adds them, one step.  b' of these rows was stepped by the fused launch.
 template <int NI>
 __global__ void __launch_bounds__(256)
-full_rows_inputs_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+full_rows_inputs_kernel(HyperParams hp, uint8_t* __restrict__ has_in, const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
                         const uint64_t* __restrict__ sorted_val, const float* __restrict__ DELTA, const float* __restrict__ dD,
                         float* __restrict__ W, float* __restrict__ W_ag, __bf16* __restrict__ Db, __bf16* __restrict__ DTb, uint32_t Ip) {
-  // a wavefront looks at 64 items, one per lane (nearly all have no positive at all in the block), then steps the few with a kept
-  // input one after the other with all its lanes
-  const uint32_t item0 = (blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE) * WAVE;
+  // a wavefront looks at the flags of 64 items, one per lane, then steps the few with a kept input one after the other with all its
+  // lanes.  Its items are strided by the number of wavefronts: popular items have neighbouring ids (and hundreds of examples each),
+  // 64 of them in one wavefront were a 340 us tail
+  const uint32_t n_waves = gridDim.x * (blockDim.x / WAVE), wave = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
-  if (item0 >= hp.num_items) return;
+  const uint32_t my_item = wave + lane * n_waves;
   uint32_t my_beg = 0, my_end = 0;
-  bool mine = false;
-  if (item0 + lane < hp.num_items) {
-    my_beg = seg_begin[item0 + lane]; my_end = seg_end[item0 + lane];
-    for (uint32_t q = my_beg; q < my_end; ++q) mine = mine || ((uint32_t)sorted_val[q] & INPUT_BIT) != 0u;
+  const bool mine = my_item < hp.num_items && has_in[my_item] != 0;
+  if (mine) {
+    my_beg = seg_begin[my_item]; my_end = seg_end[my_item];
+    has_in[my_item] = 0;                                          // (the flag is this block's: cleared by its only reader after the fused launch)
   }
   unsigned long long todo = __ballot(mine);
   const uint32_t lo = lane * NI;
   while (todo) {
     const int src = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
-    const uint32_t item = item0 + (uint32_t)src;
+    const uint32_t item = wave + (uint32_t)src * n_waves;
     const uint32_t beg = (uint32_t)__builtin_amdgcn_readlane((int)my_beg, src), end = (uint32_t)__builtin_amdgcn_readlane((int)my_end, src);
     float dd[NI], w[NI], a[NI], din[NI];
     vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);

@@ -149,6 +149,7 @@ struct cdae_hip {
   uint32_t Bp = 0, Ip = 0;
   __bf16 *d_Zb = nullptr, *d_ZTb = nullptr, *d_Db = nullptr, *d_DTb = nullptr, *d_Gb = nullptr, *d_GTb = nullptr;
   float* d_dD = nullptr;
+  uint8_t* d_has_in = nullptr;          // [I]: item has a kept input in the block being stepped (set by full_positive_fixup_kernel, cleared by full_rows_inputs_kernel)
   uint32_t* d_iota = nullptr;           // 0..B: identity unit prefix (fused full-output path: one hg partial row per user)
   uint32_t* d_bits_train = nullptr;     // [NSETS][B x ceil(I/32)] rated-item bitmap of the batch (targets of the fused full-output decode), per example-buffer set
   size_t bits_stride = 0;
@@ -202,8 +203,7 @@ struct cdae_hip {
   bool gemmw_attr_set[8] = {false, false, false, false, false, false, false, false};   // ... of the 256 x 256-tile kernel
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
   bool rows_separate = false;           // CDAE_FULL_ROWS_SEPARATE: GEMM 3 and the row step as two launches where gemm3_rows_fused_kernel would run (A/B switch)
-  bool rows_fused_dt = false;           // CDAE_FULL_ROWS_DT: the fused row step writes D^T itself (2-byte stores: slower than bf16_transpose_kernel's pass, measured; A/B switch)
-  bool fused_rows_attr_set[2][2][2] = {};   // dynamic-LDS attribute of gemm3_rows_fused_kernel<ADA, DT, KH> set on this handle's device
+  bool fused_rows_attr_set[2][2] = {};      // dynamic-LDS attribute of gemm3_rows_fused_kernel<ADA, KH> set on this handle's device
   int rows_fused_kh = 2;                // CDAE_FULL_ROWS_KH: workgroups per item tile of the fused row step (1 | 2)
 
   // data-parallel exchange
@@ -341,7 +341,7 @@ int collect_profile(cdae_hip* h, cdae_hip_stats* st) {
 
 void free_all(cdae_hip* h) {
   void* ptrs[] = {h->d_row_ptr, h->d_col, h->d_item_order, h->d_shared, h->d_Wu, h->d_Wu_ag, h->d_D0, h->d_HGpart,
-                  h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD,
+                  h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD, h->d_has_in,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of};
@@ -379,7 +379,7 @@ int free_interaction_state(cdae_hip* h) {
   void** ptrs[] = {(void**)&h->d_row_ptr, (void**)&h->d_col, (void**)&h->d_item_order, (void**)&h->d_shared,
                    (void**)&h->d_Wu, (void**)&h->d_Wu_ag, (void**)&h->d_D0, (void**)&h->d_HGpart, (void**)&h->d_sort_tmp,
                    (void**)&h->d_unit_ptr, (void**)&h->d_Hpart, (void**)&h->d_uptr_tmp, (void**)&h->d_Zb, (void**)&h->d_ZTb,
-                   (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD,
+                   (void**)&h->d_Db, (void**)&h->d_DTb, (void**)&h->d_Gb, (void**)&h->d_GTb, (void**)&h->d_dD, (void**)&h->d_has_in,
                    (void**)&h->d_Z, (void**)&h->d_Dz, (void**)&h->d_HG, (void**)&h->d_G, (void**)&h->d_touched,
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
@@ -655,30 +655,28 @@ uint32_t gemm2_k_per_split(const cdae_hip* h) {
 bool rows_fused_path(const cdae_hip* h) {
   return h->Kp == 512 && h->I >= 32768 && h->Ip % cdae::FR_ITEMS == 0 && !h->cfg.asymmetric && h->fused_images && !h->gemm_direct && !h->rows_separate;
 }
-int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uint32_t nb, __bf16* Db, __bf16* DTb) {
+int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uint32_t nb, __bf16* Db) {
   using namespace cdae;
   const uint32_t I = (uint32_t)h->I;
-#define FR_LAUNCH(ADA_, DT_, KH_)                                                                                                         \
+#define FR_LAUNCH(ADA_, KH_)                                                                                                              \
   do {                                                                                                                                    \
-    if (!h->fused_rows_attr_set[ADA_][DT_][KH_ - 1]) {                                                                                    \
-      HIPCHK(hipFuncSetAttribute((const void*)gemm3_rows_fused_kernel<ADA_, DT_, KH_>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+    if (!h->fused_rows_attr_set[ADA_][KH_ - 1]) {                                                                                         \
+      HIPCHK(hipFuncSetAttribute((const void*)gemm3_rows_fused_kernel<ADA_, KH_>, hipFuncAttributeMaxDynamicSharedMemorySize,             \
                                  (int)fused_rows_lds_bytes<KH_>()));                                                                      \
-      h->fused_rows_attr_set[ADA_][DT_][KH_ - 1] = true;                                                                                  \
+      h->fused_rows_attr_set[ADA_][KH_ - 1] = true;                                                                                       \
     }                                                                                                                                     \
     const uint32_t tiles = h->Ip / FR_ITEMS, grid = KH_ == 1 ? tiles : 16u * ((tiles + 7u) / 8u);                                         \
-    hipLaunchKernelGGL((gemm3_rows_fused_kernel<ADA_, DT_, KH_>), dim3(grid), dim3(256 / KH_), fused_rows_lds_bytes<KH_>(), st, h->hp,    \
-                       (const __bf16*)h->d_ZTb, (const __bf16*)h->d_GTb, h->Bp, h->Bp, nb, (const uint32_t*)x.seg,                        \
-                       (const uint32_t*)(x.seg + I), (const uint64_t*)x.sorted_val, h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG),           \
-                       h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_touched, Db, DTb, h->Ip);                                                \
+    hipLaunchKernelGGL((gemm3_rows_fused_kernel<ADA_, KH_>), dim3(grid), dim3(256 / KH_), fused_rows_lds_bytes<KH_>(), st, h->hp,         \
+                       (const __bf16*)h->d_ZTb, (const __bf16*)h->d_GTb, h->Bp, h->Bp, nb, (const uint8_t*)h->d_has_in,                   \
+                       h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG),                                                                        \
+                       h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_touched, Db, h->Ip);                                                     \
   } while (0)
-#define FR_LAUNCH2(ADA_, DT_) do { if (h->rows_fused_kh == 1) FR_LAUNCH(ADA_, DT_, 1); else FR_LAUNCH(ADA_, DT_, 2); } while (0)
-  if (h->cfg.using_adagrad) { if (DTb) FR_LAUNCH2(true, true); else FR_LAUNCH2(true, false); }
-  else { if (DTb) FR_LAUNCH2(false, true); else FR_LAUNCH2(false, false); }
-#undef FR_LAUNCH2
+  if (h->cfg.using_adagrad) { if (h->rows_fused_kh == 1) FR_LAUNCH(true, 1); else FR_LAUNCH(true, 2); }
+  else { if (h->rows_fused_kh == 1) FR_LAUNCH(false, 1); else FR_LAUNCH(false, 2); }
 #undef FR_LAUNCH
   // the rows kept as inputs (tied weights: one step with dD + the summed input gradient)
-  DISPATCH_NI(h->NI, full_rows_inputs_kernel, dim3((I + 255) / 256), dim3(256), 0, st, h->hp, (const uint32_t*)x.seg, (const uint32_t*)(x.seg + I),
-              (const uint64_t*)x.sorted_val, (const float*)h->delta_rows(), (const float*)h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), Db, DTb, h->Ip);
+  DISPATCH_NI(h->NI, full_rows_inputs_kernel, dim3((I + 255) / 256), dim3(256), 0, st, h->hp, h->d_has_in, (const uint32_t*)x.seg, (const uint32_t*)(x.seg + I),
+              (const uint64_t*)x.sorted_val, (const float*)h->delta_rows(), (const float*)h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), Db, (__bf16*)nullptr, h->Ip);
   return 0;
 }
 
@@ -709,7 +707,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   // encode writes those of z: no conversion launch in the steady state.  D is converted here only when something else wrote the
   // parameters (init, set_param, an exchange), Z only when the batch is shorter than the rows the images may hold.
   const bool rows_fused = rows_fused_path(h);                             // GEMM 3 + row step in one launch (Kp = 512, >= 32768 items)
-  const bool rows_write_images = h->fused_images && (I < 32768u || (rows_fused && h->rows_fused_dt));
+  const bool rows_write_images = h->fused_images && I < 32768u;
   const bool rows_write_db = h->fused_images && I >= 32768u && !rows_write_images;   // full_rows_wave_kernel: the row-major image only
   const bool need_d = !(rows_write_images && h->db_valid) && !(rows_write_db && h->db_rows_valid);
   if (rows_write_db && h->db_rows_valid)                                  // D^T from the bf16 rows the row step left (2 GB instead of 4 at 1 M x 512)
@@ -774,7 +772,8 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
-                     h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
+                     h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp,
+                     rows_fused_path(h) ? h->d_has_in : (uint8_t*)nullptr);
   // GEMM 2: hg = G D  (contraction over items, split).  Every split stores its partial [Bp x Kp] product into its own slab of
   // HGpart and hidden_finish_kernel adds the slabs in fixed order: deterministic (the first version accumulated with fp32
   // atomics into HG, whose order — and therefore rounding — changed from run to run)
@@ -828,7 +827,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
   CHK(pr.begin(h, F_INPUT, st));
   if (rows_fused)      // dD = G^T Z and the row steps from its accumulators (gemm3_rows_fused_kernel)
-    CHK(launch_rows_fused(h, st, x, nb, h->d_Db, rows_write_images ? h->d_DTb : (__bf16*)nullptr));
+    CHK(launch_rows_fused(h, st, x, nb, h->d_Db));
   else if (I >= 32768u)     // rows are plentiful and mostly without kept inputs: one wavefront per row
     DISPATCH_NI(h->NI, full_rows_wave_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
@@ -984,7 +983,6 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
   h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
   h->rows_separate = std::getenv("CDAE_FULL_ROWS_SEPARATE") != nullptr;
-  h->rows_fused_dt = std::getenv("CDAE_FULL_ROWS_DT") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
@@ -1363,6 +1361,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
     CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
     CHK(dev_alloc(&h->d_dD, (size_t)h->Ip * h->Kp));
+    CHK(dev_alloc(&h->d_has_in, (size_t)h->Ip));
+    HIPCHK(hipMemsetAsync(h->d_has_in, 0, (size_t)h->Ip, h->stream));
     {
       h->bits_stride = (size_t)B * ((I + 31) / 32);
       CHK(dev_alloc(&h->d_bits_train, cdae_hip::NSETS * h->bits_stride));     // one per example-buffer set
