@@ -660,17 +660,19 @@ gemm_nt_bf16_ldsw_kernel(const __bf16* __restrict__ A, const __bf16* __restrict_
           float g = 0.f;
           if (m_tile + ml < ep.rows_live && n < ep.cols_live) g = loss_grad(ep.loss_type, acc[i][j][r] + bias, 0.f);
           acc[i][j][r] = g;                                                // (kept for the second orientation)
-          *reinterpret_cast<__bf16*>(smemw + ml * GEMMW_TS + nl * 2u) = (__bf16)g;
+          if (ep.G) *reinterpret_cast<__bf16*>(smemw + ml * GEMMW_TS + nl * 2u) = (__bf16)g;
         }
     }
-    __syncthreads();
+    if (ep.G) {                                                            // (G = nullptr: GEMM 2 reads G^T, gemm_tn_bf16_kernel)
+      __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(smemw + row * GEMMW_TS + c16 * 16u);
-      *reinterpret_cast<bf16x8*>(ep.G + (size_t)(m_tile + row) * ep.ldg + n_tile + c16 * 8u) = v;
+      for (int q = 0; q < 16; ++q) {
+        const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(smemw + row * GEMMW_TS + c16 * 16u);
+        *reinterpret_cast<bf16x8*>(ep.G + (size_t)(m_tile + row) * ep.ldg + n_tile + c16 * 8u) = v;
+      }
+      __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -709,6 +711,112 @@ gemm_nt_bf16_ldsw_kernel(const __bf16* __restrict__ A, const __bf16* __restrict_
         }
       }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "TN" product for GEMM 2 of the K > 256 path:  C[m][n] = sum_c A[c][m] * Bm[c][n]  with BOTH operands stored contraction-row-major
+// — hg = G D as  sum_item G^T[item][user] * D[item][k]  straight from the two images the other launches already keep (G^T for
+// GEMM 3 / the row step, the row-major bf16 decoder image for GEMM 1).  With it GEMM 1 no longer writes G (2 GB per 1024-user
+// block at 1 M items, and one of its two LDS passes), and D^T — its 1 GB, and the 0.44 ms transposition per block that kept it
+// current — is not needed by the K > 256 path at all.
+// An MFMA fragment wants 8 consecutive contraction elements of one m per lane, i.e. a COLUMN of the staged slice: gfx950's
+// ds_read_b64_tr_b16 reads, per 16-lane group, a [4 c][16 m] block — lane i supplies 4 contiguous m of row i / 4 — and hands lane
+// j the four c of column j (measured, tools/tr_b16_semantics.hip); two of them are one fragment.  LDS image of a slice (64
+// contraction rows): row c = [256 m of A | 256 n of Bm | 64 bytes], ONE 1 KiB DMA instruction per row (lanes 0-31 fetch the A
+// piece, 32-63 the Bm piece), and the 1088-byte stride puts the four rows of a transposing read 64 bytes apart in the bank
+// row: conflict-free.  Same 256 x 256 tile, wavefront layout, two 68 KiB stages and epilogue as gemm_nt_bf16_ldsw_kernel; every
+// output element is the same sum in the same order (16-wide steps ascending, same contraction splits), so the slabs are
+// bit-identical to the NT kernel's (test_tn_gemm2_changes_no_bit).
+constexpr uint32_t GTN_RS = 1088;
+constexpr int GTN_STAGE_BYTES = 64 * (int)GTN_RS;
+constexpr size_t gemm_tn_lds_bytes() { return 2 * (size_t)GTN_STAGE_BYTES; }
+
+__global__ void __launch_bounds__(512)
+gemm_tn_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
+                    uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep, GemmGrid gg) {
+  extern __shared__ __attribute__((aligned(1024))) char smemt[];
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;      // wid 0..7
+  uint32_t mt, nt, zt;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, in = gg.inner();
+    const uint32_t t = j % in, o = (j / in) * 8u + xcd;
+    if (o >= gg.outer()) return;
+    if (gg.mode == 0) { mt = t; nt = o; zt = 0; }
+    else if (gg.mode == 1) { nt = t; mt = o; zt = 0; }
+    else { mt = t / gg.Nt; nt = t % gg.Nt; zt = o; }
+  }
+  const uint32_t m_tile = mt * 256u, n_tile = nt * 256u;
+  const uint32_t wm = (wid >> 1) * 64u, wn = (wid & 1u) * 128u;
+  const uint32_t m_base = m_tile + wm, n_base = n_tile + wn;
+  const uint32_t k_begin = zt * k_per_split;
+  const uint32_t k_end = min(Kd, k_begin + k_per_split);
+  const uint32_t n_steps = (k_end - k_begin) / 64u;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: contraction row r of the slice is one DMA instruction; wavefront w issues rows 8 w .. 8 w + 7
+  const __bf16* src = lane < 32u ? A + m_tile + 8u * lane : Bm + n_tile + 8u * (lane - 32u);
+  const uint32_t ld = lane < 32u ? lda : ldb;
+  auto stage = [&](uint32_t step, uint32_t slot) {
+    char* base = smemt + slot * GTN_STAGE_BYTES;
+    const uint32_t k = k_begin + step * 64u + wid * 8u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(k + q) * ld),
+                                       (__attribute__((address_space(3))) void*)(base + (wid * 8u + q) * GTN_RS), 16, 0, 0);
+  };
+  // fragment addresses: lane L of a 16-lane group supplies row 8 (L >> 5) + ((L & 15) >> 2) (+ 4 for the second read), columns
+  // 16 ((L >> 4) & 1) + 4 (L & 3) .. + 3 of the fragment's 32; lane L receives column L & 31, four rows per read
+  const uint32_t f_off = (8u * (lane >> 5) + ((lane & 15u) >> 2)) * GTN_RS + (16u * ((lane >> 4) & 1u) + 4u * (lane & 3u)) * 2u;
+  const uint32_t a_off = f_off + wm * 2u, b_off = f_off + 512u + wn * 2u;
+  auto frag = [&](const char* p) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 4u * GTN_RS));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  stage(0, 0);
+  uint32_t slot = 0;
+  for (uint32_t step = 0; step < n_steps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wavefront's DMAs of slice `step` have landed
+    __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; the other stage (slice step-1) is free
+    if (step + 1 < n_steps) stage(step + 1u, slot ^ 1u);
+    const char* base = smemt + slot * GTN_STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const char* row = base + (uint32_t)s * 16u * GTN_RS;
+      bf16x8 fa[2], fb[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = frag(row + a_off + i * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag(row + b_off + j * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    slot ^= 1u;
+  }
+  if (m_base >= M) return;
+  const uint32_t half = lane >> 5, col = lane & 31u;
+  float* C = ep.Cout + (size_t)zt * ep.split_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t n = n_base + j * 32 + col;
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        C[(size_t)m * ep.ldc + n] = acc[i][j][r];
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -931,8 +1039,8 @@ full_positive_fixup_kernel(const uint32_t* __restrict__ ex_item, const uint64_t*
   const uint32_t item = ex_item[e];
   const uint32_t slot = (uint32_t)ex_val[e] & SLOT_MASK;
   if (has_in && ((uint32_t)ex_val[e] & INPUT_BIT)) has_in[item] = 1;
-  const float g = (float)G[(size_t)slot * ldg + item] - c;
-  G[(size_t)slot * ldg + item] = (__bf16)g;
+  const float g = (float)GT[(size_t)item * ldgt + slot] - c;     // (G and G^T hold the same value)
+  if (G) G[(size_t)slot * ldg + item] = (__bf16)g;
   GT[(size_t)item * ldgt + slot] = (__bf16)g;
 }
 

@@ -202,6 +202,8 @@ struct cdae_hip {
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
   bool gemmw_attr_set[8] = {false, false, false, false, false, false, false, false};   // ... of the 256 x 256-tile kernel
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
+  bool gemm2_nt = false;                // CDAE_GEMM2_NT: hg = G D from G and D^T (gemm_nt_bf16_ldsw_kernel) where gemm_tn_bf16_kernel would read G^T and D (A/B switch)
+  bool gemm_tn_attr_set = false;        // dynamic-LDS attribute of gemm_tn_bf16_kernel set on this handle's device
   bool rows_separate = false;           // CDAE_FULL_ROWS_SEPARATE: GEMM 3 and the row step as two launches where gemm3_rows_fused_kernel would run (A/B switch)
   bool fused_rows_attr_set[2][2] = {};      // dynamic-LDS attribute of gemm3_rows_fused_kernel<ADA, KH> set on this handle's device
   int rows_fused_kh = 2;                // CDAE_FULL_ROWS_KH: workgroups per item tile of the fused row step (1 | 2)
@@ -263,6 +265,7 @@ struct cdae_hip {
   float* dec() { return cfg.asymmetric ? P(CDAE_P_V) : P(CDAE_P_W); }
   float* dec_ag() { return cfg.asymmetric ? P(CDAE_P_V_AG) : P(CDAE_P_W_AG); }
   float* delta_rows() { return cfg.linear_function ? d_delta_rows : d_HG; }
+  bool full_unfused_nt() const { return gemm_direct || gemm_two_stage || gemm_narrow; }   // developer switches that select one of the older NT kernels for all three products
 };
 
 namespace {
@@ -651,6 +654,11 @@ uint32_t gemm2_k_per_split(const cdae_hip* h) {
   return (((h->Ip + want - 1) / want + 63) / 64) * 64;
 }
 
+// GEMM 2 of the K > 256 path from G^T and the row-major decoder image (gemm_tn_bf16_kernel): then GEMM 1 writes no G and nothing reads D^T
+bool gemm2_tn_path(const cdae_hip* h) {
+  // (rows and columns of GEMM 1 in multiples of 256: it is then the 256 x 256-tile kernel, whose loss epilogue knows how to leave G out)
+  return h->Kp > 256 && h->Kp % 256 == 0 && h->Bp % 256 == 0 && h->Ip % 256 == 0 && !h->full_unfused_nt() && !h->gemm2_nt;
+}
 // GEMM 3 + row step in one launch (gemm3_rows_fused_kernel): Kp = 512 over item spaces >= 32768, i.e. BASELINE configs[4]'s path
 bool rows_fused_path(const cdae_hip* h) {
   return h->Kp == 512 && h->I >= 32768 && h->Ip % cdae::FR_ITEMS == 0 && !h->cfg.asymmetric && h->fused_images && !h->gemm_direct && !h->rows_separate;
@@ -710,7 +718,8 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   const bool rows_write_images = h->fused_images && I < 32768u;
   const bool rows_write_db = h->fused_images && I >= 32768u && !rows_write_images;   // full_rows_wave_kernel: the row-major image only
   const bool need_d = !(rows_write_images && h->db_valid) && !(rows_write_db && h->db_rows_valid);
-  if (rows_write_db && h->db_rows_valid)                                  // D^T from the bf16 rows the row step left (2 GB instead of 4 at 1 M x 512)
+  const bool tn2 = gemm2_tn_path(h);                                      // GEMM 2 reads G^T and D: no G, no D^T
+  if (rows_write_db && h->db_rows_valid && !tn2)                          // D^T from the bf16 rows the row step left (2 GB instead of 4 at 1 M x 512)
     hipLaunchKernelGGL(bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, (const __bf16*)h->d_Db, I, Kp, Ip, h->d_DTb);
   const bool z_in_encode = h->fused_images && h->zb_rows == nb;
   const bool pair_copy = Ip <= 65536 && !h->full_separate_copies && need_d && !z_in_encode;
@@ -762,9 +771,9 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     hg_parts = slices;
   } else {
   GemmEpilogue ep{};
-  ep.bp = h->P(CDAE_P_BP); ep.G = h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
+  ep.bp = h->P(CDAE_P_BP); ep.G = tn2 ? (__bf16*)nullptr : h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
   ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
-  // GEMM 1: Y = Z D^T (+ b'), g = loss'(y, 0) -> G [Bp x Ip], G^T [Ip x Bp]
+  // GEMM 1: Y = Z D^T (+ b'), g = loss'(y, 0) -> G [Bp x Ip] (unless GEMM 2 reads G^T), G^T [Ip x Bp]
   if (h->gemm_direct)
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
                        Kp, ep);
@@ -772,7 +781,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
-                     h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp,
+                     h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, tn2 ? (__bf16*)nullptr : h->d_Gb, Ip, h->d_GTb, Bp,
                      rows_fused_path(h) ? h->d_has_in : (uint8_t*)nullptr);
   // GEMM 2: hg = G D  (contraction over items, split).  Every split stores its partial [Bp x Kp] product into its own slab of
   // HGpart and hidden_finish_kernel adds the slabs in fixed order: deterministic (the first version accumulated with fp32
@@ -787,7 +796,17 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     } else {
       const uint32_t splits = (Ip + kps - 1) / kps;
       e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
-      CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
+      if (tn2) {                                                 // sum over items of G^T[item][user] D[item][k]: both images as they are
+        if (!h->gemm_tn_attr_set) {
+          HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_tn_lds_bytes()));
+          h->gemm_tn_attr_set = true;
+        }
+        const GemmGrid gg{Bp / 256, Kp / 256, splits, 2};
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(gg.workgroups()), dim3(512), gemm_tn_lds_bytes(), st, (const __bf16*)h->d_GTb,
+                           (const __bf16*)h->d_Db, Bp, Kp, Ip, Bp, Kp, kps, e2, gg);
+      } else {
+        CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
+      }
       hg_parts = splits;
       hg_rows = Bp;
     }
@@ -983,6 +1002,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
   h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
   h->rows_separate = std::getenv("CDAE_FULL_ROWS_SEPARATE") != nullptr;
+  h->gemm2_nt = std::getenv("CDAE_GEMM2_NT") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;

@@ -691,3 +691,29 @@ def test_fused_rows_first_block_is_bit_identical(built, monkeypatch):
     for w in (8, 9):
         np.testing.assert_allclose(fused[w], sep[w], rtol=2e-6, atol=1e-9)
     assert np.abs(fused[0] - w_init).max() > 0      # (the rows moved at all)
+
+
+def test_tn_gemm2_changes_no_bit(built, monkeypatch):
+    """K > 256 full-output path: hg = G D from G^T and the row-major decoder image (gemm_tn_bf16_kernel: contraction-row-major
+    operands through gfx950's transposing LDS read; GEMM 1 then writes no G and D^T is never rebuilt) against G and D^T through the
+    NT kernel (CDAE_GEMM2_NT=1).  Same products, same 16-wide steps in the same order, same contraction splits: identical slabs,
+    identical parameters after two epochs (the second one runs on the images the first one's row steps left)."""
+    d = synth.generate(600, 33_000, 36_000, seed=6, min_items=20)
+    cfg = cdae_amd.CDAEConfig(num_dim=300, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=256, full_output=True)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=4)
+        m.train_one_iteration(4, 0)
+        m.train_one_iteration(4, 1)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        rec = m.recommend_all(10, 0, 64)
+        m.close()
+        return out, rec
+
+    tn, rec_tn = run()
+    monkeypatch.setenv("CDAE_GEMM2_NT", "1")
+    nt, rec_nt = run()
+    for w in tn:
+        assert np.array_equal(tn[w], nt[w]), w
+    assert np.array_equal(rec_tn, rec_nt)
