@@ -142,6 +142,7 @@ def main():
     model = cdae_amd.CDAE(cfg, device=local_rank)
     model.set_interactions(data.num_users, data.num_items, data.train_ptr, data.train_col, user_id_offset=uid_offset)
     model.init_params(args.seed)         # identical shared parameters on every rank; Wu is private (keyed by global user id)
+    plan = model.full_output_plan        # CDAE_PLAN_* bits: which launches the full-output decode is made of (0: sampled decode)
     # Rendezvous over gloo (CPU): torch.distributed only carries the 128-byte RCCL id, the barriers and the timing reductions.
     # The data path — one all-reduce of the staged deltas per period — runs inside the library on its own RCCL communicator
     # and stream (cdae_multi.hip), created AFTER the handle's streams: with a communicator in place first the handle's
@@ -314,11 +315,23 @@ def main():
     if args.full_output:
         # dominant kernels: the three bf16 MFMA contractions, 6 K I flop per user, timed as one family
         MFMA_PEAK_TFLOPS = 2500.0       # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-        flops_launch = 6.0 * K * data.num_items * users_per_launch
+        # which of the three products the timed "decode" family holds (cdae_hip_full_output_plan): with the row steps fused into
+        # GEMM 3 (K > 256 over >= 32768 items) that launch is HBM-bound, lives in the "input" family, and the decode family holds two
+        rows_fused = bool(plan & cdae_amd.binding.PLAN_ROWS_FUSED)
+        products = 2 if rows_fused else 3
+        flops_launch = 2.0 * products * K * data.num_items * users_per_launch
         achieved_tf = flops_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "full_decode_fused_kernel + gemm_nt_bf16_kernel (+ bf16 operand copies, rated-items bitmap)",
+        step_tf = 6.0 * K * data.num_items * users_per_launch / (1e-3 * 1e3 * elapsed / args.steps) / 1e12
+        kernels = ("full_decode_fused_kernel + gemm_nt_bf16_lds_kernel (GEMM 3)" if plan & cdae_amd.binding.PLAN_FUSED_DECODE else
+                   "gemm_nt_bf16_ldsw_kernel<EPI_LOSS> (GEMM 1) + " + ("gemm_tn_bf16_kernel" if plan & cdae_amd.binding.PLAN_GEMM2_TN else "gemm_nt_bf16_ldsw_kernel")
+                   + " (GEMM 2)" + ("; GEMM 3 runs inside gemm3_rows_fused_kernel with the row steps (HBM-bound, 'input' family) and is NOT counted here"
+                                    if rows_fused else " + gemm_nt_bf16_ldsw_kernel (GEMM 3)"))
+        roofline = {"bound": "mfma", "kernel": kernels + " (+ positive fix-up, rated-items bitmap)",
                     "achieved": achieved_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / MFMA_PEAK_TFLOPS,
-                    "traffic": None, "algorithmic_flops_per_launch": flops_launch, "avg_launch_ms": ms_per_launch}
+                    "traffic": None, "algorithmic_flops_per_launch": flops_launch, "products_in_family": products,
+                    "avg_launch_ms": ms_per_launch,
+                    "whole_step": {"achieved": step_tf, "frac": step_tf / MFMA_PEAK_TFLOPS,
+                                   "note": "all three products' 6 K I flop per user over the whole step (encode, row steps and every launch boundary included)"}}
         workload = f"{shape_note}, nnz_train={data.nnz_train}, K={K}, FULL-OUTPUT decode (every unrated item a negative), CE loss, AdaGrad, q=0.5 scaled"
     else:
         # HBM roofline on the bytes the launch MUST move (never above 1); what actually bounds the kernel is stated beside it

@@ -23,6 +23,7 @@ P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG, P_UU, P_UU_
 P_UB, P_UB_AG = 12, 13
 P_COUNT = 14
 
+PLAN_FUSED_DECODE, PLAN_GEMM2_TN, PLAN_ROWS_FUSED = 1, 2, 4     # cdae_hip_full_output_plan bits (include/cdae_hip.h)
 DEFAULT_BATCH_USERS = 0        # 0 = the library's default (cdae_hip_default_batch_users: num_users / 160, within [32, 256])
 
 
@@ -59,6 +60,7 @@ EXPORTS = {
     "cdae_hip_row_stride": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_default_batch_users": (C.c_uint32, [C.c_uint64]),
     "cdae_hip_batch_users": (C.c_uint32, [C.c_void_p]),
+    "cdae_hip_full_output_plan": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_user_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_user_id_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -235,6 +237,11 @@ class CDAE:
     def batch_users(self) -> int:
         """users per parameter snapshot the handle is using (the library's choice when the config asked for 0)"""
         return int(self.lib.cdae_hip_batch_users(self.h))
+
+    @property
+    def full_output_plan(self) -> int:
+        """CDAE_PLAN_* bits (include/cdae_hip.h): which launches this handle's full-output decode is made of"""
+        return int(self.lib.cdae_hip_full_output_plan(self.h))
 
     # ---- parameters --------------------------------------------------------------------------------
     def _shape(self, which):

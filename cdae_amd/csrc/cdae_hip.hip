@@ -1108,6 +1108,11 @@ int cdae_hip_user_order(cdae_hip_t* h, uint32_t* out, size_t count) {
   return 0;
 }
 uint32_t cdae_hip_batch_users(const cdae_hip_t* h) { return !h || (h->cfg.batch_users == 0 && h->U == 0) ? 0 : h->B; }
+uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h) {
+  if (!h || !h->cfg.full_output || h->U == 0) return 0;
+  if (h->Kp <= 256 && !h->full_unfused) return CDAE_PLAN_FUSED_DECODE;
+  return (gemm2_tn_path(h) ? CDAE_PLAN_GEMM2_TN : 0u) | (rows_fused_path(h) ? CDAE_PLAN_ROWS_FUSED : 0u);
+}
 
 int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t offset) {
   if (!h) return fail("null handle");

@@ -51,8 +51,9 @@ extern "C" {
  * 5: cdae_hip_create_mf (IMF / BPR handles), CDAE_P_UB / CDAE_P_UB_AG, item-rows layout of cdae_hip_multi_*
  * 6: cdae_hip_set_profiling_families
  * 7: default batch_users capped at 256 (was 512); cdae_hip_default_batch_users, cdae_hip_batch_users; cdae_hip_user_order (IMF / BPR
- *    block schedules train in activity-grouped order; their default is one user per block) */
-#define CDAE_HIP_ABI_VERSION 7
+ *    block schedules train in activity-grouped order; their default is one user per block)
+ * 8: cdae_hip_full_output_plan */
+#define CDAE_HIP_ABI_VERSION 8
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -137,6 +138,19 @@ uint32_t cdae_hip_row_stride(const cdae_hip_t* h);
 #define CDAE_DEFAULT_BATCH_USERS_MAX 256u
 uint32_t cdae_hip_default_batch_users(uint64_t num_users);
 uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
+
+/* Which launches the full-output decode (cdae_hip_config.full_output; the reference has no counterpart: its training decode is
+ * always sampled, cdae.hpp:217-293) of this handle is made of, once cdae_hip_set_interactions has run — for a caller that prices
+ * the kernel families cdae_hip_get_stats times (bench.py: which of the three products are inside the "decode" family):
+ *   CDAE_PLAN_FUSED_DECODE  K <= 256: forward product, loss' and hidden-gradient product in one launch (full_decode_fused_kernel)
+ *   CDAE_PLAN_GEMM2_TN      K > 256: hg = G D read from G^T and the row-major decoder image (gemm_tn_bf16_kernel; GEMM 1 writes no G)
+ *   CDAE_PLAN_ROWS_FUSED    K > 256, >= 32768 items, tied weights: dD = G^T Z and the row steps in one launch (gemm3_rows_fused_kernel),
+ *                           timed in the "input" family — the "decode" family then holds two of the three products
+ * 0 for a sampled-decode handle. */
+#define CDAE_PLAN_FUSED_DECODE 1u
+#define CDAE_PLAN_GEMM2_TN 2u
+#define CDAE_PLAN_ROWS_FUSED 4u
+uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h);
 
 /* A data-parallel rank holds only its own users (rows re-based to 0).  The random streams of
  * include/cdae_rng.h are keyed by GLOBAL user id = offset + local row, so a sharded run draws the
