@@ -714,6 +714,133 @@ gemm_nt_bf16_ldsw_kernel(const __bf16* __restrict__ A, const __bf16* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// GEMM 1 of the K = 512 path with the z rows in registers:  G^T[item][user] = loss'(D[item] . z_user + b'[item], 0).
+//
+// The 256 x 256-tile kernel stages BOTH operands of every tile through LDS (512 KiB per tile, 128 flop per staged byte) and is bound
+// by that fill (~32 GB/s per CU), and its loss epilogue runs with nothing else on the CU.  Here a 512-thread workgroup owns 256
+// users for its whole life: wavefront w holds the K = 512 fragments of its 32 users in 128 registers (the MFMA A operand) and the
+// workgroup walks ITEM tiles of 128 — only D is staged (16 KiB slices of 64 k; four stages, three slices in flight: 256 flop per
+// staged byte), and because the stages are a ring of their own the next tile's slices keep arriving while the current tile's loss
+// epilogue runs.  C[user][item] puts four consecutive users of one item into a lane, so bf16(g) goes to a [128 items][256 users]
+// LDS image as 8-byte pieces and leaves as whole 512-byte rows of G^T.  Workgroups that share an item range (the user tiles) sit on
+// ONE XCD, so D comes from HBM once.  Every element is the same sum over k in the same order as gemm_nt_bf16_ldsw_kernel<EPI_LOSS>
+// (16-wide steps ascending): identical G^T (test_gemm1_zreg_changes_no_bit).
+constexpr int G1Z_STAGE_BYTES = 128 * 64 * 2;                    // one D slice: 128 items x 64 k (128-byte rows, swizzled as GEMM_SLICE)
+constexpr uint32_t G1Z_IMG_RS = 528;                             // epilogue image row: 256 users bf16 + 16 B
+constexpr size_t gemm1_zreg_lds_bytes() { return 4 * (size_t)G1Z_STAGE_BYTES + 128 * (size_t)G1Z_IMG_RS; }
+
+template <int LOSS>
+__global__ void __launch_bounds__(512)
+gemm1_loss_zreg_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf16* __restrict__ Db /* [Ip][512] */,
+                       const float* __restrict__ bp, __bf16* __restrict__ GT, uint32_t ldgt, uint32_t rows_live, uint32_t cols_live,
+                       uint32_t Ip, uint32_t user_tiles, uint32_t item_groups, uint32_t tiles_per_group) {
+  extern __shared__ __attribute__((aligned(1024))) char smemz[];
+  char* const img = smemz + 4 * G1Z_STAGE_BYTES;
+  const uint32_t lane = threadIdx.x % WAVE, wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // 0..7
+  uint32_t ut, ig;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    ut = j % user_tiles; ig = (j / user_tiles) * 8u + xcd;
+    if (ig >= item_groups) return;
+  }
+  const uint32_t n_tiles_all = Ip / 128u;
+  const uint32_t t_begin = ig * tiles_per_group, t_end = min(n_tiles_all, t_begin + tiles_per_group);
+  if (t_begin >= t_end) return;
+  const uint32_t n_tiles = t_end - t_begin, n_slices = n_tiles * 8u;
+  const uint32_t u_tile = ut * 256u;
+  const uint32_t f_row = lane & 31u, f_half = lane >> 5;
+
+  // this wavefront's 32 z rows: fragment kk = k in [16 kk, 16 kk + 16), lane holds the 8 of its half
+  bf16x8 zf[32];
+  {
+    const __bf16* zr = Zb + (size_t)(u_tile + wid * 32u + f_row) * 512u + 8u * f_half;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) zf[kk] = *reinterpret_cast<const bf16x8*>(zr + 16 * kk);
+  }
+  // staging: slice sl = (tile, ks) -> 16 DMA instructions of 1 KiB (8 rows of 128 bytes); wavefront w issues 2 w, 2 w + 1
+  const uint32_t st_row = lane >> 3, st_slot = lane & 7u;
+  auto stage = [&](uint32_t sl) {
+    const uint32_t tile = t_begin + (sl >> 3), ks = sl & 7u;
+    char* base = smemz + (sl & 3u) * G1Z_STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = (wid * 2u + q) * 8u + st_row;
+      const __bf16* src = Db + (size_t)min(tile * 128u + r, Ip - 1u) * 512u + ks * 64u + 8u * (st_slot ^ ((r >> 1) & 7u));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (wid * 2u + q) * 1024u), 16, 0, 0);
+    }
+  };
+  uint32_t d_off[4], d_sw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const uint32_t r = j * 32u + f_row; d_off[j] = r * 128u; d_sw[j] = (r >> 1) & 7u; }
+
+  stage(0);
+  if (n_slices > 1) stage(1);
+  if (n_slices > 2) stage(2);
+  f32x16 acc[4];
+  uint32_t sl = 0;
+  for (uint32_t t = 0; t < n_tiles; ++t) {
+    const uint32_t item0 = (t_begin + t) * 128u;
+    float bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t n = item0 + j * 32u + f_row; bias[j] = n < cols_live ? bp[n] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks, ++sl) {
+      // this wavefront's two DMAs of slice sl have landed.  Issued behind them: two per later slice in flight (sl + 1, sl + 2), the
+      // bias loads of this tile (ks == 0: compiler-visible, counted by its own waits) and — for the first three slices of every
+      // tile but the first — the 8 G^T stores of the previous tile's epilogue
+      const uint32_t later = min(2u, n_slices - 1u - sl);
+      const bool stores_behind = t > 0 && ks < 3;
+      if (later == 2u) { if (stores_behind) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else if (later == 1u) { if (stores_behind) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();                                        // everyone's; the stage slice sl - 1 occupied is free
+      if (sl + 3u < n_slices) stage(sl + 3u);
+      const char* base = smemz + (sl & 3u) * G1Z_STAGE_BYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const uint32_t c = 2u * s + f_half;
+        bf16x8 fd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fd[j] = *reinterpret_cast<const bf16x8*>(base + d_off[j] + ((c ^ d_sw[j]) << 4));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[ks * 4 + s], fd[j], acc[j], 0, 0, 0);
+      }
+    }
+    // loss epilogue: lane = item item0 + 32 j + f_row, acc[j][4 q + e] = user u_tile + 32 wid + 8 q + 4 f_half + e
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool n_live = item0 + j * 32u + f_row < cols_live;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t ul = wid * 32u + 8u * q + 4u * f_half;
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = acc[j][4 * q + e] + bias[j];
+          const float v = LOSS == 0 ? 2.f * y : fast_rcp(1.f + fast_exp(-y));
+          g[e] = (n_live && u_tile + ul + e < rows_live) ? v : 0.f;
+        }
+        const bf16x4 hb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
+        *reinterpret_cast<bf16x4*>(img + (j * 32u + f_row) * G1Z_IMG_RS + ul * 2u) = hb;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * G1Z_IMG_RS + c16 * 16u);
+      *reinterpret_cast<bf16x8*>(GT + (size_t)(item0 + row) * ldgt + u_tile + c16 * 8u) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // "TN" product for GEMM 2 of the K > 256 path:  C[m][n] = sum_c A[c][m] * Bm[c][n]  with BOTH operands stored contraction-row-major
 // — hg = G D as  sum_item G^T[item][user] * D[item][k]  straight from the two images the other launches already keep (G^T for
 // GEMM 3 / the row step, the row-major bf16 decoder image for GEMM 1).  With it GEMM 1 no longer writes G (2 GB per 1024-user

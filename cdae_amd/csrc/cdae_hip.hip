@@ -202,6 +202,8 @@ struct cdae_hip {
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
   bool gemmw_attr_set[8] = {false, false, false, false, false, false, false, false};   // ... of the 256 x 256-tile kernel
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
+  bool gemm1_tiled = false;             // CDAE_GEMM1_TILED: GEMM 1 as the 256 x 256-tile kernel where gemm1_loss_zreg_kernel would run (A/B switch)
+  bool gemm1_zreg_attr_set[2] = {false, false};   // dynamic-LDS attribute of gemm1_loss_zreg_kernel<LOSS> set on this handle's device
   bool gemm2_nt = false;                // CDAE_GEMM2_NT: hg = G D from G and D^T (gemm_nt_bf16_ldsw_kernel) where gemm_tn_bf16_kernel would read G^T and D (A/B switch)
   bool gemm_tn_attr_set = false;        // dynamic-LDS attribute of gemm_tn_bf16_kernel set on this handle's device
   bool rows_separate = false;           // CDAE_FULL_ROWS_SEPARATE: GEMM 3 and the row step as two launches where gemm3_rows_fused_kernel would run (A/B switch)
@@ -777,7 +779,25 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   if (h->gemm_direct)
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
                        Kp, ep);
-  else
+  else if (tn2 && Kp == 512 && !h->gemm1_tiled) {
+    // the z rows of 256 users in registers, only D staged (gemm1_loss_zreg_kernel): G^T alone, which is all GEMM 2 (TN) and GEMM 3 read
+    const uint32_t user_tiles = Bp / 256, n_tiles = Ip / 128;
+    const uint32_t item_groups = std::min<uint32_t>(((std::max<uint32_t>(1u, 256u / user_tiles) + 7u) / 8u) * 8u, ((n_tiles + 7u) / 8u) * 8u);
+    const uint32_t tiles_per_group = (n_tiles + item_groups - 1) / item_groups;
+    const dim3 grid(8u * user_tiles * ((item_groups + 7u) / 8u));
+    const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY;
+    if (!h->gemm1_zreg_attr_set[ce]) {
+      if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
+      else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
+      h->gemm1_zreg_attr_set[ce] = true;
+    }
+    if (ce)
+      hipLaunchKernelGGL(gemm1_loss_zreg_kernel<5>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+                         (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+    else
+      hipLaunchKernelGGL(gemm1_loss_zreg_kernel<0>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+                         (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+  } else
     CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
@@ -1003,6 +1023,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
   h->rows_separate = std::getenv("CDAE_FULL_ROWS_SEPARATE") != nullptr;
   h->gemm2_nt = std::getenv("CDAE_GEMM2_NT") != nullptr;
+  h->gemm1_tiled = std::getenv("CDAE_GEMM1_TILED") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;

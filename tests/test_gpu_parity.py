@@ -717,3 +717,30 @@ def test_tn_gemm2_changes_no_bit(built, monkeypatch):
     for w in tn:
         assert np.array_equal(tn[w], nt[w]), w
     assert np.array_equal(rec_tn, rec_nt)
+
+
+@pytest.mark.parametrize("loss", ["ce", "square"])
+def test_gemm1_zreg_changes_no_bit(built, monkeypatch, loss):
+    """K = 512 full-output path: GEMM 1 with the z rows of 256 users in registers and only D staged through LDS
+    (gemm1_loss_zreg_kernel) against the 256 x 256-tile kernel (CDAE_GEMM1_TILED=1).  Every G^T element is the same sum over k in
+    the same order and the same loss expression: identical parameters after two epochs, three blocks each (the last one partly
+    filled: users past the block's end and items past the last one are zero in G^T)."""
+    d = synth.generate(600, 33_000, 36_000, seed=6, min_items=20)
+    lt = cdae_amd.CROSS_ENTROPY if loss == "ce" else cdae_amd.SQUARE
+    cfg = cdae_amd.CDAEConfig(num_dim=300, lt=lt, beta=1.0, batch_users=256, full_output=True, learn_rate=0.1 if loss == "ce" else 0.02)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=4)
+        m.train_one_iteration(4, 0)
+        m.train_one_iteration(4, 1)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        m.close()
+        return out
+
+    zreg = run()
+    monkeypatch.setenv("CDAE_GEMM1_TILED", "1")
+    tiled = run()
+    for w in zreg:
+        assert np.array_equal(zreg[w], tiled[w]), w
+        assert np.isfinite(zreg[w]).all()
