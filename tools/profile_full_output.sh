@@ -20,7 +20,7 @@ rm -rf /tmp/pf_c5
 : > $O/${RND}_full_output_cfg5_pmc.txt
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pf_pmc -o res -- $C5 > $O/pmc.log 2>&1
-  for c in $set; do python $R/tools/rocpd_summary.py pmc /tmp/pf_pmc/res_results.db $c | grep -E "counter|gemm_nt|gemm_tn|gemm3_rows|full_rows|to_bf16|bf16_transpose" >> $O/${RND}_full_output_cfg5_pmc.txt; done
+  for c in $set; do python $R/tools/rocpd_summary.py pmc /tmp/pf_pmc/res_results.db $c | grep -E "counter|gemm_nt|gemm_tn|gemm1_loss|gemm3_rows|full_rows|to_bf16|bf16_transpose" >> $O/${RND}_full_output_cfg5_pmc.txt; done
   rm -rf /tmp/pf_pmc
 done
 cat $O/${RND}_full_output_cfg5_pmc.txt | cut -c1-60,108-180
