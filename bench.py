@@ -419,7 +419,12 @@ def bench_item_rows(args, rank, world):
         dist.destroy_process_group()
         return
     devices = [0] * args.logical_shards if args.logical_shards else list(range(world))
-    if args.users:
+    if args.users >= 2_000_000:          # scale run (configs[4]'s 10 M users): 20 interactions per user, uniform over the items
+        u, i, nnz = synth.SHAPES[args.shape]
+        t_gen = time.perf_counter()
+        data = synth.generate_uniform(args.users, i, per_user=20, seed=args.seed)
+        print(f"[bench] {args.users} users x 20 stratified-uniform interactions generated in {time.perf_counter() - t_gen:.1f} s", file=sys.stderr)
+    elif args.users:
         u, i, nnz = synth.SHAPES[args.shape]
         data = synth.generate(args.users, i, int(nnz * (args.users / u)), seed=args.seed)
     else:

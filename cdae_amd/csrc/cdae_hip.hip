@@ -690,6 +690,76 @@ int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uin
   return 0;
 }
 
+// The unfused (K > 256, or CDAE_FULL_UNFUSED) forward product with its loss epilogue, the positive fix-up and the hidden-gradient
+// product of one block — shared by the single-handle step (compute_batch_full) and the item shard's phase 1 (fs_phase1: the same
+// launches over the shard's own item rows).  *parts / *rows: the slabs of HGpart holding the partial hg and their row count
+// (0 parts: accumulated into d_HG by atomics, the CDAE_GEMM_DIRECT developer path).
+int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Batch& bt, uint32_t nb, uint32_t* parts, uint32_t* rows) {
+  using namespace cdae;
+  const uint32_t I = (uint32_t)h->I, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
+  const dim3 blk(256);
+  const bool tn2 = gemm2_tn_path(h);                                      // GEMM 2 reads G^T and D: no G, no D^T
+  GemmEpilogue ep{};
+  ep.bp = h->P(CDAE_P_BP); ep.G = tn2 ? (__bf16*)nullptr : h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
+  ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
+  // GEMM 1: Y = Z D^T (+ b'), g = loss'(y, 0) -> G [Bp x Ip] (unless GEMM 2 reads G^T), G^T [Ip x Bp]
+  if (h->gemm_direct)
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
+                       Kp, ep);
+  else if (tn2 && Kp == 512 && !h->gemm1_tiled) {
+    // the z rows of 256 users in registers, only D staged (gemm1_loss_zreg_kernel): G^T alone, which is all GEMM 2 (TN) and GEMM 3 read
+    const uint32_t user_tiles = Bp / 256, n_tiles = Ip / 128;
+    const uint32_t item_groups = std::min<uint32_t>(((std::max<uint32_t>(1u, 256u / user_tiles) + 7u) / 8u) * 8u, ((n_tiles + 7u) / 8u) * 8u);
+    const uint32_t tiles_per_group = (n_tiles + item_groups - 1) / item_groups;
+    const dim3 grid(8u * user_tiles * ((item_groups + 7u) / 8u));
+    const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY;
+    if (!h->gemm1_zreg_attr_set[ce]) {
+      if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
+      else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
+      h->gemm1_zreg_attr_set[ce] = true;
+    }
+    if (ce)
+      hipLaunchKernelGGL(gemm1_loss_zreg_kernel<5>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+                         (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+    else
+      hipLaunchKernelGGL(gemm1_loss_zreg_kernel<0>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+                         (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+  } else
+    CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
+  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  if (bt.E)
+    hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
+                       h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, tn2 ? (__bf16*)nullptr : h->d_Gb, Ip, h->d_GTb, Bp,
+                       rows_fused_path(h) ? h->d_has_in : (uint8_t*)nullptr);
+  // GEMM 2: hg = G D  (contraction over items, split).  Every split stores its partial [Bp x Kp] product into its own slab of
+  // HGpart and the consumer adds the slabs in fixed order: deterministic (the first version accumulated with fp32 atomics into
+  // HG, whose order — and therefore rounding — changed from run to run)
+  const uint32_t kps = gemm2_k_per_split(h);
+  GemmEpilogue e2{};
+  if (h->gemm_direct) {
+    e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + 2047) / 2048), blk, 0, st, h->d_Gb,
+                       h->d_DTb, Bp, Kp, Ip, Ip, Ip, 2048u, e2);
+    *parts = 0; *rows = nb;
+    return 0;
+  }
+  const uint32_t splits = (Ip + kps - 1) / kps;
+  e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
+  if (tn2) {                                                     // sum over items of G^T[item][user] D[item][k]: both images as they are
+    if (!h->gemm_tn_attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_tn_lds_bytes()));
+      h->gemm_tn_attr_set = true;
+    }
+    const GemmGrid gg{Bp / 256, Kp / 256, splits, 2};
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(gg.workgroups()), dim3(512), gemm_tn_lds_bytes(), st, (const __bf16*)h->d_GTb,
+                       (const __bf16*)h->d_Db, Bp, Kp, Ip, Bp, Kp, kps, e2, gg);
+  } else {
+    CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
+  }
+  *parts = splits; *rows = Bp;
+  return 0;
+}
+
 // Full-output decode of one batch (MFMA path, cdae_full_kernels.hpp).  The example list holds the positives only.
 int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoch) {
   using namespace cdae;
@@ -772,65 +842,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 #undef FUSED_LAUNCH
     hg_parts = slices;
   } else {
-  GemmEpilogue ep{};
-  ep.bp = h->P(CDAE_P_BP); ep.G = tn2 ? (__bf16*)nullptr : h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
-  ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
-  // GEMM 1: Y = Z D^T (+ b'), g = loss'(y, 0) -> G [Bp x Ip] (unless GEMM 2 reads G^T), G^T [Ip x Bp]
-  if (h->gemm_direct)
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_LOSS>), dim3(Ip / 128, Bp / 128, 1), blk, 0, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp,
-                       Kp, ep);
-  else if (tn2 && Kp == 512 && !h->gemm1_tiled) {
-    // the z rows of 256 users in registers, only D staged (gemm1_loss_zreg_kernel): G^T alone, which is all GEMM 2 (TN) and GEMM 3 read
-    const uint32_t user_tiles = Bp / 256, n_tiles = Ip / 128;
-    const uint32_t item_groups = std::min<uint32_t>(((std::max<uint32_t>(1u, 256u / user_tiles) + 7u) / 8u) * 8u, ((n_tiles + 7u) / 8u) * 8u);
-    const uint32_t tiles_per_group = (n_tiles + item_groups - 1) / item_groups;
-    const dim3 grid(8u * user_tiles * ((item_groups + 7u) / 8u));
-    const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY;
-    if (!h->gemm1_zreg_attr_set[ce]) {
-      if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
-      else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
-      h->gemm1_zreg_attr_set[ce] = true;
-    }
-    if (ce)
-      hipLaunchKernelGGL(gemm1_loss_zreg_kernel<5>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
-                         (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
-    else
-      hipLaunchKernelGGL(gemm1_loss_zreg_kernel<0>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
-                         (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
-  } else
-    CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
-  HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
-  hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
-                     h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, tn2 ? (__bf16*)nullptr : h->d_Gb, Ip, h->d_GTb, Bp,
-                     rows_fused_path(h) ? h->d_has_in : (uint8_t*)nullptr);
-  // GEMM 2: hg = G D  (contraction over items, split).  Every split stores its partial [Bp x Kp] product into its own slab of
-  // HGpart and hidden_finish_kernel adds the slabs in fixed order: deterministic (the first version accumulated with fp32
-  // atomics into HG, whose order — and therefore rounding — changed from run to run)
-  {
-    const uint32_t kps = gemm2_k_per_split(h);
-    GemmEpilogue e2{};
-    if (h->gemm_direct) {
-      e2.Cout = h->d_HG; e2.ldc = Kp; e2.rows_live = nb;
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_ATOMIC>), dim3((Kp + 127) / 128, Bp / 128, (Ip + 2047) / 2048), blk, 0, st, h->d_Gb,
-                         h->d_DTb, Bp, Kp, Ip, Ip, Ip, 2048u, e2);
-    } else {
-      const uint32_t splits = (Ip + kps - 1) / kps;
-      e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
-      if (tn2) {                                                 // sum over items of G^T[item][user] D[item][k]: both images as they are
-        if (!h->gemm_tn_attr_set) {
-          HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_tn_lds_bytes()));
-          h->gemm_tn_attr_set = true;
-        }
-        const GemmGrid gg{Bp / 256, Kp / 256, splits, 2};
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(gg.workgroups()), dim3(512), gemm_tn_lds_bytes(), st, (const __bf16*)h->d_GTb,
-                           (const __bf16*)h->d_Db, Bp, Kp, Ip, Bp, Kp, kps, e2, gg);
-      } else {
-        CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
-      }
-      hg_parts = splits;
-      hg_rows = Bp;
-    }
-  }
+  CHK(full_products_k512(h, st, x, bt, nb, &hg_parts, &hg_rows));
   }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
   // hg only; they run beside GEMM 3, and the row steps join them.
@@ -2442,7 +2454,10 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
     HIPCHK(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
+  // bf16 images of the shard's decoder rows: the fused row step (gemm3_rows_fused_kernel) leaves the row-major one current, and with
+  // GEMM 2 reading G^T and D nothing needs D^T — converted only when something else wrote the parameters
+  if (!(rows_fused_path(h) && gemm2_tn_path(h) && h->db_rows_valid))
+    hipLaunchKernelGGL(to_bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, h->dec(), I, Kp, Kp, Ip, h->d_Db, h->d_DTb);
   CHK(join_aux(h));
   // z from the ALL-REDUCED input sums: encode_finish with one "unit" per user (identity prefix)
   DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, wu_b, h->P(CDAE_P_B),
@@ -2469,18 +2484,7 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
 #undef FS_FUSED2
     parts = slices; rows = nb;
   } else {
-    GemmEpilogue ep{};
-    ep.bp = h->P(CDAE_P_BP); ep.G = h->d_Gb; ep.ldg = Ip; ep.GT = h->d_GTb; ep.ldgt = Bp;
-    ep.rows_live = nb; ep.cols_live = I; ep.loss_type = h->cfg.loss_type;
-    CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
-    if (bt.E)
-      hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
-                         h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, h->d_Gb, Ip, h->d_GTb, Bp);
-    const uint32_t kps = gemm2_k_per_split(h), splits = (Ip + kps - 1) / kps;
-    GemmEpilogue e2{};
-    e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
-    CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
-    parts = splits; rows = Bp;
+    CHK(full_products_k512(h, st, x, bt, nb, &parts, &rows));      // the single handle's launches over this shard's item rows
   }
   // local hidden gradient of the batch, raw: the shards' sums are all-reduced before delta is formed
   DISPATCH_NI(h->NI, slab_sum_kernel, grid_users, blk, 0, st, h->hp, h->d_HGpart, parts, rows, nb, h->d_HG);
@@ -2522,13 +2526,16 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
   HIPCHK(hipEventRecord(h->ev_delta, h->aux));
   hipLaunchKernelGGL(hidden_bias_kernel, dim3((Kp + 255u) / 256u), blk, 0, h->aux, h->hp, nb, h->d_HG, h->P(CDAE_P_B), h->P(CDAE_P_B_AG));
   HIPCHK(hipEventRecord(h->ev_join, h->aux));
-  {
+  const bool rows_fused = rows_fused_path(h);
+  if (!rows_fused) {
     GemmEpilogue e3{};
     e3.Cout = h->d_dD; e3.ldc = Kp;
     CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp, Bp, e3, 1, 1));
   }
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
-  if (I >= 32768u)
+  if (rows_fused)      // dD = G^T Z and the row steps from its accumulators, the row-major bf16 image left current
+    CHK(launch_rows_fused(h, st, x, nb, h->d_Db));
+  else if (I >= 32768u)
     DISPATCH_NI(h->NI, full_rows_wave_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), h->d_touched);
@@ -2536,6 +2543,8 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
     DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
+  h->db_valid = false;
+  h->db_rows_valid = rows_fused;                                 // the fused row step imaged every decoder row it stepped
   h->join_pending = true;
   HIPCHK(hipEventRecord(x.released, st));
   HIPCHK(hipGetLastError());

@@ -119,3 +119,23 @@ def generate(num_users: int, num_items: int, nnz: int, seed: int = 20141119, zip
 def generate_shape(name: str, seed: int = 20141119, **kw) -> Interactions:
     u, i, nnz = SHAPES[name]
     return generate(u, i, nnz, seed=seed, **kw)
+
+
+def generate_uniform(num_users: int, num_items: int, per_user: int = 20, seed: int = 20141119, test_ratio: float = 0.2) -> Interactions:
+    """Scale runs only (bench.py --users above 2 M: BASELINE configs[4]'s 10 M users on one box): every user has exactly `per_user`
+    interactions, one uniform draw from each of `per_user` equal strata of the item ids (unique and ascending by construction, no
+    sort, no hashing: 10 M users take seconds and a few GB); the first floor(test_ratio * per_user) of a fixed pseudo-random
+    column order go to test.  No popularity skew, no group structure: NOT an accuracy workload."""
+    rng = np.random.default_rng(seed)
+    width = num_items // per_user
+    assert width >= 1
+    items = (np.arange(per_user, dtype=np.uint32) * np.uint32(width))[None, :] + rng.integers(0, width, (num_users, per_user), dtype=np.uint32)
+    n_test = int(np.floor(test_ratio * per_user))
+    cols = np.random.default_rng(seed + 1).permutation(per_user)
+    test_cols, train_cols = np.sort(cols[:n_test]), np.sort(cols[n_test:])
+    tr_col = np.ascontiguousarray(items[:, train_cols]).reshape(-1)
+    te_col = np.ascontiguousarray(items[:, test_cols]).reshape(-1)
+    tr_ptr = np.arange(num_users + 1, dtype=np.int64) * train_cols.size
+    te_ptr = np.arange(num_users + 1, dtype=np.int64) * test_cols.size
+    return Interactions(num_users, num_items, tr_ptr, tr_col, te_ptr, te_col)
+
