@@ -3,6 +3,7 @@
 
   python tools/rocpd_summary.py stats  <results.db>            # --kernel-trace --stats summary
   python tools/rocpd_summary.py pmc    <results.db> COUNTER    # per-kernel mean of one PMC counter
+  python tools/rocpd_summary.py timeline <results.db> [N]      # the last N kernel dispatches: start / end (us from the first), queue, name
 """
 import sqlite3
 import sys
@@ -24,6 +25,20 @@ def stats(db):
         print(f"{short(n):110s} {c:6d} {tot / 1e6:10.3f} {avg / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * tot / total:6.2f} {vg or 0:5d} {sg or 0:5d} {lds or 0:6d} {scr or 0:4d}")
 
 
+def timeline(db, n):
+    cur = sqlite3.connect(db).cursor()
+    cols = [d[1] for d in cur.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+    rows = cur.execute(f"select name, start, end, {qcol or 0} from kernels order by start desc limit ?", (n,)).fetchall()[::-1]
+    t0 = rows[0][1]
+    prev_end = {}
+    print(f"{'start_us':>10s} {'end_us':>10s} {'dur_us':>8s} {'gap_same_queue':>14s} {'queue':>6s}  kernel")
+    for name, a, b, q in rows:
+        gap = (a - prev_end[q]) / 1e3 if q in prev_end else float("nan")
+        prev_end[q] = b
+        print(f"{(a - t0) / 1e3:10.2f} {(b - t0) / 1e3:10.2f} {(b - a) / 1e3:8.2f} {gap:14.2f} {q!s:>6s}  {short(name)[:90]}")
+
+
 def pmc(db, counter):
     con = sqlite3.connect(db)
     cur = con.cursor()
@@ -42,5 +57,7 @@ def pmc(db, counter):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 60)
     else:
         pmc(sys.argv[2], sys.argv[3])
