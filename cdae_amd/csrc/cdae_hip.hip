@@ -204,6 +204,7 @@ struct cdae_hip {
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
   bool gemm1_tiled = false;             // CDAE_GEMM1_TILED: GEMM 1 as the 256 x 256-tile kernel where gemm1_loss_zreg_kernel would run (A/B switch)
   bool gemm1_zreg_attr_set[2] = {false, false};   // dynamic-LDS attribute of gemm1_loss_zreg_kernel<LOSS> set on this handle's device
+  bool fused_attr_set = false;          // dynamic-LDS attribute of this handle's full_decode_fused_kernel instance set (one K and loss per handle)
   bool gemm2_nt = false;                // CDAE_GEMM2_NT: hg = G D from G and D^T (gemm_nt_bf16_ldsw_kernel) where gemm_tn_bf16_kernel would read G^T and D (A/B switch)
   bool gemm_tn_attr_set = false;        // dynamic-LDS attribute of gemm_tn_bf16_kernel set on this handle's device
   bool rows_separate = false;           // CDAE_FULL_ROWS_SEPARATE: GEMM 3 and the row step as two launches where gemm3_rows_fused_kernel would run (A/B switch)
@@ -828,7 +829,10 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     const size_t lds = full_fused_lds_bytes(Kp);
 #define FUSED_LAUNCH2(NKS_, L_)                                                                                                         \
   do {                                                                                                                                  \
-    HIPCHK(hipFuncSetAttribute((const void*)full_decode_fused_kernel<NKS_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+    if (!h->fused_attr_set) {      /* per handle (the attribute belongs to the (function, device) pair): a runtime call per batch otherwise */ \
+      HIPCHK(hipFuncSetAttribute((const void*)full_decode_fused_kernel<NKS_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      h->fused_attr_set = true;                                                                                                          \
+    }                                                                                                                                     \
     hipLaunchKernelGGL((full_decode_fused_kernel<NKS_, L_>), grid, blk, lds, st, h->hp, h->d_Zb, h->d_Db, h->d_DTb, Ip, h->P(CDAE_P_BP), \
                        bits, words, nb, tps, h->d_GTb, Bp, h->d_HGpart);                                                     \
   } while (0)
