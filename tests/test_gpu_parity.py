@@ -776,3 +776,38 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
             assert diff.max() <= 3e-2, (which, diff.max())
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
+
+
+@pytest.mark.parametrize("U,I,B", [(257, 32_768, 256), (700, 40_000, 512), (1030, 65_537, 1024)])
+def test_k512_launches_on_edge_shapes_change_no_bit(built, monkeypatch, U, I, B):
+    """The three K > 256 launches of round 3 together (gemm1_loss_zreg_kernel, gemm_tn_bf16_kernel, gemm3_rows_fused_kernel +
+    full_rows_inputs_kernel) against the launches they replace (CDAE_GEMM1_TILED, CDAE_GEMM2_NT, CDAE_FULL_ROWS_SEPARATE) on edge
+    shapes: an item count that is exactly the smallest the fused row step takes / not a multiple of anything / one past 65 536 (32-bit
+    sort keys), a last block of ONE user (257 = 256 + 1), of 188 and of 6 users, one / two / four user tiles per block.  Rows and
+    accumulators identical; b' within its summation order."""
+    d = synth.generate(U, I, 30 * U, seed=U, min_items=20)
+    cfg = cdae_amd.CDAEConfig(num_dim=257, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=B, full_output=True)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=2)
+        m.train_one_iteration(2, 0)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        plan = m.full_output_plan
+        m.close()
+        return out, plan
+
+    new, plan = run()
+    assert plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED)
+    for k in ("CDAE_GEMM1_TILED", "CDAE_GEMM2_NT", "CDAE_FULL_ROWS_SEPARATE"):
+        monkeypatch.setenv(k, "1")
+    old, plan_old = run()
+    assert plan_old == 0
+    n_blocks = -(-U // B)
+    for w in new:
+        assert np.isfinite(new[w]).all(), w
+        if w in (8, 9) or n_blocks > 1:       # b' sums its gradient in another order (and feeds the next block's forward product)
+            scale = np.abs(old[w]).max() + 1e-30
+            assert np.abs(new[w] - old[w]).max() / scale <= 2e-4, w
+        else:
+            assert np.array_equal(new[w], old[w]), w
