@@ -29,9 +29,40 @@ FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netflix_k200_
 _data = {}
 
 
+def data_seed_of(path):
+    f = np.load(path, allow_pickle=True)
+    return int(f["data_seed"]) if "data_seed" in f.files else int(f["seed"])
+
+
+_GEN = """
+import importlib.util, sys, numpy as np
+spec = importlib.util.spec_from_file_location("synth", sys.argv[1])
+synth = importlib.util.module_from_spec(spec); sys.modules["synth"] = synth; spec.loader.exec_module(synth)
+d = synth.generate_shape("netflix", seed=int(sys.argv[2]))
+np.savez(sys.argv[3], train_ptr=d.train_ptr, train_col=d.train_col, test_ptr=d.test_ptr, test_col=d.test_col, shape=np.array([d.num_users, d.num_items]))
+"""
+
+
 def netflix(seed):
+    """The Netflix-shape data set of `seed`.  The first call generates the sets of ALL committed fixtures side by side, each in a
+    child interpreter that imports nothing but numpy and cdae_amd/synth.py (one generation is ~60-80 s of numpy sorting on one core
+    and there is one per data seed: four of them one after the other were most of this module's run time).  The generator and its
+    output are the same — only where it runs differs; a box with few cores generates in this process, one set at a time."""
+    if not _data:
+        seeds = sorted({20141119} | {data_seed_of(p) for p in FIXTURES})
+        if len(seeds) > 1 and (os.cpu_count() or 1) >= 2 * len(seeds):
+            import subprocess
+            import sys
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                procs = [(s, os.path.join(tmp, f"nf{s}.npz"),) for s in seeds]
+                running = [(s, out, subprocess.Popen([sys.executable, "-c", _GEN, os.path.join(ROOT, "cdae_amd", "synth.py"), str(s), out]))
+                           for s, out in procs]
+                for s, out, pr in running:
+                    assert pr.wait() == 0, f"generation of the Netflix-shape data set {s} failed"
+                    f = np.load(out)
+                    _data[s] = synth.Interactions(int(f["shape"][0]), int(f["shape"][1]), f["train_ptr"], f["train_col"], f["test_ptr"], f["test_col"])
     if seed not in _data:
-        _data.clear()                     # one 100 M-interaction data set in memory at a time
         _data[seed] = synth.generate_shape("netflix", seed=seed)
     return _data[seed]
 
@@ -73,11 +104,6 @@ def test_netflix_shape_batch_users_one_is_the_literal_schedule(built):
 
 def test_there_is_a_netflix_fixture():
     assert len(FIXTURES) >= 1, "tests/golden/make_literal_curves.py --shape netflix --eval-users 60000"
-
-
-def data_seed_of(path):
-    f = np.load(path, allow_pickle=True)
-    return int(f["data_seed"]) if "data_seed" in f.files else int(f["seed"])
 
 
 FIXTURES.sort(key=lambda p: (data_seed_of(p) != 20141119, data_seed_of(p), p))   # one data set = one generation; the first tests' set first
