@@ -1410,17 +1410,15 @@ full_rows_wave_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, co
 //
 // The separate launches moved dD twice (2 GB written by GEMM 3, 2 GB read by the row step at 1 M items x K = 512), the row step
 // read the G^T row of every item a second time for the b' gradient (2 GB) — 13 GB for a step whose own operands are 10 GB.
-// Here a 256-thread workgroup owns 128 items x all 512 k of  dD^T[k][item] = sum_u Z^T[k][u] G^T[item][u]  (contraction over
-// the block's users) and keeps it in the accumulators (wavefront w: k in [128 w, 128 w + 128) x 128 items = 4 x 4 tiles of
-// v_mfma_f32_32x32x16_bf16, 256 registers; one wavefront per SIMD), then steps its rows from there: the C layout of the MFMA
-// puts FOUR CONSECUTIVE k of one item into a lane, so D / D_ag are read and written as 16-byte pieces of the item's row and
-// the row-major bf16 image as 8-byte pieces; pairs of lanes cover 32 contiguous bytes and the four pieces of a lane a whole
-// 128-byte line.  The b' gradient (the row sum of G^T) is summed from the operand slices that pass through LDS anyway.
-//   contraction: slices of 32 users, three 40 KiB LDS stages (512 Z^T rows + 128 G^T rows of 64 bytes; slot c of row r holds
+// Here the workgroup(s) of an item tile own 128 items x 512 k of  dD^T[k][item] = sum_u Z^T[k][u] G^T[item][u]  (contraction over
+// the block's users) and keep it in the accumulators (a wavefront: k in [128 kw, 128 kw + 128) x 128 items = 4 x 4 tiles of
+// v_mfma_f32_32x32x16_bf16, 256 registers; one wavefront per SIMD), then step the rows from there.  The b' gradient (the row sum
+// of G^T) is summed from the operand slices that pass through LDS anyway.
+//   contraction: slices of 32 users, three LDS stages (the workgroup's Z^T rows + 128 G^T rows of 64 bytes; slot c of row r holds
 //   source chunk c ^ ((r >> 2) & 3): the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots), two slices in flight
-//   across every raw barrier, counted vmcnt (10 DMA instructions per wavefront and slice);
-//   epilogue: eight stages of (32 items x 64 k) per wavefront, the next stage's 16 row pieces requested before the current
-//   stage's 64 AdaGrad steps (16 KiB in flight per wavefront: the epilogue is HBM-bound, 10 bytes per parameter).
+//   across every raw barrier, counted vmcnt (8 + GQ DMA instructions per wavefront and slice);
+//   epilogue: fr_quarter (above) — a quarter of the tile at a time through LDS, stepped as whole rows; the same piece of the next
+//   quarter is requested into the registers just read, the first quarter in front of the contraction.
 // Every dD element is the same sum over users in the same order as gemm_nt_bf16_ldsw_kernel's and the row step is
 // full_rows_wave_kernel's expression, so D / D_ag / W come out bit-identical to the separate launches; b' differs in the
 // order its gradient is summed (test_fused_rows_kernel_matches_separate_launches).
