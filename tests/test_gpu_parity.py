@@ -746,7 +746,8 @@ def test_gemm1_zreg_changes_no_bit(built, monkeypatch, loss):
         assert np.isfinite(zreg[w]).all()
 
 
-@pytest.mark.parametrize("variant", [dict(loss=cdae_amd.CROSS_ENTROPY), dict(loss=cdae_amd.SQUARE, using_adagrad=False, learn_rate=0.002, user_factor=False)])
+@pytest.mark.parametrize("variant", [dict(loss=cdae_amd.CROSS_ENTROPY), dict(loss=cdae_amd.SQUARE, using_adagrad=False, learn_rate=0.002, user_factor=False),
+                                     dict(loss=cdae_amd.CROSS_ENTROPY, asymmetric=True)])
 def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
     """The K > 256 launches of a large item space — GEMM 1 with the z rows in registers, GEMM 2 through the transposing LDS read, GEMM 3
     fused with the row step (>= 32768 items), the kept-input rows behind it — against the fp64 oracle's block schedule
@@ -757,23 +758,24 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
     kw = dict(variant)
     loss = kw.pop("loss")
     model, o = make_pair(d, K=300, B=256, loss=loss, full_output=True, **kw)
-    assert model.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED)
+    # (an asymmetric decoder keeps GEMM 3 and the row step as two launches: its input rows take a step of their own)
+    assert model.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | (0 if variant.get("asymmetric") else cdae_amd.binding.PLAN_ROWS_FUSED))
     model.train_one_iteration(seed=4, epoch=0)
     o.train_full(4, 0, 256)
     # as test_reduced_config5_k512_131072_items: a row's first block step starts from a 1e-4 accumulator, so the bf16 rounding of a
     # near-zero summed gradient becomes step-size noise on single elements of W — max 6e-2 of the range, mean far below; every
     # other parameter within 3e-2
-    for which in (0, 1, 4, 5, 6, 7, 8, 9):
+    for which in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
         ref = o.get(which)
         if not ref.size:
             continue
         diff = np.abs(model.get(which).astype(np.float64).ravel() - ref) / (1e-3 + np.abs(ref).max())
-        if which == 0:
+        if which in (0, 2):
             assert diff.max() <= 7e-2 and diff.mean() <= 5e-3, (which, diff.max(), diff.mean())
-        elif which == 1:
+        elif which in (1, 3):
             continue                                   # (accumulators: the squares of those steps)
-        else:
-            assert diff.max() <= 3e-2, (which, diff.max())
+        else:                                          # (the other accumulators hold squares: twice the relative error of what they square)
+            assert diff.max() <= (6e-2 if which % 2 else 3e-2), (which, diff.max())
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
 
