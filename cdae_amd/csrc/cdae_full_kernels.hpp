@@ -1483,7 +1483,7 @@ __device__ __forceinline__ void fr_quarter(const HyperParams& hp, const FusedRow
     fr_piece<KH>(cx, p, il, col);
     const uint32_t item = cx.tile0 + (uint32_t)C * 32u + il;                                   // wave-uniform
     const bool live = item < cx.num_items;
-    const bool deferred = ((uint32_t)__builtin_amdgcn_readlane((int)cx.in_mask, (int)il) >> C) & 1u;
+    const bool deferred = ((uint32_t)__builtin_amdgcn_readlane((int)cx.in_mask, (int)il) >> C) & 1u;      // (in_mask is 0 for an asymmetric decoder)
     const float4 dv = *reinterpret_cast<const float4*>(cx.lds + il * RS + col * 4u);
     const size_t o = (size_t)min(item, cx.num_items - 1u) * 512u + cx.kbase + col;
     float w4[4] = {wq[p].x, wq[p].y, wq[p].z, wq[p].w}, a4[4] = {aq[p].x, aq[p].y, aq[p].z, aq[p].w};
@@ -1570,7 +1570,7 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t item = tile0 + (uint32_t)j * 32u + f_row;
-    in_mask |= (item < hp.num_items ? (uint32_t)has_in[item] : 0u) << j;
+    in_mask |= (item < hp.num_items && !hp.asymmetric ? (uint32_t)has_in[item] : 0u) << j;      // (asymmetric: the decoder row V[item] has no input term, every row is stepped here)
   }
 #pragma unroll
   for (int p = 0; p < 16; ++p) fr_load_piece<0, KH>(cx, p, wq[p], aq[p]);
@@ -1635,7 +1635,7 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
   fr_quarter<3, ADA, KH>(hp, cx, acc, wq, aq);
 }
 
-// Behind gemm3_rows_fused_kernel (tied weights): the rows some user of the block kept as an input — dD from the fused launch, the
+// Behind gemm3_rows_fused_kernel: the rows some user of the block kept as an input — tied weights: dD from the fused launch, the
 // summed delta rows added as full_rows_wave_kernel adds them, one step.  b' of these rows was stepped by the fused launch.
 template <int NI>
 __global__ void __launch_bounds__(256)
@@ -1661,8 +1661,15 @@ full_rows_inputs_kernel(HyperParams hp, uint8_t* __restrict__ has_in, const uint
     todo &= todo - 1;
     const uint32_t item = wave + (uint32_t)src * n_waves;
     const uint32_t beg = (uint32_t)__builtin_amdgcn_readlane((int)my_beg, src), end = (uint32_t)__builtin_amdgcn_readlane((int)my_end, src);
+    // tied: the decoder row, with dD from the fused launch.  Asymmetric: the INPUT row W[item] alone takes this step (the fused
+    // launch stepped the decoder row V[item] itself: its gradient has no input term), dD plays no part and no image is written
     float dd[NI], w[NI], a[NI], din[NI];
-    vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);
+    if (!hp.asymmetric) {
+      vload<NI>(dd, dD + (size_t)item * hp.Kp + lo);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) dd[i] = 0.f;
+    }
     vload<NI>(w, W + (size_t)item * hp.Kp + lo);
     vload<NI>(a, W_ag + (size_t)item * hp.Kp + lo);
 #pragma unroll
@@ -1692,11 +1699,16 @@ full_rows_inputs_kernel(HyperParams hp, uint8_t* __restrict__ has_in, const uint
           for (int i = 0; i < NI; ++i) din[i] += v[t][i];
       }
     }
+    if (!hp.asymmetric) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
+      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], fmaf(hp.lambda, w[i], dd[i])));
+    } else {                                                       // full_rows_wave_kernel's expression for the input row
+#pragma unroll
+      for (int i = 0; i < NI; ++i) ada_step(hp, w[i], a[i], fmaf(hp.scale, din[i], hp.lambda * w[i]));
+    }
     vstore<NI>(W + (size_t)item * hp.Kp + lo, w);
     vstore<NI>(W_ag + (size_t)item * hp.Kp + lo, a);
-    if (Db) {
+    if (Db && !hp.asymmetric) {
       store_row_only_bf16<NI>(w, item, lo, hp.Kp, Db);
       if (DTb) {
 #pragma unroll

@@ -664,7 +664,7 @@ bool gemm2_tn_path(const cdae_hip* h) {
 }
 // GEMM 3 + row step in one launch (gemm3_rows_fused_kernel): Kp = 512 over item spaces >= 32768, i.e. BASELINE configs[4]'s path
 bool rows_fused_path(const cdae_hip* h) {
-  return h->Kp == 512 && h->I >= 32768 && h->Ip % cdae::FR_ITEMS == 0 && !h->cfg.asymmetric && h->fused_images && !h->gemm_direct && !h->rows_separate;
+  return h->Kp == 512 && h->I >= 32768 && h->Ip % cdae::FR_ITEMS == 0 && h->fused_images && !h->gemm_direct && !h->rows_separate;
 }
 int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uint32_t nb, __bf16* Db) {
   using namespace cdae;
@@ -679,7 +679,7 @@ int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uin
     const uint32_t tiles = h->Ip / FR_ITEMS, grid = KH_ == 1 ? tiles : 16u * ((tiles + 7u) / 8u);                                         \
     hipLaunchKernelGGL((gemm3_rows_fused_kernel<ADA_, KH_>), dim3(grid), dim3(256 / KH_), fused_rows_lds_bytes<KH_>(), st, h->hp,         \
                        (const __bf16*)h->d_ZTb, (const __bf16*)h->d_GTb, h->Bp, h->Bp, nb, (const uint8_t*)h->d_has_in,                   \
-                       h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG),                                                                        \
+                       h->d_dD, h->dec(), h->dec_ag(),                                                                                    \
                        h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG), h->d_touched, Db, h->Ip);                                                     \
   } while (0)
   if (h->cfg.using_adagrad) { if (h->rows_fused_kh == 1) FR_LAUNCH(true, 1); else FR_LAUNCH(true, 2); }

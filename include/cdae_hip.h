@@ -144,7 +144,7 @@ uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
  * the kernel families cdae_hip_get_stats times (bench.py: which of the three products are inside the "decode" family):
  *   CDAE_PLAN_FUSED_DECODE  K <= 256: forward product, loss' and hidden-gradient product in one launch (full_decode_fused_kernel)
  *   CDAE_PLAN_GEMM2_TN      K > 256: hg = G D read from G^T and the row-major decoder image (gemm_tn_bf16_kernel; GEMM 1 writes no G)
- *   CDAE_PLAN_ROWS_FUSED    K > 256, >= 32768 items, tied weights: dD = G^T Z and the row steps in one launch (gemm3_rows_fused_kernel),
+ *   CDAE_PLAN_ROWS_FUSED    K > 256, >= 32768 items: dD = G^T Z and the row steps in one launch (gemm3_rows_fused_kernel),
  *                           timed in the "input" family — the "decode" family then holds two of the three products
  * 0 for a sampled-decode handle. */
 #define CDAE_PLAN_FUSED_DECODE 1u

@@ -668,25 +668,27 @@ def test_fused_rows_kernel_matches_separate_launches(built, monkeypatch, adagrad
     assert abs(loss_f1 - loss_s1) <= 1e-5 * abs(loss_s1) and abs(loss_f3 - loss_s3) <= 1e-4 * abs(loss_s3)
 
 
-def test_fused_rows_first_block_is_bit_identical(built, monkeypatch):
-    """One block from fresh parameters: the decoder rows and their accumulators out of the fused launch are bit-identical to the
-    separate launches' (b' differs only in the order its gradient is summed: 1e-6)."""
+@pytest.mark.parametrize("asymmetric", [False, True])
+def test_fused_rows_first_block_is_bit_identical(built, monkeypatch, asymmetric):
+    """One block from fresh parameters: the decoder rows (W, or V with an asymmetric decoder — then the input rows W of the kept
+    items step in the second launch) and their accumulators out of the fused launch are bit-identical to the separate launches'
+    (b' differs only in the order its gradient is summed: 1e-6)."""
     d = synth.generate(500, 33_000, 30_000, seed=9, min_items=20)
-    cfg = cdae_amd.CDAEConfig(num_dim=300, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=512, full_output=True)
+    cfg = cdae_amd.CDAEConfig(num_dim=300, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=512, full_output=True, asymmetric=asymmetric)
 
     def run():
         m = cdae_amd.CDAE(cfg)
         m.reset(d, seed=3)
         w_init = m.get(0)
         m.train_one_iteration(4, 0)
-        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        out = {w: m.get(w) for w in ((0, 1, 2, 3, 4, 5, 6, 7, 8, 9) if asymmetric else (0, 1, 4, 5, 6, 7, 8, 9))}
         m.close()
         return out, w_init
 
     fused, w_init = run()
     monkeypatch.setenv("CDAE_FULL_ROWS_SEPARATE", "1")
     sep, _ = run()
-    for w in (0, 1, 4, 5, 6, 7):
+    for w in ((0, 1, 2, 3, 4, 5, 6, 7) if asymmetric else (0, 1, 4, 5, 6, 7)):
         assert np.array_equal(fused[w], sep[w]), w
     for w in (8, 9):
         np.testing.assert_allclose(fused[w], sep[w], rtol=2e-6, atol=1e-9)
@@ -758,8 +760,7 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
     kw = dict(variant)
     loss = kw.pop("loss")
     model, o = make_pair(d, K=300, B=256, loss=loss, full_output=True, **kw)
-    # (an asymmetric decoder keeps GEMM 3 and the row step as two launches: its input rows take a step of their own)
-    assert model.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | (0 if variant.get("asymmetric") else cdae_amd.binding.PLAN_ROWS_FUSED))
+    assert model.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED)
     model.train_one_iteration(seed=4, epoch=0)
     o.train_full(4, 0, 256)
     # as test_reduced_config5_k512_131072_items: a row's first block step starts from a 1e-4 accumulator, so the bf16 rounding of a
