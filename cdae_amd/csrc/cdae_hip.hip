@@ -1418,7 +1418,8 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   if (h->cfg.linear_function) { CHK(dev_alloc(&h->d_Ssum, BK)); CHK(dev_alloc(&h->d_delta_rows, BK)); }
   if (h->cfg.full_output) {
     h->Bp = (B + 127u) & ~127u;
-    h->Ip = I >= 32768 ? (((uint32_t)I + 255u) & ~255u) : (((uint32_t)I + 127u) & ~127u);   // big item spaces: 256-row GEMM tiles
+    // big item spaces and K > 256: 256-row GEMM tiles (the K > 256 launches of round 3 — gemm1_loss_zreg_kernel, gemm_tn_bf16_kernel — want them)
+    h->Ip = (I >= 32768 || h->Kp > 256) ? (((uint32_t)I + 255u) & ~255u) : (((uint32_t)I + 127u) & ~127u);
     CHK(dev_alloc(&h->d_Zb, (size_t)h->Bp * h->Kp)); CHK(dev_alloc(&h->d_ZTb, (size_t)h->Kp * h->Bp));
     CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
     CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));

@@ -530,8 +530,9 @@ def test_full_output_three_gemm_path(tiny, small, monkeypatch, K, B, unfused_env
     split-K GEMM 2, GEMM 3 — instead of the fused kernel; CDAE_FULL_UNFUSED selects them for any K.  Same oracle as
     test_full_output_mfma_decode_matches_oracle; the bf16 rounding of z and D enters y = D z through K products, so the
     tolerance on the parameters is 3e-2 of their range here (measured 2.1e-2 .. 2.5e-2 on b', the smallest-valued
-    parameter, at K = 200 .. 512; the fused kernel measures the same at K = 200) against 2e-2 at K = 24.  B = 256 rows
-    take the 256 x 128 three-stage kernel (counted vmcnt) for GEMM 1 and 2, the others the 128 x 128 one."""
+    parameter, at K = 200 .. 512; the fused kernel measures the same at K = 200) against 2e-2 at K = 24.  Since the end of
+    round 3 the item count is padded to a multiple of 256 whenever K > 256, so blocks that fill whole 256-user tiles (B = 130 and
+    256 here) take gemm1_loss_zreg_kernel and gemm_tn_bf16_kernel at these small shapes too; B = 48 keeps the tiled kernels."""
     if unfused_env:
         monkeypatch.setenv("CDAE_FULL_UNFUSED", "1")
     data = small if B >= 256 else tiny      # (with 256 of tiny's 300 users per block there are two AdaGrad steps per epoch: b' alone is 3.8e-2 off)
