@@ -1422,7 +1422,10 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     h->Ip = (I >= 32768 || h->Kp > 256) ? (((uint32_t)I + 255u) & ~255u) : (((uint32_t)I + 127u) & ~127u);
     CHK(dev_alloc(&h->d_Zb, (size_t)h->Bp * h->Kp)); CHK(dev_alloc(&h->d_ZTb, (size_t)h->Kp * h->Bp));
     CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
-    CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip)); CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
+    // G [Bp x Ip] only where a launch reads it: the NT form of GEMM 2 (K > 256 without gemm_tn_bf16_kernel, or CDAE_FULL_UNFUSED);
+    // the fused K <= 256 kernel and the TN form read G^T alone (2 GB less per handle at 1 M items x 1024 users)
+    if ((h->Kp > 256 || h->full_unfused) && !gemm2_tn_path(h)) CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip));
+    CHK(dev_alloc(&h->d_GTb, (size_t)h->Ip * h->Bp));
     CHK(dev_alloc(&h->d_dD, (size_t)h->Ip * h->Kp));
     CHK(dev_alloc(&h->d_has_in, (size_t)h->Ip));
     HIPCHK(hipMemsetAsync(h->d_has_in, 0, (size_t)h->Ip, h->stream));
