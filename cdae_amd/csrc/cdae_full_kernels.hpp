@@ -835,7 +835,7 @@ gemm1_loss_zreg_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf
     for (int q = 0; q < 8; ++q) {
       const uint32_t pc = threadIdx.x + 512u * q, row = pc >> 5, c16 = pc & 31u;
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + row * G1Z_IMG_RS + c16 * 16u);
-      *reinterpret_cast<bf16x8*>(GT + (size_t)(item0 + row) * ldgt + u_tile + c16 * 8u) = v;
+      *reinterpret_cast<bf16x8*>(GT + (size_t)(item0 + row) * ldgt + u_tile + c16 * 8u) = v;      // (nontemporal here: no difference, measured)
     }
   }
 }
@@ -1453,8 +1453,17 @@ __device__ __forceinline__ void fr_load_piece(const FusedRowsCtx& cx, int p, flo
   fr_piece<KH>(cx, p, il, col);
   const uint32_t row = min(cx.tile0 + (uint32_t)C * 32u + il, cx.num_items - 1u);
   const size_t o = (size_t)row * 512u + cx.kbase + col;
+  // D / D_ag cross the chip once per block (8 GB at 1 M items x 512: no reuse any cache could serve): nontemporal both ways,
+  // 4.82 -> 4.72 ms per block; the bf16 image and the G^T slices stay plain (the forward product and the tile's other half
+  // re-read them from L2: nontemporal there measured 5.05 ms).  -DCDAE_FR_PLAIN: plain accesses (A/B build)
+#ifndef CDAE_FR_PLAIN
+  const cdae_f4v w_ = __builtin_nontemporal_load(reinterpret_cast<const cdae_f4v*>(cx.P0 + o));
+  const cdae_f4v a_ = __builtin_nontemporal_load(reinterpret_cast<const cdae_f4v*>(cx.P0a + o));
+  wv = make_float4(w_[0], w_[1], w_[2], w_[3]); av = make_float4(a_[0], a_[1], a_[2], a_[3]);
+#else
   wv = *reinterpret_cast<const float4*>(cx.P0 + o);
   av = *reinterpret_cast<const float4*>(cx.P0a + o);
+#endif
 }
 template <int C, bool ADA, int KH>
 __device__ __forceinline__ void fr_quarter(const HyperParams& hp, const FusedRowsCtx& cx, const f32x16 (&acc)[4][4], float4 (&wq)[16], float4 (&aq)[16]) {
@@ -1494,8 +1503,14 @@ __device__ __forceinline__ void fr_quarter(const HyperParams& hp, const FusedRow
     } else if (live) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) ada_step_t<ADA>(hp, w4[e], a4[e], fmaf(hp.lambda, w4[e], d4[e]));
+#ifndef CDAE_FR_PLAIN
+      const cdae_f4v wo = {w4[0], w4[1], w4[2], w4[3]}, ao = {a4[0], a4[1], a4[2], a4[3]};
+      __builtin_nontemporal_store(wo, reinterpret_cast<cdae_f4v*>(cx.P0 + o));
+      __builtin_nontemporal_store(ao, reinterpret_cast<cdae_f4v*>(cx.P0a + o));
+#else
       *reinterpret_cast<float4*>(cx.P0 + o) = make_float4(w4[0], w4[1], w4[2], w4[3]);
       *reinterpret_cast<float4*>(cx.P0a + o) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+#endif
       const bf16x4 hb = {(__bf16)w4[0], (__bf16)w4[1], (__bf16)w4[2], (__bf16)w4[3]};
       *reinterpret_cast<bf16x4*>(cx.Db + o) = hb;
     }
