@@ -83,6 +83,8 @@ EXPORTS = {
     "cdae_hip_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "cdae_hip_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
     "cdae_hip_recommend_user": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+    "cdae_hip_set_test_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cdae_hip_eval_topn": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cdae_hip_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "cdae_hip_delta_begin": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_compute": (C.c_int, [C.c_void_p]),
@@ -111,6 +113,7 @@ EXPORTS = {
     "cdae_hip_multi_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "cdae_hip_multi_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "cdae_hip_multi_recommend_all": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "cdae_hip_multi_eval_topn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cdae_hip_multi_get_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "cdae_hip_multi_set_param": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
 }
@@ -355,6 +358,19 @@ class CDAE:
         _chk(self.lib, self.lib.cdae_hip_recommend_user(self.h, uid, r.ctypes.data, r.size, topk, out.ctypes.data))
         return out
 
+    def set_test_rows(self, test_ptr, test_col):
+        """the validation rows TOPN_Evaluation scores against (evaluation.hpp:118-120), CSR over this handle's users"""
+        tp = np.ascontiguousarray(test_ptr, dtype=np.int64)
+        tc = np.ascontiguousarray(test_col, dtype=np.uint32)
+        _chk(self.lib, self.lib.cdae_hip_set_test_rows(self.h, tp.ctypes.data, tc.ctypes.data))
+
+    def eval_topn(self, topk: int = 10, with_ids: bool = False):
+        """TOPN_Evaluation::evaluate on the device (evaluation.hpp:113-219): (rets[8], hits[3]) or (rets, hits, ids)."""
+        rets, hits = np.empty(8, dtype=np.float64), np.empty(3, dtype=np.uint64)
+        ids = np.empty((self.num_users, topk), dtype=np.uint32) if with_ids else None
+        _chk(self.lib, self.lib.cdae_hip_eval_topn(self.h, topk, rets.ctypes.data, hits.ctypes.data, ids.ctypes.data if with_ids else None))
+        return (rets, hits, ids) if with_ids else (rets, hits)
+
     def pre_recommend(self, topk: int = 10):
         self._rec = self.recommend_all(topk)
 
@@ -535,6 +551,13 @@ class MultiCDAE:
         out = np.empty((u_end - u_begin, topk), dtype=np.uint32)
         _chk(self.lib, self.lib.cdae_hip_multi_recommend_all(self.h, u_begin, u_end, topk, out.ctypes.data))
         return out
+
+    def eval_topn(self, test_ptr, test_col, topk: int = 10):
+        tp = np.ascontiguousarray(test_ptr, dtype=np.int64)
+        tc = np.ascontiguousarray(test_col, dtype=np.uint32)
+        rets, hits = np.empty(8, dtype=np.float64), np.empty(3, dtype=np.uint64)
+        _chk(self.lib, self.lib.cdae_hip_multi_eval_topn(self.h, tp.ctypes.data, tc.ctypes.data, topk, rets.ctypes.data, hits.ctypes.data, None))
+        return rets, hits
 
     _shape = CDAE._shape
 

@@ -175,6 +175,10 @@ struct cdae_hip {
   float* d_score = nullptr; size_t score_cap = 0;      // recommend, general path: score rows when num_items * 4 B exceed the LDS
   float* d_zeval = nullptr; float* d_hpart_eval = nullptr; uint32_t eval_cap = 0, eval_unit_cap = 0;   // evaluation workspace
   uint32_t* d_bits = nullptr; size_t bits_cap = 0;                                                     // recommend: rated-item bitmap
+  // TOPN metrics on the device (cdae_hip_set_test_rows / cdae_hip_eval_topn): the validation rows as CSR, per-user metric terms
+  int64_t* d_test_ptr = nullptr; uint32_t* d_test_col = nullptr; double* d_topn_pu = nullptr; double* d_topn_out = nullptr;
+  uint64_t test_users_with_rows = 0;
+  bool topn_active = false;             // recommend paths: score every chunk's lists with topn_user_kernel (cdae_hip_eval_topn)
   int sort_bits = 1;
   // prep worker: the ~12 launches that sample + sort a batch are issued by a second host thread (the training loop was bound by
   // the HOST's launch rate: ~21 runtime calls x 4.5 us per batch on one thread)
@@ -350,7 +354,8 @@ void free_all(cdae_hip* h) {
                   h->d_unit_ptr, h->d_Hpart, h->d_uptr_tmp, h->d_Zb, h->d_ZTb, h->d_Db, h->d_DTb, h->d_Gb, h->d_GTb, h->d_dD, h->d_has_in,
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
-                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of};
+                  h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
+                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -390,7 +395,8 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_uids, (void**)&h->d_rec, (void**)&h->d_base, (void**)&h->d_delta, (void**)&h->d_recv, (void**)&h->d_snap, (void**)&h->d_dup_corr, (void**)&h->d_unit_user, (void**)&h->d_zeval, (void**)&h->d_bits, (void**)&h->d_hpart_eval, (void**)&h->d_iota, (void**)&h->d_bits_train,
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
-                   (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user};
+                   (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
+                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -1790,6 +1796,12 @@ int fill_stats(cdae_hip* h, cdae_hip_stats* stats) {
 // recommend(), general path (cdae_kernels.hpp recommend_kernel): any num_dim / topk / item count; one workgroup per user.
 // rated != nullptr: ONE user whose input set and mask are the caller's list (sorted, unique) instead of the train row.
 namespace {
+// cdae_hip_eval_topn: the lists of users [u0, u0 + nu) sit in h->d_rec — score them against the test rows (same stream, no host round trip)
+void topn_chunk(cdae_hip* h, uint32_t topk, uint64_t u0, uint32_t nu) {
+  hipLaunchKernelGGL(cdae::topn_user_kernel, dim3((nu + 255) / 256), dim3(256), 0, h->stream, (const uint32_t*)h->d_rec, topk, u0, nu,
+                     (const int64_t*)h->d_test_ptr, (const uint32_t*)h->d_test_col, (double)h->test_users_with_rows, h->d_topn_pu,
+                     reinterpret_cast<unsigned long long*>(h->d_topn_out + 8));
+}
 int recommend_general(cdae_hip* h, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out, const uint32_t* rated, uint32_t n_rated) {
   const size_t lds_scores = (size_t)h->I * sizeof(float) + 64;
   const bool in_lds = lds_scores <= 160 * 1024;
@@ -1839,8 +1851,9 @@ int recommend_general(cdae_hip* h, uint64_t u_begin, uint64_t u_end, uint32_t to
     DISPATCH_NI(h->NI, cdae::recommend_kernel, dim3(nb), dim3(256), shmem, h->stream, h->hp, h->d_row_ptr, h->d_col, s0,
                 h->mf ? h->d_Wu + (size_t)s0 * h->Kp : h->d_Z, h->dec(), h->P(CDAE_P_BP), topk, h->d_rec, in_lds ? (float*)nullptr : h->d_score, (const uint32_t*)d_rated, n_rated, (float*)nullptr);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && h->topn_active) { topn_chunk(h, topk, s0, nb); e = hipGetLastError(); }
+    if (e == hipSuccess && out) e = hipMemcpyAsync(out + (s0 - u_begin) * topk, h->d_rec, (size_t)nb * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && out) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) rc = fail("recommend: %s", hipGetErrorString(e));
   }
   if (d_rated) (void)hipFree(d_rated);
@@ -2059,7 +2072,7 @@ int cdae_hip_penalty_loss(cdae_hip_t* h, double* out) {
 }
 
 int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out) {
-  if (!h || !h->d_shared || !out) return fail("bad argument");
+  if (!h || !h->d_shared || (!out && !h->topn_active)) return fail("bad argument");
   if (u_begin > u_end || u_end > h->U) return fail("bad user range");
   if (topk == 0 || topk > h->I) return fail("topk must be in [1, num_items]");
   HIPCHK(hipSetDevice(h->device));
@@ -2113,12 +2126,91 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
       switch (nch) { case 4: REC_LAUNCH(4); break; case 8: REC_LAUNCH(8); break; case 16: REC_LAUNCH(16); break; case 25: REC_LAUNCH(25); break; default: REC_LAUNCH(32); break; }
 #undef REC_LAUNCH
       HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(out + (c0 - u_begin) * topk, h->d_rec, (size_t)nu * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
+      if (h->topn_active) { topn_chunk(h, topk, c0, nu); HIPCHK(hipGetLastError()); }
+      if (out) {
+        HIPCHK(hipMemcpyAsync(out + (c0 - u_begin) * topk, h->d_rec, (size_t)nu * topk * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+      }
     }
     return 0;
   }
   return recommend_general(h, u_begin, u_end, topk, out, nullptr, 0);
+}
+
+// The validation rows TOPN_Evaluation scores against (evaluation.hpp:118-120 builds them as a hashtable on every call): CSR over
+// the handle's users, items ascending and unique inside a row; copied to the device once per data set.
+int cdae_hip_set_test_rows(cdae_hip_t* h, const int64_t* test_row_ptr, const uint32_t* test_col) {
+  if (!h || !h->d_shared || !test_row_ptr) return fail("bad argument (cdae_hip_set_interactions first)");
+  HIPCHK(hipSetDevice(h->device));
+  const uint64_t U = h->U;
+  if (test_row_ptr[0] != 0) return fail("test_row_ptr[0] must be 0");
+  uint64_t with_rows = 0;
+  for (uint64_t u = 0; u < U; ++u) {
+    if (test_row_ptr[u + 1] < test_row_ptr[u]) return fail("test_row_ptr must be non-decreasing");
+    with_rows += test_row_ptr[u + 1] > test_row_ptr[u];
+    for (int64_t p = test_row_ptr[u] + 1; p < test_row_ptr[u + 1]; ++p)
+      if (test_col[p] <= test_col[p - 1]) return fail("test row %llu is not ascending and unique", (unsigned long long)u);
+  }
+  const uint64_t nnz = (uint64_t)test_row_ptr[U];
+  if (nnz && !test_col) return fail("bad argument");
+  for (uint64_t p = 0; p < nnz; ++p) if (test_col[p] >= (h->item_shard ? h->I_global : h->I)) return fail("test item id out of range");
+  CHK(quiesce(h));
+  void** old[] = {(void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out};
+  for (void** p : old) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+  CHK(dev_alloc(&h->d_test_ptr, U + 1));
+  CHK(dev_alloc(&h->d_test_col, std::max<uint64_t>(nnz, 1)));
+  CHK(dev_alloc(&h->d_topn_pu, U * 8));
+  CHK(dev_alloc(&h->d_topn_out, 16));
+  HIPCHK(hipMemcpy(h->d_test_ptr, test_row_ptr, (U + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  if (nnz) HIPCHK(hipMemcpy(h->d_test_col, test_col, nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+  h->test_users_with_rows = with_rows;
+  return 0;
+}
+
+// TOPN_Evaluation::evaluate (evaluation.hpp:113-181): every user's top-`topk` list over the unrated items (cdae_hip_recommend_all)
+// scored against the test rows on the device; rets = P@1 P@5 P@10 R@1 R@5 R@10 MAP@5 MAP@10 averaged over the users with test
+// items, summed in user order (the bits of a sequential host loop); hits = summed hit counts in the first 1 / 5 / 10 places.
+int cdae_hip_eval_topn(cdae_hip_t* h, uint32_t topk, double* rets8, uint64_t* hits3, uint32_t* ids_out) {
+  if (!h || !h->d_shared || !rets8) return fail("bad argument");
+  if (!h->d_test_ptr) return fail("cdae_hip_eval_topn: cdae_hip_set_test_rows first");
+  if (h->item_shard) return fail("cdae_hip_eval_topn applies to a whole model (item shards: cdae_hip_multi_eval_topn)");
+  if (h->test_users_with_rows == 0) return fail("no user has test items");
+  HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
+  if (!h->user_perm.empty()) {
+    // IMF / BPR block schedules keep their rows in training order: take the lists by user id, score them from a staged copy
+    std::vector<uint32_t> all((size_t)h->U * topk);
+    CHK(cdae_hip_recommend_all(h, 0, h->U, topk, all.data()));
+    if (ids_out) std::copy(all.begin(), all.end(), ids_out);
+    const uint32_t UC = (uint32_t)std::min<uint64_t>(h->U, EVAL_CHUNK);
+    if (h->rec_cap < (size_t)UC * topk) {
+      if (h->d_rec) HIPCHK(hipFree(h->d_rec));
+      h->d_rec = nullptr; h->rec_cap = 0;
+      CHK(dev_alloc(&h->d_rec, (size_t)UC * topk));
+      h->rec_cap = (size_t)UC * topk;
+    }
+    HIPCHK(hipMemsetAsync(h->d_topn_out, 0, 16 * sizeof(double), h->stream));
+    for (uint64_t c0 = 0; c0 < h->U; c0 += UC) {
+      const uint32_t nu = (uint32_t)std::min<uint64_t>(UC, h->U - c0);
+      HIPCHK(hipMemcpyAsync(h->d_rec, all.data() + c0 * topk, (size_t)nu * topk * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+      topn_chunk(h, topk, c0, nu);
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+  } else {
+    HIPCHK(hipMemsetAsync(h->d_topn_out, 0, 16 * sizeof(double), h->stream));
+    h->topn_active = true;
+    const int rc = cdae_hip_recommend_all(h, 0, h->U, topk, ids_out);
+    h->topn_active = false;
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(cdae::topn_sum_kernel, dim3(1), dim3(64), 0, h->stream, (const double*)h->d_topn_pu, h->U, h->d_topn_out);
+  HIPCHK(hipGetLastError());
+  double host[16];
+  HIPCHK(hipMemcpyAsync(host, h->d_topn_out, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int c = 0; c < 8; ++c) rets8[c] = host[c];
+  if (hits3) std::memcpy(hits3, host + 8, 3 * sizeof(uint64_t));
+  return 0;
 }
 
 int cdae_hip_recommend_user(cdae_hip_t* h, uint64_t uid, const uint32_t* rated_items, size_t n_rated, uint32_t topk, uint32_t* out) {

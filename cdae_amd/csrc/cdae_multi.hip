@@ -19,7 +19,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -71,8 +74,19 @@ local_sum_kernel(PeerPtrs peers, int n_peers, float* __restrict__ out, size_t n)
   }
 }
 
+// One process, one host thread per GPU (cdae_hip_multi_*): a thread whose shard fails inside an epoch must not leave its peers
+// waiting in a collective that will never complete.  It raises `failed` and ABORTS every communicator of the group
+// (ncclCommAbort is the one call RCCL allows from another thread while a rank is blocked) under the exclusive side of `mu`;
+// the other threads hold the shared side only while they ISSUE a collective and check the flag first, so nobody issues on a
+// communicator that is being aborted.
+struct GroupGuard {
+  std::shared_mutex mu;
+  std::atomic<int> failed{0};
+};
+
 // Exchange state of one handle (rank).
 struct Exchange {
+  GroupGuard* guard = nullptr;           // set while the shards of one process run an epoch on their own threads
   cdae_hip_t* h = nullptr;
   int world = 1, rank = 0;
   ncclComm_t comm = nullptr;             // RCCL communicator (nullptr: single rank, or a local group)
@@ -164,8 +178,13 @@ int boundary_reduce(Exchange* x) {
     HIPCHK(hipGetLastError());
   } else {
     HIPCHK(hipStreamWaitEvent(x->cstream, x->ev_staged, 0));
-    if (x->comm && x->world > 1) NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
-    else if (x->comm) NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));   // one rank: identity, same stream semantics
+    if (x->guard) {
+      std::shared_lock<std::shared_mutex> lk(x->guard->mu);
+      if (x->guard->failed.load()) return fail("a peer shard failed: epoch abandoned");
+      NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
+    } else if (x->comm) {
+      NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));   // (one rank: identity, same stream semantics)
+    }
   }
   HIPCHK(hipEventRecord(x->ev_reduced, x->cstream));
   x->pending = true;
@@ -302,6 +321,17 @@ struct cdae_hip_multi {
   std::vector<uint64_t> icut;
   float* d_tmp = nullptr; size_t tmp_cap = 0;      // single-device all-reduce: the sum before it is copied back to every shard
   hipEvent_t ev_done = nullptr;
+  bool comm_aborted = false;             // a shard's thread failed inside an epoch: the communicators were aborted so that its peers
+                                         // could unwind; the handle answers every later call with that error
+  std::string abort_reason;
+  GroupGuard guard;
+  // called by the failing shard's thread
+  void give_up() {
+    std::unique_lock<std::shared_mutex> lk(guard.mu);
+    if (guard.failed.exchange(1)) return;
+    for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+    comm_aborted = true;
+  }
 };
 
 namespace {
@@ -414,9 +444,16 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
     // one shard per GPU: one host thread per shard, like the user-sharded layout (a batch is ~15 launches per shard; from one
     // thread the HOST would pace N GPUs).  Every thread issues the same sequence — phases on its shard's main stream, the two
     // all-reduces on its own communicator of the ncclCommInitAll group — so the collectives pair up without a group call.
+    // (a failing shard's thread aborts the group's communicators so that its peers unwind: GroupGuard above)
     std::vector<int> rc(S, 0);
     std::vector<std::string> err(S);
     std::vector<std::thread> th;
+    auto all_reduce = [&](size_t s, float* buf, size_t n, hipStream_t st) -> int {
+      std::shared_lock<std::shared_mutex> lk(m->guard.mu);
+      if (m->guard.failed.load()) return fail("item shard %zu: a peer shard failed, epoch abandoned", s);
+      NCCLCHK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, m->comms[s], st));
+      return 0;
+    };
     auto run = [&](size_t s) -> int {
       cdae_hip_t* h = m->shard[s];
       HIPCHK(hipSetDevice(m->devices[s]));
@@ -425,10 +462,10 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
       for (size_t t = 0; t < plan.size(); ++t) {
         const Bt& b = plan[t];
         CHK(cdae_internal::fs_phase0(h, seed, epoch, b.s0, b.nb, b.c));
-        NCCLCHK(ncclAllReduce(hs[s], hs[s], (size_t)b.nb * Kp * blocks, ncclFloat32, ncclSum, m->comms[s], st));
+        CHK(all_reduce(s, hs[s], (size_t)b.nb * Kp * blocks, st));
         if (t + 1 < plan.size()) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[t + 1].s0, plan[t + 1].nb, plan[t + 1].c));
         CHK(cdae_internal::fs_phase1(h, b.s0, b.nb));
-        NCCLCHK(ncclAllReduce(hg[s], hg[s], (size_t)b.nb * Kp, ncclFloat32, ncclSum, m->comms[s], st));
+        CHK(all_reduce(s, hg[s], (size_t)b.nb * Kp, st));
         CHK(cdae_internal::fs_phase2(h, b.s0, b.nb));
       }
       return cdae_hip_synchronize(h);
@@ -436,10 +473,14 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
     for (size_t s = 0; s < S; ++s)
       th.emplace_back([&, s] {
         rc[s] = run(s);
-        if (rc[s]) err[s] = cdae_hip_last_error();
+        if (rc[s]) { err[s] = cdae_hip_last_error(); m->give_up(); }
       });
     for (std::thread& t : th) t.join();
-    for (size_t s = 0; s < S; ++s) if (rc[s]) return fail("item shard %zu: %s", s, err[s].c_str());
+    for (size_t s = 0; s < S; ++s)
+      if (rc[s]) {
+        if (m->comm_aborted) m->abort_reason = err[s];
+        return fail("item shard %zu: %s", s, err[s].c_str());
+      }
     return 0;
   }
   for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[0].s0, plan[0].nb, plan[0].c));
@@ -473,6 +514,7 @@ int item_encode_chunk(cdae_hip_multi* m, uint64_t u0, uint32_t nu, int mode, uin
 
 int check_multi(const cdae_hip_multi* m, bool need_data) {
   if (!m) return fail("null multi handle");
+  if (m->comm_aborted) return fail("the communicators of this handle were aborted after a shard failed (%s): destroy it", m->abort_reason.c_str());
   if (need_data && m->U == 0) return fail("cdae_hip_multi_set_interactions must be called first");
   return 0;
 }
@@ -676,11 +718,17 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
     std::vector<std::thread> th;
     for (size_t s = 0; s < S; ++s)
       th.emplace_back([&, s] {
+        xof(m->shard[s])->guard = &m->guard;
         rc[s] = shard_epoch(m, s, pl, seed, epoch);
-        if (rc[s]) err[s] = cdae_hip_last_error();         // thread-local: carry it to the caller's thread
+        if (rc[s]) { err[s] = cdae_hip_last_error(); m->give_up(); }   // thread-local message: carry it to the caller's thread; free the peers
+        xof(m->shard[s])->guard = nullptr;
       });
     for (std::thread& t : th) t.join();
-    for (size_t s = 0; s < S; ++s) if (rc[s]) return fail("shard %zu: %s", s, err[s].c_str());
+    for (size_t s = 0; s < S; ++s)
+      if (rc[s]) {
+        if (m->comm_aborted) { m->abort_reason = err[s]; for (cdae_hip_t* h : m->shard) xof(h)->comm = nullptr; }
+        return fail("shard %zu: %s", s, err[s].c_str());
+      }
   }
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
@@ -769,6 +817,49 @@ int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t
     const uint64_t a = std::max(u_begin, m->cut[s]), b = std::min(u_end, m->cut[s + 1]);
     if (b > a) CHK(cdae_hip_recommend_all(m->shard[s], a - m->cut[s], b - m->cut[s], topk, out + (a - u_begin) * topk));
   }
+  return 0;
+}
+
+// TOPN_Evaluation::evaluate over the shards (evaluation.hpp:113-181, evaluate_rec_list :183-219).  The merged top-k table of a
+// sharded model is assembled on the host (the item shards' candidates meet there), so the eight columns are summed there too:
+// one tight pass in user order — the same expressions, the same order of additions as cdae_hip_eval_topn's kernels and the
+// reference's sequential loop — instead of num_thread workers each building a vector per user.
+int cdae_hip_multi_eval_topn(cdae_hip_multi_t* m, const int64_t* test_row_ptr, const uint32_t* test_col, uint32_t topk,
+                             double* rets8, uint64_t* hits3, uint32_t* ids_out) {
+  CHK(check_multi(m, true));
+  if (!test_row_ptr || !rets8 || topk == 0) return fail("bad argument");
+  std::vector<uint32_t> own;
+  uint32_t* ids = ids_out;
+  if (!ids) { own.resize((size_t)m->U * topk); ids = own.data(); }
+  CHK(cdae_hip_multi_recommend_all(m, 0, m->U, topk, ids));
+  double n_test_users = 0;
+  for (uint64_t u = 0; u < m->U; ++u) n_test_users += test_row_ptr[u + 1] > test_row_ptr[u] ? 1. : 0.;
+  if (n_test_users == 0) return fail("no user has test items");
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t h1 = 0, h5 = 0, h10 = 0;
+  const uint32_t top = std::min<uint32_t>(20u, topk);
+  for (uint64_t u = 0; u < m->U; ++u) {
+    const int64_t t0 = test_row_ptr[u], t1 = test_row_ptr[u + 1];
+    if (t1 <= t0) continue;
+    const double nt = (double)(t1 - t0);
+    double r[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hit = 0, map5 = 0, map10 = 0;
+    for (uint32_t i = 0; i < top; ++i) {
+      if (std::binary_search(test_col + t0, test_col + t1, ids[u * topk + i])) {
+        hit += 1.;
+        if (i < 5) map5 += hit / (double)(i + 1);
+        if (i < 10) map10 += hit / (double)(i + 1);
+        h1 += i < 1; h5 += i < 5; h10 += i < 10;
+      }
+      if (i == 0) { r[0] = hit; r[3] = hit / nt; }
+      else if (i == 4) { r[1] = hit / 5.; r[4] = hit / nt; }
+      else if (i == 9) { r[2] = hit / 10.; r[5] = hit / nt; }
+    }
+    r[6] = map5 / std::min(5., nt);
+    r[7] = map10 / std::min(10., nt);
+    for (int c = 0; c < 8; ++c) acc[c] += r[c] / n_test_users;
+  }
+  for (int c = 0; c < 8; ++c) rets8[c] = acc[c];
+  if (hits3) { hits3[0] = h1; hits3[1] = h5; hits3[2] = h10; }
   return 0;
 }
 

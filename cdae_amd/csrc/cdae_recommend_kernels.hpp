@@ -169,4 +169,71 @@ recommend_mfma_kernel(HyperParams hp, const float* __restrict__ Z /* [nu x Kp] *
   }
 }
 
+// ---- TOPN metrics on the device (TOPN_Evaluation::evaluate evaluation.hpp:113-181, evaluate_rec_list :183-219) ------------------
+// The reference scores each user's top-10 list against the user's test items on num_thread host threads and averages the eight
+// columns P@1 P@5 P@10 R@1 R@5 R@10 MAP@5 MAP@10 over the users that have test items (:160-166).  Here the lists never leave the
+// device: topn_user_kernel turns the list of one user (a thread each) into that user's eight fp64 terms r[c] / n_test_users —
+// the same expressions in the same order as evaluate_rec_list, membership by binary search in the sorted test row — and
+// topn_sum_kernel adds the terms of all users IN USER ORDER, one lane per column, so that the eight means carry the bits of the
+// reference's sequential `rets[c] += r[c] / n` loop (users without test items contribute +0.0, which changes no bit of a
+// non-negative sum).  The integer hit counts at 1 / 5 / 10 are summed with atomics (order-free).
+__global__ void __launch_bounds__(256)
+topn_user_kernel(const uint32_t* __restrict__ rec, uint32_t topk, uint64_t u0, uint32_t nu, const int64_t* __restrict__ test_ptr,
+                 const uint32_t* __restrict__ test_col, double n_test_users, double* __restrict__ per_user,
+                 unsigned long long* __restrict__ hits) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nu) return;
+  const uint64_t u = u0 + slot;
+  const int64_t t0 = test_ptr[u], t1 = test_ptr[u + 1];
+  double r[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  if (t1 > t0) {
+    const double nt = (double)(t1 - t0);
+    const uint32_t top = topk < 20u ? topk : 20u;                       // evaluation.hpp:186,191
+    double hit = 0., map5 = 0., map10 = 0.;
+    uint32_t h1 = 0, h5 = 0, h10 = 0;
+    for (uint32_t i = 0; i < top; ++i) {
+      const uint32_t item = rec[(size_t)slot * topk + i];
+      int64_t lo = t0, hi = t1;                                         // first position with test_col >= item
+      while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (test_col[mid] < item) lo = mid + 1; else hi = mid; }
+      if (lo < t1 && test_col[lo] == item) {
+        hit += 1.;
+        if (i < 5) map5 += hit / (double)(i + 1);
+        if (i < 10) map10 += hit / (double)(i + 1);
+        h1 += i < 1; h5 += i < 5; h10 += i < 10;
+      }
+      if (i == 0) { r[0] = hit; r[3] = hit / nt; }
+      else if (i == 4) { r[1] = hit / 5.; r[4] = hit / nt; }
+      else if (i == 9) { r[2] = hit / 10.; r[5] = hit / nt; }
+    }
+    r[6] = map5 / (nt < 5. ? nt : 5.);
+    r[7] = map10 / (nt < 10. ? nt : 10.);
+    if (h1) atomicAdd(hits + 0, (unsigned long long)h1);
+    if (h5) atomicAdd(hits + 1, (unsigned long long)h5);
+    if (h10) atomicAdd(hits + 2, (unsigned long long)h10);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = r[c] / n_test_users;             // evaluation.hpp:162-166 divides per user, then adds
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) per_user[u * 8 + c] = r[c];
+}
+
+// out[c] = ((per_user[0][c] + per_user[1][c]) + per_user[2][c]) + ...  — one wavefront, lane c < 8 owns column c; 16 users'
+// terms are requested ahead of the dependent chain of fp64 adds
+__global__ void __launch_bounds__(64)
+topn_sum_kernel(const double* __restrict__ per_user, uint64_t num_users, double* __restrict__ out) {
+  const uint32_t c = threadIdx.x;
+  if (c >= 8) return;
+  double acc = 0.;
+  uint64_t u = 0;
+  for (; u + 16 <= num_users; u += 16) {
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = per_user[(u + j) * 8 + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += v[j];
+  }
+  for (; u < num_users; ++u) acc += per_user[u * 8 + c];
+  out[c] = acc;
+}
+
 }  // namespace cdae

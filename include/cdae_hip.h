@@ -52,8 +52,9 @@ extern "C" {
  * 6: cdae_hip_set_profiling_families
  * 7: default batch_users capped at 256 (was 512); cdae_hip_default_batch_users, cdae_hip_batch_users; cdae_hip_user_order (IMF / BPR
  *    block schedules train in activity-grouped order; their default is one user per block)
- * 8: cdae_hip_full_output_plan */
-#define CDAE_HIP_ABI_VERSION 8
+ * 8: cdae_hip_full_output_plan
+ * 9: cdae_hip_set_test_rows, cdae_hip_eval_topn, cdae_hip_multi_eval_topn (TOPN metrics on the device) */
+#define CDAE_HIP_ABI_VERSION 9
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -239,6 +240,19 @@ int cdae_hip_penalty_loss(cdae_hip_t* h, double* out);
 int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint32_t topk,
                            uint32_t* out);
 
+/* TOPN_Evaluation::evaluate (evaluation.hpp:113-181) with evaluate_rec_list (evaluation.hpp:183-219) on the device: the top-`topk`
+ * list of EVERY user over the items outside the user's train row (what cdae_hip_recommend_all returns) is scored against the
+ * user's validation row without leaving the GPU.  cdae_hip_set_test_rows hands the validation rows over once per data set — CSR
+ * over the handle's users, items ascending and unique inside a row (the uid -> {iid} table evaluation.hpp:118-120 rebuilds on
+ * every call); copied.  cdae_hip_eval_topn returns
+ *   rets[8] = P@1 P@5 P@10 R@1 R@5 R@10 MAP@5 MAP@10, each the sum over the users WITH test items of r / (number of such users),
+ *             added in user order: the bits of the reference's sequential loop (evaluation.hpp:160-166) in fp64;
+ *   hits[3] = hits in the first 1 / 5 / 10 places summed over all users (integers; may be NULL);
+ *   ids_out = the [num_users x topk] table itself (may be NULL: then nothing but 16 numbers crosses PCIe).
+ * topk is what the evaluation asks recommend() for (10, evaluation.hpp:145); only the first 20 places are scored (:186). */
+int cdae_hip_set_test_rows(cdae_hip_t* h, const int64_t* test_row_ptr, const uint32_t* test_col);
+int cdae_hip_eval_topn(cdae_hip_t* h, uint32_t topk, double* rets8, uint64_t* hits3, uint32_t* ids_out);
+
 /* recommend(uid, topk, rated_item_set) (cdae.hpp:162-196) for a rated set that is NOT the user's train row: the hidden
  * layer is encoded from `rated_items` (scale 1, cdae.hpp:169) and exactly those items are excluded (cdae.hpp:177-179).
  * Items need not be sorted; duplicates are an error.  out is [topk] uint32 on the host. */
@@ -367,6 +381,10 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
 int cdae_hip_multi_data_loss(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, double* out);
 int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out);
 int cdae_hip_multi_recommend_all(cdae_hip_multi_t* m, uint64_t u_begin, uint64_t u_end, uint32_t topk, uint32_t* out);
+/* cdae_hip_eval_topn for a sharded model: the shards' lists are merged on the host (cdae_hip_multi_recommend_all), the eight means
+ * are summed there in user order (same expressions and order of additions as the single-handle kernels) */
+int cdae_hip_multi_eval_topn(cdae_hip_multi_t* m, const int64_t* test_row_ptr, const uint32_t* test_col, uint32_t topk,
+                             double* rets8, uint64_t* hits3, uint32_t* ids_out);
 int cdae_hip_multi_get_param(cdae_hip_multi_t* m, uint32_t which, float* host, size_t count);
 int cdae_hip_multi_set_param(cdae_hip_multi_t* m, uint32_t which, const float* host, size_t count);
 

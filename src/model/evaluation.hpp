@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <iomanip>
@@ -109,6 +110,17 @@ class TOPN_Evaluation : public Evaluation<Model> {
       CHECK_EQ(num_users, sets->size());
     }
     Timer t;
+    if (self_rows) {
+      // a model that keeps its train rows on the GPU scores its own top-10 lists there (cdae_hip_eval_topn): same expressions, same
+      // order of additions as the loop below — the lists never cross PCIe and no per-user vector is built
+      double dev[8];
+      if (device_topn(model, val, dev, std::integral_constant<bool, has_device_topn<Model>::value>())) {
+        std::stringstream ds;
+        for (size_t c = 0; c < 8; ++c) ds << std::setw(8) << std::setprecision(5) << dev[c] << "|";
+        ds << std::setw(8) << std::setprecision(3) << t.elapsed();
+        return ds.str();
+      }
+    }
     std::vector<std::vector<double>> per_user(num_users, std::vector<double>(8, 0.));
     model.pre_recommend();                                         // evaluation.hpp:135
     dynamic_parallel_for(0, num_users, [&](size_t uid) {           // recommend() is called concurrently
@@ -142,6 +154,19 @@ class TOPN_Evaluation : public Evaluation<Model> {
     template <class> static std::false_type test(...);
     static const bool value = decltype(test<M>(0))::value;
   };
+  template <class M>
+  struct has_device_topn {
+    template <class T> static auto test(int) -> decltype(std::declval<const T&>().eval_topn_device(uint64_t(0), std::declval<const std::vector<int64_t>&>(),
+                                                                                                   std::declval<const std::vector<uint32_t>&>(), size_t(0),
+                                                                                                   static_cast<double*>(nullptr)), std::true_type());
+    template <class> static std::false_type test(...);
+    static const bool value = decltype(test<M>(0))::value;
+  };
+  static bool device_topn(const Model& model, const Rows& val, double* rets8, std::true_type) {
+    if (std::getenv("CDAE_HOST_TOPN")) return false;            // developer switch: the host loop (A/B, tests)
+    return model.eval_topn_device(val.generation, val.row_ptr, val.col, 10, rets8);
+  }
+  static bool device_topn(const Model&, const Rows&, double*, std::false_type) { return false; }
   static bool own_rows(const Model& model, const Data& train, std::true_type) { return model.trained_on(train); }
   static bool own_rows(const Model&, const Data&, std::false_type) { return false; }
   static std::vector<size_t> recommend_own(Model& model, size_t uid, std::true_type) { return model.recommend_train_row(uid, 10); }

@@ -11,6 +11,7 @@
 //   train_one_user_corruption (198-358)               cdae_hip_train_one_user_corruption
 //   data_loss (78-101) / penalty_loss (103-107)       cdae_hip_data_loss / cdae_hip_penalty_loss
 //   pre_recommend + recommend (162-196)               cdae_hip_recommend_all, then lock-free table reads
+//   TOPN_Evaluation::evaluate (evaluation.hpp:113-219) cdae_hip_set_test_rows + cdae_hip_eval_topn (eval_topn_device below)
 //   get_user_representations (148-159)                cdae_hip_encode
 //
 // Environment knobs (not in the reference): CDAE_BATCH_USERS (users per parameter snapshot; 1 = the
@@ -20,10 +21,11 @@
 // 0,1,2,3: Solver<CDAE>::train runs data-parallel over these GPUs through cdae_hip_multi_* — users sharded, shared
 // parameters exchanged by RCCL inside the library; a repeated id, e.g. 0,0, makes logical shards of one GPU),
 // CDAE_EXCHANGE_EVERY (0 = synchronous exchange at every step, the default; k = pipelined every k steps),
-// CDAE_LAYOUT=item_rows (the shards cut the ITEM rows instead of the users, every shard sees every user, the user node is sharded by
-// user: the exact single-GPU schedule — sampled decode, or with CDAE_FULL_OUTPUT=1 the full-output one, BASELINE configs[4]'s
-// layout — two small all-reduces per batch, no accuracy cost).
-// The default user-sharded delta exchange is NOT inside the accuracy envelope of the single-GPU schedule.
+// CDAE_LAYOUT (with CDAE_DEVICES): item_rows — THE DEFAULT — the shards cut the ITEM rows, every shard sees every user, the user node
+// is sharded by user: the exact single-GPU schedule (sampled decode, or with CDAE_FULL_OUTPUT=1 the full-output one, BASELINE
+// configs[4]'s layout), two small all-reduces per batch, no accuracy cost; users — user shards + exchange of the shared parameters'
+// deltas (the north star's partitioning): a throughput setting that is NOT inside the accuracy envelope of the single-GPU schedule
+// (DESIGN.md §7), taken only when asked for by name.
 #ifndef CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 #define CDAE_HOST_MODEL_RECSYS_CDAE_HPP_
 
@@ -116,13 +118,16 @@ class CDAE : public RecsysModelBase {
       CDAE_HIP_CHECK(cdae_hip_multi_create(&c, static_cast<int>(devices.size()), devices.data(), &raw));
       multi_.reset(raw, [](cdae_hip_multi_t* m) { cdae_hip_multi_destroy(m); });
       CDAE_HIP_CHECK(cdae_hip_multi_set_exchange(raw, static_cast<int>(env_u64("CDAE_EXCHANGE_EVERY", 0))));
-      const char* layout = std::getenv("CDAE_LAYOUT");      // "item_rows": the shards cut the item rows (exact single-GPU schedule)
-      item_rows_ = layout && std::string(layout) == "item_rows";
+      // the certified schedule is the default: item rows (exact single-GPU schedule); "users" selects the delta exchange by name
+      const char* layout = std::getenv("CDAE_LAYOUT");
+      CHECK(!layout || std::string(layout) == "item_rows" || std::string(layout) == "users") << "CDAE_LAYOUT must be item_rows or users";
+      item_rows_ = !(layout && std::string(layout) == "users");
       if (item_rows_) CDAE_HIP_CHECK(cdae_hip_multi_set_layout(raw, CDAE_LAYOUT_ITEM_ROWS));
       CDAE_HIP_CHECK(cdae_hip_multi_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
       CDAE_HIP_CHECK(cdae_hip_multi_init_params(raw, seed_));
-      if (item_rows_) LOG(INFO) << "CDAE: " << devices.size() << " item-row shards (CDAE_DEVICES, CDAE_LAYOUT=item_rows): the single-GPU schedule over item shards";
-      else LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES), exchange every " << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
+      if (item_rows_) LOG(INFO) << "CDAE: " << devices.size() << " item-row shards (CDAE_DEVICES; CDAE_LAYOUT=item_rows is the default): the single-GPU schedule over item shards";
+      else LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES, CDAE_LAYOUT=users: outside the single-GPU accuracy envelope), exchange every "
+                     << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
     } else {
       cdae_hip_t* raw = nullptr;
       CDAE_HIP_CHECK(cdae_hip_create(&c, devices.empty() ? static_cast<int>(env_u64("CDAE_DEVICE", 0)) : devices[0], &raw));
@@ -132,6 +137,7 @@ class CDAE : public RecsysModelBase {
     }
     epoch_ = 0;
     rec_.reset();
+    test_generation_ = std::make_shared<uint64_t>(0);          // a new handle holds no validation rows
   }
 
   // ---- training: cdae.hpp:136-146 -----------------------------------------------------------------------
@@ -238,6 +244,25 @@ class CDAE : public RecsysModelBase {
     for (size_t i = 0; i < topk; ++i) out[i] = t->ids[uid * topk + i];
     return out;
   }
+  // TOPN_Evaluation on the device (evaluation.hpp:113-219 -> cdae_hip_eval_topn): the validation rows go over once per data set
+  // (`generation` identifies their contents), the eight means come back; the top-10 table never leaves the GPU.  Sharded models:
+  // the lists meet on the host anyway (cdae_hip_multi_eval_topn sums there, in the same order).
+  bool eval_topn_device(uint64_t generation, const std::vector<int64_t>& val_ptr, const std::vector<uint32_t>& val_col, size_t topk,
+                        double* rets8) const {
+    std::lock_guard<std::mutex> lk(*mu_);
+    CHECK(ready()) << "reset() must be called first";
+    CHECK_EQ(val_ptr.size(), num_users_ + 1);
+    if (multi_) {
+      CDAE_HIP_CHECK(cdae_hip_multi_eval_topn(multi_.get(), val_ptr.data(), val_col.data(), static_cast<uint32_t>(topk), rets8, nullptr, nullptr));
+      return true;
+    }
+    if (*test_generation_ != generation || generation == 0) {
+      CDAE_HIP_CHECK(cdae_hip_set_test_rows(dev_.get(), val_ptr.data(), val_col.data()));
+      *test_generation_ = generation;
+    }
+    CDAE_HIP_CHECK(cdae_hip_eval_topn(dev_.get(), static_cast<uint32_t>(topk), rets8, nullptr, nullptr));
+    return true;
+  }
   // is `d` the data set this model was reset with?  (Evaluation: recommend_train_row answers for exactly those rows)
   bool trained_on(const Data& d) const { return train_generation_ != 0 && d.generation() == train_generation_; }
   // the train rows the model was reset with, as CSR (sorted item ids per user)
@@ -307,6 +332,7 @@ class CDAE : public RecsysModelBase {
   mutable std::shared_ptr<const Table> rec_;
   std::shared_ptr<const Csr> train_csr_;             // host copy of the train rows (recommend: is the caller's set the train row?)
   uint64_t train_generation_ = 0;                    // Data::generation() of the set reset() saw
+  std::shared_ptr<uint64_t> test_generation_ = std::make_shared<uint64_t>(0);   // ... of the validation rows the handle holds (shared with copies, like dev_)
   uint64_t seed_ = 0;
   uint32_t epoch_ = 0;
 };

@@ -67,6 +67,7 @@ class IMF : public RecsysModelBase {
     CDAE_HIP_CHECK(cdae_hip_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
     csr_ = csr;
     train_generation_ = data_->generation();
+    test_generation_ = std::make_shared<uint64_t>(0);          // a new handle holds no validation rows
     seed_ = std::getenv("CDAE_SEED") ? mf_env_u64("CDAE_SEED", 0) : Random::next_u64();
     CDAE_HIP_CHECK(cdae_hip_init_params(raw, seed_));
     epoch_ = 0;
@@ -88,10 +89,7 @@ class IMF : public RecsysModelBase {
     CHECK_LT(uid, num_users_); CHECK_LT(iid, num_items_);
     // the four parameter arrays come from the device ONCE per training epoch (a loop over (uid, iid) pairs would otherwise move
     // the whole model over PCIe per call); train_one_iteration / reset drop the copy
-    std::shared_ptr<const HostParams> p = host_params();
-    double s = p->ub[uid] + p->ib[iid];
-    for (size_t k = 0; k < num_dim_; ++k) s += static_cast<double>(p->u[uid * num_dim_ + k]) * p->v[iid * num_dim_ + k];
-    return s;
+    return score(*host_params(), uid, iid);
   }
   DMatrix get_user_vecs() { return matrix(CDAE_P_WU, num_users_); }      // imf.hpp:121-123
   DMatrix get_item_vecs() { return matrix(CDAE_P_W, num_items_); }       // imf.hpp:125-127
@@ -110,7 +108,35 @@ class IMF : public RecsysModelBase {
   std::vector<size_t> recommend(size_t uid, size_t topk, const std::unordered_map<size_t, double>& rated) const {
     CHECK_LT(uid, num_users_);
     if (is_train_row(uid, rated)) return recommend_train_row(uid, topk);
-    return RecsysModelBase::recommend(uid, topk, rated);
+    // the generic scan (recsys_model_base.hpp:77-104) with the parameters fetched ONCE for the call: predict_user_item_rating takes
+    // the model's lock and a shared_ptr copy per (user, item) pair, which serialised the evaluation threads on one mutex
+    const std::shared_ptr<const HostParams> p = host_params();
+    typedef std::pair<size_t, double> P;
+    Heap<P> heap(sort_by_second_desc<size_t, double>, topk);
+    for (size_t item = 0; item < num_items_; ++item) {
+      if (rated.count(item)) continue;
+      const P cand(item, score(*p, uid, item));
+      if (heap.size() < topk) heap.push(cand); else heap.push_and_pop(cand);
+    }
+    CHECK_EQ(heap.size(), topk);
+    const std::vector<P> sorted = heap.get_sorted_data();
+    std::vector<size_t> out(topk);
+    for (size_t i = 0; i < topk; ++i) out[i] = sorted[i].first;
+    return out;
+  }
+  // TOPN_Evaluation on the device (evaluation.hpp:113-219 -> cdae_hip_eval_topn): the validation rows go over once per data set
+  // (`generation` identifies their contents), the eight means come back; nothing else crosses PCIe
+  bool eval_topn_device(uint64_t generation, const std::vector<int64_t>& val_ptr, const std::vector<uint32_t>& val_col, size_t topk,
+                        double* rets8) const {
+    std::lock_guard<std::mutex> lk(*mu_);
+    CHECK(dev_ != nullptr) << "reset() must be called first";
+    if (*test_generation_ != generation || generation == 0) {
+      CHECK_EQ(val_ptr.size(), num_users_ + 1);
+      CDAE_HIP_CHECK(cdae_hip_set_test_rows(dev_.get(), val_ptr.data(), val_col.data()));
+      *test_generation_ = generation;
+    }
+    CDAE_HIP_CHECK(cdae_hip_eval_topn(dev_.get(), static_cast<uint32_t>(topk), rets8, nullptr, nullptr));
+    return true;
   }
 
  protected:
@@ -127,6 +153,11 @@ class IMF : public RecsysModelBase {
   }
   struct Csr { std::vector<int64_t> row_ptr; std::vector<uint32_t> col; };
   struct HostParams { std::vector<float> u, v, ub, ib; };
+  double score(const HostParams& p, size_t uid, size_t iid) const {           // imf.hpp:117-119
+    double s = p.ub[uid] + p.ib[iid];
+    for (size_t k = 0; k < num_dim_; ++k) s += static_cast<double>(p.u[uid * num_dim_ + k]) * p.v[iid * num_dim_ + k];
+    return s;
+  }
   bool is_train_row(size_t uid, const std::unordered_map<size_t, double>& rated) const {
     if (!csr_) return false;
     const int64_t a = csr_->row_ptr[uid], b = csr_->row_ptr[uid + 1];
@@ -185,6 +216,7 @@ class IMF : public RecsysModelBase {
   mutable std::shared_ptr<const HostParams> host_;   // parameters on the host for predict_user_item_rating; dropped when they change
   std::shared_ptr<const Csr> csr_;                   // the train rows the handle was reset with
   uint64_t train_generation_ = 0;
+  std::shared_ptr<uint64_t> test_generation_ = std::make_shared<uint64_t>(0);   // Data::generation() of the validation rows the handle holds (shared with copies, like dev_)
   uint64_t seed_ = 0;
   uint32_t epoch_ = 0;
 };

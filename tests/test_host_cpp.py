@@ -250,9 +250,10 @@ def test_reference_yelp_app_trains_cdae_full_output_k50(host_bins, tmp_path):
 
 @pytest.mark.gpu
 def test_reference_yelp_app_trains_data_parallel_through_the_c_abi(host_bins, tmp_path):
-    """CDAE_DEVICES=0,0: the UNMODIFIED yelp app drives Solver<CDAE>::train over two user shards through cdae_hip_multi_*
-    (logical shards of GPU 0 here; distinct ids = one shard per GPU with a library-owned RCCL communicator), synchronous
-    and pipelined exchange.  Loss and TOPN rows come from the sharded model; identical seeds give identical tables."""
+    """CDAE_DEVICES=0,0 CDAE_LAYOUT=users: the UNMODIFIED yelp app drives Solver<CDAE>::train over two user shards through
+    cdae_hip_multi_* (logical shards of GPU 0 here; distinct ids = one shard per GPU with a library-owned RCCL communicator),
+    synchronous and pipelined exchange.  Loss and TOPN rows come from the sharded model; identical seeds give identical tables.
+    The user-sharded delta exchange is taken only when asked for BY NAME (round 4: CDAE_DEVICES alone selects the item-rows layout)."""
     yelp = os.path.join(host_bins, "yelp")
     if not os.path.exists(yelp):
         pytest.skip("no build/yelp (reference sources were not present at build time)")
@@ -260,7 +261,8 @@ def test_reference_yelp_app_trains_data_parallel_through_the_c_abi(host_bins, tm
     for task in ("prepare", "split"):
         assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
     tables = []
-    for env in ({"CDAE_DEVICES": "0,0"}, {"CDAE_DEVICES": "0,0"}, {"CDAE_DEVICES": "0,0,0", "CDAE_EXCHANGE_EVERY": "2"}):
+    for env in ({"CDAE_DEVICES": "0,0", "CDAE_LAYOUT": "users"}, {"CDAE_DEVICES": "0,0", "CDAE_LAYOUT": "users"},
+                {"CDAE_DEVICES": "0,0,0", "CDAE_EXCHANGE_EVERY": "2", "CDAE_LAYOUT": "users"}):
         rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.4", "--scaled=true",
                        "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "32", **env})
         assert rc == 0, out[-3000:]
@@ -300,9 +302,9 @@ def test_reference_yelp_app_trains_full_output_in_the_item_rows_layout(host_bins
 
 @pytest.mark.gpu
 def test_reference_yelp_app_trains_the_sampled_decode_in_the_item_rows_layout(host_bins, tmp_path):
-    """CDAE_LAYOUT=item_rows + CDAE_DEVICES without CDAE_FULL_OUTPUT: the unmodified yelp app on the multi-GPU schedule that carries
-    the single-GPU accuracy claim (sampled decode over item shards; logical shards of GPU 0 here).  It is the single-GPU schedule,
-    so its `Train Loss` / TOPN table is the single-GPU run's."""
+    """CDAE_DEVICES alone (no CDAE_LAYOUT, no CDAE_FULL_OUTPUT): the unmodified yelp app takes the multi-GPU schedule that carries the
+    single-GPU accuracy claim — the sampled decode over item shards (logical shards of GPU 0 here) — BY DEFAULT; CDAE_LAYOUT=item_rows
+    names the same thing.  It is the single-GPU schedule, so its `Train Loss` / TOPN table is the single-GPU run's."""
     yelp = os.path.join(host_bins, "yelp")
     if not os.path.exists(yelp):
         pytest.skip("no build/yelp (reference sources were not present at build time)")
@@ -310,13 +312,15 @@ def test_reference_yelp_app_trains_the_sampled_decode_in_the_item_rows_layout(ho
     for task in ("prepare", "split"):
         assert run([yelp, f"--task={task}"], tmp_path)[0] == 255
     tables = []
-    for env in ({}, {"CDAE_DEVICES": "0,0,0,0", "CDAE_LAYOUT": "item_rows"}):
+    for env in ({}, {"CDAE_DEVICES": "0,0,0,0"}, {"CDAE_DEVICES": "0,0,0,0", "CDAE_LAYOUT": "item_rows"}):
         rc, out = run([yelp, "--task=test", "--method=CDAE", "--num_dim=50", "--loss_type=CE", "--cratio=0.5", "--scaled=true",
                        "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "64", **env})
         assert rc == 0, out[-3000:]
+        assert ("item-row shards" in out) == bool(env)
         rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
         assert len(rows) == 2 + 51
         tables.append(np.array([[float(x) for x in r.split("|")[2:10]] for r in rows[2:]]))
+    assert np.array_equal(tables[1], tables[2])                    # the default IS the item-rows layout
     loss_a, loss_b = tables[0][1:, 0], tables[1][1:, 0]
     assert np.abs(loss_b / loss_a - 1).max() < 2e-4                # the same schedule up to fp32 association of two sums
     assert np.abs(tables[1][:, 6] - tables[0][:, 6]).max() < 0.003  # Recall@10 column (300 users: one hit on one user = 0.0007)
