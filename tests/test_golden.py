@@ -136,3 +136,66 @@ def test_hip_reproduces_loss_curve(built, name):
     np.testing.assert_array_equal(rec[clear], g[f"{name}_rec"][clear])
     met = orc.eval_topn(rec, g["test_ptr"], g["test_col"])
     assert np.abs(met - g[f"{name}_metrics"]).max() < 0.02
+
+
+# ---- reference-sequenced mode: the reference's own generators in the reference's own order (tests/golden/make_ref_sequenced.py) ----
+REF_PARAMS = (("W", ob.P_W, cdae_amd.P_W), ("W_ag", ob.P_W_AG, cdae_amd.P_W_AG), ("Wu", ob.P_WU, cdae_amd.P_WU), ("Wu_ag", ob.P_WU_AG, cdae_amd.P_WU_AG),
+              ("b", ob.P_B, cdae_amd.P_B), ("b_ag", ob.P_B_AG, cdae_amd.P_B_AG), ("bp", ob.P_BP, cdae_amd.P_BP), ("bp_ag", ob.P_BP_AG, cdae_amd.P_BP_AG))
+
+
+def _ref_cfg(g):
+    c = {k: v for k, v in g["cfg"]}
+    return dict(num_dim=int(c["num_dim"]), loss_type=int(c["loss_type"]), beta=float(c["beta"]), corruption_ratio=float(c["corruption_ratio"]),
+                num_neg=int(c["num_neg"]), scaled=c["scaled"] == "True", learn_rate=float(c["learn_rate"]), lambda_=float(c["lambda_"]))
+
+
+def test_oracle_reproduces_the_reference_sequenced_fixture(built):
+    """srand(1) / mt19937_64 / unordered_map order -> the same initial values, the same draws for every user and the same
+    parameters after one epoch as the committed file (regression pin of oracle_ref_*: recsys_model_base.hpp:46-57,
+    random.hpp:34-37, cdae.hpp:112-120, 142, 217-220, 361-371)."""
+    g = np.load(os.path.join(HERE, "golden", "ref_sequenced_tiny.npz"), allow_pickle=True)
+    cfg = _ref_cfg(g)
+    mk = lambda: orc.Oracle(orc.OracleConfig(**cfg), int(g["num_users"]), int(g["num_items"]), g["train_ptr"], g["train_col"])  # noqa: E731
+    a, b = mk(), mk()
+    for o in (a, b):
+        o.ref_seed(int(g["mt_seed"]), int(g["rand_seed"]))
+        o.ref_init_params()
+    for name, w, _ in REF_PARAMS:
+        assert np.array_equal(a.get(w), g[f"init_{name}"].ravel())
+    pos, inp, neg = [], [], []
+    for u in range(int(g["num_users"])):
+        p, i, n = b.ref_draw_user(u)
+        pos.append(p); inp.append(i); neg.append(n)
+    assert np.array_equal(np.concatenate(pos), g["pos_order"])
+    assert np.array_equal(np.concatenate(inp), g["inputs"]) and np.array_equal(np.concatenate(neg), g["negatives"])
+    a.train_reference_sequenced()
+    for name, w, _ in REF_PARAMS:
+        np.testing.assert_allclose(a.get(w), g[f"final_{name}"].ravel(), rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_trains_on_the_references_own_draws(built):
+    """The HIP path fed the REFERENCE's draw sequence: every user's dropout mask and negatives as the reference's generators hand
+    them out (committed fixture: glibc rand() after srand(1), mt19937_64, the unordered_map's visiting order), one user at a time
+    through cdae_hip_train_one_user_corruption — the public per-user step of cdae.hpp:198-200 — starting from the rand()-drawn initial
+    values.  After the epoch the fp32 device parameters are the fixture's fp64 ones to 2e-4 of each parameter's range.  No oracle
+    code runs in this test."""
+    g = np.load(os.path.join(HERE, "golden", "ref_sequenced_tiny.npz"), allow_pickle=True)
+    cfg = _ref_cfg(g)
+    U, I = int(g["num_users"]), int(g["num_items"])
+    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=cfg["num_dim"], lt=cdae_amd.CROSS_ENTROPY, beta=cfg["beta"], corruption_ratio=cfg["corruption_ratio"],
+                                          num_neg=cfg["num_neg"], scaled=cfg["scaled"], learn_rate=cfg["learn_rate"], lambda_=cfg["lambda_"],
+                                          batch_users=1))
+    m.set_interactions(U, I, g["train_ptr"], g["train_col"])
+    m.init_params(1)
+    for name, _, w in REF_PARAMS:
+        m.set(w, g[f"init_{name}"])
+    tp, ip, nn = g["train_ptr"], g["in_ptr"], cfg["num_neg"]
+    for u in range(U):
+        negs = g["negatives"][tp[u] * nn:tp[u + 1] * nn]
+        m.train_one_user_corruption(u, g["inputs"][ip[u]:ip[u + 1]], negs)
+    for name, _, w in REF_PARAMS:
+        ref = g[f"final_{name}"].ravel()
+        err = np.abs(m.get(w).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max())
+        assert err < 2e-4, (name, err)
+    m.close()
