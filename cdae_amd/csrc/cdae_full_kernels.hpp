@@ -841,6 +841,228 @@ gemm1_loss_zreg_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf
 }
 
 // ------------------------------------------------------------------------------------------------
+// GEMM 1 of the K = 512 path, round 4 experiment (CDAE_GEMM1_PIPE=1; NOT the default — it measured no faster): the loss epilogue
+// issued under the matrix cores.
+//
+// gemm1_loss_zreg_kernel walks item tiles of 128 and every wavefront reaches a tile's loss epilogue — 64 x (exp, rcp, two packs)
+// per lane — at the same barrier, so ~40 % of the launch ran with the matrix cores idle (rocprofv3: MFMA busy 42 %).  A second
+// accumulator set does not fit beside the 128 registers of z fragments at two wavefronts per SIMD, so the tile is halved instead:
+// HALF-TILES of 64 items (two 32 x 32 accumulator tiles per wavefront) in TWO register sets.  While half-tile h is contracted into
+// one set, one eighth of half-tile h - 1's epilogue (a [4 users] group of one item block: bias, loss', bf16, one 8-byte write into an
+// LDS image) is issued behind every slice's MFMAs from the other set, and one 512-byte row of half-tile h - 2's image leaves for
+// G^T per wavefront and slice.  Staging: slices of 64 items x 64 k (8 KiB: one 1 KiB DMA instruction per wavefront), a ring of eight
+// stages with six slices in flight; per slice a wavefront issues exactly one DMA and (from the third half-tile on) one store, and two
+// bias loads per half-tile, so the counted `s_waitcnt vmcnt(N)` in front of every raw barrier is
+//   N = later slices in flight + stores issued since the awaited slice's DMA + the bias loads in that window.
+// Every element is the same sum over k in the same order as before (16-wide steps ascending) and the same loss expression: G^T is
+// bit-identical (test_gemm1_zreg_changes_no_bit covers this kernel too).
+constexpr int G1P_ITEMS = 64, G1P_STAGES = 8, G1P_AHEAD = 6;
+// developer builds (-DG1P_X_...=1: timing experiments, WRONG results): which part of a step costs what
+#ifndef G1P_X_NOSTAGE
+#define G1P_X_NOSTAGE 0
+#endif
+#ifndef G1P_X_NOMFMA
+#define G1P_X_NOMFMA 0
+#endif
+#ifndef G1P_X_NOEPI
+#define G1P_X_NOEPI 0
+#endif
+#ifndef G1P_X_NOSTORE
+#define G1P_X_NOSTORE 0
+#endif
+constexpr int G1P_STAGE_BYTES = G1P_ITEMS * 64 * 2;              // 8 KiB
+constexpr uint32_t G1P_IMG_RS = 528;                             // image row: 256 users bf16 + 16 B
+constexpr size_t gemm1_pipe_lds_bytes() { return (size_t)G1P_STAGES * G1P_STAGE_BYTES + 2 * (size_t)G1P_ITEMS * G1P_IMG_RS + 2 * 8 * 64 * sizeof(float); }
+
+__device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n) {     // n is wave-uniform
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+    case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0F7C); break;             // 12: the most this kernel ever has behind a slice
+  }
+}
+
+template <int LOSS>
+__global__ void __launch_bounds__(512)
+gemm1_loss_zreg_pipe_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf16* __restrict__ Db /* [Ip][512] */,
+                            const float* __restrict__ bp, __bf16* __restrict__ GT, uint32_t ldgt, uint32_t rows_live, uint32_t cols_live,
+                            uint32_t Ip, uint32_t user_tiles, uint32_t item_groups, uint32_t tiles_per_group) {
+  extern __shared__ __attribute__((aligned(1024))) char smemp[];
+  char* const img0 = smemp + G1P_STAGES * G1P_STAGE_BYTES;
+  char* const bias0 = img0 + 2 * G1P_ITEMS * G1P_IMG_RS;                 // [set][wavefront][64 items] floats: every wavefront keeps its own copy
+  const uint32_t lane = threadIdx.x % WAVE, wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // 0..7
+  uint32_t ut, ig;
+  {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    ut = j % user_tiles; ig = (j / user_tiles) * 8u + xcd;
+    if (ig >= item_groups) return;
+  }
+  const uint32_t n_tiles_all = Ip / 128u;
+  const uint32_t t_begin = ig * tiles_per_group, t_end = min(n_tiles_all, t_begin + tiles_per_group);
+  if (t_begin >= t_end) return;
+  const uint32_t H = (t_end - t_begin) * 2u, n_slices = H * 8u;          // half-tiles, slices
+  const uint32_t first_item = t_begin * 128u;
+  const uint32_t u_tile = ut * 256u;
+  const uint32_t f_row = lane & 31u, f_half = lane >> 5;
+
+  bf16x8 zf[32];
+  {
+    const __bf16* zr = Zb + (size_t)(u_tile + wid * 32u + f_row) * 512u + 8u * f_half;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) zf[kk] = *reinterpret_cast<const bf16x8*>(zr + 16 * kk);
+  }
+  // staging: slice sl = (half-tile, ks): wavefront w brings rows 8 w .. 8 w + 7 (one DMA instruction of 1 KiB)
+  const uint32_t st_r = wid * 8u + (lane >> 3), st_slot = lane & 7u;
+  const uint32_t st_col = 8u * (st_slot ^ ((st_r >> 1) & 7u));
+  auto stage = [&](uint32_t sl) {
+    const uint32_t item = first_item + (sl >> 3) * (uint32_t)G1P_ITEMS + st_r, ks = sl & 7u;
+    const __bf16* src = Db + (size_t)min(item, Ip - 1u) * 512u + ks * 64u + st_col;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smemp + (sl % (uint32_t)G1P_STAGES) * G1P_STAGE_BYTES + wid * 1024u), 16, 0, 0);
+  };
+  // b' of a half-tile's 64 items: one 4-byte-per-lane DMA instruction into this wavefront's own copy (no global load whose wait the
+  // compiler would place — it put vmcnt(0) in front of every use of a register loaded across the loop's back edge)
+  auto stage_bias = [&](uint32_t item_h, int set) {
+    const float* src = bp + min(item_h + lane, cols_live - 1u);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(bias0 + ((uint32_t)set * 8u + wid) * 256u), 4, 0, 0);
+  };
+  const uint32_t d_sw = (f_row >> 1) & 7u;
+  const uint32_t d_off0 = f_row * 128u, d_off1 = (32u + f_row) * 128u;
+  // bit 4 q + e: user u_tile + 32 wid + 8 q + 4 f_half + e of this lane's accumulator element is a live row of the block
+  uint32_t live_bits = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) live_bits |= (u_tile + wid * 32u + 8u * (uint32_t)(i >> 2) + 4u * f_half + (uint32_t)(i & 3) < rows_live ? 1u : 0u) << i;
+
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // the z fragments have landed: the counted waits below start from zero
+#pragma unroll
+  for (int q = 0; q < G1P_AHEAD; ++q) if ((uint32_t)q < n_slices) stage((uint32_t)q);
+
+  f32x16 acc[2][2];                                        // [register set][item block of 32]
+
+  // the loss of one accumulator element, masked to +0 outside the live rows / items (bit masks: v * 0 would leave -0 for y < 0)
+  auto loss_bits = [&](float a, float b, uint32_t mask) -> float {
+    const float y = a + b;
+    const float v = LOSS == 0 ? 2.f * y : fast_rcp(1.f + fast_exp(-y));
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & mask);
+  };
+  // one row of a finished image -> G^T (wavefront w, slice ks: row 8 ks + w; 64 lanes x 8 bytes = the 256 users of this workgroup)
+  auto store_row = [&](const char* img, uint32_t item_base, int ks) {
+    const uint32_t row = (uint32_t)ks * 8u + wid;
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(img + row * G1P_IMG_RS + lane * 8u);
+    *reinterpret_cast<bf16x4*>(GT + (size_t)(item_base + row) * ldgt + u_tile + lane * 4u) = v;
+  };
+
+  // A step of half-tile h in register set CUR: wait for slice sl, barrier, request slice sl + AHEAD, then per 16-wide k step two
+  // fragment reads, two MFMAs and — in program order BETWEEN them, so that it issues while the matrix pipe works — one element of
+  // half-tile h - 1's epilogue group (set PRV, item block ks / 4, user group ks % 4); the group's 8 bytes go to the image, one row
+  // of half-tile h - 2's image goes to G^T.
+#define G1P_PHASE(CUR, PRV)                                                                                                           \
+  do {                                                                                                                                \
+    const uint32_t item_h = first_item + h * (uint32_t)G1P_ITEMS;                                                                     \
+    char* const img_prev = img0 + (PRV) * (G1P_ITEMS * G1P_IMG_RS);           /* half-tile h - 1 is written here */                  \
+    const char* const img_out = img0 + (CUR) * (G1P_ITEMS * G1P_IMG_RS);      /* half-tile h - 2 leaves from here */                 \
+    const bool do_epi = h >= 1u, do_store = h >= 2u;                                                                                  \
+    float bprev[2] = {0.f, 0.f};                                                                                                      \
+    uint32_t nmask[2] = {0u, 0u};                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[CUR][j][r] = 0.f;                \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                                \
+      const uint32_t sl = h * 8u + (uint32_t)ks;                                                                                      \
+      const uint32_t later = min((uint32_t)G1P_AHEAD - 1u, n_slices - 1u - sl);                                                       \
+      const uint32_t stores = sl > 16u ? min((uint32_t)G1P_AHEAD, sl - 16u) : 0u;                                                     \
+      wait_vmcnt_at_most(later + stores + ((ks >= 1 && ks <= 6) ? 1u : 0u));                                                          \
+      if (ks == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         /* the previous phase's image writes, before anyone reads them */ \
+      __builtin_amdgcn_s_barrier();                                                                                                   \
+      if (!G1P_X_NOSTAGE && sl + (uint32_t)G1P_AHEAD < n_slices) stage(sl + (uint32_t)G1P_AHEAD);                                     \
+      if (ks == 0) {                                                                                                                  \
+        stage_bias(item_h, CUR);                                                                                                      \
+        if (do_epi) {                                                                                                                 \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                             \
+            bprev[j] = *reinterpret_cast<const float*>(bias0 + ((uint32_t)(PRV) * 8u + wid) * 256u + ((uint32_t)j * 32u + f_row) * 4u); \
+            nmask[j] = item_h - (uint32_t)G1P_ITEMS + (uint32_t)j * 32u + f_row < cols_live ? 0xFFFFFFFFu : 0u;                       \
+          }                                                                                                                           \
+        }                                                                                                                             \
+      }                                                                                                                               \
+      const char* base = smemp + (sl % (uint32_t)G1P_STAGES) * G1P_STAGE_BYTES;                                                       \
+      /* the epilogue element of each 16-wide k step sits BETWEEN that step's MFMAs in program order.  (Measured, round 4: this  */    \
+      /* hides nothing — 1.17 ms against the whole-tile kernel's 1.15 at 1 M items x 1024 users, 0.52 ms with the epilogue and the */   \
+      /* stores compiled out; the two blocks in opposite order on the two wavefronts of a SIMD: 2.4 ms.  Kept as an A/B build.)    */   \
+      float g[4] = {0.f, 0.f, 0.f, 0.f};                                                                                              \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                                 \
+        const uint32_t c = ((2u * (uint32_t)s + f_half) ^ d_sw) << 4;                                                                 \
+        const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(base + d_off0 + c);                                                       \
+        const bf16x8 fd1 = *reinterpret_cast<const bf16x8*>(base + d_off1 + c);                                                       \
+        if (!G1P_X_NOMFMA) {                                                                                                          \
+          acc[CUR][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[ks * 4 + s], fd0, acc[CUR][0], 0, 0, 0);                           \
+          acc[CUR][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[ks * 4 + s], fd1, acc[CUR][1], 0, 0, 0);                           \
+        } else { acc[CUR][0][s] += (float)fd0[0]; acc[CUR][1][s] += (float)fd1[0]; }                                                  \
+        if (!G1P_X_NOEPI) {                                                                                                           \
+          const uint32_t rmask = (uint32_t)((int32_t)(live_bits << (31 - (4 * (ks & 3) + s))) >> 31);                                 \
+          g[s] = loss_bits(acc[PRV][ks >> 2][4 * (ks & 3) + s], bprev[ks >> 2], nmask[ks >> 2] & rmask);                              \
+        }                                                                                                                             \
+      }                                                                                                                               \
+      if (do_epi && !G1P_X_NOEPI) {                                                                                                   \
+        const bf16x4 hb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};                                                   \
+        *reinterpret_cast<bf16x4*>(img_prev + ((uint32_t)(ks >> 2) * 32u + f_row) * G1P_IMG_RS +                                      \
+                                   (wid * 32u + 8u * (uint32_t)(ks & 3) + 4u * f_half) * 2u) = hb;                                    \
+      }                                                                                                                               \
+      if (do_store && !G1P_X_NOSTORE) store_row(img_out, item_h - 2u * (uint32_t)G1P_ITEMS, ks);                                      \
+    }                                                                                                                                 \
+  } while (0)
+
+  uint32_t h = 0;
+  for (; h + 1u < H; h += 2u) {
+    G1P_PHASE(0, 1);
+    ++h;
+    G1P_PHASE(1, 0);
+    --h;
+  }
+#undef G1P_PHASE
+  // H is even (tiles of 128 items = two half-tiles): the last half-tile H - 1 sits in set 1, H - 2's image (image 0) is complete
+  {
+    const uint32_t item_last = first_item + (H - 1u) * (uint32_t)G1P_ITEMS;
+    char* const img_a = img0;                                  // half-tile H - 2
+    char* const img_b = img0 + G1P_ITEMS * G1P_IMG_RS;         // half-tile H - 1 (half-tile H - 3 left from here during the last phase)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // (the last bias row has landed)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // H - 2's image is complete; everyone is done reading H - 3's
+    float blast[2];
+    uint32_t nlast[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      blast[j] = *reinterpret_cast<const float*>(bias0 + (8u + wid) * 256u + ((uint32_t)j * 32u + f_row) * 4u);
+      nlast[j] = item_last + (uint32_t)j * 32u + f_row < cols_live ? 0xFFFFFFFFu : 0u;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t rmask = (uint32_t)((int32_t)(live_bits << (31 - (4 * (c & 3) + e))) >> 31);
+        g[e] = loss_bits(acc[1][c >> 2][4 * (c & 3) + e], blast[c >> 2], nlast[c >> 2] & rmask);
+      }
+      const bf16x4 hb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
+      *reinterpret_cast<bf16x4*>(img_b + ((uint32_t)(c >> 2) * 32u + f_row) * G1P_IMG_RS + (wid * 32u + 8u * (uint32_t)(c & 3) + 4u * f_half) * 2u) = hb;
+      store_row(img_a, item_last - (uint32_t)G1P_ITEMS, c);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) store_row(img_b, item_last, c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // "TN" product for GEMM 2 of the K > 256 path:  C[m][n] = sum_c A[c][m] * Bm[c][n]  with BOTH operands stored contraction-row-major
 // — hg = G D as  sum_item G^T[item][user] * D[item][k]  straight from the two images the other launches already keep (G^T for
 // GEMM 3 / the row step, the row-major bf16 decoder image for GEMM 1).  With it GEMM 1 no longer writes G (2 GB per 1024-user

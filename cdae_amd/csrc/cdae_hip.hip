@@ -208,6 +208,8 @@ struct cdae_hip {
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
   bool gemm1_tiled = false;             // CDAE_GEMM1_TILED: GEMM 1 as the 256 x 256-tile kernel where gemm1_loss_zreg_kernel would run (A/B switch)
   bool gemm1_zreg_attr_set[2] = {false, false};   // dynamic-LDS attribute of gemm1_loss_zreg_kernel<LOSS> set on this handle's device
+  bool gemm1_whole_tiles = true;        // false with CDAE_GEMM1_PIPE=1: gemm1_loss_zreg_pipe_kernel (half-tiles, epilogue issued between the MFMAs: bit-identical, measured 2 % slower) where gemm1_loss_zreg_kernel runs (A/B switch)
+  bool gemm1_pipe_attr_set[2] = {false, false};
   bool fused_attr_set = false;          // dynamic-LDS attribute of this handle's full_decode_fused_kernel instance set (one K and loss per handle)
   bool gemm2_nt = false;                // CDAE_GEMM2_NT: hg = G D from G and D^T (gemm_nt_bf16_ldsw_kernel) where gemm_tn_bf16_kernel would read G^T and D (A/B switch)
   bool gemm_tn_attr_set = false;        // dynamic-LDS attribute of gemm_tn_bf16_kernel set on this handle's device
@@ -720,6 +722,20 @@ int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Ba
     const uint32_t tiles_per_group = (n_tiles + item_groups - 1) / item_groups;
     const dim3 grid(8u * user_tiles * ((item_groups + 7u) / 8u));
     const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY;
+    if (!h->gemm1_whole_tiles) {
+      // round 4 experiment (CDAE_GEMM1_PIPE=1): half-tiles of 64 items in two accumulator sets, the loss epilogue of one issued between the MFMAs of the next
+      if (!h->gemm1_pipe_attr_set[ce]) {
+        if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_pipe_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_pipe_lds_bytes()));
+        else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_pipe_lds_bytes()));
+        h->gemm1_pipe_attr_set[ce] = true;
+      }
+      if (ce)
+        hipLaunchKernelGGL(gemm1_loss_zreg_pipe_kernel<5>, grid, dim3(512), gemm1_pipe_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+                           (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+      else
+        hipLaunchKernelGGL(gemm1_loss_zreg_pipe_kernel<0>, grid, dim3(512), gemm1_pipe_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+                           (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+    } else {
     if (!h->gemm1_zreg_attr_set[ce]) {
       if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
       else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_zreg_lds_bytes()));
@@ -731,6 +747,7 @@ int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Ba
     else
       hipLaunchKernelGGL(gemm1_loss_zreg_kernel<0>, grid, dim3(512), gemm1_zreg_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
                          (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
+    }
   } else
     CHK(launch_gemm_lds<EPI_LOSS>(h, st, h->d_Zb, h->d_Db, Bp, Ip, Kp, Kp, Kp, Kp, ep, 1, 0));
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
@@ -1048,6 +1065,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm1_tiled = std::getenv("CDAE_GEMM1_TILED") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
+  h->gemm1_whole_tiles = std::getenv("CDAE_GEMM1_PIPE") == nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
   h->full_separate_copies = std::getenv("CDAE_FULL_SEPARATE_COPIES") != nullptr;

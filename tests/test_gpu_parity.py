@@ -741,11 +741,15 @@ def test_gemm1_zreg_changes_no_bit(built, monkeypatch, loss):
         m.close()
         return out
 
-    zreg = run()
+    zreg = run()                                   # gemm1_loss_zreg_kernel
+    monkeypatch.setenv("CDAE_GEMM1_PIPE", "1")
+    whole = run()                                  # round 4's gemm1_loss_zreg_pipe_kernel (half-tiles, epilogue between the MFMAs: A/B build, not faster)
+    monkeypatch.delenv("CDAE_GEMM1_PIPE")
     monkeypatch.setenv("CDAE_GEMM1_TILED", "1")
     tiled = run()
     for w in zreg:
         assert np.array_equal(zreg[w], tiled[w]), w
+        assert np.array_equal(whole[w], tiled[w]), w
         assert np.isfinite(zreg[w]).all()
 
 

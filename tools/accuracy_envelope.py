@@ -38,8 +38,8 @@ def fixtures(shape, K, loss, seeds):
     return out
 
 
-def run_single(d, seed, K, lt, B, epochs):
-    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER))
+def run_single(d, seed, K, lt, B, epochs, full_output=False):
+    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, full_output=full_output, **HYPER))
     m.reset(d, seed=seed)
     rec, loss, secs = [], [], 0.0
     for ep in range(epochs):
@@ -169,6 +169,34 @@ def run_sharded(d, seed, K, lt, B, epochs, shards, period, rule=0):
     return rec, loss, d.num_users * epochs / secs
 
 
+def full_output_envelope(args, lt):
+    """--full-output: the block schedule of the full-output decode (one summed step per decoder row per block of B users, DESIGN.md
+    §5b) against its B = 1 limit — the reference loop cdae.hpp:225-293 fed every unrated item — per seed: Recall@10 / reported loss
+    per epoch at every block size, the literal curve (committed fp64 fixture `*_full1_seed*.npz` when there is one, else the HIP
+    path at batch_users = 1), the first epoch at which a block size reaches the literal's best Recall@10, and users/s."""
+    for seed in (args.seeds or [20141119]):
+        d = synth.generate_shape(args.shape, seed=seed)
+        fx = os.path.join(ROOT, "tests", "golden", f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_full1_seed{seed}.npz")
+        ep = args.epochs or 20
+        if os.path.exists(fx):
+            f = np.load(fx, allow_pickle=True)
+            lit_r, lit_l, src = [float(x) for x in f["recall10"]], [float(x) for x in f["train_loss"]], "fp64 fixture"
+        else:
+            lit_r, lit_l, _ = run_single(d, seed, args.num_dim, lt, 1, args.literal_epochs or ep, full_output=True)
+            src = "hip batch_users=1"
+        best = max(lit_r)
+        print(json.dumps({"run": "full-output literal", "source": src, "shape": args.shape, "seed": seed, "recall10": [round(x, 5) for x in lit_r],
+                          "loss": [round(x, 1) for x in lit_l], "best_recall10": round(best, 5)}), flush=True)
+        for B in args.batch_users:
+            rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep, full_output=True)
+            n = min(len(rec), len(lit_r))
+            reach = next((i + 1 for i, r in enumerate(rec) if r >= best), None)
+            print(json.dumps({"run": "hip full-output", "shape": args.shape, "seed": seed, "batch_users": B, "recall10": [round(x, 5) for x in rec],
+                              "loss": [round(x, 1) for x in loss], "d_recall_vs_literal_same_epoch": [round(rec[i] - lit_r[i], 5) for i in range(n)],
+                              "epochs_to_literal_best": reach, "users_per_s": round(ups),
+                              "seconds_to_literal_best": None if reach is None else round(reach * d.num_users / ups, 4)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="ml10m")
@@ -181,8 +209,12 @@ def main():
     ap.add_argument("--period", type=int, nargs="+", default=[0], help="exchange period of the sharded runs (0 = synchronous)")
     ap.add_argument("--rule", type=int, default=0, help="0 sum, 1 touch-mean (synchronous only)")
     ap.add_argument("--warm-epochs", type=int, default=0, help="sharded runs: first N epochs on the single-GPU schedule (batch_users 256)")
+    ap.add_argument("--full-output", action="store_true", help="the full-output block schedule against its B = 1 limit (see full_output_envelope)")
+    ap.add_argument("--literal-epochs", type=int, default=0, help="--full-output without a fixture: epochs of the HIP batch_users = 1 run")
     args = ap.parse_args()
     lt = cdae_amd.CROSS_ENTROPY if args.loss == "CE" else cdae_amd.SQUARE
+    if args.full_output:
+        return full_output_envelope(args, lt)
     fx = fixtures(args.shape, args.num_dim, args.loss, args.seeds)
     if not fx:
         raise SystemExit("no fixture found (tests/golden/make_literal_curves.py makes them)")
