@@ -2501,6 +2501,13 @@ static int stage_own_rows(cdae_hip* h, uint64_t u0, uint32_t n, float* buf) {
                 buf + (size_t)(blk++) * n * h->Kp);
   return 0;
 }
+// block 0 = the users' input sums over this shard's rows, blocks 1.. = stage_own_rows' blocks — one launch (unit_sum_stage_kernel)
+static int sum_and_stage(cdae_hip* h, const float* hpart, const uint32_t* uptr, uint64_t u0, uint32_t n, float* buf) {
+  const float* ta = h->cfg.user_factor ? h->d_Wu : (h->cfg.linear_function ? h->d_Uu : nullptr);
+  const float* tb = h->cfg.user_factor && h->cfg.linear_function ? h->d_Uu : nullptr;
+  DISPATCH_NI(h->NI, cdae::unit_sum_stage_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->hp, hpart, uptr, n, u0, ta, tb, buf);
+  return 0;
+}
 // the gathered rows inside an all-reduced buffer (nullptr when the configuration has none)
 static const float* gathered_wu(const cdae_hip* h, const float* buf, uint32_t n) { return h->cfg.user_factor ? buf + (size_t)n * h->Kp : nullptr; }
 static const float* gathered_uu(const cdae_hip* h, const float* buf, uint32_t n) {
@@ -2537,8 +2544,7 @@ int fs_phase0(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_
     DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
                 h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Hpart,
                 (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user, (const uint32_t*)h->d_gpos);
-  DISPATCH_NI(h->NI, cdae::unit_sum_kernel, dim3((nb + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_Hpart, uptr, nb, h->d_Hsum);
-  CHK(stage_own_rows(h, s0, nb, h->d_Hsum));
+  CHK(sum_and_stage(h, h->d_Hpart, uptr, s0, nb, h->d_Hsum));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2689,8 +2695,7 @@ int ev_phase0(cdae_hip_t* h, uint64_t u0, uint32_t nu, int mode, uint32_t cidx, 
     DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
                 h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, u0, nu, mode, mode ? CDAE_STREAM_LOSS_CORRUPT : CDAE_STREAM_CORRUPT, cidx,
                 seed, epoch, h->d_hpart_eval, (const uint32_t*)nullptr, 0u, (const uint32_t*)h->d_unit_user, (const uint32_t*)h->d_gpos);
-  DISPATCH_NI(h->NI, cdae::unit_sum_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_hpart_eval, uptr, nu, h->d_hsum_eval);
-  CHK(stage_own_rows(h, u0, nu, h->d_hsum_eval));
+  CHK(sum_and_stage(h, h->d_hpart_eval, uptr, u0, nu, h->d_hsum_eval));
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1874,6 +1874,48 @@ unit_sum_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t*
   }
   vstore<NI>(Hsum + (size_t)slot * hp.Kp + lo, acc);
 }
+// Item shard, phase 0 in ONE launch (round 4; was unit_sum_kernel + one own_rows_stage_kernel per private matrix): block 0 of the
+// all-reduce buffer = the slot's input sum as above, blocks 1.. = the slot's rows of the private matrices the encode needs (Wu, then
+// Uu) when this shard owns the user, zeros otherwise — the same values in the same places, one launch boundary instead of two or three.
+template <int NI>
+__global__ void __launch_bounds__(256)
+unit_sum_stage_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t* __restrict__ uptr, uint32_t nb, uint64_t u0,
+                      const float* __restrict__ table_a, const float* __restrict__ table_b, float* __restrict__ out /* [blocks][nb][Kp] */) {
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  const uint32_t lane = threadIdx.x % WAVE;
+  if (slot >= nb) return;
+  const uint32_t lo = lane * NI;
+  // the rows of the private matrices first: their loads travel while the partial sums are added
+  const uint64_t uid = u0 + slot;
+  const bool own = cdae_xa::owns_user(uid, hp.own_u0, hp.own_u1);          // wave-uniform
+  float ra[NI], rb[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) ra[i] = rb[i] = 0.f;
+  if (own && table_a) vload<NI>(ra, table_a + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
+  if (own && table_b) vload<NI>(rb, table_b + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
+  for (uint32_t u = ub; u < ue; ++u) {
+    float part[NI];
+    vload<NI>(part, Hpart + (size_t)u * hp.Kp + lo);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[i] += part[i];
+  }
+  vstore<NI>(out + (size_t)slot * hp.Kp + lo, acc);
+  uint32_t blk = 1;
+  if (table_a) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ra[i] = cdae_xa::own_row_contribution(own, ra[i]);
+    vstore<NI>(out + ((size_t)(blk++) * nb + slot) * hp.Kp + lo, ra);
+  }
+  if (table_b) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rb[i] = cdae_xa::own_row_contribution(own, rb[i]);
+    vstore<NI>(out + ((size_t)blk * nb + slot) * hp.Kp + lo, rb);
+  }
+}
 // HG[slot] = sum over the n_parts slabs of HGpart[x][rows][Kp] (fixed order)
 template <int NI>
 __global__ void __launch_bounds__(256)

@@ -55,6 +55,7 @@ namespace {
 // recv[i] = sum over the peers' staged buffers, in shard order (deterministic; the single-device stand-in for ncclAllReduce)
 constexpr int MAX_LOCAL_PEERS = 16;
 struct PeerPtrs { const float* p[MAX_LOCAL_PEERS]; };
+struct PeerOuts { float* p[MAX_LOCAL_PEERS]; };
 __global__ void __launch_bounds__(256)
 local_sum_kernel(PeerPtrs peers, int n_peers, float* __restrict__ out, size_t n) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -70,6 +71,28 @@ local_sum_kernel(PeerPtrs peers, int n_peers, float* __restrict__ out, size_t n)
       float acc = peers.p[0][j];
       for (int r = 1; r < n_peers; ++r) acc += peers.p[r][j];
       out[j] = acc;
+    }
+  }
+}
+// the same sum, written IN PLACE to every peer's buffer by the launch itself (item-rows layout, logical shards: the all-reduce of
+// [batch x row stride] floats was one sum kernel + one device-to-device copy per shard — sixteen copy launches per batch at eight
+// shards, more stream time than the phases they separate).  An element is read from every peer and then written to every peer by
+// ONE thread, so the in-place form has no hazard.
+__global__ void __launch_bounds__(256)
+local_allreduce_kernel(PeerOuts bufs, int n_peers, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    float4 acc = *reinterpret_cast<const float4*>(bufs.p[0] + i);
+    for (int r = 1; r < n_peers; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(bufs.p[r] + i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    for (int r = 0; r < n_peers; ++r) *reinterpret_cast<float4*>(bufs.p[r] + i) = acc;
+  } else {
+    for (size_t j = i; j < n; ++j) {
+      float acc = bufs.p[0][j];
+      for (int r = 1; r < n_peers; ++r) acc += bufs.p[r][j];
+      for (int r = 0; r < n_peers; ++r) bufs.p[r][j] = acc;
     }
   }
 }
@@ -406,24 +429,17 @@ int all_reduce_bufs(cdae_hip_multi* m, const std::vector<float*>& bufs, size_t n
     return 0;
   }
   HIPCHK(hipSetDevice(m->devices[0]));
-  if (m->tmp_cap < n) {
-    if (m->d_tmp) HIPCHK(hipFree(m->d_tmp));
-    m->d_tmp = nullptr; m->tmp_cap = 0;
-    HIPCHK(hipMalloc((void**)&m->d_tmp, n * sizeof(float)));
-    m->tmp_cap = n;
-  }
   if (!m->ev_done) HIPCHK(hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming));
   hipStream_t s0 = cdae_internal::main_stream(m->shard[0]);
-  PeerPtrs pp{};
+  PeerOuts pp{};
   for (size_t s = 0; s < S; ++s) {
     Exchange* x = xof(m->shard[s]);
     HIPCHK(hipEventRecord(x->ev_staged, cdae_internal::main_stream(m->shard[s])));
     HIPCHK(hipStreamWaitEvent(s0, x->ev_staged, 0));
     pp.p[s] = bufs[s];
   }
-  hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, s0, pp, (int)S, m->d_tmp, n);
+  hipLaunchKernelGGL(local_allreduce_kernel, dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, s0, pp, (int)S, n);
   HIPCHK(hipGetLastError());
-  for (size_t s = 0; s < S; ++s) HIPCHK(hipMemcpyAsync(bufs[s], m->d_tmp, n * sizeof(float), hipMemcpyDeviceToDevice, s0));
   HIPCHK(hipEventRecord(m->ev_done, s0));
   for (size_t s = 1; s < S; ++s) HIPCHK(hipStreamWaitEvent(cdae_internal::main_stream(m->shard[s]), m->ev_done, 0));
   return 0;

@@ -30,6 +30,9 @@ SHAPES = {
     "cfg5_items": (20_000, 1_000_000, 2_000_000),
     # reduced configs[4] for the parity fixture: > 65 536 items (32-bit sort keys, 256-row GEMM tiles) at K = 512
     "cfg5_small": (256, 131_072, 25_600),
+    # accuracy envelope of the K = 512 full-output block schedule (tools/accuracy_envelope.py --full-output): the smallest item space
+    # that takes configs[4]'s launches (>= 32768 items: GEMM 3 fused with the row step) with enough users for Recall@10 to mean something
+    "cfg5_env": (16_384, 32_768, 1_638_400),
     "tiny": (300, 120, 9_000),
     "small": (4_000, 1_500, 240_000),
 }

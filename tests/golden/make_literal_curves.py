@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--loss", default="CE", choices=["CE", "SQUARE"])
     ap.add_argument("--full-output-batch", type=int, default=0,
                     help="> 0: the full-output block schedule (Oracle.train_full) with this many users per block instead of the literal one")
+    ap.add_argument("--full-output-literal", action="store_true",
+                    help="the B = 1 limit of the full-output decode — the reference loop cdae.hpp:225-293 fed EVERY unrated item as a negative "
+                         "(= --full-output-batch 1; file tag `full1`): what tools/accuracy_envelope.py --full-output and "
+                         "tests/test_gpu_accuracy.py measure the block schedule against")
     ap.add_argument("--data-seed", type=int, default=None,
                     help="seed of the synthetic DATA SET when it should differ from --seed (which then only keys the random streams: initial "
                          "values, dropout masks, negatives) — several stream seeds on one data set cost the GPU test one data generation")
@@ -51,6 +55,8 @@ def main():
                     help="> 0: Recall@10 over the first N users only (the fp64 top-10 of 480 000 x 17 700 x 200 is ~20 min of one core "
                          "per epoch; training and the reported loss always cover every user)")
     args = ap.parse_args()
+    if args.full_output_literal:
+        args.full_output_batch = 1
 
     data_seed = args.seed if args.data_seed is None else args.data_seed
     d = synth.generate_shape(args.shape, seed=data_seed)

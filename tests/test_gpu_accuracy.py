@@ -172,36 +172,84 @@ def test_item_rows_sampled_layout_holds_the_accuracy_bounds_at_ml10m_shape(built
 
 
 # ---- BASELINE configs[1]: Yelp-shape K=50 FULL-OUTPUT decode (bf16 MFMA), CE ---------------------------------------
-# The reference has no full-output training; the expected curve is the oracle's block schedule
-# (Oracle.train_full: every unrated item a negative with target 0, per-block summed decoder gradient, fp64) at the same
-# block size.  The HIP path rounds Z, D and g to bf16 for the three products (fp32 accumulate), so the tolerance is a
-# bf16 one: Recall@10 within 0.003, train loss within 1 %, per epoch.
+# The reference has no full-output training.  Two anchors, both committed fp64 fixtures of the oracle:
+#   * `yelp_k50_ce_full512_seed*.npz` — the BLOCK schedule at bench.py's block size (Oracle.train_full: every unrated item a negative
+#     with target 0, one summed AdaGrad step per decoder row per block of 512 users), 40 epochs: what the HIP kernels must compute.
+#     The HIP path rounds Z, D and g to bf16 for the three products (fp32 accumulate), so the tolerance is a bf16 one.
+#   * `yelp_k50_ce_full1_seed*.npz` — the B = 1 LIMIT, i.e. the reference's own loop (cdae.hpp:225-293) fed every unrated item, 30
+#     epochs: what "the reference's semantics" means for this north-star extension (tests/test_oracle.py pins full-output(1) == the
+#     literal step fed all unrated items).
+# Round 4 measured what relates them (tools/accuracy_envelope.py --full-output, DESIGN.md §5c, four seeds): NO block size above 1
+# follows the literal loop's trajectory — a block takes ONE step per decoder row where the loop takes B, so at equal epochs a larger
+# block is behind early (epoch 5: literal 0.154, B = 64 0.171, B = 512 0.065) and every block size ends ABOVE it (the literal loop
+# plateaus at Recall@10 0.20 after 30 epochs; blocks of 16 ... 256 reach 0.26, 512 reaches 0.254 at epoch 40 and is still rising).
+# The claim the bench block size can be held to is therefore ONE-SIDED and a mean over seeds: the block schedule reaches the literal
+# loop's 30-epoch best Recall@10 within a stated number of epochs and stays above it.
 FULL_FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "yelp_k50_ce_full512_seed*.npz")))
+FULL_LITERAL = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "yelp_k50_ce_full1_seed*.npz")))
+FULL_BENCH_BLOCK = 512                     # bench.py --full-output --shape yelp --num-dim 50 runs this block size (configs[1])
+FULL_EPOCHS_TO_LITERAL_BEST = 28           # measured 24 / 26 / 27 / 26 on the four seeds (fp64 oracle) — asserted per seed with two epochs of slack
+_full_curves = {}
+
+
+def full_curves_of(path):
+    if path not in _full_curves:
+        f = np.load(path, allow_pickle=True)
+        seed, K, B = int(f["seed"]), int(f["num_dim"]), int(f["full_output_batch"])
+        assert K == 50 and B == FULL_BENCH_BLOCK
+        d = synth.generate_shape("yelp", seed=seed)
+        assert d.nnz_train == int(f["nnz_train"])
+        m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, full_output=True, **HYPER))
+        m.reset(d, seed=seed)
+        m.set_test_rows(d.test_ptr, d.test_col)
+        rec, loss, probes = [], [], None
+        for ep in range(len(f["recall10"])):
+            m.train_one_iteration(seed, ep)
+            loss.append(m.current_loss(seed, ep))
+            rec.append(m.eval_topn(10)[0][5])
+        W = m.get(cdae_amd.P_W).astype(np.float64)
+        probes = (np.abs(W[f["probe_items"]] - f["W_rows"]).max() / float(f["W_absmax"]),
+                  np.abs(m.get(cdae_amd.P_B) - f["b"]).max() / max(1e-3, np.abs(f["b"]).max()))
+        m.close()
+        _full_curves[path] = (np.array(rec), np.asarray(f["recall10"]), np.array(loss), np.asarray(f["train_loss"]), probes, seed)
+    return _full_curves[path]
 
 
 @pytest.mark.parametrize("path", FULL_FIXTURES, ids=[os.path.basename(p)[:-4] for p in FULL_FIXTURES])
 def test_yelp_shape_full_output_k50_curve(built, path):
-    f = np.load(path, allow_pickle=True)
-    seed, K, B = int(f["seed"]), int(f["num_dim"]), int(f["full_output_batch"])
-    assert K == 50 and B == 512
-    d = synth.generate_shape("yelp", seed=seed)
-    assert d.nnz_train == int(f["nnz_train"])
-    m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, full_output=True, **HYPER))
-    m.reset(d, seed=seed)
-    rec, loss = [], []
-    for ep in range(len(f["recall10"])):
-        m.train_one_iteration(seed, ep)
-        loss.append(m.current_loss(seed, ep))
-        rec.append(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5])
-    rec, loss = np.array(rec), np.array(loss)
-    print(f"\nseed {seed}: recall@10 hip {np.round(rec, 5)} oracle {np.round(f['recall10'], 5)}; loss hip/oracle - 1 {np.round(loss / f['train_loss'] - 1, 5)}")
-    assert np.abs(rec - f["recall10"]).max() <= 0.003
-    assert np.abs(loss / f["train_loss"] - 1.0).max() <= 0.01
-    # parameters at the probes: bf16 operand rounding, 2e-2 of the parameter's range (as tests/test_gpu_parity.py)
-    W = m.get(cdae_amd.P_W).astype(np.float64)
-    assert np.abs(W[f["probe_items"]] - f["W_rows"]).max() <= 2e-2 * float(f["W_absmax"])
-    assert np.abs(m.get(cdae_amd.P_B) - f["b"]).max() <= 2e-2 * max(1e-3, np.abs(f["b"]).max())
-    m.close()
+    """schedule parity: the HIP block schedule IS the oracle's block schedule at the bench block size, epoch by epoch over 40 epochs"""
+    rec, ref_rec, loss, ref_loss, probes, seed = full_curves_of(path)
+    print(f"\nseed {seed}: max |recall@10 hip - oracle| {np.abs(rec - ref_rec).max():.5f} (first 10 epochs {np.abs(rec - ref_rec)[:10].max():.5f}); "
+          f"max |loss hip/oracle - 1| {np.abs(loss / ref_loss - 1).max():.5f}; probes W {probes[0]:.4f} b {probes[1]:.4f}")
+    # the first epochs: the bf16 tolerance of round 2 (0.003 / 1 %); over 40 epochs the rounding of 800 block steps accumulates and the
+    # steep part of the curve (epochs 20-35, +0.015 Recall@10 per epoch) turns a small lag into a visible difference: 0.01 / 1 %
+    assert np.abs(rec - ref_rec)[:10].max() <= 0.003
+    assert np.abs(rec - ref_rec).max() <= 0.01
+    assert np.abs(loss / ref_loss - 1.0).max() <= 0.01
+    assert probes[0] <= 3e-2 and probes[1] <= 3e-2
+
+
+def test_full_output_block_schedule_reaches_the_literal_loops_quality(built):
+    """the accuracy claim of the full-output bench line (config.accuracy): at the bench block size the mean-over-seeds Recall@10 is at
+    or above the literal B = 1 loop's 30-epoch best from epoch 28 on (one-sided, +-0.002 on the mean), every seed reaches ITS literal
+    twin's best within 28 epochs, and the block schedule never falls back below it afterwards"""
+    assert len(FULL_LITERAL) >= 4 and len(FULL_FIXTURES) >= 4
+    lit = {int(np.load(p, allow_pickle=True)["seed"]): np.load(p, allow_pickle=True)["recall10"] for p in FULL_LITERAL}
+    rows = []
+    for p in FULL_FIXTURES:
+        rec, _, _, _, _, seed = full_curves_of(p)
+        assert seed in lit, seed
+        best = float(lit[seed].max())
+        reach = next(i + 1 for i, r in enumerate(rec) if r >= best)
+        rows.append((seed, best, reach, rec))
+        assert reach <= FULL_EPOCHS_TO_LITERAL_BEST + 2, (seed, reach)
+        assert (rec[reach - 1:] >= best - 0.002).all(), seed
+    mean_rec = np.mean([r[3] for r in rows], axis=0)
+    mean_best = float(np.mean([r[1] for r in rows]))
+    print(f"\nfull-output, {FULL_BENCH_BLOCK} users per block, {len(rows)} seeds: literal loop's 30-epoch best Recall@10 {mean_best:.4f} (mean); block schedule "
+          f"epochs 10 / 20 / 28 / 30 / 40: {np.round(mean_rec[[9, 19, 27, 29, 39]], 4)}; epochs to the literal best per seed {[r[2] for r in rows]}")
+    assert (mean_rec[FULL_EPOCHS_TO_LITERAL_BEST - 1:] >= mean_best - 0.002).all()
+    assert mean_rec[-1] >= mean_best + 0.03          # and ends well above: 0.254 against 0.201
 
 
 # ---- reduced BASELINE configs[4]: K=512 full-output over > 65 536 items (three-GEMM path, 256-row tiles, 32-bit keys) --

@@ -81,3 +81,57 @@ def test_config5_item_space_a_pass_of_blocks(built, monkeypatch):
         scale = np.abs(old[w]).max() + 1e-30
         assert np.abs(new[w] - old[w]).max() / scale <= 2e-4, w
     assert (rec == rec_o).mean() >= 0.97          # (b' differs in its summation order: a tie can flip)
+
+
+def test_config5_at_its_stated_scale_ten_million_users_in_eight_item_shards(built):
+    """BASELINE configs[4] as BASELINE.json states it — 10 000 000 users x 1 000 000 items, K = 512, full-output bf16 decode, eight
+    shards in the item-rows layout — instantiated on ONE MI355X as eight logical shards (the driver's boxes have one GPU; on eight
+    devices each shard is one GPU's share).  20 stratified-uniform interactions per user (synth.generate_uniform: a scale run, not an
+    accuracy workload).  Checked: the memory the layout promises (the user node sharded by user: ~4.8 GiB per shard instead of 38 GiB
+    replicated; everything under 64 GiB), two 1024-user blocks train, the reported loss and every parameter read back are finite,
+    top-10 lists over the million items are valid, and the first two blocks leave the item-side parameters where ONE handle holding
+    those users leaves them (the layout is the single-GPU schedule; 5e-3 of range: a last-bit difference in z moves a bf16 product)."""
+    import torch
+    U, I, K, B = 10_000_000, 1_000_000, 512, 1024
+    d = synth.generate_uniform(U, I, per_user=20, seed=20141119)
+    assert d.num_users == U and d.num_items == I and d.nnz_train == 16 * U
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0,
+                              lambda_=0.01, using_adagrad=True, user_factor=True, batch_users=B, full_output=True)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    m = cdae_amd.MultiCDAE(cfg, devices=[0] * 8, item_rows=True)
+    m.reset(d, seed=7)
+    torch.cuda.synchronize()
+    used_gib = (free0 - torch.cuda.mem_get_info(0)[0]) / 2**30
+    cuts = m.shards()                                          # item ranges in this layout
+    assert len(cuts) == 8 and cuts[0][0] == 0 and cuts[-1][1] == I and all(b > a for a, b in cuts)
+    user_node_gib = 2 * U * K * 4 / 2**30                      # Wu + Wu_ag over all shards: 38.1 GiB in total, one eighth per shard
+    print(f"\n10 M users x 1 M items x K=512 in 8 item shards: {used_gib:.1f} GiB on the device ({used_gib / 8:.2f} per shard; user node "
+          f"{user_node_gib / 8:.2f} GiB per shard, {user_node_gib:.1f} if replicated)")
+    assert user_node_gib < used_gib < 64.0                     # (replicating the user node on eight shards would be 305 GiB)
+    st = m.train_users(7, 0, 0, 2 * B)
+    assert st.users == 2 * B and st.batches == 2
+    loss = m.current_loss(7, 0)
+    assert np.isfinite(loss) and loss > 0
+    rec = m.recommend_all(10, 0, 64)
+    assert rec.shape == (64, 10) and rec.max() < I
+    for u in range(64):
+        row = d.train_col[d.train_ptr[u]:d.train_ptr[u + 1]]
+        assert len(set(rec[u].tolist())) == 10 and not np.isin(rec[u], row).any()
+    got = {w: m.get(w) for w in (cdae_amd.P_W, cdae_amd.P_BP, cdae_amd.P_B)}
+    m.close()
+    for w in got:
+        assert np.isfinite(got[w]).all(), w
+    # the same two blocks on ONE handle that holds just those users (initial values and random streams are keyed by global user /
+    # item id, so they are the same numbers)
+    sub = d.user_range(0, 2 * B)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(sub, seed=7)
+    one.train_users(7, 0, 0, 2 * B)
+    for w in got:
+        ref = one.get(w)
+        err = float(np.abs(got[w] - ref).max()) / (1e-3 + float(np.abs(ref).max()))
+        assert err <= 5e-3, (w, err)
+    rec_one = one.recommend_all(10, 0, 64)
+    one.close()
+    assert (rec == rec_one).mean() >= 0.9

@@ -169,6 +169,71 @@ def run_sharded(d, seed, K, lt, B, epochs, shards, period, rule=0):
     return rec, loss, d.num_users * epochs / secs
 
 
+def run_hybrid(d, seed, K, lt, B, epochs, shards, hot):
+    """The hot-row / tail HYBRID of the data-parallel schedule, emulated at parameter level on one GPU (would
+    owner-computed popular rows bring user shards + delta all-reduce inside the single-GPU accuracy envelope?).
+    Per global step (every shard trains B of its users from the same replicated parameters):
+      (b) the user-sharded step as the product runs it — `shards` handles, cdae_hip_delta_stage / sum / _merge, synchronous;
+      (a) the SAME users through ONE handle that holds every user, shard range after shard range (batch_users = B): every item row
+          takes its examples strictly one after the other — what the owner of a row would compute over the global batch;
+      composed state = (b) for the tail rows of W / W_ag / b' / b'_ag, (a) for the `hot` most popular item rows, for the hidden bias
+      b / b_ag (the other strictly sequential chain) and for the user node; both sides continue from the composed state.
+    Optimistic by construction where it departs from a real implementation (the owner's chain sees z refreshed after every shard
+    range instead of once per global step; Wu comes from the exact side), so a FAILING envelope here closes the question."""
+    cuts = shard_cuts(d.train_ptr, d.num_users, shards)
+    ms = []
+    for r, (u0, u1) in enumerate(cuts):
+        sd = d.user_range(u0, u1)
+        m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER))
+        m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
+        m.init_params(seed)
+        ms.append(m)
+    a = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, **HYPER))
+    a.reset(d, seed=seed)
+    pop = np.bincount(d.train_col, minlength=d.num_items)
+    H = np.argsort(-pop, kind="stable")[:hot]
+    SHARED = (cdae_amd.P_W, cdae_amd.P_W_AG, cdae_amd.P_BP, cdae_amd.P_BP_AG)
+    sizes = [u1 - u0 for u0, u1 in cuts]
+    steps = -(-max(sizes) // B)
+    per = [-(-n // steps) for n in sizes]
+    rec, loss, secs = [], [], 0.0
+    for ep in range(epochs):
+        t0 = time.perf_counter()
+        for t in range(steps):
+            base = {w: ms[0].get(w) for w in SHARED + (cdae_amd.P_B, cdae_amd.P_B_AG)}          # replicas agree at a step's start
+            # (b): every shard's users from the common state; the summed deltas of the shared block
+            delta = {w: np.zeros_like(base[w], dtype=np.float64) for w in SHARED}
+            for r, m in enumerate(ms):
+                lo, hi = min(sizes[r], t * per[r]), min(sizes[r], (t + 1) * per[r])
+                if hi > lo:
+                    m.train_users(seed, ep, lo, hi)
+                    for w in SHARED:
+                        delta[w] += m.get(w).astype(np.float64) - base[w]
+            # (a): the same users, shard range after shard range, through the handle that holds everybody
+            for r, (u0, u1) in enumerate(cuts):
+                lo, hi = min(sizes[r], t * per[r]), min(sizes[r], (t + 1) * per[r])
+                if hi > lo:
+                    a.train_users(seed, ep, u0 + lo, u0 + hi)
+            comp = {w: (base[w].astype(np.float64) + delta[w]).astype(np.float32) for w in SHARED}
+            for w in SHARED:
+                exact = a.get(w)
+                comp[w][H] = exact[H]
+            comp[cdae_amd.P_B], comp[cdae_amd.P_B_AG] = a.get(cdae_amd.P_B), a.get(cdae_amd.P_B_AG)
+            wu, wu_ag = a.get(cdae_amd.P_WU), a.get(cdae_amd.P_WU_AG)
+            for w, v in comp.items():
+                a.set(w, v)
+            for r, (m, (u0, u1)) in enumerate(zip(ms, cuts)):
+                for w, v in comp.items():
+                    m.set(w, v)
+                m.set(cdae_amd.P_WU, wu[u0:u1]); m.set(cdae_amd.P_WU_AG, wu_ag[u0:u1])
+        secs += time.perf_counter() - t0
+        loss.append(a.current_loss(seed, ep))
+        rec.append(float(orc.eval_topn(a.recommend_all(10), d.test_ptr, d.test_col)[5]))
+    for m in ms + [a]:
+        m.close()
+    return rec, loss, d.num_users * epochs / secs
+
+
 def full_output_envelope(args, lt):
     """--full-output: the block schedule of the full-output decode (one summed step per decoder row per block of B users, DESIGN.md
     §5b) against its B = 1 limit — the reference loop cdae.hpp:225-293 fed every unrated item — per seed: Recall@10 / reported loss
@@ -209,6 +274,8 @@ def main():
     ap.add_argument("--period", type=int, nargs="+", default=[0], help="exchange period of the sharded runs (0 = synchronous)")
     ap.add_argument("--rule", type=int, default=0, help="0 sum, 1 touch-mean (synchronous only)")
     ap.add_argument("--warm-epochs", type=int, default=0, help="sharded runs: first N epochs on the single-GPU schedule (batch_users 256)")
+    ap.add_argument("--hybrid-hot", type=int, default=-1, help="--shards N: the hot-row / tail hybrid (run_hybrid) with this many owner-computed "
+                    "popular rows (0: only b and the user node are exact)")
     ap.add_argument("--full-output", action="store_true", help="the full-output block schedule against its B = 1 limit (see full_output_envelope)")
     ap.add_argument("--literal-epochs", type=int, default=0, help="--full-output without a fixture: epochs of the HIP batch_users = 1 run")
     args = ap.parse_args()
@@ -228,7 +295,9 @@ def main():
         for shards in args.shards:
             for period in (args.period if shards > 1 else [0]):
                 for B in args.batch_users:
-                    if shards == 1:
+                    if shards > 1 and args.hybrid_hot >= 0:
+                        rec, loss, ups = run_hybrid(d, seed, args.num_dim, lt, B, ep, shards, args.hybrid_hot)
+                    elif shards == 1:
                         rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep)
                     elif args.rule == 0:
                         rec, loss, ups = run_multi(d, seed, args.num_dim, lt, B, ep, shards, period, args.warm_epochs)
@@ -236,7 +305,7 @@ def main():
                         rec, loss, ups = run_sharded(d, seed, args.num_dim, lt, B, ep, shards, period, args.rule)
                     dr = np.abs(np.array(rec) - ref_r)
                     dl = np.array(loss) / ref_l - 1.0
-                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "rule": args.rule, "warm_epochs": args.warm_epochs if shards > 1 else 0, "batch_users": B,
+                    print(json.dumps({"run": "hip", "seed": seed, "shards": shards, "period": period, "rule": args.rule, "hybrid_hot": args.hybrid_hot, "warm_epochs": args.warm_epochs if shards > 1 else 0, "batch_users": B,
                                       "recall10": [round(x, 5) for x in rec], "abs_d_recall": [round(float(x), 5) for x in dr],
                                       "max_abs_d_recall": round(float(dr.max()), 5), "rel_d_loss": [round(float(x), 4) for x in dl],
                                       "users_per_s": round(ups)}), flush=True)
