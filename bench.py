@@ -500,6 +500,15 @@ def bench_item_rows(args, rank, world):
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
+    # per-kernel record (untimed pass behind the timed region): HIP events around shard 0's decode / row launches of a few batches
+    model.shard_stats(0)
+    model.shard_profiling(0, 1, [3, 5])
+    run(args.warmup + args.steps, min(8, args.steps))
+    st0 = model.shard_stats(0)
+    model.shard_profiling(0, 0)
+    k_launches = max(1, int(st0.launches_decode))
+    ms_decode0, ms_rows0 = st0.ms_decode / k_launches, st0.ms_input / k_launches
+    i0, i1 = model.shards()[0]
     n_gpus = len(set(devices))
     Kp = 64 * (1 if K <= 64 else 2 if K <= 128 else 4 if K <= 256 else 8)
     par = f"item-rows x{len(devices)}" + (" (logical shards of one GPU)" if args.logical_shards else "")
@@ -510,8 +519,17 @@ def bench_item_rows(args, rank, world):
         metric = f"users/sec (whole node) K={K} {args.shape}-shape full-output, item-rows layout"
         work = "FULL-OUTPUT decode, CE loss, AdaGrad, q=0.5 scaled"
         accuracy = "the single-GPU full-output schedule exactly (tests/test_gpu_multi.py: parameters within 5e-3 of range of the single handle)"
+        I0, Bp0 = float(i1 - i0), float(-(-B // 256) * 256)
+        shard0 = {"item_rows": int(i1 - i0), "decode_family_ms": ms_decode0, "row_family_ms": ms_rows0,
+                  "decode_mfma_floor_ms": 4.0 * K * I0 * B / (MFMA_PEAK_TFLOPS * 1e12) * 1e3,
+                  "decode_hbm_floor_ms": (4.0 * I0 * Kp + 4.0 * I0 * Bp0) / (HBM_PEAK_GBS * 1e9) * 1e3,
+                  "rows_mfma_floor_ms": 2.0 * K * I0 * B / (MFMA_PEAK_TFLOPS * 1e12) * 1e3,
+                  "rows_hbm_floor_ms": (I0 * Kp * 18.0 + 2.0 * I0 * Bp0) / (HBM_PEAK_GBS * 1e9) * 1e3,
+                  "note": "shard 0's own launches over its item rows (HIP events, untimed pass): forward + loss' + hidden-gradient products ('decode') and "
+                          "GEMM 3 + row steps ('row'), each beside its two floors (algorithmic flops at the bf16 peak, algorithmic bytes at 8 TB/s)"}
         roofline = {"bound": "mfma", "kernel": "whole step per GPU (three bf16 products over the local item rows + row steps + replicated hidden layer)",
-                    "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None}
+                    "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                    "shard0_launches": shard0}
     else:
         ex_per_batch = data.nnz_train * 6.0 / n_batches
         comp = compulsory_decode_bytes(K, Kp, data.num_items, ex_per_batch, B) / n_gpus      # every GPU moves its share of the rows once
@@ -527,7 +545,13 @@ def bench_item_rows(args, rank, world):
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "frac_definition": "this GPU's share of the decode's compulsory bytes / WHOLE step time / HBM peak — a lower bound of the "
                                        "decode kernel's own fraction; the step is bound by two latency-bound all-reduces and the longest row "
-                                       "chain, not by bandwidth (DESIGN.md §7b cost model)"}
+                                       "chain, not by bandwidth (DESIGN.md §7b cost model)",
+                    # the decode launch of shard 0 on its own (HIP events, untimed pass behind the timed region): its rows' compulsory bytes / its time
+                    "shard0_decode": {"item_rows": int(i1 - i0), "avg_launch_ms": ms_decode0,
+                                      "compulsory_bytes": compulsory_decode_bytes(K, Kp, int(i1 - i0), ex_per_batch * (i1 - i0) / data.num_items, B),
+                                      "frac": (compulsory_decode_bytes(K, Kp, int(i1 - i0), ex_per_batch * (i1 - i0) / data.num_items, B) / (ms_decode0 * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                               if ms_decode0 > 0 else None),
+                                      "note": "examples of shard 0 estimated as its share of the item rows (negatives are uniform over items)"}}
     out = {"metric": metric,
            "value": users / elapsed, "unit": "users/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

@@ -521,6 +521,22 @@ class MultiCDAE:
     def init_params(self, seed: int):
         _chk(self.lib, self.lib.cdae_hip_multi_init_params(self.h, seed))
 
+    def shard_profiling(self, shard: int, period: int, families=None):
+        """cdae_hip_set_profiling (+ _families) on ONE shard's handle: HIP events around that shard's decode / row launches"""
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_multi_shard(self.h, shard, C.byref(h), None, None))
+        _chk(self.lib, self.lib.cdae_hip_set_profiling(h, period))
+        if families is not None:
+            _chk(self.lib, self.lib.cdae_hip_set_profiling_families(h, sum(1 << f for f in families)))
+
+    def shard_stats(self, shard: int) -> Stats:
+        """the counters and HIP-event kernel times ONE shard's handle accumulated since they were last collected"""
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_multi_shard(self.h, shard, C.byref(h), None, None))
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_collect_stats(h, C.byref(st)))
+        return st
+
     def shards(self):
         """[(u_begin, u_end)] of every shard"""
         out = []

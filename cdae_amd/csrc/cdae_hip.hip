@@ -1203,7 +1203,10 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint64_t nblk = (U + h->B - 1) / h->B;
     std::vector<uint32_t> blk(nblk);
     std::iota(blk.begin(), blk.end(), 0u);
-    std::stable_sort(blk.begin(), blk.end(), [](uint32_t a, uint32_t b) { return (uint32_t)(a * 2654435761u) < (uint32_t)(b * 2654435761u); });
+    // the short last group (U % B users, the least active) stays LAST: make_plan cuts batches at multiples of B from position 0, so
+    // a short group in the middle made every later batch straddle two unrelated activity groups and last as long as the heavier one
+    const uint64_t shuffled = (U % h->B) ? nblk - 1 : nblk;
+    std::stable_sort(blk.begin(), blk.begin() + shuffled, [](uint32_t a, uint32_t b) { return (uint32_t)(a * 2654435761u) < (uint32_t)(b * 2654435761u); });
     h->user_perm.reserve(U);
     for (uint32_t k : blk)
       for (uint64_t t = (uint64_t)k * h->B; t < std::min<uint64_t>(U, (uint64_t)(k + 1) * h->B); ++t) h->user_perm.push_back(by_len[t]);
@@ -1597,6 +1600,12 @@ int cdae_hip_get_param(cdae_hip_t* h, uint32_t which, float* host, size_t count)
 
 int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, size_t* padded_count) {
   if (!h || !h->d_shared || which >= CDAE_P_COUNT || !device_ptr) return fail("bad argument");
+  const bool user_indexed = which == CDAE_P_WU || which == CDAE_P_WU_AG || which == CDAE_P_UU || which == CDAE_P_UU_AG || which == CDAE_P_UB || which == CDAE_P_UB_AG;
+  if (user_indexed && !h->user_perm.empty())
+    return fail("cdae_hip_param_device_ptr: the user-indexed arrays of an IMF / BPR block-schedule handle are stored in TRAINING order "
+                "(cdae_hip_user_order), not by user id: use cdae_hip_get_param / cdae_hip_set_param");
+  // the pointer is writable: whoever writes the parameters through it must find the full-output path re-imaging the decoder
+  h->db_valid = h->db_rows_valid = false;
   *device_ptr = h->P(which);
   if (padded_count) *padded_count = h->cnt[which];
   return 0;
@@ -2567,7 +2576,10 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
     DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, wu_b, h->P(CDAE_P_B),
                 (const uint32_t*)h->d_iota, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, uu_b, h->d_Ssum);
     HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+    Prof pr;                                                  // (cdae_hip_set_profiling on a shard's handle: the decode launch of this shard's rows)
+    CHK(pr.begin(h, F_DECODE, st, h->seq));
     CHK(launch_decode(h, x));
+    CHK(pr.end());
     // local hidden gradient: the user's examples on THIS shard's rows (the others are VOID), partial rows per unit of the whole rows
     const uint32_t n_gunits = gunits_of(h, bt), halves = h->gather_halves;
     const uint32_t* guptr = h->d_gunit_ptr + s0;
@@ -2608,7 +2620,10 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
 #undef FS_FUSED2
     parts = slices; rows = nb;
   } else {
+    Prof prd;
+    CHK(prd.begin(h, F_DECODE, st, h->seq));
     CHK(full_products_k512(h, st, x, bt, nb, &parts, &rows));      // the single handle's launches over this shard's item rows
+    CHK(prd.end());
   }
   // local hidden gradient of the batch, raw: the shards' sums are all-reduced before delta is formed
   DISPATCH_NI(h->NI, slab_sum_kernel, grid_users, blk, 0, st, h->hp, h->d_HGpart, parts, rows, nb, h->d_HG);
@@ -2657,6 +2672,8 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
     CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp, Bp, e3, 1, 1));
   }
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
+  Prof pri;
+  CHK(pri.begin(h, F_INPUT, st, h->seq));
   if (rows_fused)      // dD = G^T Z and the row steps from its accumulators, the row-major bf16 image left current
     CHK(launch_rows_fused(h, st, x, nb, h->d_Db));
   else if (I >= 32768u)
@@ -2667,6 +2684,7 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
     DISPATCH_NI(h->NI, full_rows_kernel, dim3(I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched);
+  CHK(pri.end());
   h->db_valid = false;
   h->db_rows_valid = rows_fused;                                 // the fused row step imaged every decoder row it stepped
   h->join_pending = true;

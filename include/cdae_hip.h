@@ -166,6 +166,10 @@ int cdae_hip_init_params(cdae_hip_t* h, uint64_t seed);
 /* dense [rows x num_dim] (or [n]) fp32 host arrays, unpadded */
 int cdae_hip_set_param(cdae_hip_t* h, uint32_t which, const float* host, size_t count);
 int cdae_hip_get_param(cdae_hip_t* h, uint32_t which, float* host, size_t count);
+/* The device array itself (row stride cdae_hip_row_stride(), padded_count elements).  The pointer is WRITABLE: the call marks the
+ * full-output path's bf16 images of the decoder stale, so a caller that writes parameters through it trains on what it wrote (write
+ * before the next training call, not during one).  Refused for the user-indexed arrays (Wu, Uu, user bias) of an IMF / BPR handle with
+ * batch_users > 1, whose rows are stored in training order (cdae_hip_user_order), not by user id. */
 int cdae_hip_param_device_ptr(cdae_hip_t* h, uint32_t which, void** device_ptr, size_t* padded_count);
 
 /* One pass over users [u_begin, u_end) x num_corruptions in batches of batch_users

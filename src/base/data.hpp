@@ -261,12 +261,34 @@ class Data {
     info_->feature_group_infos_.resize(ng);
     for (auto& g : info_->feature_group_infos_) g.read(i);
     uint64_t n = 0, uniform = 0; io_detail::get(i, n); io_detail::get(i, uniform); io_detail::get(i, uniform_label_);
+    CHECK(i.good()) << "truncated cache (header)";
+    {
+      // a corrupt count must not drive a huge resize, and a truncated file must not leave zero-filled columns behind (user 0 / item 0
+      // are valid ids: they would train silently on wrong data)
+      const std::istream::pos_type here = i.tellg();
+      if (here != std::istream::pos_type(-1)) {
+        i.seekg(0, std::ios::end);
+        const uint64_t left = static_cast<uint64_t>(i.tellg() - here);
+        i.seekg(here);
+        const uint64_t need = n * (2 * sizeof(uint32_t) + (uniform ? 0 : sizeof(double)));
+        CHECK(n <= left && need <= left) << "cache claims " << n << " ratings but only " << left << " bytes follow: truncated or corrupt";
+      }
+    }
     for (size_t g = 0; g < 2; ++g) {
       col_[g].resize(n);
       i.read(reinterpret_cast<char*>(col_[g].data()), (std::streamsize)(n * sizeof(uint32_t)));
+      CHECK(i.good() && static_cast<uint64_t>(i.gcount()) == n * sizeof(uint32_t)) << "truncated cache (column " << g << ")";
     }
     label_.clear();
-    if (!uniform) { label_.resize(n); i.read(reinterpret_cast<char*>(label_.data()), (std::streamsize)(n * sizeof(double))); }
+    if (!uniform) {
+      label_.resize(n);
+      i.read(reinterpret_cast<char*>(label_.data()), (std::streamsize)(n * sizeof(double)));
+      CHECK(i.good() && static_cast<uint64_t>(i.gcount()) == n * sizeof(double)) << "truncated cache (labels)";
+    }
+    for (size_t g = 0; g < 2; ++g) {
+      const size_t dim = info_->feature_group_infos_[g].size();
+      for (uint32_t v : col_[g]) CHECK_LT(static_cast<size_t>(v), dim) << "cache holds an id outside its dictionary (group " << g << ")";
+    }
     finalize_dimensions();
     generation_ = next_generation();
   }

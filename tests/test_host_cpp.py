@@ -75,6 +75,11 @@ def test_reference_yelp_app_builds_unmodified_and_runs_config1_plumbing(host_bin
     assert 0.05 < recall10 < 0.6
     # the reference's --task=train falls through to `return -1` (yelp.cpp:88-104)
     assert run([yelp, "--task=train"], tmp_path)[0] != 0
+    # a truncated cache must abort (glog CHECK convention), not train on zero-filled columns: user 0 / item 0 are valid ids
+    blob = open(tmp_path / "yelp.bin", "rb").read()
+    open(tmp_path / "yelp.bin", "wb").write(blob[:len(blob) - len(blob) // 3])
+    rc, out = run([yelp, "--task=split"], tmp_path)
+    assert rc not in (0, 255) and "truncated" in out, (rc, out[-500:])
 
 
 def test_text_ingest_split_and_csr_are_pinned(host_bins, tmp_path):
