@@ -713,7 +713,12 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
       for (size_t s = 0; s < S; ++s) {
         cdae_hip_stats st;
         CHK(cdae_hip_collect_stats(m->shard[s], &st));
-        if (s == 0) { stats->users = st.users; stats->batches = st.batches; }     // every shard sees every user
+        if (s == 0) {                                                             // every shard sees every user
+          stats->users = st.users; stats->batches = st.batches;
+          // HIP-event kernel times are shard 0's (cdae_hip_set_profiling on that shard's handle): its own launches over its rows
+          stats->ms_sample = st.ms_sample; stats->ms_sort = st.ms_sort; stats->ms_encode = st.ms_encode; stats->ms_decode = st.ms_decode;
+          stats->ms_hidden = st.ms_hidden; stats->ms_input = st.ms_input; stats->launches_decode = st.launches_decode;
+        }
         // full output: a shard lists its own positives; sampled: every shard walks the whole list (other shards' examples VOID)
         if (m->cfg.full_output || s == 0) stats->examples += st.examples;
       }

@@ -73,7 +73,8 @@ tile_hist_kernel(const uint32_t* __restrict__ ex_item, uint32_t n_ex, uint32_t n
     const uint32_t e = base + j * TILE_THREADS + threadIdx.x;
     if (e < n_ex) {
       const uint32_t it = ex_item[e];
-      atomicAdd(&tile_cnt[it >> 1], 1u << (16u * (it & 1u)));              // LDS
+      // (item shard, sampled decode: an example on another shard's row carries VOID = num_items — it takes no ticket and no place)
+      if (it < num_items) atomicAdd(&tile_cnt[it >> 1], 1u << (16u * (it & 1u)));              // LDS
     }
   }
   __syncthreads();
@@ -159,7 +160,8 @@ tile_scatter_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __rest
     }
   }
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) prefix[num_items] = n_ex;
+    // one past the last item's segment = the number of examples that have a place (n_ex unless some are VOID)
+    if (threadIdx.x == 0) prefix[num_items] = block_base[(num_items - 1u) >> 8] + local_prefix[num_items - 1u] + item_count[num_items - 1u];
     if (threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
   }
   __syncthreads();
@@ -167,7 +169,10 @@ tile_scatter_kernel(const uint32_t* __restrict__ ex_item, const uint64_t* __rest
 #pragma unroll
   for (uint32_t j = 0; j < TILE_EX / TILE_THREADS; ++j) {
     const uint32_t e = base + j * TILE_THREADS + threadIdx.x;
-    if (e < n_ex) bucketed_val[atomicAdd(&tile_cur[ex_item[e]], 1u)] = ex_val[e];
+    if (e < n_ex) {
+      const uint32_t it = ex_item[e];
+      if (it < num_items) bucketed_val[atomicAdd(&tile_cur[it], 1u)] = ex_val[e];
+    }
   }
 }
 

@@ -23,6 +23,8 @@
  *   CDAE::data_loss                      cdae.hpp:78-101     cdae_hip_data_loss
  *   CDAE::penalty_loss                   cdae.hpp:103-107    cdae_hip_penalty_loss
  *   CDAE::recommend (all users, top-k)   cdae.hpp:162-196    cdae_hip_recommend_all
+ *   TOPN_Evaluation::evaluate            evaluation.hpp:113-181, evaluate_rec_list :183-219
+ *                                                            cdae_hip_set_test_rows + cdae_hip_eval_topn
  *   (data-parallel exchange; no reference counterpart)       cdae_hip_delta_*, cdae_hip_comm_*, cdae_hip_exchange_*,
  *                                                            cdae_hip_multi_* (Solver<CDAE>::train on N GPUs)
  *
@@ -151,6 +153,10 @@ uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
 #define CDAE_PLAN_FUSED_DECODE 1u
 #define CDAE_PLAN_GEMM2_TN 2u
 #define CDAE_PLAN_ROWS_FUSED 4u
+/*   CDAE_PLAN_GEMM2_OVERLAPPED  (with the two above) GEMM 2 and the hidden layer run on the library's second stream BESIDE the fused row
+ *                           launch: the "decode" family then times GEMM 1 + fix-up, the "hidden" family GEMM 2 + hidden layer, the
+ *                           "input" family the row launches — three spans that overlap in time */
+#define CDAE_PLAN_GEMM2_OVERLAPPED 8u
 uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h);
 
 /* A data-parallel rank holds only its own users (rows re-based to 0).  The random streams of

@@ -404,3 +404,28 @@ def test_item_rows_layout_shards_the_user_node_by_user(built):
         rows.append(r)
         at += r
     assert sum(rows) == d.num_users and max(rows) < d.num_users and min(rows) > 0
+
+
+@pytest.mark.parametrize("K,B,shards,kw", [(24, 48, 1, {}), (24, 48, 3, {}), (200, 64, 4, {}), (24, 300, 5, dict(num_corruptions=2)), (40, 37, 2, dict(asymmetric=True))])
+def test_item_rows_sampled_with_the_tile_counting_sort_changes_no_bit(built, monkeypatch, K, B, shards, kw):
+    """Round 4: a sampled item shard may order its example list with the four tile kernels of cdae_sort_kernels.hpp instead of the
+    library radix sort (CDAE_SORT_TILE; the kernels give an example on another shard's row — VOID — no ticket and no place).  The
+    item-major order, the segment table and the duplicate marks are the same, so two epochs end on the same bits."""
+    d = synth.generate_shape("small", seed=5)
+    cfg = cfg_of(K=K, B=B, **kw)
+
+    def run():
+        mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards, item_rows=True)
+        mm.reset(d, seed=11)
+        for ep in range(2):
+            mm.train_one_iteration(3, ep)
+        extra = [cdae_amd.P_V, cdae_amd.P_V_AG] if kw.get("asymmetric") else []
+        out = _all_params(mm, extra)
+        mm.close()
+        return out
+
+    lib = run()
+    monkeypatch.setenv("CDAE_SORT_TILE", "1")
+    tile = run()
+    for w in lib:
+        np.testing.assert_array_equal(lib[w], tile[w], err_msg=f"parameter {w}")
