@@ -333,21 +333,14 @@ def main():
             # takes most of the step, which is the HBM-bound one (round 3 reported the matrix-core fraction of the other family only).
             I_, Bp_ = float(data.num_items), float(-(-int(users_per_launch) // 256) * 256)
             ms_rows = acc["ms_input"] / max(1, acc["launches_decode"])
-            overlapped = bool(plan & cdae_amd.binding.PLAN_GEMM2_OVERLAPPED)      # GEMM 2 + hidden layer on the second stream, beside the row launch
             fam = {
                 # GEMM 1 (forward + loss', z rows in registers: reads the bf16 image of D, writes G^T) + GEMM 2 (reads G^T and the image)
-                "decode": ({"kernels": "gemm1_loss_zreg_kernel + full_positive_fixup_kernel", "ms": ms_per_launch,
-                            "flops": 2.0 * K * I_ * users_per_launch, "bytes": 2.0 * I_ * Kp + 2.0 * I_ * Bp_} if overlapped else
-                           {"kernels": "gemm1_loss_zreg_kernel + full_positive_fixup_kernel + gemm_tn_bf16_kernel", "ms": ms_per_launch,
-                            "flops": 4.0 * K * I_ * users_per_launch, "bytes": 2.0 * (2.0 * I_ * Kp) + 2.0 * (2.0 * I_ * Bp_)}),
+                "decode": {"kernels": "gemm1_loss_zreg_kernel + full_positive_fixup_kernel + gemm_tn_bf16_kernel", "ms": ms_per_launch,
+                           "flops": 4.0 * K * I_ * users_per_launch, "bytes": 2.0 * (2.0 * I_ * Kp) + 2.0 * (2.0 * I_ * Bp_)},
                 # GEMM 3 + the row steps: D and D_ag read and written once (fp32), the bf16 image written, G^T read once
                 "rows": {"kernels": "gemm3_rows_fused_kernel + full_rows_inputs_kernel", "ms": ms_rows,
                          "flops": 2.0 * K * I_ * users_per_launch, "bytes": I_ * Kp * (4 * 4 + 2) + 2.0 * I_ * Bp_},
             }
-            if overlapped:          # timed on the stream it runs on; it overlaps the row launch, so the step is NOT the sum of the three
-                fam["gemm2_hidden"] = {"kernels": "gemm_tn_bf16_kernel + hidden_finish_kernel (second stream, beside the row launch)",
-                                       "ms": acc["ms_hidden"] / max(1, acc["launches_decode"]),
-                                       "flops": 2.0 * K * I_ * users_per_launch, "bytes": 2.0 * I_ * Kp + 2.0 * I_ * Bp_}
             for f in fam.values():
                 f["mfma_floor_ms"] = f["flops"] / (MFMA_PEAK_TFLOPS * 1e12) * 1e3
                 f["hbm_floor_ms"] = f["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3
@@ -357,8 +350,7 @@ def main():
                 f["achieved_gbs"] = f["bytes"] / (f["ms"] * 1e-3) / 1e9 if f["ms"] > 0 else 0.0
             dom = max(fam.values(), key=lambda f: f["ms"])
             traffic, traffic_source = measured_full_traffic(args.shape, K, B)
-            # floor of the whole step: the main stream's chain (GEMM 1, then the row launch); GEMM 2 hides beside the row launch when overlapped
-            floors = sum(max(f["mfma_floor_ms"], f["hbm_floor_ms"]) for k, f in fam.items() if not (overlapped and k == "gemm2_hidden"))
+            floors = sum(max(f["mfma_floor_ms"], f["hbm_floor_ms"]) for f in fam.values())
             roofline = {"bound": dom["bound"], "kernel": dom["kernels"],
                         "achieved": dom["achieved_gbs"] if dom["bound"] == "hbm" else dom["achieved_tflops"],
                         "peak": HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_PEAK_TFLOPS,

@@ -23,7 +23,7 @@ P_W, P_W_AG, P_V, P_V_AG, P_WU, P_WU_AG, P_B, P_B_AG, P_BP, P_BP_AG, P_UU, P_UU_
 P_UB, P_UB_AG = 12, 13
 P_COUNT = 14
 
-PLAN_FUSED_DECODE, PLAN_GEMM2_TN, PLAN_ROWS_FUSED, PLAN_GEMM2_OVERLAPPED = 1, 2, 4, 8     # cdae_hip_full_output_plan bits (include/cdae_hip.h)
+PLAN_FUSED_DECODE, PLAN_GEMM2_TN, PLAN_ROWS_FUSED = 1, 2, 4     # cdae_hip_full_output_plan bits (include/cdae_hip.h)
 DEFAULT_BATCH_USERS = 0        # 0 = the library's default (cdae_hip_default_batch_users: num_users / 160, within [32, 256])
 
 

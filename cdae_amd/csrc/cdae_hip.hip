@@ -160,11 +160,6 @@ struct cdae_hip {
   // be non-zero (the encode only writes the batch's users: a shorter batch takes the zero-filling conversion kernel once)
   bool db_valid = false;
   bool db_rows_valid = false;           // item spaces >= 32768: d_Db (only) holds the current decoder — the batch starts with a bf16 -> bf16 transposition
-  // K > 256 over >= 32768 items, round 4: the hidden-gradient product (GEMM 2: reads G^T and the block-start image of D) runs on the
-  // second stream BESIDE the fused row launch (HBM-bound; writes the NEXT image) instead of in front of it.  Two row-major images:
-  // d_Db = the one this block's products read, d_Db_alt = the one its row steps write; swapped after every block.
-  __bf16* d_Db_alt = nullptr;
-  bool overlap_gemm2 = false;           // (CDAE_FULL_NO_OVERLAP=1: GEMM 2 in front of the row launch on the main stream, one image — round 3's order)
   uint32_t zb_rows = 0xFFFFFFFFu;
   bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
@@ -362,7 +357,7 @@ void free_all(cdae_hip* h) {
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
-                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_Db_alt};
+                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -403,7 +398,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
                    (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
-                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_Db_alt};
+                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -679,11 +674,9 @@ bool gemm2_tn_path(const cdae_hip* h) {
 bool rows_fused_path(const cdae_hip* h) {
   return h->Kp == 512 && h->I >= 32768 && h->Ip % cdae::FR_ITEMS == 0 && h->fused_images && !h->gemm_direct && !h->rows_separate;
 }
-// part 1: the fused launch itself (needs G^T and Z^T); part 2: the rows some user kept as an input (needs delta and part 1)
-int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uint32_t nb, __bf16* Db, bool part1 = true, bool part2 = true) {
+int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uint32_t nb, __bf16* Db) {
   using namespace cdae;
   const uint32_t I = (uint32_t)h->I;
-  if (part1) {
 #define FR_LAUNCH(ADA_, KH_)                                                                                                              \
   do {                                                                                                                                    \
     if (!h->fused_rows_attr_set[ADA_][KH_ - 1]) {                                                                                         \
@@ -700,8 +693,6 @@ int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uin
   if (h->cfg.using_adagrad) { if (h->rows_fused_kh == 1) FR_LAUNCH(true, 1); else FR_LAUNCH(true, 2); }
   else { if (h->rows_fused_kh == 1) FR_LAUNCH(false, 1); else FR_LAUNCH(false, 2); }
 #undef FR_LAUNCH
-  }
-  if (!part2) return 0;
   // the rows kept as inputs (tied weights: one step with dD + the summed input gradient)
   DISPATCH_NI(h->NI, full_rows_inputs_kernel, dim3((I + 255) / 256), dim3(256), 0, st, h->hp, h->d_has_in, (const uint32_t*)x.seg, (const uint32_t*)(x.seg + I),
               (const uint64_t*)x.sorted_val, (const float*)h->delta_rows(), (const float*)h->d_dD, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), Db, (__bf16*)nullptr, h->Ip);
@@ -712,9 +703,7 @@ int launch_rows_fused(cdae_hip* h, hipStream_t st, const cdae_hip::ExBuf& x, uin
 // product of one block — shared by the single-handle step (compute_batch_full) and the item shard's phase 1 (fs_phase1: the same
 // launches over the shard's own item rows).  *parts / *rows: the slabs of HGpart holding the partial hg and their row count
 // (0 parts: accumulated into d_HG by atomics, the CDAE_GEMM_DIRECT developer path).
-// st2 != nullptr: GEMM 2 goes to that stream behind an event recorded once G^T is complete (compute_batch_full's overlapped order).
-int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Batch& bt, uint32_t nb, uint32_t* parts, uint32_t* rows,
-                       hipStream_t st2 = nullptr, hipEvent_t ev_gt = nullptr, Prof* span2 = nullptr) {
+int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Batch& bt, uint32_t nb, uint32_t* parts, uint32_t* rows) {
   using namespace cdae;
   const uint32_t I = (uint32_t)h->I, Kp = h->Kp, Bp = h->Bp, Ip = h->Ip;
   const dim3 blk(256);
@@ -766,12 +755,6 @@ int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Ba
     hipLaunchKernelGGL(full_positive_fixup_kernel, dim3((uint32_t)((bt.E + 255) / 256)), blk, 0, st, x.item, x.val, (uint32_t)bt.E,
                        h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY ? 1.f : 2.f, tn2 ? (__bf16*)nullptr : h->d_Gb, Ip, h->d_GTb, Bp,
                        rows_fused_path(h) ? h->d_has_in : (uint8_t*)nullptr);
-  if (st2) {                                                     // G^T (GEMM 1 + fix-up) is complete: the hidden-gradient product may start beside whatever the main stream does next
-    HIPCHK(hipEventRecord(ev_gt, st));
-    HIPCHK(hipStreamWaitEvent(st2, ev_gt, 0));
-    st = st2;
-    if (span2) CHK(span2->begin(h, F_HIDDEN, st2));             // the "hidden" family of this order: GEMM 2 + the hidden layer, on the second stream
-  }
   // GEMM 2: hg = G D  (contraction over items, split).  Every split stores its partial [Bp x Kp] product into its own slab of
   // HGpart and the consumer adds the slabs in fixed order: deterministic (the first version accumulated with fp32 atomics into
   // HG, whose order — and therefore rounding — changed from run to run)
@@ -832,7 +815,6 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   const bool rows_write_db = h->fused_images && I >= 32768u && !rows_write_images;   // full_rows_wave_kernel: the row-major image only
   const bool need_d = !(rows_write_images && h->db_valid) && !(rows_write_db && h->db_rows_valid);
   const bool tn2 = gemm2_tn_path(h);                                      // GEMM 2 reads G^T and D: no G, no D^T
-  const bool overlap = rows_fused && tn2 && h->overlap_gemm2 && h->d_Db_alt != nullptr && !h->gemm_direct;
   if (rows_write_db && h->db_rows_valid && !tn2)                          // D^T from the bf16 rows the row step left (2 GB instead of 4 at 1 M x 512)
     hipLaunchKernelGGL(bf16_transpose_kernel, dim3(Kp / 64, Ip / 64), blk, 0, st, (const __bf16*)h->d_Db, I, Kp, Ip, h->d_DTb);
   const bool z_in_encode = h->fused_images && h->zb_rows == nb;
@@ -850,8 +832,6 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   }
   CHK(pr.end());
 
-  Prof pa2;                                                       // (overlapped order: GEMM 2 + hidden layer on the second stream)
-  pa2.on = false;
   CHK(pr.begin(h, F_DECODE, st));
   // bf16 operand copies Z, Z^T (rows >= nb zero) where the encode did not write them
   if (pair_copy)
@@ -889,22 +869,23 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
 #undef FUSED_LAUNCH
     hg_parts = slices;
   } else {
-  CHK(full_products_k512(h, st, x, bt, nb, &hg_parts, &hg_rows, overlap ? h->aux : nullptr, h->ev_fork, overlap ? &pa2 : nullptr));
+  CHK(full_products_k512(h, st, x, bt, nb, &hg_parts, &hg_rows));
   }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
-  // hg only; they run beside GEMM 3, and the row steps join them.  (Overlapped order: the second stream already runs GEMM 2 behind
-  // the fork event; the hidden layer follows it there.)
-  if (!overlap) {
-    HIPCHK(hipEventRecord(h->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
-  }
+  // hg only; they run beside GEMM 3, and the row steps join them.
+  // (Round 4 measured GEMM 2 on this stream too, BESIDE the fused row launch of the K = 512 path, which needs G^T and Z^T only — two
+  // bf16 images of the decoder, swapped per block: 5.0 ms per 1024-user block against 4.75 in order.  The two launches stretch each
+  // other — GEMM 2 + hidden layer 1.2 -> 3.7 ms, row launch 2.3 -> 3.8 — because GEMM 2's LDS fill and the row launch's streams share
+  // the L2s and the fabric, and a CU holds one or the other, not both (139 KiB / 2 x 72 KiB of LDS).  Removed.)
+  HIPCHK(hipEventRecord(h->ev_fork, st));
+  HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
   {
     Prof pa;
-    if (!overlap) CHK(pa.begin(h, F_HIDDEN, h->aux));
+    CHK(pa.begin(h, F_HIDDEN, h->aux));
     DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, hg_parts ? (const uint32_t*)h->d_iota : uptr,
                 hg_parts ? hg_rows : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts,
                 h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
-    if (overlap) CHK(pa2.end()); else CHK(pa.end());
+    CHK(pa.end());
   }
   HIPCHK(hipEventRecord(h->ev_delta, h->aux));
   hipLaunchKernelGGL(hidden_bias_kernel, dim3((Kp + 255u) / 256u), blk, 0, h->aux, h->hp, nb, h->d_HG, h->P(CDAE_P_B), h->P(CDAE_P_B_AG));
@@ -925,15 +906,6 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   }
   CHK(pr.end());
 
-  if (overlap) {
-    // the fused row launch needs G^T and Z^T only: it starts at once, beside GEMM 2 and the hidden layer on the second stream, and
-    // writes the OTHER image; the kept-input rows behind it need delta
-    CHK(pr.begin(h, F_INPUT, st));
-    CHK(launch_rows_fused(h, st, x, nb, h->d_Db_alt, true, false));
-    HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
-    CHK(launch_rows_fused(h, st, x, nb, h->d_Db_alt, false, true));
-    std::swap(h->d_Db, h->d_Db_alt);                            // the next block's products read what this block's row steps wrote
-  } else {
   HIPCHK(hipStreamWaitEvent(st, h->ev_delta, 0));
   CHK(pr.begin(h, F_INPUT, st));
   if (rows_fused)      // dD = G^T Z and the row steps from its accumulators (gemm3_rows_fused_kernel)
@@ -947,7 +919,6 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), (float*)nullptr, (float*)nullptr, h->d_touched,
                 rows_write_images ? h->d_Db : (__bf16*)nullptr, rows_write_images ? h->d_DTb : (__bf16*)nullptr, Ip);
-  }
   h->db_valid = rows_write_images;                             // every decoder row was stepped and imaged by this launch
   h->db_rows_valid = rows_write_db;
   h->join_pending = true;                                      // the aux stream (b recurrence) is joined by its next consumer: join_aux
@@ -1205,8 +1176,7 @@ uint32_t cdae_hip_batch_users(const cdae_hip_t* h) { return !h || (h->cfg.batch_
 uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h) {
   if (!h || !h->cfg.full_output || h->U == 0) return 0;
   if (h->Kp <= 256 && !h->full_unfused) return CDAE_PLAN_FUSED_DECODE;
-  return (gemm2_tn_path(h) ? CDAE_PLAN_GEMM2_TN : 0u) | (rows_fused_path(h) ? CDAE_PLAN_ROWS_FUSED : 0u) |
-         (h->d_Db_alt && h->overlap_gemm2 ? CDAE_PLAN_GEMM2_OVERLAPPED : 0u);
+  return (gemm2_tn_path(h) ? CDAE_PLAN_GEMM2_TN : 0u) | (rows_fused_path(h) ? CDAE_PLAN_ROWS_FUSED : 0u);
 }
 
 int cdae_hip_set_user_id_offset(cdae_hip_t* h, uint64_t offset) {
@@ -1485,8 +1455,6 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     h->Ip = (I >= 32768 || h->Kp > 256) ? (((uint32_t)I + 255u) & ~255u) : (((uint32_t)I + 127u) & ~127u);
     CHK(dev_alloc(&h->d_Zb, (size_t)h->Bp * h->Kp)); CHK(dev_alloc(&h->d_ZTb, (size_t)h->Kp * h->Bp));
     CHK(dev_alloc(&h->d_Db, (size_t)h->Ip * h->Kp)); CHK(dev_alloc(&h->d_DTb, (size_t)h->Kp * h->Ip));
-    h->overlap_gemm2 = std::getenv("CDAE_FULL_NO_OVERLAP") == nullptr && !h->item_shard;
-    if (h->overlap_gemm2 && rows_fused_path(h) && gemm2_tn_path(h)) CHK(dev_alloc(&h->d_Db_alt, (size_t)h->Ip * h->Kp));
     // G [Bp x Ip] only where a launch reads it: the NT form of GEMM 2 (K > 256 without gemm_tn_bf16_kernel, or CDAE_FULL_UNFUSED);
     // the fused K <= 256 kernel and the TN form read G^T alone (2 GB less per handle at 1 M items x 1024 users)
     if ((h->Kp > 256 || h->full_unfused) && !gemm2_tn_path(h)) CHK(dev_alloc(&h->d_Gb, (size_t)h->Bp * h->Ip));
@@ -2223,7 +2191,7 @@ int cdae_hip_set_test_rows(cdae_hip_t* h, const int64_t* test_row_ptr, const uin
   if (nnz && !test_col) return fail("bad argument");
   for (uint64_t p = 0; p < nnz; ++p) if (test_col[p] >= (h->item_shard ? h->I_global : h->I)) return fail("test item id out of range");
   CHK(quiesce(h));
-  void** old[] = {(void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_Db_alt};
+  void** old[] = {(void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out};
   for (void** p : old) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   CHK(dev_alloc(&h->d_test_ptr, U + 1));
   CHK(dev_alloc(&h->d_test_col, std::max<uint64_t>(nnz, 1)));

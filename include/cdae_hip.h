@@ -153,10 +153,6 @@ uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
 #define CDAE_PLAN_FUSED_DECODE 1u
 #define CDAE_PLAN_GEMM2_TN 2u
 #define CDAE_PLAN_ROWS_FUSED 4u
-/*   CDAE_PLAN_GEMM2_OVERLAPPED  (with the two above) GEMM 2 and the hidden layer run on the library's second stream BESIDE the fused row
- *                           launch: the "decode" family then times GEMM 1 + fix-up, the "hidden" family GEMM 2 + hidden layer, the
- *                           "input" family the row launches — three spans that overlap in time */
-#define CDAE_PLAN_GEMM2_OVERLAPPED 8u
 uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h);
 
 /* A data-parallel rank holds only its own users (rows re-based to 0).  The random streams of

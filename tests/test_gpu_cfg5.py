@@ -48,7 +48,7 @@ def test_config5_item_space_first_block_is_bit_identical_to_the_replaced_launche
     d = data()
     assert d.num_items == 1_000_000
     new, plan, _, _, _ = run(1)
-    assert plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED | cdae_amd.binding.PLAN_GEMM2_OVERLAPPED)
+    assert plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED)
     for k in SWITCHES:
         monkeypatch.setenv(k, "1")
     old, plan_old, _, _, _ = run(1)
@@ -56,20 +56,6 @@ def test_config5_item_space_first_block_is_bit_identical_to_the_replaced_launche
     assert np.array_equal(new[cdae_amd.P_W], old[cdae_amd.P_W]) and np.array_equal(new[cdae_amd.P_W_AG], old[cdae_amd.P_W_AG])
     assert np.array_equal(new[cdae_amd.P_B], old[cdae_amd.P_B])
     np.testing.assert_allclose(new[cdae_amd.P_BP], old[cdae_amd.P_BP], rtol=1e-5, atol=1e-8)
-
-
-def test_config5_item_space_overlapped_gemm2_changes_no_bit(built, monkeypatch):
-    """Round 4: the hidden-gradient product (GEMM 2) and the hidden layer run on the second stream BESIDE the fused row launch, which
-    writes the other of two bf16 images of the decoder; CDAE_FULL_NO_OVERLAP=1 is round 3's order (GEMM 2 first, one image).  Same
-    launches on the same operands: four blocks end on the same bits, b' included."""
-    new, plan, _, loss_new, rec_new = run(4)
-    assert plan & cdae_amd.binding.PLAN_GEMM2_OVERLAPPED
-    monkeypatch.setenv("CDAE_FULL_NO_OVERLAP", "1")
-    old, plan_old, _, loss_old, rec_old = run(4)
-    assert not (plan_old & cdae_amd.binding.PLAN_GEMM2_OVERLAPPED)
-    for w in new:
-        assert np.array_equal(new[w], old[w]), w
-    assert loss_new == loss_old and np.array_equal(rec_new, rec_old)
 
 
 def test_config5_item_space_a_pass_of_blocks(built, monkeypatch):

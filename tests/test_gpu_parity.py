@@ -765,7 +765,7 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
     kw = dict(variant)
     loss = kw.pop("loss")
     model, o = make_pair(d, K=300, B=256, loss=loss, full_output=True, **kw)
-    assert model.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED | cdae_amd.binding.PLAN_GEMM2_OVERLAPPED)
+    assert model.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED)
     model.train_one_iteration(seed=4, epoch=0)
     o.train_full(4, 0, 256)
     # as test_reduced_config5_k512_131072_items: a row's first block step starts from a 1e-4 accumulator, so the bf16 rounding of a
@@ -806,7 +806,7 @@ def test_k512_launches_on_edge_shapes_change_no_bit(built, monkeypatch, U, I, B)
         return out, plan
 
     new, plan = run()
-    assert plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED | cdae_amd.binding.PLAN_GEMM2_OVERLAPPED)
+    assert plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED)
     for k in ("CDAE_GEMM1_TILED", "CDAE_GEMM2_NT", "CDAE_FULL_ROWS_SEPARATE"):
         monkeypatch.setenv(k, "1")
     old, plan_old = run()
