@@ -125,7 +125,9 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   // item rows of the NEXT group of PF instances travel while the current group is stepped (IN_PLACE: rows move under the loop,
   // nothing is fetched ahead).  Two register sets and a copy at the group boundary: the ring-of-slots form (fetch x + PF into
   // slot x % PF) made the compiler wait for every load in flight at each instance, the one just issued included.
-  constexpr int PF = IN_PLACE ? 1 : (PAIR || NI > 4) ? 8 : 16;
+  // IN_PLACE (round 4): the rows AND accumulators of the next group of 4 instances travel too; an instance whose item was
+  // stepped inside the window its prefetch could not see — the 2 PF instances before it — is re-read after the stores have landed
+  constexpr int PF = IN_PLACE ? 4 : (PAIR || NI > 4) ? 8 : 16;
   // this lane's item id(s) of the current chunk of 64 instances and, when the item side does not move under this kernel, their
   // biases (one gather per chunk instead of one dependent scalar load per instance)
   uint32_t ci = 0, cj = 0, ni = 0, nj = 0;
@@ -149,6 +151,10 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
     const float tl = PAIR ? 1.f : ((c0 + lane) % per == 0u) ? 1.f : neg_label;
     float gl = 0.f;
     float ri[PF][NI], rj[PF][NI], qi[PF][NI], qj[PF][NI];
+    // IN_PLACE only: the rows' AdaGrad accumulators and the item biases (value, accumulator) of the same instances
+    constexpr int PA = IN_PLACE ? PF : 1, PJ = IN_PLACE && PAIR ? PF : 1;
+    float ai[PA][NI], aj[PJ][NI], pai[PA][NI], paj[PJ][NI];
+    float bi[PA][2], bj[PJ][2], pbi[PA][2], pbj[PJ][2];
     auto fetch = [&](float (&di)[NI], float (&dj)[NI], uint32_t idx) {      // rows of chunk instance idx
       const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, idx);
       if (IN_PLACE) vload_coherent<NI>(di, IV + (size_t)it * hp.Kp + lo); else vload<NI>(di, IV + (size_t)it * hp.Kp + lo);
@@ -157,20 +163,59 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
         if (IN_PLACE) vload_coherent<NI>(dj, IV + (size_t)jt * hp.Kp + lo); else vload<NI>(dj, IV + (size_t)jt * hp.Kp + lo);
       }
     };
+    // IN_PLACE: everything an instance's step reads from the item side — rows, accumulators, biases — in one go (L1-bypassing loads:
+    // this wavefront wrote some of these lines earlier and a store does not update the L1)
+    auto fetch_all = [&](int s, float (&di)[NI], float (&dj)[NI], float (&dai)[NI], float (&daj)[NI], float (&dbi)[2], float (&dbj)[2], uint32_t idx) {
+      (void)s;
+      const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, idx);
+      vload_coherent<NI>(di, IV + (size_t)it * hp.Kp + lo);
+      vload_coherent<NI>(dai, IV_ag + (size_t)it * hp.Kp + lo);
+      dbi[0] = __hip_atomic_load(IB + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dbi[1] = __hip_atomic_load(IB_ag + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (PAIR) {
+        const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)cj, idx);
+        vload_coherent<NI>(dj, IV + (size_t)jt * hp.Kp + lo);
+        vload_coherent<NI>(daj, IV_ag + (size_t)jt * hp.Kp + lo);
+        dbj[0] = __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dbj[1] = __hip_atomic_load(IB_ag + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    };
     auto fetch_group = [&](uint32_t g0) {              // past the end of the chunk: the last row again (in bounds, never used)
 #pragma unroll
-      for (int s = 0; s < PF; ++s) fetch(qi[s], qj[s], min(g0 + (uint32_t)s, cnt - 1u));
+      for (int s = 0; s < PF; ++s) {
+        if (IN_PLACE) fetch_all(s, qi[s], qj[s], pai[s % PA], paj[s % PJ], pbi[s % PA], pbj[s % PJ], min(g0 + (uint32_t)s, cnt - 1u));
+        else fetch(qi[s], qj[s], min(g0 + (uint32_t)s, cnt - 1u));
+      }
     };
     auto take_group = [&]() {
 #pragma unroll
-      for (int s = 0; s < PF; ++s)
+      for (int s = 0; s < PF; ++s) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) { ri[s][i] = qi[s][i]; if (PAIR) rj[s][i] = qj[s][i]; }
+        if (IN_PLACE) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) { ai[s % PA][i] = pai[s % PA][i]; if (PAIR) aj[s % PJ][i] = paj[s % PJ][i]; }
+          bi[s % PA][0] = pbi[s % PA][0]; bi[s % PA][1] = pbi[s % PA][1];
+          if (PAIR) { bj[s % PJ][0] = pbj[s % PJ][0]; bj[s % PJ][1] = pbj[s % PJ][1]; }
+        }
+      }
     };
     auto step = [&](int s, uint32_t x) __attribute__((always_inline)) {   // instance x of the chunk, its rows in register set s
       const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, x);
       const uint32_t jt = PAIR ? (uint32_t)__builtin_amdgcn_readlane((int)cj, x) : 0u;
-      if (IN_PLACE) fetch(ri[s], rj[s], x);
+      if (IN_PLACE) {
+        // this instance's rows were requested up to 2 PF - 1 instances ago (fetch_group of the group before its own ran in front of
+        // that group's steps): if one of the instances x - 2 PF .. x - 1 of this chunk stepped one of its rows, what sits in the
+        // registers is from before that step — wait for the stores and read again.  (Negatives are rejected against the user's
+        // positives, so this is a duplicate negative inside eight instances, or BPR's positive item, which its num_neg pairs share.)
+        const uint32_t w0 = x > 2u * (uint32_t)PF ? x - 2u * (uint32_t)PF : 0u;
+        const bool in_window = lane >= w0 && lane < x;
+        const bool hit = in_window && (ci == it || (PAIR && (cj == it || ci == jt || cj == jt)));
+        if (__builtin_amdgcn_ballot_w64(hit) != 0ull || (PAIR && it == jt)) {
+          __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+          fetch_all(s, ri[s], rj[s], ai[s % PA], aj[s % PJ], bi[s % PA], bj[s % PJ], x);
+        }
+      }
       float d[NI];                                   // the item-side vector of the user step: iv[i] (IMF) or iv[i] - iv[j] (BPR)
 #pragma unroll
       for (int i = 0; i < NI; ++i) d[i] = PAIR ? ri[s][i] - rj[s][i] : ri[s][i];
@@ -179,10 +224,10 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
       for (int i = 0; i < NI; ++i) dot = fmaf(uv[i], d[i], dot);
       float pred = wave_sum(dot);
       float truth;
-      const float ibi = IN_PLACE ? __hip_atomic_load(IB + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+      const float ibi = IN_PLACE ? bi[s % PA][0]
                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cib), x));
       if (PAIR) {                                                                  // bpr.hpp:73-76 (ub cancels in the difference)
-        pred += ibi - (IN_PLACE ? __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+        pred += ibi - (IN_PLACE ? bj[s % PJ][0]
                                 : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cjb), x)));
         truth = 1.f;
       } else {                                                                     // imf.hpp:117-119, 80-84
@@ -197,34 +242,50 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
       } else {
         // the reference loop: item row(s) stepped at once with the user vector from BEFORE its own step (imf.hpp:94-114)
         float w[NI], a[NI];
-        vload_coherent<NI>(a, IV_ag + (size_t)it * hp.Kp + lo);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { w[i] = ri[s][i]; ada_step_t<ADA>(hp, w[i], a[i], fmaf(g, uv[i], lam2 * w[i])); }
+        for (int i = 0; i < NI; ++i) { w[i] = ri[s][i]; a[i] = ai[s % PA][i]; ada_step_t<ADA>(hp, w[i], a[i], fmaf(g, uv[i], lam2 * w[i])); }
         vstore<NI>(IV + (size_t)it * hp.Kp + lo, w);
         vstore<NI>(IV_ag + (size_t)it * hp.Kp + lo, a);
         if (bias_term && lane == 0) {
-          float b = ibi, ba = __hip_atomic_load(IB_ag + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          float b = ibi, ba = bi[s % PA][1];
           ada_step_t<ADA>(hp, b, ba, fmaf(lam2, b, g)); IB[it] = b; IB_ag[it] = ba;
         }
         if (PAIR) {
-          vload_coherent<NI>(a, IV_ag + (size_t)jt * hp.Kp + lo);
+          // (it == jt cannot happen: a negative is never one of the user's positives; the re-read above covers it all the same)
 #pragma unroll
-          for (int i = 0; i < NI; ++i) { w[i] = rj[s][i]; ada_step_t<ADA>(hp, w[i], a[i], fmaf(-g, uv[i], lam2 * w[i])); }
+          for (int i = 0; i < NI; ++i) { w[i] = rj[s][i]; a[i] = aj[s % PJ][i]; ada_step_t<ADA>(hp, w[i], a[i], fmaf(-g, uv[i], lam2 * w[i])); }
           vstore<NI>(IV + (size_t)jt * hp.Kp + lo, w);
           vstore<NI>(IV_ag + (size_t)jt * hp.Kp + lo, a);
           if (bias_term && lane == 0) {
-            float b = __hip_atomic_load(IB + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ba = __hip_atomic_load(IB_ag + jt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float b = bj[s % PJ][0], ba = bj[s % PJ][1];
             ada_step_t<ADA>(hp, b, ba, fmaf(lam2, b, -g)); IB[jt] = b; IB_ag[jt] = ba;
           }
         }
-        __builtin_amdgcn_s_waitcnt(WAIT_VM0);          // the next instance may hit the same row (duplicate negative): stores first
+        // (no wait here: the stores are only waited for where a later instance's re-read needs them, and at the chunk's end)
       }
       if (!PAIR && bias_term) ada_step_t<ADA>(hp, ub, uba, fmaf(lam2, ub, g));            // imf.hpp:97-101, 108-111 (BPR never steps ub)
 #pragma unroll
       for (int i = 0; i < NI; ++i) ada_step_t<ADA>(hp, uv[i], ua[i], fmaf(g, d[i], lam2 * uv[i]));
     };
     if (IN_PLACE) {
-      for (uint32_t x = 0; x < cnt; ++x) step(0, x);
+      // the grouped walk below, with the item side stepped in place; the conflict window is counted inside ONE chunk, so every chunk
+      // starts with nothing of the previous one in flight
+      __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+      fetch_group(0);
+      take_group();
+      uint32_t x0 = 0;
+      for (; x0 + PF < cnt; x0 += PF) {
+        fetch_group(x0 + PF);
+#pragma unroll
+        for (int s = 0; s < PF; ++s) step(s, x0 + (uint32_t)s);
+        take_group();
+      }
+#pragma unroll
+      for (int s = 0; s < PF; ++s) {
+        if (x0 + (uint32_t)s >= cnt) break;
+        step(s, x0 + (uint32_t)s);
+      }
+      __builtin_amdgcn_s_waitcnt(WAIT_VM0);
     } else {
       // a full group with a successor: fetch the successor, step the group, take the successor -- one straight path, so the wait
       // before the take is a count of the stores issued since (not "everything")
