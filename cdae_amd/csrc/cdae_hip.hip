@@ -75,6 +75,7 @@ int fail(const char* fmt, ...) {
     }                                                                                             \
   } while (0)
 
+constexpr uint32_t MF_SEQ_USERS = 256;     // IMF / BPR sequential default: users per launch window (cdae_hip::mf_seq)
 enum Family { F_SAMPLE = 0, F_SORT, F_ENCODE, F_DECODE, F_HIDDEN, F_INPUT, F_COUNT };
 
 struct Span { int family; hipEvent_t a, b; };
@@ -222,6 +223,14 @@ struct cdae_hip {
   void* xchg = nullptr; void (*xchg_free)(void*) = nullptr;   // communicator + schedule of the exchange (cdae_multi.hip)
   // IMF / BPR handles (cdae_hip_create_mf, cdae_mf_kernels.hpp): 0 = CDAE, 1 = IMF, 2 = BPR
   uint32_t mf = 0, mf_bias = 1;
+  // IMF / BPR, batch_users = 1 (the library default: the reference's strictly sequential loop): the users are still taken one after the
+  // other and every instance still steps the user vector and the item row(s) in place — but LAUNCHES cover MF_SEQ_USERS users: one
+  // sampling launch for all of them (the draws are keyed by user, not by batch) and one mf_user_kernel<IN_PLACE> launch in which a
+  // single wavefront walks them in order.  Through round 3 every user was a batch of its own: a sampling launch, a library sort and
+  // a segment pass nobody read, ~20 runtime calls.  h->B is then the launch window (capacities, plans); cdae_hip_batch_users still
+  // answers 1 and the stats count one block per user.
+  bool mf_seq = false;
+  bool prep_force_sort = false;         // cdae_hip_debug_sample_batch: the item-major lists are wanted although training would not read them
   // IMF / BPR block schedule (batch_users > 1): the users are trained in ACTIVITY-GROUPED order — sorted by train-row length, cut
   // into blocks of batch_users, the blocks visited in a fixed pseudo-random order — because a block lasts as long as its most active
   // user's serial chain (a heavy-tailed mix made every block as slow as its heaviest user: 3 ms against 0.24 ms for the average
@@ -460,6 +469,8 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
   if (bt.E == 0) {
     // nothing to order
+  } else if (h->mf_seq && !h->prep_force_sort) {
+    // the in-place loop reads the user-major list only: no item-major order, no segment table
   } else if (h->counting_sort) {
     // item-major order by counting, four launches (cdae_sort_kernels.hpp)
     const uint32_t n_tiles = (uint32_t)((bt.E + TILE_EX - 1) / TILE_EX);
@@ -934,7 +945,9 @@ int compute_batch_mf(cdae_hip* h, int b, const Batch& bt) {
   cdae_hip::ExBuf& x = h->ex[b];
   hipStream_t st = h->stream;
   const uint32_t I = (uint32_t)h->I, nb = bt.nb;
-  const dim3 blk(256), grid_users((nb + 3) / 4);
+  // in place = the reference loop: a block of one user, or (mf_seq) a launch window of users that ONE wavefront walks in order
+  const bool in_place = nb == 1 || h->mf_seq;
+  const dim3 blk(in_place ? 64 : 256), grid_users(in_place ? 1 : (nb + 3) / 4);
   Prof pr;
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
   CHK(pr.begin(h, F_DECODE, st));
@@ -944,14 +957,14 @@ int compute_batch_mf(cdae_hip* h, int b, const Batch& bt) {
                      h->d_UVpre, h->d_G)
 #define MF_USER_NI(NI_)                                                              \
   do {                                                                               \
-    if (h->mf == 2) { if (nb == 1) MF_USER(NI_, true, true); else MF_USER(NI_, true, false); }     \
-    else { if (nb == 1) MF_USER(NI_, false, true); else MF_USER(NI_, false, false); }              \
+    if (h->mf == 2) { if (in_place) MF_USER(NI_, true, true); else MF_USER(NI_, true, false); }     \
+    else { if (in_place) MF_USER(NI_, false, true); else MF_USER(NI_, false, false); }              \
   } while (0)
   switch (h->NI) { case 1: MF_USER_NI(1); break; case 2: MF_USER_NI(2); break; case 4: MF_USER_NI(4); break; default: MF_USER_NI(8); break; }
 #undef MF_USER_NI
 #undef MF_USER
   CHK(pr.end());
-  if (nb > 1) {
+  if (!in_place) {
     CHK(pr.begin(h, F_INPUT, st));
     DISPATCH_NI(h->NI, mf_item_kernel, dim3((I + 3) / 4), blk, 0, st, h->hp, h->mf_bias, h->d_item_order, x.seg, x.seg + I, x.sorted_val,
                 h->d_UVpre, h->d_G, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_BP), h->P(CDAE_P_BP_AG));
@@ -1157,6 +1170,7 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
   cdae_hip* h = *out;
   h->mf = mc->pairwise ? 2u : 1u;
   h->mf_bias = mc->using_bias_term ? 1u : 0u;
+  if (c.batch_users == 1u && std::getenv("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr) { h->mf_seq = true; h->B = MF_SEQ_USERS; }   // (the switch: round 3's launches, A/B)
   h->hp.loss_type = mc->loss_type;
   h->hp.lambda = (float)(2.0 * mc->lambda);                // imf.hpp:92-95, bpr.hpp:78-82: the gradients regularise with 2 * lambda
   return 0;
@@ -1172,7 +1186,7 @@ int cdae_hip_user_order(cdae_hip_t* h, uint32_t* out, size_t count) {
   for (uint64_t pos = 0; pos < h->U; ++pos) out[pos] = h->user_perm.empty() ? (uint32_t)pos : h->user_perm[pos];
   return 0;
 }
-uint32_t cdae_hip_batch_users(const cdae_hip_t* h) { return !h || (h->cfg.batch_users == 0 && h->U == 0) ? 0 : h->B; }
+uint32_t cdae_hip_batch_users(const cdae_hip_t* h) { return !h || (h->cfg.batch_users == 0 && h->U == 0) ? 0 : (h->mf_seq ? 1u : h->B); }
 uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h) {
   if (!h || !h->cfg.full_output || h->U == 0) return 0;
   if (h->Kp <= 256 && !h->full_unfused) return CDAE_PLAN_FUSED_DECODE;
@@ -1197,7 +1211,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   std::vector<int64_t> perm_ptr;
   std::vector<uint32_t> perm_col;
   h->user_perm.clear(); h->user_inv.clear();
-  if (h->mf && h->B > 1 && U > h->B) {
+  if (h->mf && !h->mf_seq && h->B > 1 && U > h->B) {
     for (uint64_t u = 0; u < U; ++u)
       if (row_ptr[u + 1] < row_ptr[u]) return fail("row_ptr is not monotone at user %llu", (unsigned long long)u);
     // activity-grouped training order (see cdae_hip::user_perm)
@@ -1809,7 +1823,7 @@ int enqueue_users(cdae_hip* h, uint64_t seed, uint32_t epoch, uint64_t u_begin, 
     else if (h->cfg.full_output) CHK(compute_batch_full(h, set, plan[t], seed, epoch));
     else CHK(compute_batch(h, set, plan[t], seed, epoch));
     h->seq++;
-    h->acc_examples += plan[t].E; h->acc_batches++; h->acc_users += plan[t].nb;
+    h->acc_examples += plan[t].E; h->acc_batches += h->mf_seq ? plan[t].nb : 1u; h->acc_users += plan[t].nb;     // (mf_seq: a block is one user)
   }
   return 0;
 }
@@ -1998,7 +2012,9 @@ int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, ui
   const int set = set_of(h->seq);
   const int prof = h->profiling;
   h->profiling = 0;
+  h->prep_force_sort = true;
   const int rc = prep_batch(h, set, Batch{u_begin, n_users, cidx, E}, seed, epoch);
+  h->prep_force_sort = false;
   h->profiling = prof;
   if (rc) return rc;
   CHK(sync_prep(h));

@@ -100,15 +100,13 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
                float* __restrict__ UB_ag, float* __restrict__ IV, float* __restrict__ IV_ag, float* __restrict__ IB,
                float* __restrict__ IB_ag, float* __restrict__ UVpre /* [instances][Kp] */, float* __restrict__ G /* [instances] */) {
   // wave-uniform by construction; said so, everything derived from it (row bounds, counts, loop control) stays scalar
-  const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
+  const uint32_t wave_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE));
   const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
-  const uint64_t uid = u0 + slot;
-  const int64_t r0 = row_ptr[uid];
-  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  // IN_PLACE: ONE wavefront walks the launch's users in order (the reference's `for uid` loop, imf.hpp:71-86 / bpr.hpp:56-70: a block
+  // of one user, or the sequential default's launch window); otherwise a wavefront per user of the block
+  if (wave_slot >= (IN_PLACE ? 1u : nb)) return;
+  const uint32_t slot_first = IN_PLACE ? 0u : wave_slot, slot_end = IN_PLACE ? nb : wave_slot + 1u;
   const uint32_t per = PAIR ? hp.num_neg : 1u + hp.num_neg;
-  const uint64_t inst0 = (uint64_t)(r0 - row_ptr[u0]) * per;
-  const uint32_t n_inst = n * per;
   const uint32_t lo = lane * NI;
   const float lam2 = hp.lambda;                      // the host stores 2 * lambda here (imf.hpp:92-95 regularise with 2 lambda)
   const float neg_label = mf_negative_label(hp.loss_type);
@@ -118,6 +116,12 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   auto run = [&](auto ada_tag, auto lt_tag) __attribute__((always_inline)) {
   constexpr bool ADA = decltype(ada_tag)::value;
   constexpr int LT = decltype(lt_tag)::value;
+  for (uint32_t slot = slot_first; slot < slot_end; ++slot) {
+  const uint64_t uid = u0 + slot;
+  const int64_t r0 = row_ptr[uid];
+  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
+  const uint64_t inst0 = (uint64_t)(r0 - row_ptr[u0]) * per;
+  const uint32_t n_inst = n * per;
   float uv[NI], ua[NI];
   vload<NI>(uv, UV + (size_t)uid * hp.Kp + lo);
   vload<NI>(ua, UV_ag + (size_t)uid * hp.Kp + lo);
@@ -309,6 +313,7 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   vstore<NI>(UV + (size_t)uid * hp.Kp + lo, uv);
   vstore<NI>(UV_ag + (size_t)uid * hp.Kp + lo, ua);
   if (lane == 0) { UB[uid] = ub; UB_ag[uid] = uba; }
+  }
   };
   using any_loss = std::integral_constant<int, -1>;
   if (IN_PLACE) {                                      // the literal loop (blocks of one user): not a speed path
