@@ -2574,6 +2574,18 @@ int fs_phase0(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t s0, uint32_
   CHK(fs_batch(h, s0, nb, cidx, &bt));
   const uint32_t n_units = units_of(h, bt);
   const uint32_t* uptr = h->d_unit_ptr + s0;
+  if (!h->encode_two_launches && nb <= h->encode_users_max) {
+    // one launch (round 4): the training encode's workgroup-per-user kernel, stopped at the raw input sum of the local rows, with the
+    // owner's private rows staged behind it — the same sums in the same order as the single handle's encode for every user
+    const float* ta = h->cfg.user_factor ? h->d_Wu : (h->cfg.linear_function ? h->d_Uu : nullptr);
+    const float* tb = h->cfg.user_factor && h->cfg.linear_function ? h->d_Uu : nullptr;
+    DISPATCH_NI(h->NI, cdae::encode_users_kernel, dim3(nb), dim3(cdae::ENC_WAVES * cdae::WAVE), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
+                h->P(CDAE_P_W), uptr, s0, nb, cidx, seed, epoch, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                (float*)nullptr, (const float*)nullptr, (float*)nullptr, (cdae::BF16_T*)nullptr, (cdae::BF16_T*)nullptr, 0u, h->d_Hsum, ta, tb,
+                (const uint32_t*)h->d_gpos);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (n_units)
     DISPATCH_NI(h->NI, cdae::encode_partial_kernel, dim3((n_units + 3) / 4), dim3(256), 0, h->stream, h->hp, h->d_row_ptr, h->d_col,
                 h->P(CDAE_P_W), uptr, n_units, (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, cidx, seed, epoch, h->d_Hpart,

@@ -537,7 +537,12 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
                     uint32_t cidx, uint64_t seed, uint32_t epoch, const float* __restrict__ Wu, const float* __restrict__ b,
                     float* __restrict__ Z, float* __restrict__ Dz, float* __restrict__ HGzero,
                     const float* __restrict__ Uu /* linear_function only */, float* __restrict__ Ssum /* linear_function only */,
-                    BF16_T* __restrict__ Zb = nullptr, BF16_T* __restrict__ ZTb = nullptr, uint32_t Bp = 0 /* as encode_finish_kernel */) {
+                    BF16_T* __restrict__ Zb = nullptr, BF16_T* __restrict__ ZTb = nullptr, uint32_t Bp = 0 /* as encode_finish_kernel */,
+                    // item shard, phase 0 (round 4): stop at the RAW input sum of the local rows — block 0 of the all-reduce buffer
+                    // `raw_out` [blocks][nb][Kp] — and stage the owner's rows of the private matrices (`raw_a`, then `raw_b`; zeros when
+                    // another shard owns the user) behind it: what encode_partial_kernel + unit_sum_stage_kernel wrote, in one launch
+                    float* __restrict__ raw_out = nullptr, const float* __restrict__ raw_a = nullptr, const float* __restrict__ raw_b = nullptr,
+                    const uint32_t* __restrict__ gpos = nullptr /* item shard: see encode_partial_kernel */) {
   __shared__ float part[ENC_WAVES][64 * NI];
   const uint32_t slot = blockIdx.x, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const unsigned long long t0 = trace_begin(hp);
@@ -546,10 +551,17 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
   const uint32_t n_units = uptr[slot + 1] - uptr[slot];
   // wavefront 0 requests what the finish needs before anything else (it was a round trip behind the sums)
   float bb[NI], wu[NI], uu[NI];
-  if (wid == 0) {
+  const bool own = raw_out && cdae_xa::owns_user(uid, hp.own_u0, hp.own_u1);          // (raw mode: the private rows this shard holds)
+  if (wid == 0 && !raw_out) {
     vload<NI>(bb, b + lo);
     if (hp.user_factor) vload<NI>(wu, Wu + (size_t)uid * hp.Kp + lo);
     if (hp.linear_function) vload<NI>(uu, Uu + (size_t)uid * hp.Kp + lo);
+  }
+  if (wid == 0 && raw_out) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) wu[i] = uu[i] = 0.f;
+    if (own && raw_a) vload<NI>(wu, raw_a + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
+    if (own && raw_b) vload<NI>(uu, raw_b + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
   }
   float acc[NI];
 #pragma unroll
@@ -559,6 +571,8 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
     const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
     const uint32_t* row = col + r0;
     const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
+    // item shard: `row` is the slice of the user's row on this shard's items; the dropout stream is indexed by position in the WHOLE row
+    const uint32_t n_rng = gpos ? gpos[2 * uid] : n, p_rng0 = gpos ? gpos[2 * uid + 1] : 0u;
 #ifndef CDAE_ENCODE_UN
 #define CDAE_ENCODE_UN 8
 #endif
@@ -574,7 +588,7 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
         int keep = 0;
         if (p < p_end) {
           item = row[p];
-          keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n + p), hp.keep_thr);
+          keep = cdae_keep(cdae_rng_draw(key_c, (uint64_t)cidx * n_rng + p_rng0 + p), hp.keep_thr);
         }
         unsigned long long mask = __ballot(keep);
         while (mask) {
@@ -611,6 +625,22 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
   for (uint32_t w = 0; w < nw; ++w)
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] += part[w][lo + i];
+  if (raw_out) {
+    vstore<NI>(raw_out + (size_t)slot * hp.Kp + lo, acc);
+    uint32_t blk = 1;
+    if (raw_a) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wu[i] = cdae_xa::own_row_contribution(own, wu[i]);
+      vstore<NI>(raw_out + ((size_t)(blk++) * nb + slot) * hp.Kp + lo, wu);
+    }
+    if (raw_b) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) uu[i] = cdae_xa::own_row_contribution(own, uu[i]);
+      vstore<NI>(raw_out + ((size_t)blk * nb + slot) * hp.Kp + lo, uu);
+    }
+    trace_end(hp, 2, slot, t0);
+    return;
+  }
   if (hp.linear_function) {                                      // h1 = Uu[u] (.) h1   cdae.hpp:382-384
     if (Ssum) vstore<NI>(Ssum + (size_t)slot * hp.Kp + lo, acc);
 #pragma unroll

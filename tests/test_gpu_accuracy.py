@@ -254,6 +254,35 @@ def test_full_output_block_schedule_reaches_the_literal_loops_quality(built):
     assert mean_rec[-1] >= mean_best + 0.03          # and ends well above: 0.254 against 0.201
 
 
+def test_k512_block_schedule_reaches_the_device_literal_loops_quality(built):
+    """The same one-sided statement on configs[4]'s LAUNCHES (K = 512 over 32 768 items: GEMM 1 with the z rows in registers, GEMM 2
+    through the transposing read, GEMM 3 fused with the row step), 16 384 users, one seed.  The literal loop here is the HIP path at
+    batch_users = 1 — an fp64 CPU epoch of this shape is ~2 h of one core; at Yelp shape the device's batch_users = 1 reproduces the fp64
+    literal fixture's Recall@10 to 1e-4 (profiles/r04_full_output_envelope_yelp.txt).  Blocks of 256 users (64 block steps per epoch)
+    must be at or above the loop's ten-epoch best after ten epochs — measured 0.1597 against 0.1485; DESIGN.md §5c has four seeds x 20
+    epochs x six block sizes."""
+    seed, K, EP = 20141119, 512, 10
+    d = synth.generate_shape("cfg5_env", seed=seed)
+
+    def curve(B):
+        m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, batch_users=B, full_output=True, **HYPER))
+        m.reset(d, seed=seed)
+        assert m.full_output_plan == (cdae_amd.binding.PLAN_GEMM2_TN | cdae_amd.binding.PLAN_ROWS_FUSED) or B == 1
+        m.set_test_rows(d.test_ptr, d.test_col)
+        rec = []
+        for ep in range(EP):
+            m.train_one_iteration(seed, ep)
+            rec.append(m.eval_topn(10)[0][5])
+        m.close()
+        return np.array(rec)
+
+    lit, blk = curve(1), curve(256)
+    print(f"\nK=512 x 32768 items, seed {seed}: literal loop (device, batch_users 1) {np.round(lit, 4)}; 256 users per block {np.round(blk, 4)}")
+    assert 0.12 < lit.max() < 0.18                       # the envelope's curve (0.1485 at epoch 9), not a degenerate run
+    assert blk[-1] >= lit.max() - 0.002
+    assert blk[0] < lit[0]                               # ... and it is NOT the loop's trajectory: behind at epoch 1 (0.062 against 0.107)
+
+
 # ---- reduced BASELINE configs[4]: K=512 full-output over > 65 536 items (three-GEMM path, 256-row tiles, 32-bit keys) --
 CFG5_FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "cfg5_small_k512_ce_full128_seed*.npz")))
 
