@@ -162,6 +162,11 @@ struct cdae_hip {
   bool db_valid = false;
   bool db_rows_valid = false;           // item spaces >= 32768: d_Db (only) holds the current decoder — the batch starts with a bf16 -> bf16 transposition
   uint32_t zb_rows = 0xFFFFFFFFu;
+  // full-output, small item spaces: blocks of at most this many users run on ONE stream, the b recurrence as leading workgroups of the row
+  // launch (CDAE_FULL_ONE_STREAM_MAX; 0 = always the two-stream order).  Measured (Yelp shape K=50 / ML-10M shape K=200, ms per block,
+  // two streams -> one): 64 users 0.074 -> 0.052, 256: 0.076 -> 0.056, 512: 0.083 -> 0.073 / 0.124 -> 0.105, 1024: 0.100 -> 0.100 /
+  // 0.142 -> 0.141, 2048: 0.196 -> 0.215 — the recurrence costs 41 ns per user, the two stream hand-offs ~15 us each
+  uint32_t full_one_stream_max = 768;
   bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
@@ -882,6 +887,38 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   } else {
   CHK(full_products_k512(h, st, x, bt, nb, &hg_parts, &hg_rows));
   }
+  // Small item spaces, short blocks (round 4): everything on ONE stream, the b recurrence as the leading workgroups of the row launch
+  // (full_rows_kernel's bias role).  A hand-off between two streams through an event costs ~15 us on this part against 2.7 us for
+  // a launch boundary (tools/grid_barrier_cost.hip), and at <= one_stream_max users per block the recurrence (41 ns per user) is
+  // shorter than the two hand-offs that would put it beside the row step.
+  const bool one_stream = !rows_fused && I < 32768u && nb <= h->full_one_stream_max && hg_parts != 0 && !h->cfg.linear_function;   // (the gate's rows receive Uu (.) delta, b the plain delta)
+  if (one_stream) {
+    Prof pa;
+    CHK(pa.begin(h, F_HIDDEN, st));
+    DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, (const uint32_t*)h->d_iota, hg_rows, s0, nb, h->d_HGpart, h->d_Dz,
+                h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
+    CHK(pa.end());
+    GemmEpilogue e3{};
+    e3.Cout = h->d_dD; e3.ldc = Kp;
+    if (h->gemm_direct)
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
+                         Bp, Bp, Bp, Bp, e3);
+    else
+      CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_GTb, h->d_ZTb, Ip, Kp, Bp, Bp, Bp, Bp, e3, 1, 1));
+    CHK(pr.end());
+    CHK(pr.begin(h, F_INPUT, st));
+    const uint32_t bias_blocks = (Kp + 255u) / 256u;
+    DISPATCH_NI(h->NI, full_rows_kernel, dim3(bias_blocks + I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
+                h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
+                h->P(CDAE_P_BP_AG), h->P(CDAE_P_B), h->P(CDAE_P_B_AG), h->d_touched,
+                rows_write_images ? h->d_Db : (__bf16*)nullptr, rows_write_images ? h->d_DTb : (__bf16*)nullptr, Ip);
+    h->db_valid = rows_write_images;
+    h->db_rows_valid = false;
+    CHK(pr.end());
+    HIPCHK(hipEventRecord(x.released, st));
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   // Second stream: delta_u, the Wu steps and then the strictly sequential hidden-bias recurrence (2048 users x 58 ns) need
   // hg only; they run beside GEMM 3, and the row steps join them.
   // (Round 4 measured GEMM 2 on this stream too, BESIDE the fused row launch of the K = 512 path, which needs G^T and Z^T only — two
@@ -1082,6 +1119,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm1_tiled = std::getenv("CDAE_GEMM1_TILED") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
+  if (const char* v = std::getenv("CDAE_FULL_ONE_STREAM_MAX")) h->full_one_stream_max = (uint32_t)std::strtoul(v, nullptr, 10);
   h->gemm1_whole_tiles = std::getenv("CDAE_GEMM1_PIPE") == nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;

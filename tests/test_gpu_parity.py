@@ -819,3 +819,29 @@ def test_k512_launches_on_edge_shapes_change_no_bit(built, monkeypatch, U, I, B)
             assert np.abs(new[w] - old[w]).max() / scale <= 2e-4, w
         else:
             assert np.array_equal(new[w], old[w]), w
+
+
+@pytest.mark.parametrize("K,B,kw", [(24, 64, {}), (50, 128, dict(asymmetric=True)), (200, 96, dict(lt=cdae_amd.SQUARE, learn_rate=0.02))])
+def test_full_output_one_stream_order_changes_no_bit(built, monkeypatch, K, B, kw):
+    """Full-output path, small item spaces: the whole block on ONE stream with the b recurrence as the leading workgroups of the row
+    launch (CDAE_FULL_ONE_STREAM_MAX users per block and below) against the two-stream order (hidden layer and recurrence on the second
+    stream, joined through events).  Same kernels on the same operands in the same order per stream: identical parameters."""
+    d = synth.generate_shape("small", seed=5)
+    lt = kw.pop("lt", cdae_amd.CROSS_ENTROPY)
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=lt, beta=1.0, batch_users=B, full_output=True, **kw)
+
+    def run():
+        m = cdae_amd.CDAE(cfg)
+        m.reset(d, seed=4)
+        for ep in range(2):
+            m.train_one_iteration(4, ep)
+        out = {w: m.get(w) for w in ((0, 1, 4, 5, 6, 7, 8, 9) + ((2, 3) if kw.get("asymmetric") else ()))}
+        m.close()
+        return out
+
+    monkeypatch.setenv("CDAE_FULL_ONE_STREAM_MAX", "0")
+    two = run()
+    monkeypatch.setenv("CDAE_FULL_ONE_STREAM_MAX", "100000")
+    one = run()
+    for w in two:
+        assert np.array_equal(one[w], two[w]), w
