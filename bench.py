@@ -591,7 +591,7 @@ def full_output_accuracy(B, num_users):
     if B <= FULL_OUTPUT_CERTIFIED_BLOCK:
         return head + ("certified ONE-SIDEDLY as a mean over four seeds (tests/test_gpu_accuracy.py::test_full_output_block_schedule_reaches_the_literal_loops_quality): "
                        "Recall@10 reaches the loop's 30-epoch best within 4 / 5 / 7 / 11 / 16 / 27 epochs at 16 / 32 / 64 / 128 / 256 / 512 users per block - 0.12 / 0.079 / "
-                       "0.054 / 0.044 / 0.036 / 0.040 s of training on one MI355X - and stays above it")
+                       "0.054 / 0.044 / 0.035 / 0.036 s of training on one MI355X - and stays above it")
     return head + (f"this block size is ABOVE the certified ones (<= {FULL_OUTPUT_CERTIFIED_BLOCK}): what decides is block steps per epoch = users / block "
                    f"({num_users / B:.0f} on this data set; at Yelp shape 1024 users per block = 10 steps per epoch need >= 38 epochs to reach the loop's best, "
                    "2048 do not in 40): a throughput figure unless the data set is large against the block (DESIGN.md §5c)")

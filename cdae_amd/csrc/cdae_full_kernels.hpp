@@ -133,6 +133,12 @@ struct GemmEpilogue {
   // EPI_STORE with a split contraction: split z stores its partial product at Cout + z * split_stride (summed in fixed order
   // by the consumer: deterministic, unlike EPI_ATOMIC); 0 when the contraction is not split
   size_t split_stride;
+  // EPI_STORE in gemm_nt_bf16_lds_kernel only (round 4, full-output small shapes on one stream): bias_blocks > 0 = the launch's leading
+  // workgroups run the hidden-bias recurrence (hidden_bias_role) over the users whose delta rows start at bias_delta — the first half
+  // of the block's users beside GEMM 3, the second half beside the row launch — instead of all of them beside the row launch alone
+  uint32_t bias_blocks, bias_nb;
+  const float* bias_delta; float* bias_b; float* bias_b_ag;
+  HyperParams bias_hp;
 };
 
 // Epilogue of one wavefront's 64 x 64 tile (2 x 2 MFMA tiles), shared by the direct and the LDS-staged kernel.
@@ -242,9 +248,18 @@ gemm_nt_bf16_lds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__
                         uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep, GemmGrid gg) {
   __shared__ __attribute__((aligned(1024))) char smem[2 * 2 * GEMM_SLICE_BYTES];     // [buffer][A | B][128 rows][128 B]
   const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;
+  uint32_t bid = blockIdx.x;
+  if (EPI == EPI_STORE && ep.bias_blocks) {                                // leading workgroups: part of the hidden-bias recurrence (see GemmEpilogue)
+    if (bid < ep.bias_blocks) {
+      if (ep.bias_hp.adagrad) hidden_bias_role<true>(ep.bias_hp, bid * blockDim.x + threadIdx.x, ep.bias_nb, ep.bias_delta, ep.bias_b, ep.bias_b_ag);
+      else hidden_bias_role<false>(ep.bias_hp, bid * blockDim.x + threadIdx.x, ep.bias_nb, ep.bias_delta, ep.bias_b, ep.bias_b_ag);
+      return;
+    }
+    bid -= ep.bias_blocks;
+  }
   uint32_t mt, nt, zt;
   {
-    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, in = gg.inner();
+    const uint32_t xcd = bid & 7u, j = bid >> 3, in = gg.inner();
     const uint32_t t = j % in, o = (j / in) * 8u + xcd;
     if (o >= gg.outer()) return;                                           // (whole workgroup)
     if (gg.mode == 0) { mt = t; nt = o; zt = 0; }
@@ -1439,11 +1454,14 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
                  float* __restrict__ W, float* __restrict__ W_ag, float* __restrict__ V, float* __restrict__ V_ag,
                  float* __restrict__ bp, float* __restrict__ bp_ag, float* __restrict__ b, float* __restrict__ b_ag,
                  uint32_t* __restrict__ touched,
-                 __bf16* __restrict__ Db = nullptr /* [Ip][Kp] */, __bf16* __restrict__ DTb = nullptr /* [Kp][Ip] */, uint32_t Ip = 0) {
+                 __bf16* __restrict__ Db = nullptr /* [Ip][Kp] */, __bf16* __restrict__ DTb = nullptr /* [Kp][Ip] */, uint32_t Ip = 0,
+                 uint32_t bias_u0 = 0 /* the bias role starts at this user of the block (the users before it were taken beside GEMM 3) */,
+                 const float* __restrict__ BIAS_DELTA = nullptr /* the plain delta rows the recurrence reads (default: DELTA) */) {
   const uint32_t bias_blocks = b ? (hp.Kp + blockDim.x - 1) / blockDim.x : 0u;   // b == nullptr: the recurrence runs in hidden_bias_kernel
   if (blockIdx.x < bias_blocks) {
-    if (hp.adagrad) hidden_bias_role<true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
-    else hidden_bias_role<false>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb, DELTA, b, b_ag);
+    const float* dl = (BIAS_DELTA ? BIAS_DELTA : DELTA) + (size_t)bias_u0 * hp.Kp;
+    if (hp.adagrad) hidden_bias_role<true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb - bias_u0, dl, b, b_ag);
+    else hidden_bias_role<false>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb - bias_u0, dl, b, b_ag);
     return;
   }
   // One workgroup per item row: its four wavefronts split the row's kept inputs (a popular row has ~500 of them per

@@ -162,11 +162,13 @@ struct cdae_hip {
   bool db_valid = false;
   bool db_rows_valid = false;           // item spaces >= 32768: d_Db (only) holds the current decoder — the batch starts with a bf16 -> bf16 transposition
   uint32_t zb_rows = 0xFFFFFFFFu;
-  // full-output, small item spaces: blocks of at most this many users run on ONE stream, the b recurrence as leading workgroups of the row
-  // launch (CDAE_FULL_ONE_STREAM_MAX; 0 = always the two-stream order).  Measured (Yelp shape K=50 / ML-10M shape K=200, ms per block,
-  // two streams -> one): 64 users 0.074 -> 0.052, 256: 0.076 -> 0.056, 512: 0.083 -> 0.073 / 0.124 -> 0.105, 1024: 0.100 -> 0.100 /
-  // 0.142 -> 0.141, 2048: 0.196 -> 0.215 — the recurrence costs 41 ns per user, the two stream hand-offs ~15 us each
-  uint32_t full_one_stream_max = 768;
+  // full-output, small item spaces: blocks of at most this many users run on ONE stream, the b recurrence as leading workgroups of the
+  // GEMM 3 launch (first half of the users) and of the row launch (the rest) (CDAE_FULL_ONE_STREAM_MAX; 0 = always the two-stream
+  // order).  Measured (Yelp shape K=50 / ML-10M shape K=200, ms per block, two streams -> one): 64 users 0.074 -> 0.051, 256: 0.076 ->
+  // 0.055, 512: 0.083 -> 0.067 / 0.124 -> 0.106, 1024: 0.099 -> 0.088 / 0.145 -> 0.132, 2048: - / 0.197 -> 0.188, 4096: - / 0.327 -> 0.327
+  // — a hand-off between two streams costs ~15 us, the recurrence 41 ns per user
+  uint32_t full_one_stream_max = 2048;
+  bool full_bias_unsplit = false;       // CDAE_FULL_BIAS_UNSPLIT: the whole recurrence beside the row launch (A/B)
   bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_delta = nullptr;
@@ -669,9 +671,15 @@ int launch_gemm_lds(cdae_hip* h, hipStream_t st, const __bf16* A, const __bf16* 
                        kps, ep, gg);
   } else {
     const GemmGrid gg{M / 128, Nt, splits, mode};
-    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI>), dim3(gg.workgroups()), dim3(256), 0, st, A, Bm, M, N, Kd, lda, ldb, kps, ep, gg);
+    hipLaunchKernelGGL((gemm_nt_bf16_lds_kernel<EPI>), dim3(gg.workgroups() + (EPI == EPI_STORE ? ep.bias_blocks : 0u)), dim3(256), 0, st, A, Bm, M, N,
+                       Kd, lda, ldb, kps, ep, gg);
   }
   return 0;
+}
+// does launch_gemm_lds take the 128 x 128 kernel — the one that can host a bias role (GemmEpilogue::bias_blocks) — for this shape?
+bool gemm_lds_is_128(const cdae_hip* h, uint32_t M, uint32_t N) {
+  if (M % 256 == 0 && N % 256 == 0 && !h->gemm_two_stage && !h->gemm_narrow) return false;
+  return !(M % 256 == 0 && !h->gemm_two_stage);
 }
 
 // contraction split of GEMM 2 (hg = G D, K > 256 / unfused path): about 2048 workgroups in all, splits a multiple of 64 items
@@ -900,6 +908,14 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     CHK(pa.end());
     GemmEpilogue e3{};
     e3.Cout = h->d_dD; e3.ldc = Kp;
+    // the b recurrence (41 ns per user, strictly in user order) in two parts: the first half of the block's users as leading workgroups
+    // of the GEMM 3 launch, the rest as leading workgroups of the row launch — each launch then lasts about as long as its own work
+    uint32_t bias_u0 = 0;
+    if (!h->gemm_direct && gemm_lds_is_128(h, Ip, Kp) && nb >= 64 && !h->full_bias_unsplit) {
+      bias_u0 = nb / 2;
+      e3.bias_blocks = (Kp + 255u) / 256u; e3.bias_nb = bias_u0; e3.bias_delta = h->d_HG; e3.bias_b = h->P(CDAE_P_B); e3.bias_b_ag = h->P(CDAE_P_B_AG);
+      e3.bias_hp = h->hp;
+    }
     if (h->gemm_direct)
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPI_STORE>), dim3((Kp + 127) / 128, Ip / 64, 1), dim3(128), 0, st, h->d_GTb, h->d_ZTb, Ip, Kp,
                          Bp, Bp, Bp, Bp, e3);
@@ -911,7 +927,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
     DISPATCH_NI(h->NI, full_rows_kernel, dim3(bias_blocks + I), blk, 0, st, h->hp, x.seg, x.seg + I, x.sorted_val, h->delta_rows(),
                 h->d_dD, h->d_GTb, Bp, nb, h->P(CDAE_P_W), h->P(CDAE_P_W_AG), h->P(CDAE_P_V), h->P(CDAE_P_V_AG), h->P(CDAE_P_BP),
                 h->P(CDAE_P_BP_AG), h->P(CDAE_P_B), h->P(CDAE_P_B_AG), h->d_touched,
-                rows_write_images ? h->d_Db : (__bf16*)nullptr, rows_write_images ? h->d_DTb : (__bf16*)nullptr, Ip);
+                rows_write_images ? h->d_Db : (__bf16*)nullptr, rows_write_images ? h->d_DTb : (__bf16*)nullptr, Ip, bias_u0, (const float*)h->d_HG);
     h->db_valid = rows_write_images;
     h->db_rows_valid = false;
     CHK(pr.end());
@@ -1119,6 +1135,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm1_tiled = std::getenv("CDAE_GEMM1_TILED") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
+  h->full_bias_unsplit = std::getenv("CDAE_FULL_BIAS_UNSPLIT") != nullptr;
   if (const char* v = std::getenv("CDAE_FULL_ONE_STREAM_MAX")) h->full_one_stream_max = (uint32_t)std::strtoul(v, nullptr, 10);
   h->gemm1_whole_tiles = std::getenv("CDAE_GEMM1_PIPE") == nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
