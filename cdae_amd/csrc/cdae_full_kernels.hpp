@@ -1091,13 +1091,49 @@ gemm1_loss_zreg_pipe_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const
 // row: conflict-free.  Same 256 x 256 tile, wavefront layout, two 68 KiB stages and epilogue as gemm_nt_bf16_ldsw_kernel; every
 // output element is the same sum in the same order (16-wide steps ascending, same contraction splits), so the slabs are
 // bit-identical to the NT kernel's (test_tn_gemm2_changes_no_bit).
-constexpr uint32_t GTN_RS = 1088;
-constexpr int GTN_STAGE_BYTES = 64 * (int)GTN_RS;
-constexpr size_t gemm_tn_lds_bytes() { return 2 * (size_t)GTN_STAGE_BYTES; }
+// Transposing LDS reads as inline asm (round 4).  Through the builtin (__builtin_amdgcn_ds_read_tr16_b64_*) the compiler's wait-count pass
+// sees an LDS read with no alias information behind an LDS DMA (global_load_lds) and puts `s_waitcnt vmcnt(0)` in front of the first
+// read after every stage() — i.e. the NEXT slice's fill was waited for before the current slice was contracted, fills and matrix work
+// never overlapped, and a 64-row step lasted fill round trip + contraction (2.25 us for 0.85 us of MFMAs: the 0.37 of round 3).  As asm
+// the reads are invisible to that pass; their own completion is waited for by hand (lgkm_wait: the fragments are in/out operands of
+// the s_waitcnt, so every MFMA that consumes them is ordered behind it).
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_read_tr16(uint32_t addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_frag_tr16(uint32_t addr) {      // rows r..r+3 and r+4..r+7 of one 16-row sub-step
+  const bf16x4 lo = lds_read_tr16<OFF>(addr);
+  const bf16x4 hi = lds_read_tr16<OFF + 4 * 1088>(addr);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait(bf16x8 (&a)[2], bf16x8 (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
 
+constexpr uint32_t GTN_RS = 1088;
+// Staging depth and wavefront shape (round 4, measured after the transposing reads became asm — see lds_read_tr16): two 64-row
+// stages 0.94 ms per launch at 1 M items x 1024 users; the same 136 KiB as 32-row stages with two / three of them in flight behind the
+// one being contracted (ROWS = 32, NST = 3 / 4, CDAE_GEMM2_STAGES; counted vmcnt) 0.97 / 0.97; four wavefronts of 128 x 128 outputs (a
+// third fewer LDS reads, built and removed) 1.00.  With parts compiled out (GTN_X_*): no MFMAs 0.83, no fills 0.70, no LDS reads
+// beyond the first sub-step 0.84 — the fills (8.6 GB from the L2s per launch: each G^T piece is staged by two workgroups, each decoder
+// piece by four) and the contraction each take most of the launch and overlap only partly.  All variants bit-identical.
+template <int ROWS, int NST>
+constexpr size_t gemm_tn_lds_bytes() { return (size_t)NST * ROWS * GTN_RS; }
+
+template <int ROWS /* contraction rows per stage: 64 or 32 */, int NST /* stages */>
 __global__ void __launch_bounds__(512)
 gemm_tn_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm, uint32_t M, uint32_t N, uint32_t Kd,
                     uint32_t lda, uint32_t ldb, uint32_t k_per_split, GemmEpilogue ep, GemmGrid gg) {
+  static_assert(ROWS % 16 == 0 && ROWS % 8 == 0 && NST >= 2 && NST <= 4, "stage shape");
+  constexpr int STAGE_BYTES = ROWS * (int)GTN_RS;
+  constexpr int PER_WAVE = ROWS / 8;                                       // DMA instructions per wavefront and stage
   extern __shared__ __attribute__((aligned(1024))) char smemt[];
   const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE;      // wid 0..7
   uint32_t mt, nt, zt;
@@ -1114,7 +1150,7 @@ gemm_tn_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm,
   const uint32_t m_base = m_tile + wm, n_base = n_tile + wn;
   const uint32_t k_begin = zt * k_per_split;
   const uint32_t k_end = min(Kd, k_begin + k_per_split);
-  const uint32_t n_steps = (k_end - k_begin) / 64u;
+  const uint32_t n_steps = (k_end - k_begin) / (uint32_t)ROWS;
   f32x16 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1123,49 +1159,88 @@ gemm_tn_bf16_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__ Bm,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: contraction row r of the slice is one DMA instruction; wavefront w issues rows 8 w .. 8 w + 7
+  // staging: contraction row r of the slice is one DMA instruction; wavefront w issues rows PER_WAVE w .. PER_WAVE w + PER_WAVE - 1
   const __bf16* src = lane < 32u ? A + m_tile + 8u * lane : Bm + n_tile + 8u * (lane - 32u);
   const uint32_t ld = lane < 32u ? lda : ldb;
   auto stage = [&](uint32_t step, uint32_t slot) {
-    char* base = smemt + slot * GTN_STAGE_BYTES;
-    const uint32_t k = k_begin + step * 64u + wid * 8u;
+    char* base = smemt + slot * STAGE_BYTES;
+    const uint32_t k = k_begin + step * (uint32_t)ROWS + wid * (uint32_t)PER_WAVE;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < PER_WAVE; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(k + q) * ld),
-                                       (__attribute__((address_space(3))) void*)(base + (wid * 8u + q) * GTN_RS), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(base + (wid * (uint32_t)PER_WAVE + q) * GTN_RS), 16, 0, 0);
   };
   // fragment addresses: lane L of a 16-lane group supplies row 8 (L >> 5) + ((L & 15) >> 2) (+ 4 for the second read), columns
   // 16 ((L >> 4) & 1) + 4 (L & 3) .. + 3 of the fragment's 32; lane L receives column L & 31, four rows per read
   const uint32_t f_off = (8u * (lane >> 5) + ((lane & 15u) >> 2)) * GTN_RS + (16u * ((lane >> 4) & 1u) + 4u * (lane & 3u)) * 2u;
-  const uint32_t a_off = f_off + wm * 2u, b_off = f_off + 512u + wn * 2u;
-  auto frag = [&](const char* p) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p + 4u * GTN_RS));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  };
+  const uint32_t lds0 = lds_addr_of(smemt);
+  const uint32_t a_off = lds0 + f_off + wm * 2u, b_off = lds0 + f_off + 512u + wn * 2u;
+#define GTN_READ(FA_, FB_, S_)                                                          \
+  do {                                                                                  \
+    if (GTN_X_NOREAD && (S_) != 0) break;                                               \
+    FA_[0] = lds_frag_tr16<(S_) * 16 * (int)GTN_RS>(a_cur);                             \
+    FA_[1] = lds_frag_tr16<(S_) * 16 * (int)GTN_RS + 64>(a_cur);                        \
+    FB_[0] = lds_frag_tr16<(S_) * 16 * (int)GTN_RS>(b_cur);                             \
+    FB_[1] = lds_frag_tr16<(S_) * 16 * (int)GTN_RS + 64>(b_cur);                        \
+    FB_[2] = lds_frag_tr16<(S_) * 16 * (int)GTN_RS + 128>(b_cur);                       \
+    FB_[3] = lds_frag_tr16<(S_) * 16 * (int)GTN_RS + 192>(b_cur);                       \
+  } while (0)
+#ifndef GTN_X_NOMFMA      // developer switches (tools/build_variant.sh): parts of the launch compiled out, to see what bounds it
+#define GTN_X_NOMFMA 0
+#endif
+#ifndef GTN_X_NODMA
+#define GTN_X_NODMA 0
+#endif
+#ifndef GTN_X_NOREAD
+#define GTN_X_NOREAD 0
+#endif
+#define GTN_MFMA(FA_, FB_)                                                                                        \
+  do {                                                                                                            \
+    if (GTN_X_NOMFMA) { acc[0][0][0] += (float)FA_[0][0] + (float)FA_[1][0] + (float)FB_[0][0] + (float)FB_[1][0] + (float)FB_[2][0] + (float)FB_[3][0]; break; } \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                               \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_[i], FB_[j], acc[i][j], 0, 0, 0);                  \
+  } while (0)
 
-  stage(0, 0);
+#pragma unroll
+  for (int p = 0; p < NST - 1; ++p)
+    if ((uint32_t)p < n_steps) stage((uint32_t)p, (uint32_t)p);
   uint32_t slot = 0;
   for (uint32_t step = 0; step < n_steps; ++step) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wavefront's DMAs of slice `step` have landed
-    __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; the other stage (slice step-1) is free
-    if (step + 1 < n_steps) stage(step + 1u, slot ^ 1u);
-    const char* base = smemt + slot * GTN_STAGE_BYTES;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const char* row = base + (uint32_t)s * 16u * GTN_RS;
-      bf16x8 fa[2], fb[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag(row + a_off + i * 64);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = frag(row + b_off + j * 64);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    // this wavefront's DMAs of slice `step` have landed: the stages behind it (at most NST - 2 of them) stay in flight
+    const uint32_t behind = min((uint32_t)(NST - 2), n_steps - 1u - step);
+    wait_vmcnt_at_most(behind * (uint32_t)PER_WAVE);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                          // ... and everyone else's; the stage of slice step-1 is free
+    if (step + (uint32_t)(NST - 1) < n_steps && !(GTN_X_NODMA && step > 2u)) stage(step + (uint32_t)(NST - 1), (slot + (uint32_t)(NST - 1)) % (uint32_t)NST);
+    // fragments of sub-step s + 1 are requested in front of sub-step s's MFMAs, behind the wait for sub-step s's own (never more
+    // than 12 LDS reads outstanding: lgkmcnt counts to 15)
+    const uint32_t a_cur = a_off + slot * (uint32_t)STAGE_BYTES, b_cur = b_off + slot * (uint32_t)STAGE_BYTES;
+    bf16x8 fa0[2], fb0[4], fa1[2], fb1[4];
+    GTN_READ(fa0, fb0, 0);
+    lgkm_wait<0>(fa0, fb0);
+    GTN_READ(fa1, fb1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    GTN_MFMA(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ROWS == 64) {
+      lgkm_wait<0>(fa1, fb1);
+      GTN_READ(fa0, fb0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      GTN_MFMA(fa1, fb1);
+      __builtin_amdgcn_sched_barrier(0);
+      lgkm_wait<0>(fa0, fb0);
+      GTN_READ(fa1, fb1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      GTN_MFMA(fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    slot ^= 1u;
+    lgkm_wait<0>(fa1, fb1);                                                // (all of this stage's reads are done before the next barrier)
+    GTN_MFMA(fa1, fb1);
+    slot = slot + 1u == (uint32_t)NST ? 0u : slot + 1u;
   }
+#undef GTN_READ
+#undef GTN_MFMA
   if (m_base >= M) return;
   const uint32_t half = lane >> 5, col = lane & 31u;
   float* C = ep.Cout + (size_t)zt * ep.split_stride;

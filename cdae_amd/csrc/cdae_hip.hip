@@ -220,6 +220,7 @@ struct cdae_hip {
   bool gemm1_pipe_attr_set[2] = {false, false};
   bool fused_attr_set = false;          // dynamic-LDS attribute of this handle's full_decode_fused_kernel instance set (one K and loss per handle)
   bool gemm2_nt = false;                // CDAE_GEMM2_NT: hg = G D from G and D^T (gemm_nt_bf16_ldsw_kernel) where gemm_tn_bf16_kernel would read G^T and D (A/B switch)
+  int gemm2_stages = 2;                 // CDAE_GEMM2_STAGES: LDS stages of gemm_tn_bf16_kernel (2 = 64-row stages; 3 / 4 = 32-row stages, measured no faster)
   bool gemm_tn_attr_set = false;        // dynamic-LDS attribute of gemm_tn_bf16_kernel set on this handle's device
   bool rows_separate = false;           // CDAE_FULL_ROWS_SEPARATE: GEMM 3 and the row step as two launches where gemm3_rows_fused_kernel would run (A/B switch)
   bool fused_rows_attr_set[2][2] = {};      // dynamic-LDS attribute of gemm3_rows_fused_kernel<ADA, KH> set on this handle's device
@@ -794,13 +795,23 @@ int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Ba
   const uint32_t splits = (Ip + kps - 1) / kps;
   e2.Cout = h->d_HGpart; e2.ldc = Kp; e2.rows_live = nb; e2.split_stride = (size_t)Bp * Kp;
   if (tn2) {                                                     // sum over items of G^T[item][user] D[item][k]: both images as they are
-    if (!h->gemm_tn_attr_set) {
-      HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_tn_lds_bytes()));
-      h->gemm_tn_attr_set = true;
-    }
     const GemmGrid gg{Bp / 256, Kp / 256, splits, 2};
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(gg.workgroups()), dim3(512), gemm_tn_lds_bytes(), st, (const __bf16*)h->d_GTb,
-                       (const __bf16*)h->d_Db, Bp, Kp, Ip, Bp, Kp, kps, e2, gg);
+#define GEMM_TN(ROWS_, NST_)                                                                                                              \
+  do {                                                                                                                                    \
+    constexpr size_t lds_ = gemm_tn_lds_bytes<ROWS_, NST_>();                                                                             \
+    if (!h->gemm_tn_attr_set) {                                                                                                           \
+      HIPCHK(hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<ROWS_, NST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));  \
+      h->gemm_tn_attr_set = true;                                                                                                         \
+    }                                                                                                                                     \
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<ROWS_, NST_>), dim3(gg.workgroups()), dim3(512), lds_, st,                                    \
+                       (const __bf16*)h->d_GTb, (const __bf16*)h->d_Db, Bp, Kp, Ip, Bp, Kp, kps, e2, gg);                                 \
+  } while (0)
+    // two 64-row stages; CDAE_GEMM2_STAGES=3 / 4: the same 136 KiB as 32-row stages with two / three of them in flight behind the one
+    // being contracted — bit-identical, 0.97 against 0.94 ms at 1 M items (A/B switch; cdae_full_kernels.hpp has the table)
+    if (h->gemm2_stages == 3) GEMM_TN(32, 3);
+    else if (h->gemm2_stages == 4) GEMM_TN(32, 4);
+    else GEMM_TN(64, 2);
+#undef GEMM_TN
   } else {
     CHK(launch_gemm_lds<EPI_STORE>(h, st, h->d_Gb, h->d_DTb, Bp, Kp, Ip, Ip, Ip, kps, e2, splits, 2));
   }
@@ -1132,6 +1143,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
   h->rows_separate = std::getenv("CDAE_FULL_ROWS_SEPARATE") != nullptr;
   h->gemm2_nt = std::getenv("CDAE_GEMM2_NT") != nullptr;
+  if (const char* ev = std::getenv("CDAE_GEMM2_STAGES")) h->gemm2_stages = std::max(2, std::min(4, std::atoi(ev)));
   h->gemm1_tiled = std::getenv("CDAE_GEMM1_TILED") != nullptr;
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
