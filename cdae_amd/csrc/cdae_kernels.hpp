@@ -1440,6 +1440,62 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   trace_end(hp, 5, (unit * 8u + part) * halves + half, t0, n_ex);
 }
 
+// hidden_gather_kernel's partial rows of the units [ub, ue) of one user added to hg in a FIXED order (unit-major, then partition):
+// deterministic, and the same sum in hidden_finish_kernel (single handle) and hg_raw_kernel (item shard).  Eight partitions (the
+// training path): two units' 16 partial rows are in flight per trip (a user has 2-3 units at ML-10M shape; the second unit is clamped
+// and added as 0 past the end)
+template <int NI>
+__device__ __forceinline__ void add_partial_rows(float (&hg)[NI], const float* __restrict__ HGpart, uint32_t n_units, uint32_t n_parts,
+                                                 uint32_t ub, uint32_t ue, uint32_t Kp, uint32_t lo) {
+  if (n_parts == 8u) {
+    const size_t slab = (size_t)n_units * Kp;
+    for (uint32_t u = ub; u < ue; u += 2) {
+      const bool two = u + 1u < ue;                                // wave-uniform
+      const float* p0 = HGpart + (size_t)u * Kp + lo;
+      const float* p1 = HGpart + (size_t)(two ? u + 1u : u) * Kp + lo;
+      float a0[8][NI], a1[8][NI];
+#pragma unroll
+      for (int x = 0; x < 8; ++x) vload<NI>(a0[x], p0 + x * slab);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) vload<NI>(a1[x], p1 + x * slab);
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += a0[x][i];
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += two ? a1[x][i] : 0.f;
+    }
+  } else if (n_parts == 16u) {                                     // two wavefronts per (unit, partition): one unit's 16 rows per trip
+    const size_t slab = (size_t)n_units * Kp;
+    for (uint32_t u = ub; u < ue; ++u) {
+      const float* p0 = HGpart + (size_t)u * Kp + lo;
+      float a0[16][NI];
+#pragma unroll
+      for (int x = 0; x < 16; ++x) vload<NI>(a0[x], p0 + x * slab);
+#pragma unroll
+      for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hg[i] += a0[x][i];
+    }
+  } else {                                                         // any other count (the full-output slabs): eight rows in flight per trip
+    const size_t slab = (size_t)n_units * Kp;
+    for (uint32_t u = ub; u < ue; ++u) {
+      const float* p0 = HGpart + (size_t)u * Kp + lo;
+      for (uint32_t x0 = 0; x0 < n_parts; x0 += 8u) {
+        float a0[8][NI];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) vload<NI>(a0[x], p0 + (size_t)min(x0 + (uint32_t)x, n_parts - 1u) * slab);
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) hg[i] = x0 + (uint32_t)x < n_parts ? hg[i] + a0[x][i] : hg[i];     // (wave-uniform; no + 0.f: -0 stays -0)
+      }
+    }
+  }
+}
+
 // K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
 //       and the private user-node step Wu[u]                                      cdae.hpp:317-331
 template <int NI>
@@ -1469,50 +1525,7 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
   vload<NI>(dz, Dz + o);
   if (hp.user_factor && own) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
   const uint32_t ub = n_parts ? uptr[slot] - uptr[0] : 0u, ue = n_parts ? uptr[slot + 1] - uptr[0] : 0u;
-  // fixed order (unit-major, then partition): deterministic.  Eight partitions (the training path): two units' 16 partial
-  // rows are in flight per trip (a user has 2-3 units at ML-10M shape; the second unit is clamped and added as 0 past the end)
-  if (n_parts == 8u) {
-    const size_t slab = (size_t)n_units * hp.Kp;
-    for (uint32_t u = ub; u < ue; u += 2) {
-      const bool two = u + 1u < ue;                                // wave-uniform
-      const float* p0 = HGpart + (size_t)u * hp.Kp + lo;
-      const float* p1 = HGpart + (size_t)(two ? u + 1u : u) * hp.Kp + lo;
-      float a0[8][NI], a1[8][NI];
-#pragma unroll
-      for (int x = 0; x < 8; ++x) vload<NI>(a0[x], p0 + x * slab);
-#pragma unroll
-      for (int x = 0; x < 8; ++x) vload<NI>(a1[x], p1 + x * slab);
-#pragma unroll
-      for (int x = 0; x < 8; ++x)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) hg[i] += a0[x][i];
-#pragma unroll
-      for (int x = 0; x < 8; ++x)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) hg[i] += two ? a1[x][i] : 0.f;
-    }
-  } else if (n_parts == 16u) {                                     // two wavefronts per (unit, partition): one unit's 16 rows per trip
-    const size_t slab = (size_t)n_units * hp.Kp;
-    for (uint32_t u = ub; u < ue; ++u) {
-      const float* p0 = HGpart + (size_t)u * hp.Kp + lo;
-      float a0[16][NI];
-#pragma unroll
-      for (int x = 0; x < 16; ++x) vload<NI>(a0[x], p0 + x * slab);
-#pragma unroll
-      for (int x = 0; x < 16; ++x)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) hg[i] += a0[x][i];
-    }
-  } else {
-    for (uint32_t u = ub; u < ue; ++u) {
-      for (uint32_t x = 0; x < n_parts; ++x) {
-        float part[NI];
-        vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) hg[i] += part[i];
-      }
-    }
-  }
+  add_partial_rows<NI>(hg, HGpart, n_units, n_parts, ub, ue, hp.Kp, lo);
 #pragma unroll
   for (int i = 0; i < NI; ++i) delta[i] = hg[i] * dz[i];
   vstore<NI>(HG + o, delta);
@@ -1957,12 +1970,7 @@ slab_sum_kernel(HyperParams hp, const float* __restrict__ HGpart, uint32_t n_par
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
-  for (uint32_t x = 0; x < n_parts; ++x) {
-    float part[NI];
-    vload<NI>(part, HGpart + ((size_t)x * rows + slot) * hp.Kp + lo);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) acc[i] += part[i];
-  }
+  add_partial_rows<NI>(acc, HGpart, rows, n_parts, slot, slot + 1u, hp.Kp, lo);      // slab x, row `slot`: x ascending
   vstore<NI>(HG + (size_t)slot * hp.Kp + lo, acc);
 }
 
@@ -2001,13 +2009,7 @@ hg_raw_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_unit
   float hg[NI];
   vload<NI>(hg, HG + o);
   const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
-  for (uint32_t u = ub; u < ue; ++u)
-    for (uint32_t x = 0; x < n_parts; ++x) {
-      float part[NI];
-      vload<NI>(part, HGpart + ((size_t)x * n_units + u) * hp.Kp + lo);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) hg[i] += part[i];
-    }
+  add_partial_rows<NI>(hg, HGpart, n_units, n_parts, ub, ue, hp.Kp, lo);     // (16 partial rows in flight per trip: the loop of single loads was a 15-26 us chain)
   vstore<NI>(HG + o, hg);
 }
 
