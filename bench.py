@@ -589,9 +589,10 @@ def full_output_accuracy(B, num_users, shape=None, K=None):
             "objective than its B = 1 limit, the reference loop cdae.hpp:225-293 fed every unrated item; trajectory-equal to that loop at NO block size "
             "above 1 (DESIGN.md §5c); ")
     measured = {   # builder-run envelopes, four seeds each (profiles/r04_full_output_envelope_*.txt): epochs to the loop's best Recall@10
-        ("ml10m", 200, 2048): "measured at this shape and block size: reaches the loop's 25-epoch best Recall@10 (0.161) within 15-16 epochs (0.11 s of training) "
-                              "and is above it through epoch 25 (0.171); smaller blocks get there sooner (512 users: 5-6 epochs) but over-train afterwards "
-                              "(Recall@10 declines from epoch ~10 on)",
+        ("ml10m", 200, 2048): "at this shape and block size (tests/test_gpu_accuracy.py::test_ml10m_shape_bench_block_reaches_the_literal_loops_quality, driver-run, two "
+                              "seeds; four in DESIGN.md §5c): reaches the loop's 25-epoch best Recall@10 (0.161) within 15-16 epochs (0.11 s of training) and is "
+                              "above it through epoch 25 (0.171); smaller blocks get there sooner (512 users: 5-6 epochs) but over-train afterwards (Recall@10 "
+                              "declines from epoch ~10 on)",
         ("ml10m", 200, 512): "measured at this shape and block size: reaches the loop's 25-epoch best Recall@10 (0.161) within 5-6 epochs, peaks at 0.167 around "
                              "epoch 10 and then over-trains (0.152 at epoch 25)",
     }

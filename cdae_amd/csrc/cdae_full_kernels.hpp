@@ -1913,24 +1913,33 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
     const uint32_t nslot = slot == 0 ? 2u : slot - 1u;
     if (step + 2 < n_steps) stage(step + 2u, nslot);
     const char* base = smemf + slot * STAGE;
+    // Both sub-steps' fragments are requested before the first MFMA (round 4): the workgroup runs ONE wavefront per SIMD, so a
+    // read waited for right behind its issue (what hipcc schedules by itself: read pair, lgkmcnt(0), two MFMAs) is latency no
+    // other wavefront covers.  CDAE_FR_READ_LATE: the loop as the compiler orders it (A/B build)
+    static_assert(FR_BK == 32, "two 16-wide sub-steps per slice");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    bf16x8 fa[2][4], fb[2][4];
+    u32x4 gu[2];
 #pragma unroll
-    for (int s = 0; s < FR_BK / 16; ++s) {
+    for (int s = 0; s < 2; ++s) {
       const uint32_t c16 = ((2u * s + f_half) ^ f_sw) << 4;
-      bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048u + c16);
+      for (int i = 0; i < 4; ++i) fa[s][i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 2048u + c16);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048u + c16);
-      {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 u = *reinterpret_cast<const u32x4*>(base + b_off + gblk * 2048u + c16);      // G^T piece of this wavefront's b' rows
+      for (int j = 0; j < 4; ++j) fb[s][j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 2048u + c16);
+      gu[s] = *reinterpret_cast<const u32x4*>(base + b_off + gblk * 2048u + c16);                  // G^T piece of this wavefront's b' rows
+    }
+#ifndef CDAE_FR_READ_LATE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-        for (int d = 0; d < 4; ++d) gs += __builtin_bit_cast(float, u[d] << 16) + __builtin_bit_cast(float, u[d] & 0xFFFF0000u);
-      }
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) gs += __builtin_bit_cast(float, gu[s][d] << 16) + __builtin_bit_cast(float, gu[s][d] & 0xFFFF0000u);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
     }
     slot = slot == 2 ? 0u : slot + 1u;
   }
