@@ -24,6 +24,7 @@ P_UB, P_UB_AG = 12, 13
 P_COUNT = 14
 
 PLAN_FUSED_DECODE, PLAN_GEMM2_TN, PLAN_ROWS_FUSED = 1, 2, 4     # cdae_hip_full_output_plan bits (include/cdae_hip.h)
+IMF_DEFAULT_BATCH_USERS = 16   # CDAE_IMF_DEFAULT_BATCH_USERS (include/cdae_hip.h): what an IMF handle created with batch_users = 0 trains; BPR: 1
 DEFAULT_BATCH_USERS = 0        # 0 = the library's default (cdae_hip_default_batch_users: num_users / 160, within [32, 256])
 
 

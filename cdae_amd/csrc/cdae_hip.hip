@@ -1229,9 +1229,11 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
   c.num_dim = mc->num_dim; c.num_neg = mc->num_neg; c.num_corruptions = 1;
   c.loss_type = CDAE_LOSS_SQUARE;                          // (validated above; the MF kernels read hp.loss_type, set below)
   c.using_adagrad = mc->using_adagrad; c.user_factor = 1;
-  // default: one user per block = the reference's strictly sequential loop (imf.hpp:71-115, bpr.hpp:56-106).  Larger blocks are a
-  // throughput setting the caller asks for: their accuracy envelope is not certified
-  c.batch_users = mc->batch_users ? mc->batch_users : 1u;
+  // default: IMF blocks of CDAE_IMF_DEFAULT_BATCH_USERS users — the largest block inside the +-0.002 mean-over-seeds bound against the
+  // sequential loop (imf.hpp:71-115; DESIGN.md §8b, tests/test_gpu_mf.py) —, BPR one user per block = the reference's strictly
+  // sequential loop (bpr.hpp:56-106: its block schedule is 0.008 low in the first epochs at every block size).  Larger blocks are a
+  // throughput setting the caller asks for
+  c.batch_users = mc->batch_users ? mc->batch_users : (mc->pairwise ? 1u : CDAE_IMF_DEFAULT_BATCH_USERS);
   c.lambda = mc->lambda; c.learn_rate = mc->learn_rate; c.corruption_ratio = 0.; c.beta = mc->beta;
   CHK(cdae_hip_create(&c, device_id, out));
   cdae_hip* h = *out;

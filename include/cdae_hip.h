@@ -55,8 +55,9 @@ extern "C" {
  * 7: default batch_users capped at 256 (was 512); cdae_hip_default_batch_users, cdae_hip_batch_users; cdae_hip_user_order (IMF / BPR
  *    block schedules train in activity-grouped order; their default is one user per block)
  * 8: cdae_hip_full_output_plan
- * 9: cdae_hip_set_test_rows, cdae_hip_eval_topn, cdae_hip_multi_eval_topn (TOPN metrics on the device) */
-#define CDAE_HIP_ABI_VERSION 9
+ * 9: cdae_hip_set_test_rows, cdae_hip_eval_topn, cdae_hip_multi_eval_topn (TOPN metrics on the device)
+ * 10: an IMF handle created with batch_users = 0 trains blocks of CDAE_IMF_DEFAULT_BATCH_USERS users (was 1); BPR's default stays 1 */
+#define CDAE_HIP_ABI_VERSION 10
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -311,8 +312,8 @@ int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous perio
  * concurrently against the block-start item rows; 1 == the reference's strictly sequential loop.  data_loss / penalty_loss are
  * 0 for these models, as in the reference (ModelBase defaults, model_base.hpp:36-45); cdae_hip_encode, the explicit-input step
  * and the full-output decode do not apply. */
-/* Training order.  A CDAE handle, and an IMF / BPR handle with one user per block, visit the users in id order like the reference.
- * An IMF / BPR handle with batch_users > 1 (the block schedule: a throughput setting) trains them in ACTIVITY-GROUPED order — users
+/* Training order.  A CDAE handle, and an IMF / BPR handle with one user per block (BPR's default), visit the users in id order like the reference.
+ * An IMF / BPR handle with batch_users > 1 (the block schedule: IMF's default, a throughput setting beyond it) trains them in ACTIVITY-GROUPED order — users
  * sorted by train-row length, cut into blocks of batch_users, the blocks visited in a fixed pseudo-random order — because a block
  * lasts as long as its most active user's serial chain.  cdae_hip_user_order returns that order: out[position] = user id
  * (count = num_users; the identity for every other handle).  The random streams, cdae_hip_train_users' range and
@@ -327,12 +328,19 @@ typedef struct cdae_mf_config {
   uint32_t using_adagrad;    /* imf.hpp:22                                               */
   uint32_t using_bias_term;  /* imf.hpp:21                                               */
   uint32_t pairwise;         /* 0: IMF (pointwise instances), 1: BPR (pairs)             */
-  uint32_t batch_users;      /* 0 -> 1 (the reference's sequential loop); > 1: block     */
-                             /* schedule in activity-grouped order (cdae_hip_user_order) */
+  uint32_t batch_users;      /* 1: the reference's sequential loop; > 1: block schedule  */
+                             /* in activity-grouped order (cdae_hip_user_order).  0 ->   */
+                             /* IMF: CDAE_IMF_DEFAULT_BATCH_USERS, BPR: 1 (below)         */
   double lambda;             /* imf.hpp:16                                               */
   double learn_rate;         /* imf.hpp:14                                               */
   double beta;               /* imf.hpp:15                                               */
 } cdae_mf_config;
+/* The IMF default block: the largest size measured INSIDE the sampled CDAE path's accuracy bound — Recall@10 within +-0.002 of the
+ * sequential loop at every epoch as a mean over six seeds (ML-10M shape K=200: tests/test_gpu_mf.py, fp64 fixtures of the loop;
+ * Yelp shape K=50: tools/mf_envelope.py) — 32 users per block sit up to +0.0035, 64 up to +0.005.  43 x the sequential loop's
+ * users/s at ML-10M shape.  BPR's block schedule is 0.008 low in the first two epochs at every block size (a user's pairs see the
+ * block-start row of their shared positive item), so a BPR handle keeps one user per block unless told otherwise. */
+#define CDAE_IMF_DEFAULT_BATCH_USERS 16u
 int cdae_hip_create_mf(const cdae_mf_config* cfg, int device_id, cdae_hip_t** out);
 
 /* ---- library-owned RCCL communicator and exchange schedule (one process per GPU: bench.py --gpus N) -----------------

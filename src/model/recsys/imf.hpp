@@ -4,8 +4,9 @@
 //
 //   method (reference lines)                         -> C ABI
 //   reset (57-69)                                     cdae_hip_create_mf, _set_interactions, _init_params
-//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default: one user per block = the reference loop itself;
-//                                                                                    CDAE_BATCH_USERS > 1: block schedule, throughput setting)
+//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default: blocks of 16 users, inside the +-0.002 mean-over-seeds
+//                                                                                    Recall@10 bound against the loop — DESIGN.md §8b; CDAE_BATCH_USERS=1:
+//                                                                                    the reference loop itself; larger blocks: throughput setting)
 //   predict_user_item_rating (117-119)                host dot product over parameters fetched once (cdae_hip_get_param)
 //   recommend (RecsysModelBase, 77-104)               cdae_hip_recommend_all in pre_recommend, then table reads
 //   get_user_vecs / get_item_vecs (121-127)           cdae_hip_get_param

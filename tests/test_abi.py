@@ -29,9 +29,9 @@ def test_header_symbols_are_all_exported_and_bound(built):
 
 def test_abi_version_and_config_layout(built):
     lib = cdae_amd.load_library()
-    assert lib.cdae_hip_abi_version() == 9
+    assert lib.cdae_hip_abi_version() == 10
     hdr = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
-    assert "#define CDAE_HIP_ABI_VERSION 9" in hdr
+    assert "#define CDAE_HIP_ABI_VERSION 10" in hdr
     # 14 uint32 + 4 double, naturally aligned
     assert ctypes.sizeof(binding._Config) == 14 * 4 + 4 * 8
     assert ctypes.sizeof(binding.Stats) == 8 * 11

@@ -1,4 +1,4 @@
-"""-m gpu: the TOPN metrics on the device (cdae_hip_set_test_rows / cdae_hip_eval_topn, ABI 9) against the oracle's restatement of
+"""-m gpu: the TOPN metrics on the device (cdae_hip_set_test_rows / cdae_hip_eval_topn, since ABI 9) against the oracle's restatement of
 TOPN_Evaluation::evaluate + evaluate_rec_list (/root/reference/src/model/evaluation.hpp:113-181, 183-219).
 
 The lists are integer work and the eight columns are sums of per-user fp64 terms added in user order, so the bar is BIT equality:
