@@ -24,7 +24,8 @@ P_UB, P_UB_AG = 12, 13
 P_COUNT = 14
 
 PLAN_FUSED_DECODE, PLAN_GEMM2_TN, PLAN_ROWS_FUSED = 1, 2, 4     # cdae_hip_full_output_plan bits (include/cdae_hip.h)
-IMF_DEFAULT_BATCH_USERS = 16   # CDAE_IMF_DEFAULT_BATCH_USERS (include/cdae_hip.h): what an IMF handle created with batch_users = 0 trains; BPR: 1
+IMF_DEFAULT_BATCH_USERS = 16   # CDAE_IMF_DEFAULT_BATCH_USERS / CDAE_BPR_DEFAULT_BATCH_USERS (include/cdae_hip.h): what an IMF / BPR handle created
+BPR_DEFAULT_BATCH_USERS = 8    # with batch_users = 0 trains on a BASELINE-sized data set (cdae_hip_mf_default_batch_users); 1 on smaller ones
 DEFAULT_BATCH_USERS = 0        # 0 = the library's default (cdae_hip_default_batch_users: num_users / 160, within [32, 256])
 
 
@@ -60,6 +61,7 @@ EXPORTS = {
     "cdae_hip_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cdae_hip_row_stride": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_default_batch_users": (C.c_uint32, [C.c_uint64]),
+    "cdae_hip_mf_default_batch_users": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "cdae_hip_batch_users": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_full_output_plan": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_user_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -238,6 +238,7 @@ struct cdae_hip {
   // a segment pass nobody read, ~20 runtime calls.  h->B is then the launch window (capacities, plans); cdae_hip_batch_users still
   // answers 1 and the stats count one block per user.
   bool mf_seq = false;
+  bool mf_auto = false;                 // IMF / BPR handle created with batch_users = 0: the block size is chosen per data set (set_interactions)
   bool prep_force_sort = false;         // cdae_hip_debug_sample_batch: the item-major lists are wanted although training would not read them
   // IMF / BPR block schedule (batch_users > 1): the users are trained in ACTIVITY-GROUPED order — sorted by train-row length, cut
   // into blocks of batch_users, the blocks visited in a fixed pseudo-random order — because a block lasts as long as its most active
@@ -1229,16 +1230,17 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
   c.num_dim = mc->num_dim; c.num_neg = mc->num_neg; c.num_corruptions = 1;
   c.loss_type = CDAE_LOSS_SQUARE;                          // (validated above; the MF kernels read hp.loss_type, set below)
   c.using_adagrad = mc->using_adagrad; c.user_factor = 1;
-  // default: IMF blocks of CDAE_IMF_DEFAULT_BATCH_USERS users — the largest block inside the +-0.002 mean-over-seeds bound against the
-  // sequential loop (imf.hpp:71-115; DESIGN.md §8b, tests/test_gpu_mf.py) —, BPR one user per block = the reference's strictly
-  // sequential loop (bpr.hpp:56-106: its block schedule is 0.008 low in the first epochs at every block size).  Larger blocks are a
-  // throughput setting the caller asks for
-  c.batch_users = mc->batch_users ? mc->batch_users : (mc->pairwise ? 1u : CDAE_IMF_DEFAULT_BATCH_USERS);
+  // default (cdae_hip_mf_default_batch_users): the largest block measured inside the +-0.002 mean-over-seeds Recall@10 bound against the
+  // sequential loop (imf.hpp:71-115, bpr.hpp:56-106; DESIGN.md §8b, tests/test_gpu_mf.py) at the BASELINE shapes, one user per block
+  // — the reference loop itself — on data sets smaller than the ones it was measured on.  Larger blocks are a throughput setting
+  // (batch_users = 0: decided in cdae_hip_set_interactions, where the number of users is known — cdae_hip_mf_default_batch_users)
+  c.batch_users = mc->batch_users ? mc->batch_users : 1u;
   c.lambda = mc->lambda; c.learn_rate = mc->learn_rate; c.corruption_ratio = 0.; c.beta = mc->beta;
   CHK(cdae_hip_create(&c, device_id, out));
   cdae_hip* h = *out;
   h->mf = mc->pairwise ? 2u : 1u;
   h->mf_bias = mc->using_bias_term ? 1u : 0u;
+  h->mf_auto = mc->batch_users == 0u;
   if (c.batch_users == 1u && std::getenv("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr) { h->mf_seq = true; h->B = MF_SEQ_USERS; }   // (the switch: round 3's launches, A/B)
   h->hp.loss_type = mc->loss_type;
   h->hp.lambda = (float)(2.0 * mc->lambda);                // imf.hpp:92-95, bpr.hpp:78-82: the gradients regularise with 2 * lambda
@@ -1246,6 +1248,10 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
 }
 
 uint32_t cdae_hip_row_stride(const cdae_hip_t* h) { return h ? h->Kp : 0; }
+uint32_t cdae_hip_mf_default_batch_users(uint64_t U, uint32_t pairwise) {
+  if (pairwise) return U >= CDAE_BPR_DEFAULT_MIN_USERS ? CDAE_BPR_DEFAULT_BATCH_USERS : 1u;
+  return U >= CDAE_IMF_DEFAULT_MIN_USERS ? CDAE_IMF_DEFAULT_BATCH_USERS : 1u;
+}
 uint32_t cdae_hip_default_batch_users(uint64_t U) {
   return (uint32_t)std::min<uint64_t>(CDAE_DEFAULT_BATCH_USERS_MAX, std::max<uint64_t>(32, (U / 160) & ~(uint64_t)31));
 }
@@ -1280,6 +1286,12 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   std::vector<int64_t> perm_ptr;
   std::vector<uint32_t> perm_col;
   h->user_perm.clear(); h->user_inv.clear();
+  if (h->mf && h->mf_auto) {
+    const uint32_t b = cdae_hip_mf_default_batch_users(U, h->mf == 2u ? 1u : 0u);
+    h->cfg.batch_users = b;
+    h->mf_seq = b == 1u && std::getenv("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr;
+    h->B = h->mf_seq ? MF_SEQ_USERS : b;
+  }
   if (h->mf && !h->mf_seq && h->B > 1 && U > h->B) {
     for (uint64_t u = 0; u < U; ++u)
       if (row_ptr[u + 1] < row_ptr[u]) return fail("row_ptr is not monotone at user %llu", (unsigned long long)u);

@@ -135,7 +135,17 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   // this lane's item id(s) of the current chunk of 64 instances and, when the item side does not move under this kernel, their
   // biases (one gather per chunk instead of one dependent scalar load per instance)
   uint32_t ci = 0, cj = 0, ni = 0, nj = 0;
-  float cib = 0.f, cjb = 0.f;
+  float cib = 0.f, cjb = 0.f, ciba = 0.f;
+  // BPR block schedule (round 4): the user's num_neg pairs of one positive share that item, and the loop steps its row between them
+  // (bpr.hpp:84-105).  The wavefront carries a PRIVATE copy of the positive's row, accumulators and bias from pair to pair — the
+  // block-start values at the positive's first pair, then stepped with each pair's own g and the user vector from before its step —
+  // and forms the next pair's prediction and user step from it.  Phase I is unchanged (it steps the real row with the same g's).
+  // Without the copy every block size sat 0.008 low in Recall@10 for the first two epochs (tools/mf_envelope.py).
+  constexpr bool CARRY = PAIR && !IN_PLACE;
+  float pw[NI], pa[NI], pb = 0.f, pba = 0.f;
+  uint32_t p_item = 0xFFFFFFFFu;                     // wave-uniform: the positive whose private copy the registers hold
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { pw[i] = 0.f; pa[i] = 1.f; }
   auto load_ids = [&](uint32_t c0, uint32_t& a, uint32_t& b) {
     const uint32_t t = c0 + lane;
     a = 0; b = 0;
@@ -148,7 +158,7 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
   for (uint32_t c0 = 0; c0 < n_inst; c0 += WAVE) {
     ci = ni; cj = nj;
     if (c0 + WAVE < n_inst) load_ids(c0 + WAVE, ni, nj);     // the next chunk's ids travel while this one is stepped
-    if (!IN_PLACE) { cib = IB[ci]; if (PAIR) cjb = IB[cj]; }
+    if (!IN_PLACE) { cib = IB[ci]; if (PAIR) cjb = IB[cj]; if (CARRY) ciba = IB_ag[ci]; }
     const uint32_t cnt = min((uint32_t)WAVE, n_inst - c0);
     // per lane: the label of chunk instance `lane` (imf.hpp:80-84: a positive, then its negatives), and the slot its loss
     // gradient is parked in until the chunk's 64 go out in one store
@@ -156,12 +166,13 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
     float gl = 0.f;
     float ri[PF][NI], rj[PF][NI], qi[PF][NI], qj[PF][NI];
     // IN_PLACE only: the rows' AdaGrad accumulators and the item biases (value, accumulator) of the same instances
-    constexpr int PA = IN_PLACE ? PF : 1, PJ = IN_PLACE && PAIR ? PF : 1;
+    constexpr int PA = (IN_PLACE || CARRY) ? PF : 1, PJ = IN_PLACE && PAIR ? PF : 1;
     float ai[PA][NI], aj[PJ][NI], pai[PA][NI], paj[PJ][NI];
     float bi[PA][2], bj[PJ][2], pbi[PA][2], pbj[PJ][2];
-    auto fetch = [&](float (&di)[NI], float (&dj)[NI], uint32_t idx) {      // rows of chunk instance idx
+    auto fetch = [&](float (&di)[NI], float (&dj)[NI], float (&dai)[NI], uint32_t idx) {      // rows of chunk instance idx
       const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)ci, idx);
       if (IN_PLACE) vload_coherent<NI>(di, IV + (size_t)it * hp.Kp + lo); else vload<NI>(di, IV + (size_t)it * hp.Kp + lo);
+      if (CARRY) vload<NI>(dai, IV_ag + (size_t)it * hp.Kp + lo);          // (the positive's accumulators: its private copy starts from them)
       if (PAIR) {
         const uint32_t jt = (uint32_t)__builtin_amdgcn_readlane((int)cj, idx);
         if (IN_PLACE) vload_coherent<NI>(dj, IV + (size_t)jt * hp.Kp + lo); else vload<NI>(dj, IV + (size_t)jt * hp.Kp + lo);
@@ -188,7 +199,7 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
 #pragma unroll
       for (int s = 0; s < PF; ++s) {
         if (IN_PLACE) fetch_all(s, qi[s], qj[s], pai[s % PA], paj[s % PJ], pbi[s % PA], pbj[s % PJ], min(g0 + (uint32_t)s, cnt - 1u));
-        else fetch(qi[s], qj[s], min(g0 + (uint32_t)s, cnt - 1u));
+        else fetch(qi[s], qj[s], pai[s % PA], min(g0 + (uint32_t)s, cnt - 1u));
       }
     };
     auto take_group = [&]() {
@@ -201,6 +212,9 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
           for (int i = 0; i < NI; ++i) { ai[s % PA][i] = pai[s % PA][i]; if (PAIR) aj[s % PJ][i] = paj[s % PJ][i]; }
           bi[s % PA][0] = pbi[s % PA][0]; bi[s % PA][1] = pbi[s % PA][1];
           if (PAIR) { bj[s % PJ][0] = pbj[s % PJ][0]; bj[s % PJ][1] = pbj[s % PJ][1]; }
+        } else if (CARRY) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) ai[s % PA][i] = pai[s % PA][i];
         }
       }
     };
@@ -220,15 +234,24 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
           fetch_all(s, ri[s], rj[s], ai[s % PA], aj[s % PJ], bi[s % PA], bj[s % PJ], x);
         }
       }
+      const bool carried = CARRY && it == p_item;    // wave-uniform: a later pair of the positive whose private copy is held
+      if (CARRY && !carried) {                       // the positive's first pair: the block-start row, accumulators and bias
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { pw[i] = ri[s][i]; pa[i] = ai[s % PA][i]; }
+        pb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cib), x));
+        pba = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ciba), x));
+        p_item = it;
+      }
       float d[NI];                                   // the item-side vector of the user step: iv[i] (IMF) or iv[i] - iv[j] (BPR)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) d[i] = PAIR ? ri[s][i] - rj[s][i] : ri[s][i];
+      for (int i = 0; i < NI; ++i) d[i] = CARRY ? pw[i] - rj[s][i] : PAIR ? ri[s][i] - rj[s][i] : ri[s][i];
       float dot = 0.f;
 #pragma unroll
       for (int i = 0; i < NI; ++i) dot = fmaf(uv[i], d[i], dot);
       float pred = wave_sum(dot);
       float truth;
       const float ibi = IN_PLACE ? bi[s % PA][0]
+                        : CARRY  ? pb
                                  : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cib), x));
       if (PAIR) {                                                                  // bpr.hpp:73-76 (ub cancels in the difference)
         pred += ibi - (IN_PLACE ? bj[s % PJ][0]
@@ -243,6 +266,11 @@ mf_user_kernel(HyperParams hp, uint32_t bias_term, const int64_t* __restrict__ r
       if (!IN_PLACE) {
         vstore<NI>(UVpre + (size_t)inst * hp.Kp + lo, uv);
         gl = lane == x ? g : gl;
+        if (CARRY) {                                 // the private copy takes the loop's step of the positive (bpr.hpp:79, 84-87, 93-96)
+          if (bias_term) ada_step_t<ADA>(hp, pb, pba, fmaf(lam2, pb, g));
+#pragma unroll
+          for (int i = 0; i < NI; ++i) ada_step_t<ADA>(hp, pw[i], pa[i], fmaf(g, uv[i], lam2 * pw[i]));
+        }
       } else {
         // the reference loop: item row(s) stepped at once with the user vector from BEFORE its own step (imf.hpp:94-114)
         float w[NI], a[NI];

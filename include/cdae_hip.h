@@ -56,7 +56,8 @@ extern "C" {
  *    block schedules train in activity-grouped order; their default is one user per block)
  * 8: cdae_hip_full_output_plan
  * 9: cdae_hip_set_test_rows, cdae_hip_eval_topn, cdae_hip_multi_eval_topn (TOPN metrics on the device)
- * 10: an IMF handle created with batch_users = 0 trains blocks of CDAE_IMF_DEFAULT_BATCH_USERS users (was 1); BPR's default stays 1 */
+ * 10: IMF / BPR handles created with batch_users = 0 train the certified block of their model (cdae_hip_mf_default_batch_users: 16 / 8
+ *     users on the BASELINE-sized data sets, was 1); BPR's phase U carries the positive item's row from pair to pair */
 #define CDAE_HIP_ABI_VERSION 10
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
@@ -330,17 +331,27 @@ typedef struct cdae_mf_config {
   uint32_t pairwise;         /* 0: IMF (pointwise instances), 1: BPR (pairs)             */
   uint32_t batch_users;      /* 1: the reference's sequential loop; > 1: block schedule  */
                              /* in activity-grouped order (cdae_hip_user_order).  0 ->   */
-                             /* IMF: CDAE_IMF_DEFAULT_BATCH_USERS, BPR: 1 (below)         */
+                             /* cdae_hip_mf_default_batch_users(num_users, pairwise)      */
   double lambda;             /* imf.hpp:16                                               */
   double learn_rate;         /* imf.hpp:14                                               */
   double beta;               /* imf.hpp:15                                               */
 } cdae_mf_config;
-/* The IMF default block: the largest size measured INSIDE the sampled CDAE path's accuracy bound — Recall@10 within +-0.002 of the
- * sequential loop at every epoch as a mean over six seeds (ML-10M shape K=200: tests/test_gpu_mf.py, fp64 fixtures of the loop;
- * Yelp shape K=50: tools/mf_envelope.py) — 32 users per block sit up to +0.0035, 64 up to +0.005.  43 x the sequential loop's
- * users/s at ML-10M shape.  BPR's block schedule is 0.008 low in the first two epochs at every block size (a user's pairs see the
- * block-start row of their shared positive item), so a BPR handle keeps one user per block unless told otherwise. */
+/* The default blocks (batch_users = 0): the largest sizes measured INSIDE the sampled CDAE path's accuracy bound — Recall@10 within
+ * +-0.002 of the sequential loop at every epoch as a mean over six seeds, against fp64 fixtures of the loop at ML-10M shape K=200
+ * (tests/test_gpu_mf.py; tools/mf_envelope.py has the other sizes and Yelp shape) — chosen when the data set is known
+ * (cdae_hip_set_interactions):
+ *   IMF  16 users per block from 8 192 users on (measured at 10 000 and 70 000 users; 32 users per block sit up to +0.0035, 64 up to
+ *        +0.005): 43 x the loop's users/s at ML-10M shape;
+ *   BPR   8 users per block from 65 536 users on (70 000 users: inside the bound; 10 000 users: +0.003 in the first two epochs, so
+ *        smaller data sets keep the loop): 22 x the loop's users/s.  Since ABI 10 a BPR user's pairs see their shared positive item's
+ *        row as the loop leaves it between them (a private copy carried through phase U); before, every block size was 0.008 low
+ *        in the first two epochs.
+ * Smaller data sets train one user per block: the reference loop itself. */
 #define CDAE_IMF_DEFAULT_BATCH_USERS 16u
+#define CDAE_IMF_DEFAULT_MIN_USERS 8192u
+#define CDAE_BPR_DEFAULT_BATCH_USERS 8u
+#define CDAE_BPR_DEFAULT_MIN_USERS 65536u
+uint32_t cdae_hip_mf_default_batch_users(uint64_t num_users, uint32_t pairwise);
 int cdae_hip_create_mf(const cdae_mf_config* cfg, int device_id, cdae_hip_t** out);
 
 /* ---- library-owned RCCL communicator and exchange schedule (one process per GPU: bench.py --gpus N) -----------------

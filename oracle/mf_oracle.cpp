@@ -127,10 +127,24 @@ struct Mf {
     std::vector<double> uvs;                                           // user vectors before their steps, one per instance / pair
     for (size_t u = s0; u < s1; ++u) {
       const size_t n = (size_t)(row_ptr[u + 1] - row_ptr[u]);
+      // BPR (round 4): a user's num_neg pairs share their positive item and the loop steps that item's row between them
+      // (bpr.hpp:84-105), so the user side carries a PRIVATE copy of the positive's row, accumulators and bias from pair to pair — taken
+      // from the block-start row at the positive's first pair, stepped with the pair's own g and the user vector from before its
+      // step.  (Without it every block size sat 0.008 low in Recall@10 for the first two epochs.)  Phase I is unchanged: it steps the
+      // real row with the same g's in (user, pair) order.
+      std::vector<double> pw(K), pa(K);
+      double pb = 0., pba = 0.;
+      long carried = -1;
       auto user_side = [&](size_t i, long j, double r) {
-        double pred = ub[u] + ib[i];
-        for (size_t k = 0; k < K; ++k) pred += uv[u * K + k] * iv[i * K + k];
-        if (j >= 0) {                                                  // pairwise: pred_i - pred_j (ub cancels)
+        const bool pair = j >= 0;
+        if (pair && carried != (long)i) {
+          for (size_t k = 0; k < K; ++k) { pw[k] = iv[i * K + k]; pa[k] = iv_ag[i * K + k]; }
+          pb = ib[i]; pba = ib_ag[i];
+          carried = (long)i;
+        }
+        double pred = ub[u] + (pair ? pb : ib[i]);
+        for (size_t k = 0; k < K; ++k) pred += uv[u * K + k] * (pair ? pw[k] : iv[i * K + k]);
+        if (pair) {                                                    // pairwise: pred_i - pred_j (ub cancels)
           double pj = ub[u] + ib[(size_t)j];
           for (size_t k = 0; k < K; ++k) pj += uv[u * K + k] * iv[(size_t)j * K + k];
           pred -= pj;
@@ -139,11 +153,15 @@ struct Mf {
         const size_t at = uvs.size();
         uvs.insert(uvs.end(), uv.begin() + u * K, uv.begin() + (u + 1) * K);
         recs.push_back(Rec{(uint32_t)i, 1., g, at});
-        if (j >= 0) recs.push_back(Rec{(uint32_t)j, -1., g, at});
-        if (c.using_bias_term && j < 0) step(ub[u], ub_ag[u], g + 2. * c.lambda * ub[u]);     // (BPR never steps ub)
+        if (pair) recs.push_back(Rec{(uint32_t)j, -1., g, at});
+        if (c.using_bias_term && !pair) step(ub[u], ub_ag[u], g + 2. * c.lambda * ub[u]);     // (BPR never steps ub)
         for (size_t k = 0; k < K; ++k) {
-          const double d = j >= 0 ? iv[i * K + k] - iv[(size_t)j * K + k] : iv[i * K + k];
+          const double d = pair ? pw[k] - iv[(size_t)j * K + k] : iv[i * K + k];
           step(uv[u * K + k], uv_ag[u * K + k], g * d + 2. * c.lambda * uv[u * K + k]);
+        }
+        if (pair) {                                                    // the private copy of the positive: bpr.hpp:79, 84-87, 93-96
+          if (c.using_bias_term) step(pb, pba, g + 2. * c.lambda * pb);
+          for (size_t k = 0; k < K; ++k) step(pw[k], pa[k], g * uvs[at + k] + 2. * c.lambda * pw[k]);
         }
       };
       for (size_t p = 0; p < n; ++p) {

@@ -4,7 +4,7 @@
 //
 //   method (reference lines)                         -> C ABI
 //   reset (57-69)                                     cdae_hip_create_mf, _set_interactions, _init_params
-//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default: blocks of 16 users, inside the +-0.002 mean-over-seeds
+//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default: blocks of 16 users (BPR: 8) on BASELINE-sized data sets, inside the +-0.002 mean-over-seeds
 //                                                                                    Recall@10 bound against the loop — DESIGN.md §8b; CDAE_BATCH_USERS=1:
 //                                                                                    the reference loop itself; larger blocks: throughput setting)
 //   predict_user_item_rating (117-119)                host dot product over parameters fetched once (cdae_hip_get_param)

@@ -48,6 +48,10 @@ def test_default_batch_users_is_the_certified_one(built):
     assert lib.cdae_hip_default_batch_users(70_000) == bench.DEFAULT_BATCH_USERS          # ML-10M shape (BASELINE configs[2])
     assert lib.cdae_hip_default_batch_users(480_000) == bench.DEFAULT_BATCH_USERS         # Netflix shape (configs[3])
     assert lib.cdae_hip_default_batch_users(10_000) == 32 and lib.cdae_hip_default_batch_users(17) == 32
+    # the sibling models (ABI 10): the certified block of each on BASELINE-sized data sets, the reference loop on smaller ones
+    mf = lib.cdae_hip_mf_default_batch_users
+    assert (mf(70_000, 0), mf(480_000, 0), mf(10_000, 0), mf(8_191, 0), mf(1, 0)) == (16, 16, 16, 1, 1)
+    assert (mf(70_000, 1), mf(480_000, 1), mf(65_535, 1), mf(10_000, 1), mf(1, 1)) == (8, 8, 1, 1, 1)
     assert max(lib.cdae_hip_default_batch_users(u) for u in (1, 5_000, 40_000, 41_000, 10**7, 2**30 - 1)) <= cap
 
 

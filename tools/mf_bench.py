@@ -3,8 +3,8 @@
 
     python tools/mf_bench.py --shape ml10m --num-dim 200 --batch-users 1 64 256 1024 4096 [--cpu-users 2000]
 One JSON line per (model, batch_users): users/s of cdae_hip_train_epoch (one epoch after a warm-up epoch), Recall@10 after it.
-batch_users = 1 is the reference's sequential loop (BPR's default); IMF's default is blocks of 16 users (the certified block size,
-DESIGN.md §8b); larger blocks are the activity-grouped block schedule as a throughput setting.
+batch_users = 1 is the reference's sequential loop; the library defaults are blocks of 16 (IMF) / 8 (BPR) users on BASELINE-sized data
+sets (the certified block sizes); larger blocks are the activity-grouped block schedule as a throughput setting.
 """
 import argparse
 import json
@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="ml10m")
     ap.add_argument("--num-dim", type=int, default=200)
-    ap.add_argument("--batch-users", type=int, nargs="+", default=[1, 16, 256, 1024, 4096])
+    ap.add_argument("--batch-users", type=int, nargs="+", default=[1, 8, 16, 256, 1024, 4096])
     ap.add_argument("--cpu-users", type=int, default=2000)
     ap.add_argument("--seed", type=int, default=20141119)
     args = ap.parse_args()
@@ -35,7 +35,7 @@ def main():
             m.train_one_iteration(args.seed, 0)
             st = m.train_one_iteration(args.seed, 1)
             rec = float(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5])
-            print(json.dumps({"model": name, "batch_users": B, "library_default": B == (1 if pairwise else cdae_amd.binding.IMF_DEFAULT_BATCH_USERS), "users_per_s": round(st.users / st.wall_seconds), "ms_per_block": round(1e3 * st.wall_seconds / st.batches, 3),
+            print(json.dumps({"model": name, "batch_users": B, "library_default": B == int(cdae_amd.binding.load_library().cdae_hip_mf_default_batch_users(d.num_users, int(pairwise))), "users_per_s": round(st.users / st.wall_seconds), "ms_per_block": round(1e3 * st.wall_seconds / st.batches, 3),
                               "recall10_after_2_epochs": round(rec, 5)}), flush=True)
             m.close()
         n = min(args.cpu_users, d.num_users)

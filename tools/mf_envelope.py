@@ -20,8 +20,8 @@ import cdae_amd  # noqa: E402
 from cdae_amd import synth  # noqa: E402
 
 
-def curve(d, seed, K, lt, pairwise, B, epochs):
-    m = cdae_amd.MF(cdae_amd.MFConfig(num_dim=K, lt=lt, pairwise=pairwise, batch_users=B))
+def curve(d, seed, K, lt, pairwise, B, epochs, num_neg=5):
+    m = cdae_amd.MF(cdae_amd.MFConfig(num_dim=K, lt=lt, pairwise=pairwise, batch_users=B, num_neg=num_neg))
     m.reset(d, seed=seed)
     m.set_test_rows(d.test_ptr, d.test_col)
     rec, ups = [], []
@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--seeds", type=int, nargs="+", default=[20141119, 7, 1234, 42])
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--models", nargs="+", default=["IMF", "BPR"])
+    ap.add_argument("--num-neg", type=int, default=5)
     args = ap.parse_args()
     kinds = {"IMF": (False, cdae_amd.SQUARE), "BPR": (True, cdae_amd.LOG)}
     for name in args.models:
@@ -49,11 +50,11 @@ def main():
         speed = {B: [] for B in [1] + args.batch_users}
         for seed in args.seeds:
             d = synth.generate_shape(args.shape, seed=seed)
-            lit, u1 = curve(d, seed, args.num_dim, lt, pairwise, 1, args.epochs)
+            lit, u1 = curve(d, seed, args.num_dim, lt, pairwise, 1, args.epochs, args.num_neg)
             speed[1].append(u1)
             print(json.dumps({"model": name, "shape": args.shape, "seed": seed, "batch_users": 1, "recall10": np.round(lit, 5).tolist(), "users_per_s": round(u1)}), flush=True)
             for B in args.batch_users:
-                rec, ups = curve(d, seed, args.num_dim, lt, pairwise, B, args.epochs)
+                rec, ups = curve(d, seed, args.num_dim, lt, pairwise, B, args.epochs, args.num_neg)
                 diffs[B].append(rec - lit)
                 speed[B].append(ups)
                 print(json.dumps({"model": name, "shape": args.shape, "seed": seed, "batch_users": B, "recall10": np.round(rec, 5).tolist(),
