@@ -251,8 +251,8 @@ gemm_nt_bf16_lds_kernel(const __bf16* __restrict__ A, const __bf16* __restrict__
   uint32_t bid = blockIdx.x;
   if (EPI == EPI_STORE && ep.bias_blocks) {                                // leading workgroups: part of the hidden-bias recurrence (see GemmEpilogue)
     if (bid < ep.bias_blocks) {
-      if (ep.bias_hp.adagrad) hidden_bias_role<true>(ep.bias_hp, bid * blockDim.x + threadIdx.x, ep.bias_nb, ep.bias_delta, ep.bias_b, ep.bias_b_ag);
-      else hidden_bias_role<false>(ep.bias_hp, bid * blockDim.x + threadIdx.x, ep.bias_nb, ep.bias_delta, ep.bias_b, ep.bias_b_ag);
+      if (ep.bias_hp.adagrad) hidden_bias_role<true, true>(ep.bias_hp, bid * blockDim.x + threadIdx.x, ep.bias_nb, ep.bias_delta, ep.bias_b, ep.bias_b_ag);
+      else hidden_bias_role<false, true>(ep.bias_hp, bid * blockDim.x + threadIdx.x, ep.bias_nb, ep.bias_delta, ep.bias_b, ep.bias_b_ag);
       return;
     }
     bid -= ep.bias_blocks;
@@ -1488,8 +1488,8 @@ full_positive_fixup_kernel(const uint32_t* __restrict__ ex_item, const uint64_t*
 __global__ void __launch_bounds__(256)
 hidden_bias_kernel(HyperParams hp, uint32_t nb, const float* __restrict__ DELTA, float* __restrict__ b, float* __restrict__ b_ag) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (hp.adagrad) hidden_bias_role<true>(hp, k, nb, DELTA, b, b_ag);
-  else hidden_bias_role<false>(hp, k, nb, DELTA, b, b_ag);
+  if (hp.adagrad) hidden_bias_role<true, true>(hp, k, nb, DELTA, b, b_ag);
+  else hidden_bias_role<false, true>(hp, k, nb, DELTA, b, b_ag);
 }
 
 // bf16 images of a decoder row that has just been stepped, written by the kernel that holds it in registers (round 3: the separate
@@ -1535,8 +1535,8 @@ full_rows_kernel(HyperParams hp, const uint32_t* __restrict__ seg_begin, const u
   const uint32_t bias_blocks = b ? (hp.Kp + blockDim.x - 1) / blockDim.x : 0u;   // b == nullptr: the recurrence runs in hidden_bias_kernel
   if (blockIdx.x < bias_blocks) {
     const float* dl = (BIAS_DELTA ? BIAS_DELTA : DELTA) + (size_t)bias_u0 * hp.Kp;
-    if (hp.adagrad) hidden_bias_role<true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb - bias_u0, dl, b, b_ag);
-    else hidden_bias_role<false>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb - bias_u0, dl, b, b_ag);
+    if (hp.adagrad) hidden_bias_role<true, true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb - bias_u0, dl, b, b_ag);
+    else hidden_bias_role<false, true>(hp, blockIdx.x * blockDim.x + threadIdx.x, nb - bias_u0, dl, b, b_ag);
     return;
   }
   // One workgroup per item row: its four wavefronts split the row's kept inputs (a popular row has ~500 of them per

@@ -168,6 +168,7 @@ struct cdae_hip {
   // 0.055, 512: 0.083 -> 0.067 / 0.124 -> 0.106, 1024: 0.099 -> 0.088 / 0.145 -> 0.132, 2048: - / 0.197 -> 0.188, 4096: - / 0.327 -> 0.327
   // — a hand-off between two streams costs ~15 us, the recurrence 41 ns per user
   uint32_t full_one_stream_max = 2048;
+  bool full_b_summed = false;           // CDAE_FULL_B_SUMMED (experiment, see hidden_bias_role)
   bool full_bias_unsplit = false;       // CDAE_FULL_BIAS_UNSPLIT: the whole recurrence beside the row launch (A/B)
   bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
@@ -1149,6 +1150,9 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
   h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->full_bias_unsplit = std::getenv("CDAE_FULL_BIAS_UNSPLIT") != nullptr;
+  if (std::getenv("CDAE_FULL_B_SUMMED")) {        // EXPERIMENT (hidden_bias_role): one summed step of b per full-output block; a sum cannot be hosted in two halves
+    h->full_bias_unsplit = true; h->full_one_stream_max = 0xFFFFFFFFu; h->full_b_summed = true;
+  }
   if (const char* v = std::getenv("CDAE_FULL_ONE_STREAM_MAX")) h->full_one_stream_max = (uint32_t)std::strtoul(v, nullptr, 10);
   h->gemm1_whole_tiles = std::getenv("CDAE_GEMM1_PIPE") == nullptr;
   h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
@@ -1196,6 +1200,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
     if (hp.trace) (void)hipMemset(hp.trace, 0, 4 * cdae::TRACE_CAP * sizeof(unsigned long long));
   }
   hp.debug_skip = std::getenv("CDAE_DEBUG_SKIP_ROLES") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_SKIP_ROLES"), nullptr, 10) : 0u;
+  if (std::getenv("CDAE_FULL_B_SUMMED")) hp.debug_skip |= 64u;
   hp.debug_rank = std::getenv("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
   *out = h;
   return 0;

@@ -54,7 +54,7 @@ struct HyperParams {
   uint32_t debug_rank;       // -DCDAE_DECODE_TIMING builds: the row whose timeline decode_rows_kernel records
   unsigned long long* trace; // CDAE_WAVE_TRACE (developer aid, tools/wave_trace.py): per-wavefront {tag, start, end, extra} records, or nullptr
   uint32_t trace_odd;        // (wave trace) 1 on batches with an odd sequence number
-  uint32_t debug_skip;       // CDAE_DEBUG_SKIP_ROLES (timing experiments only, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows
+  uint32_t debug_skip;       // CDAE_DEBUG_SKIP_ROLES (timing experiments only, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows; 64 = CDAE_FULL_B_SUMMED (hidden_bias_role)
   // users whose private rows (Wu, Wu_ag, Uu, Uu_ag) THIS handle holds, table row 0 = user own_u0.  Everything except an item
   // shard owns every user ([0, 2^64)); an item shard owns a contiguous range (the user node is sharded by user)
   uint64_t own_u0, own_u1;
@@ -1566,12 +1566,18 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
 // One thread per coordinate; the recurrence is elementwise, the delta loads run 16 users ahead of it.
 // It needs only delta, like the input rows, so it runs as the leading workgroup(s) of input_rows_kernel
 // instead of a launch of its own.
-template <bool ADAGRAD>
+// FULL (the full-output callers) + debug_skip bit 64 (CDAE_FULL_B_SUMMED=1, an EXPERIMENT of round 4, not a shipped schedule): ONE step of
+// b per block with the block's summed delta — what the decoder and input rows of that schedule take — instead of a step per user.
+// Measured (profiles/r04_full_output_envelope_*_bsummed.txt): at Yelp shape the loop's best Recall@10 in 2-5 epochs instead
+// of 4-27; at ML-10M shape and at K = 512 the blocks then stay BELOW the loop (0.14 against 0.16).  The default stays a step per user.
+template <bool ADAGRAD, bool FULL = false>
 __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uint32_t nb,
                                                  const float* __restrict__ DELTA, float* __restrict__ b,
                                                  float* __restrict__ b_ag) {
   if (k >= hp.Kp || nb == 0) return;
   hp.adagrad = ADAGRAD;
+  const bool summed = FULL && (hp.debug_skip & 64u) != 0u;
+  float sum = 0.f;
   float p = b[k], acc = b_ag[k];
   // One dependent AdaGrad chain per coordinate (7 instructions per user) bounds this role: the loop is branch-free, and
   // the deltas run UN users ahead of it in a register ring — slot j is refilled (index clamped, never guarded) as soon as
@@ -1594,12 +1600,13 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
     for (uint32_t j = 0; j < UN; ++j) {
       const float x = d[j];
       d[j] = delta_of(u + UN + j);
-      ada_step(hp, p, acc, fmaf(hp.lambda, p, x));
+      if (FULL && summed) sum += x; else ada_step(hp, p, acc, fmaf(hp.lambda, p, x));
     }
   }
 #pragma unroll
   for (uint32_t j = 0; j < UN; ++j)                            // the last nb % UN users
-    if (u + j < nb) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
+    if (u + j < nb) { if (FULL && summed) sum += d[j]; else ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j])); }
+  if (FULL && summed) ada_step(hp, p, acc, fmaf(hp.lambda, p, sum));
   b[k] = p;
   b_ag[k] = acc;
 }

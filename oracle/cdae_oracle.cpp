@@ -506,12 +506,19 @@ struct Oracle {
             dbp[j] += g;
           }
         }
+        // EXPERIMENT of round 4 (CDAE_ORACLE_B_SUMMED=1; the HIP path's CDAE_FULL_B_SUMMED): b takes ONE step per block with the summed delta
+        // instead of a step per user.  Not the schedule the fixtures hold — DESIGN.md §5c has what it does to the curves.
+        static const bool b_summed = std::getenv("CDAE_ORACLE_B_SUMMED") != nullptr;
+        std::vector<double> bsum(K, 0.);
         for (size_t s = 0; s < nb; ++s) {                      // hidden layer: delta, b (user order), Wu[u]
           const size_t uid = s0 + s;
           double* delta = &DELTA[s * K];
           for (size_t k = 0; k < K; ++k) delta[k] = HG[s * K + k] * Dv[s * K + k];
-          for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * b[k];
-          ada_row(b.data(), b_ag.data(), grad.data());
+          if (b_summed) { for (size_t k = 0; k < K; ++k) bsum[k] += delta[k]; }
+          else {
+            for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * b[k];
+            ada_row(b.data(), b_ag.data(), grad.data());
+          }
           if (c.user_factor) {
             double* wu = &Wu[uid * K];
             for (size_t k = 0; k < K; ++k) grad[k] = delta[k] + c.lambda * wu[k];
@@ -519,6 +526,10 @@ struct Oracle {
           }
           if (c.linear_function) uu_step(uid, delta, &SSUM[s * K], grad.data());
           for (uint32_t j : kept[s]) { has_in[j] = 1; for (size_t k = 0; k < K; ++k) dIn[(size_t)j * K + k] += sc * delta[k]; }
+        }
+        if (b_summed) {
+          for (size_t k = 0; k < K; ++k) grad[k] = bsum[k] + c.lambda * b[k];
+          ada_row(b.data(), b_ag.data(), grad.data());
         }
         for (size_t j = 0; j < I; ++j) {                       // one step per row with the block's summed gradient
           ada1(bp[j], bp_ag[j], dbp[j] + c.lambda * bp[j]);

@@ -243,9 +243,17 @@ def full_output_envelope(args, lt):
         d = synth.generate_shape(args.shape, seed=seed)
         fx = os.path.join(ROOT, "tests", "golden", f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_full1_seed{seed}.npz")
         ep = args.epochs or 20
-        if os.path.exists(fx):
+        prev = None
+        if args.literal_from:                       # the device's batch_users = 1 curve of an earlier envelope file (the B = 1 loop does not change
+            for line in open(args.literal_from):    # when the block schedule does; 70 000 block steps per epoch at ML-10M shape are 3 min of GPU per seed)
+                r = json.loads(line)
+                if r.get("run") == "full-output literal" and r.get("shape") == args.shape and int(r.get("seed")) == seed:
+                    prev = r
+        if os.path.exists(fx) and len(np.load(fx, allow_pickle=True)["recall10"]) >= (args.literal_epochs or 0):
             f = np.load(fx, allow_pickle=True)
             lit_r, lit_l, src = [float(x) for x in f["recall10"]], [float(x) for x in f["train_loss"]], "fp64 fixture"
+        elif prev is not None:
+            lit_r, lit_l, src = prev["recall10"], prev["loss"], prev["source"] + " (from " + os.path.basename(args.literal_from) + ")"
         else:
             lit_r, lit_l, _ = run_single(d, seed, args.num_dim, lt, 1, args.literal_epochs or ep, full_output=True)
             src = "hip batch_users=1"
@@ -277,6 +285,7 @@ def main():
     ap.add_argument("--hybrid-hot", type=int, default=-1, help="--shards N: the hot-row / tail hybrid (run_hybrid) with this many owner-computed "
                     "popular rows (0: only b and the user node are exact)")
     ap.add_argument("--full-output", action="store_true", help="the full-output block schedule against its B = 1 limit (see full_output_envelope)")
+    ap.add_argument("--literal-from", default="", help="--full-output: take the literal (batch_users = 1) curves from this earlier envelope file")
     ap.add_argument("--literal-epochs", type=int, default=0, help="--full-output without a fixture: epochs of the HIP batch_users = 1 run")
     args = ap.parse_args()
     lt = cdae_amd.CROSS_ENTROPY if args.loss == "CE" else cdae_amd.SQUARE
