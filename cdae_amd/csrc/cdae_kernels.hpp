@@ -1595,18 +1595,31 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
 #pragma unroll
   for (uint32_t j = 0; j < UN; ++j) d[j] = delta_of(j);
   uint32_t u = 0;
-  for (; u + UN <= nb; u += UN) {
+  if (FULL && summed) {                                        // (the experiment: its own loop, so that the shipped chain below carries no test)
+    for (; u + UN <= nb; u += UN) {
 #pragma unroll
-    for (uint32_t j = 0; j < UN; ++j) {
-      const float x = d[j];
-      d[j] = delta_of(u + UN + j);
-      if (FULL && summed) sum += x; else ada_step(hp, p, acc, fmaf(hp.lambda, p, x));
+      for (uint32_t j = 0; j < UN; ++j) {
+        sum += d[j];
+        d[j] = delta_of(u + UN + j);
+      }
     }
-  }
 #pragma unroll
-  for (uint32_t j = 0; j < UN; ++j)                            // the last nb % UN users
-    if (u + j < nb) { if (FULL && summed) sum += d[j]; else ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j])); }
-  if (FULL && summed) ada_step(hp, p, acc, fmaf(hp.lambda, p, sum));
+    for (uint32_t j = 0; j < UN; ++j)
+      if (u + j < nb) sum += d[j];
+    ada_step(hp, p, acc, fmaf(hp.lambda, p, sum));
+  } else {
+    for (; u + UN <= nb; u += UN) {
+#pragma unroll
+      for (uint32_t j = 0; j < UN; ++j) {
+        const float x = d[j];
+        d[j] = delta_of(u + UN + j);
+        ada_step(hp, p, acc, fmaf(hp.lambda, p, x));
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < UN; ++j)                            // the last nb % UN users
+      if (u + j < nb) ada_step(hp, p, acc, fmaf(hp.lambda, p, d[j]));
+  }
   b[k] = p;
   b_ag[k] = acc;
 }
