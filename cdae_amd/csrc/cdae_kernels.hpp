@@ -1597,17 +1597,21 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
   uint32_t u = 0;
   if (FULL && summed) {                                        // (the experiment: its own loop, so that the shipped chain below carries no test)
     float sq = 0.f;                                            // bit 128 on top: the accumulator grows with the per-user squares, not with the square of the sum
+    const bool chunked = (hp.debug_skip & 256u) != 0u;         // bit 256 on top: one step per 32 users (their summed delta) instead of one per block
     for (; u + UN <= nb; u += UN) {
 #pragma unroll
       for (uint32_t j = 0; j < UN; ++j) {
         sum += d[j]; sq = fmaf(d[j], d[j], sq);
         d[j] = delta_of(u + UN + j);
       }
+      if (chunked && ((u / UN) & 1u)) { ada_step(hp, p, acc, fmaf(hp.lambda, p, sum)); sum = 0.f; }
     }
 #pragma unroll
     for (uint32_t j = 0; j < UN; ++j)
       if (u + j < nb) { sum += d[j]; sq = fmaf(d[j], d[j], sq); }
-    if (hp.debug_skip & 128u) {
+    if (chunked && sum == 0.f && nb % (2u * UN) == 0u) {
+      // (every chunk has been stepped)
+    } else if (hp.debug_skip & 128u) {
       const float g = fmaf(hp.lambda, p, sum);
       if (ADAGRAD) { acc += sq; p = fmaf(-hp.lr * g, fast_rcp(fast_sqrt(acc) + hp.beta), p); } else p = fmaf(-hp.lr, g, p);
     } else
