@@ -1841,7 +1841,6 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
                         float* __restrict__ bp, float* __restrict__ bp_ag, uint32_t* __restrict__ touched,
                         __bf16* __restrict__ Db /* [Ip][512] */, uint32_t Ip) {
   extern __shared__ __attribute__((aligned(1024))) char smemf[];
-  constexpr uint32_t KP = 512;
   constexpr uint32_t NW = 4 / KH, ZROWS = 512 / KH, GQ = 8 / NW;              // wavefronts, staged Z^T rows, G^T DMA instructions per wavefront
   constexpr uint32_t STAGE = (uint32_t)fr_stage_bytes<KH>();
   const uint32_t lane = threadIdx.x % WAVE, wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // 0 .. NW-1

@@ -2609,19 +2609,8 @@ float* hg_buf(cdae_hip_t* h) { return h->d_HG; }
 float* ev_hsum_buf(cdae_hip_t* h) { return h->d_hsum_eval; }
 uint32_t eval_chunk() { return EVAL_CHUNK; }
 
-// blocks 1.. of the input-sum all-reduce buffer `buf` ([blocks][n][Kp]): the Wu / Uu rows of users [u0, u0 + n) this shard owns
-// (zeros for everybody else's): after the all-reduce(sum) every shard holds the owners' rows, bit for bit
-static int stage_own_rows(cdae_hip* h, uint64_t u0, uint32_t n, float* buf) {
-  uint32_t blk = 1;
-  if (h->cfg.user_factor)
-    DISPATCH_NI(h->NI, cdae::own_rows_stage_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->hp, (const float*)h->d_Wu, u0, n,
-                buf + (size_t)(blk++) * n * h->Kp);
-  if (h->cfg.linear_function)
-    DISPATCH_NI(h->NI, cdae::own_rows_stage_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, h->hp, (const float*)h->d_Uu, u0, n,
-                buf + (size_t)(blk++) * n * h->Kp);
-  return 0;
-}
-// block 0 = the users' input sums over this shard's rows, blocks 1.. = stage_own_rows' blocks — one launch (unit_sum_stage_kernel)
+// block 0 = the users' input sums over this shard's rows; blocks 1.. = the Wu / Uu rows of the users this shard owns (zeros for everybody
+// else's: after the all-reduce(sum) every shard holds the owners' rows, bit for bit) — one launch (unit_sum_stage_kernel)
 static int sum_and_stage(cdae_hip* h, const float* hpart, const uint32_t* uptr, uint64_t u0, uint32_t n, float* buf) {
   const float* ta = h->cfg.user_factor ? h->d_Wu : (h->cfg.linear_function ? h->d_Uu : nullptr);
   const float* tb = h->cfg.user_factor && h->cfg.linear_function ? h->d_Uu : nullptr;

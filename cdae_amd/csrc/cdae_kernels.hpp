@@ -1946,7 +1946,7 @@ unit_sum_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint32_t*
   }
   vstore<NI>(Hsum + (size_t)slot * hp.Kp + lo, acc);
 }
-// Item shard, phase 0 in ONE launch (round 4; was unit_sum_kernel + one own_rows_stage_kernel per private matrix): block 0 of the
+// Item shard, phase 0 in ONE launch (round 4; was unit_sum_kernel + one staging launch per private matrix): block 0 of the
 // all-reduce buffer = the slot's input sum as above, blocks 1.. = the slot's rows of the private matrices the encode needs (Wu, then
 // Uu) when this shard owns the user, zeros otherwise — the same values in the same places, one launch boundary instead of two or three.
 template <int NI>
@@ -2003,26 +2003,6 @@ slab_sum_kernel(HyperParams hp, const float* __restrict__ HGpart, uint32_t n_par
   vstore<NI>(HG + (size_t)slot * hp.Kp + lo, acc);
 }
 
-// Item shard, user node sharded by user: the private rows of a batch's users reach every shard through the SAME
-// all-reduce(sum) that carries the input sums — the owner contributes the row, everybody else zeros, and x + 0 + ... + 0 is exact,
-// so the gathered rows are the owner's bits.  out[slot] = table[uid - own_u0] if this handle owns user u0 + slot, else 0.
-template <int NI>
-__global__ void __launch_bounds__(256)
-own_rows_stage_kernel(HyperParams hp, const float* __restrict__ table, uint64_t u0, uint32_t nb, float* __restrict__ out) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
-  const uint64_t uid = u0 + slot;
-  const uint32_t lo = lane * NI;
-  float v[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) v[i] = 0.f;
-  const bool own = cdae_xa::owns_user(uid, hp.own_u0, hp.own_u1);          // wave-uniform
-  if (own) vload<NI>(v, table + (size_t)(uid - hp.own_u0) * hp.Kp + lo);
-#pragma unroll
-  for (int i = 0; i < NI; ++i) v[i] = cdae_xa::own_row_contribution(own, v[i]);
-  vstore<NI>(out + (size_t)slot * hp.Kp + lo, v);
-}
 // Item shard, sampled decode: the RAW local hidden gradient of every user of the batch — HG (decode's overflow corrections) plus
 // hidden_gather_kernel's partial rows, added in exactly hidden_finish_kernel's order (unit-major, then partition), so that with one
 // shard the all-reduced sum is the single-GPU hg bit for bit.  delta is formed after the all-reduce (hidden_finish, n_parts = 0).
