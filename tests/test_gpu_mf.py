@@ -225,6 +225,15 @@ IMF_SEQ = sorted(glob.glob(os.path.join(_GOLD, "ml10m_k200_imf_seq_seed*.npz")))
 BPR_SEQ = sorted(glob.glob(os.path.join(_GOLD, "ml10m_k200_bpr_seq_seed*.npz")))
 
 
+_ML10M = {}
+
+
+def _ml10m_data(seed):                   # (the two models' runs share the six synthetic data sets: ~5 s each to generate)
+    if seed not in _ML10M:
+        _ML10M[seed] = synth.generate_shape("ml10m", seed=seed)
+    return _ML10M[seed]
+
+
 @pytest.mark.parametrize("name", ["IMF", "BPR"])
 def test_library_default_block_holds_the_accuracy_bound_at_ml10m_shape(built, name):
     """north_star's tolerance as the sampled CDAE path states it: Recall@10 within +-0.002 of the reference loop at every
@@ -240,7 +249,7 @@ def test_library_default_block_holds_the_accuracy_bound_at_ml10m_shape(built, na
     for p in fixtures:
         f = np.load(p, allow_pickle=True)
         seed = int(f["seed"])
-        d = synth.generate_shape("ml10m", seed=seed)
+        d = _ml10m_data(seed)
         assert d.nnz_train == int(f["nnz_train"]) and str(f["model"]) == name
         m = cdae_amd.MF(cdae_amd.MFConfig(num_dim=200, lt=cdae_amd.LOG if pairwise else cdae_amd.SQUARE, pairwise=pairwise, batch_users=0))
         m.reset(d, seed=seed)
