@@ -1200,7 +1200,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
     if (hp.trace) (void)hipMemset(hp.trace, 0, 4 * cdae::TRACE_CAP * sizeof(unsigned long long));
   }
   hp.debug_skip = std::getenv("CDAE_DEBUG_SKIP_ROLES") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_SKIP_ROLES"), nullptr, 10) : 0u;
-  if (const char* v = std::getenv("CDAE_FULL_B_SUMMED")) hp.debug_skip |= (std::atoi(v) == 2 ? 192u : std::atoi(v) == 3 ? 320u : 64u);     // 2: summed gradient, per-user accumulator; 3: a step per 32 users
+  if (const char* v = std::getenv("CDAE_FULL_B_SUMMED")) hp.debug_skip |= (std::atoi(v) == 2 ? 192u : std::atoi(v) == 3 ? 320u : std::atoi(v) == 4 ? 832u : 64u);     // 2: summed gradient, per-user accumulator; 3 / 4: a step per 32 / 16 users
   hp.debug_rank = std::getenv("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
   *out = h;
   return 0;

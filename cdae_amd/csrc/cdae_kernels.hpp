@@ -1604,12 +1604,12 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
         sum += d[j]; sq = fmaf(d[j], d[j], sq);
         d[j] = delta_of(u + UN + j);
       }
-      if (chunked && ((u / UN) & 1u)) { ada_step(hp, p, acc, fmaf(hp.lambda, p, sum)); sum = 0.f; }
+      if (chunked && (((u / UN) & 1u) || (hp.debug_skip & 512u))) { ada_step(hp, p, acc, fmaf(hp.lambda, p, sum)); sum = 0.f; }     // (bit 512: per 16 users)
     }
 #pragma unroll
     for (uint32_t j = 0; j < UN; ++j)
       if (u + j < nb) { sum += d[j]; sq = fmaf(d[j], d[j], sq); }
-    if (chunked && sum == 0.f && nb % (2u * UN) == 0u) {
+    if (chunked && sum == 0.f && nb % ((hp.debug_skip & 512u) ? UN : 2u * UN) == 0u) {
       // (every chunk has been stepped)
     } else if (hp.debug_skip & 128u) {
       const float g = fmaf(hp.lambda, p, sum);
