@@ -62,6 +62,54 @@ def compulsory_decode_bytes(K, Kp, num_items, examples, batch_users):
     return rows * (5.0 * 4.0 * Kp + 16.0) + batch_users * 4.0 * Kp + examples * 12.0
 
 
+class Watchdog:
+    """N > 1 only.  `with WATCHDOG.stage("what", seconds):` around every step that can wait on ANOTHER rank (communicator set-up,
+    collectives, barriers): if it does not return in time this rank prints one parseable JSON line with "error" and exits with
+    status 4 instead of hanging until the driver's own limit kills the job (a rank that never reaches ncclCommInitRank, a
+    collective whose peer died).  One timer thread per armed stage; nothing on the hot path (steps between two syncs are queued
+    asynchronously and never armed)."""
+
+    def __init__(self):
+        self.rank, self.world, self.args = 0, 1, None
+
+    def configure(self, rank, world, args):
+        self.rank, self.world, self.args = rank, world, args
+
+    def stage(self, what, seconds):
+        import contextlib
+        import threading
+        if self.world <= 1:
+            return contextlib.nullcontext()
+        wd = self
+
+        class _Stage:
+            def __enter__(self_):
+                self_.t = threading.Timer(seconds, wd.fire, args=(what, seconds))
+                self_.t.daemon = True
+                self_.t.start()
+
+            def __exit__(self_, *exc):
+                self_.t.cancel()
+                return False
+        return _Stage()
+
+    def fire(self, what, seconds):
+        a = self.args
+        line = {"metric": "users/sec (whole node)", "value": None, "unit": "users/s", "n_gpus": self.world, "steps": getattr(a, "steps", None),
+                "warmup": getattr(a, "warmup", None), "error": f"rank {self.rank}: '{what}' did not complete within {seconds} s (watchdog): "
+                "a peer rank is missing or a collective cannot complete", "higher_is_better": True}
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+        os._exit(4)
+
+
+WATCHDOG = Watchdog()
+# limits (seconds): rendezvous + communicator set-up, and one synchronisation of the whole job (a sync drains up to a few hundred queued
+# steps of ~0.1-10 ms each, plus the first collective's lazy RCCL connect)
+WD_INIT_S = float(os.environ.get("CDAE_BENCH_WATCHDOG_INIT_S", 30))
+WD_SYNC_S = float(os.environ.get("CDAE_BENCH_WATCHDOG_SYNC_S", 120))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +159,7 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
 
+    WATCHDOG.configure(rank, world, args)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the CDAE hot path has no CPU fallback")
@@ -154,15 +203,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        ids = [cdae_amd.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        if os.environ.get("CDAE_BENCH_NO_COMM"):
-            pass                                                        # developer aid: the exchange schedule without any RCCL object
-        elif args.share_device and world > 1:
-            model.comm_init_rank(1, 0, cdae_amd.comm_unique_id())      # functional smoke test: RCCL refuses duplicate devices
-        else:
-            model.comm_init_rank(world, rank, ids[0])
+        with WATCHDOG.stage("gloo rendezvous + ncclCommInitRank", WD_INIT_S):
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=WD_INIT_S))
+            ids = [cdae_amd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            if os.environ.get("CDAE_BENCH_NO_COMM"):
+                pass                                                        # developer aid: the exchange schedule without any RCCL object
+            elif args.share_device and world > 1:
+                model.comm_init_rank(1, 0, cdae_amd.comm_unique_id())      # functional smoke test: RCCL refuses duplicate devices
+            else:
+                model.comm_init_rank(world, rank, ids[0])
         model.exchange_configure(max(0, args.exchange_every) if args.exchange_every >= 0 else 1 << 30)
 
     n_batches = (data.num_users + B - 1) // B
@@ -202,12 +253,13 @@ def main():
         return float(t[0])
 
     def sync():
-        if dist is not None:
-            dist.barrier()
-        model.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        with WATCHDOG.stage("barrier + device synchronisation (queued steps and their collectives)", WD_SYNC_S):
+            if dist is not None:
+                dist.barrier()
+            model.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
 
     exchange_note = None
     if exchanging and args.exchange_every < 0:
@@ -454,7 +506,8 @@ def bench_item_rows(args, rank, world):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with WATCHDOG.stage("gloo rendezvous", WD_INIT_S):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if rank != 0:                        # the other ranks own no GPU work in this layout: they keep the job's barriers
         dist.barrier(); dist.barrier()
         dist.destroy_process_group()

@@ -7,6 +7,7 @@ constructing a CDAE without the HIP library or without a GPU raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from dataclasses import dataclass
@@ -15,6 +16,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CDAE_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libcdae_hip.so")   # (developer builds: another .so of the same ABI)
+# the -DCDAE_DEVELOPER build of the same sources (made by __graft_entry__.build()): the only library that reads the developer
+# environment switches; loaded by the tests that flip one (developer_library() below), never by the product path
+DEV_LIB_PATH = os.path.join(os.path.dirname(_HERE), "build", "libcdae_hip_dev.so")
 
 # libcf::LossType values (/root/reference/src/model/loss.hpp:10-18)
 SQUARE, LOGISTIC, LOG, HINGE, SQUARED_HINGE, CROSS_ENTROPY, LOGM = range(7)
@@ -94,6 +98,7 @@ EXPORTS = {
     "cdae_hip_delta_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_delta_apply": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "cdae_hip_delta_stage": (C.c_int, [C.c_void_p]),
+    "cdae_hip_delta_set_combine": (C.c_int, [C.c_void_p, C.c_uint32]),
     "cdae_hip_delta_recv_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cdae_hip_delta_merge": (C.c_int, [C.c_void_p]),
     "cdae_hip_delta_merge_stage": (C.c_int, [C.c_void_p]),
@@ -111,6 +116,7 @@ EXPORTS = {
     "cdae_hip_multi_set_interactions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cdae_hip_multi_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_int]),
+    "cdae_hip_multi_set_schedule": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cdae_hip_multi_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
     "cdae_hip_multi_train_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "cdae_hip_multi_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
@@ -122,14 +128,15 @@ EXPORTS = {
 }
 COMM_ID_BYTES = 128
 
-_lib = None
+_libs = {}                 # path -> loaded library
+_default_path = LIB_PATH   # what load_library() without a path returns (developer_library swaps it for the length of a test)
 
 
-def load_library(path: str = LIB_PATH):
+def load_library(path: str | None = None):
     """dlopen the C-ABI library and bind every declared export.  Raises if it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    path = path or _default_path
+    if path in _libs:
+        return _libs[path]
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -150,8 +157,22 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
+
+
+
+@contextlib.contextmanager
+def developer_library():
+    """Inside the block every new CDAE / MultiCDAE / MF object is created on the DEVELOPER build (environment switches compiled in).
+    Handles of the two libraries are not interchangeable; a comparison of a switched path with the default one runs both sides here."""
+    global _default_path
+    load_library(DEV_LIB_PATH)
+    prev, _default_path = _default_path, DEV_LIB_PATH
+    try:
+        yield _libs[DEV_LIB_PATH]
+    finally:
+        _default_path = prev
 
 
 class CDAEError(RuntimeError):
@@ -402,6 +423,9 @@ class CDAE:
     def delta_apply(self, world_size: int, rule: int = 0):
         _chk(self.lib, self.lib.cdae_hip_delta_apply(self.h, world_size, rule))
 
+    def delta_set_combine(self, combine: int):
+        _chk(self.lib, self.lib.cdae_hip_delta_set_combine(self.h, combine))
+
     def delta_stage(self):
         _chk(self.lib, self.lib.cdae_hip_delta_stage(self.h))
 
@@ -479,6 +503,14 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+COMBINE_SUM, COMBINE_GLOBAL_ACC = 0, 1
+
+
+class _MultiSchedule(C.Structure):
+    _fields_ = [("period", C.c_int32), ("combine", C.c_uint32), ("sync_batch_users", C.c_uint32), ("reserved", C.c_uint32),
+                ("relay_epochs", C.c_double)]
+
+
 class MultiCDAE:
     """Several user shards behind one handle (cdae_hip_multi_*): the data-parallel form of libcf::CDAE in one process.
 
@@ -510,6 +542,12 @@ class MultiCDAE:
 
     def set_exchange(self, period: int):
         _chk(self.lib, self.lib.cdae_hip_multi_set_exchange(self.h, period))
+
+    def set_schedule(self, period: int = 0, combine: int = COMBINE_SUM, sync_batch_users: int = 0, relay_epochs: float = 0.0):
+        """cdae_hip_multi_set_schedule (user-sharded layout): the first `relay_epochs` epochs (fractions allowed) on the single-GPU
+        schedule handed from shard to shard, the rest as exchanged steps of `sync_batch_users` users per shard folded in by `combine`"""
+        sc = _MultiSchedule(period, combine, sync_batch_users, 0, relay_epochs)
+        _chk(self.lib, self.lib.cdae_hip_multi_set_schedule(self.h, C.byref(sc)))
 
     def set_interactions(self, num_users, num_items, row_ptr, col_idx):
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
@@ -579,6 +617,14 @@ class MultiCDAE:
         return rets, hits
 
     _shape = CDAE._shape
+
+    def shard_get(self, shard: int, which) -> np.ndarray:
+        """a SHARED parameter (item-side matrices, biases) as ONE shard's replica holds it (user-sharded layout: the replicas must agree)"""
+        h = C.c_void_p()
+        _chk(self.lib, self.lib.cdae_hip_multi_shard(self.h, shard, C.byref(h), None, None))
+        out = np.empty(self._shape(which), dtype=np.float32)
+        _chk(self.lib, self.lib.cdae_hip_get_param(h, which, out.ctypes.data, out.size))
+        return out
 
     def get(self, which) -> np.ndarray:
         out = np.empty(self._shape(which), dtype=np.float32)

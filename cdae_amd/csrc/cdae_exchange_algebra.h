@@ -9,6 +9,7 @@
 #ifndef CDAE_EXCHANGE_ALGEBRA_H_
 #define CDAE_EXCHANGE_ALGEBRA_H_
 
+#include <math.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -38,6 +39,31 @@ CDAE_XA_FN void pipe_elem(float& c, float& A, float& snap, float& s, float& r) {
   if (MODE != MERGE) {
     const float d = c - A;
     s = d; r = d; snap = c;
+  }
+}
+
+// COMBINE RULE "global accumulator" (CDAE_COMBINE_GLOBAL_ACC, AdaGrad only).  The plain rule above sums every replica's accumulated
+// steps, each preconditioned by an accumulator that has seen only that replica's examples (eight summed first steps of a
+// young accumulator are not one sequence of eight steps).  This rule exchanges, per (parameter p, accumulator a) pair, the replica's
+// accumulator growth da = a - A_a (exactly its sum of squared gradients, cdae.hpp:254) and its step with the replica's own
+// preconditioner taken back out, dp * (beta + sqrt(a)) ~ -lr * (the replica's summed gradient); after the all-reduce(sum) everybody
+// takes ONE step with the accumulator that has seen all replicas:  A_a += sum da ;  A_p += sum(...) / (beta + sqrt(A_a)).
+// A row that a single replica touched moves exactly as that replica moved it (a == A_a + da).  With lr folded into dp nothing else
+// is needed from the optimiser.  Same agreement property as pipe_elem: A moves only by all-reduced bits.
+template <int MODE>
+CDAE_XA_FN void pipe_pair(float& cp, float& ca, float& Ap, float& Aa, float& snp, float& sna, float& sp, float& sa, float& rp, float& ra,
+                          float beta) {
+  if (MODE != STAGE) {
+    Aa += ra;
+    const float den = beta + sqrtf(Aa);
+    Ap += den > 0.f ? rp / den : 0.f;
+    cp = Ap + (cp - snp);
+    ca = Aa + (ca - sna);
+  }
+  if (MODE != MERGE) {
+    const float da = ca - Aa, dp = (cp - Ap) * (beta + sqrtf(ca));
+    sp = dp; rp = dp; sa = da; ra = da;
+    snp = cp; sna = ca;
   }
 }
 

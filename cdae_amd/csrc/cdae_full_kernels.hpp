@@ -1850,7 +1850,7 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
   const uint32_t tile0 = tile * FR_ITEMS;
   if (tile0 >= Ip) return;
   const uint32_t kw = kh * NW + wid;                                       // this wavefront's k block of 128: [128 kw, 128 kw + 128)
-  const uint32_t n_steps = (hp.debug_skip & 32u) ? 0u : (nb + FR_BK - 1) / FR_BK;     // columns >= nb of Z^T and G^T are zero (debug_skip: timing experiments only)
+  const uint32_t n_steps = CDAE_SKIP_ROLE(hp, 32u) ? 0u : (nb + FR_BK - 1) / FR_BK;     // columns >= nb of Z^T and G^T are zero (debug_skip: timing experiments only)
   f32x16 acc[4][4];                                                        // [k block][item block]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1956,7 +1956,7 @@ gemm3_rows_fused_kernel(HyperParams hp, const __bf16* __restrict__ ZT /* [512][l
     }
   }
 
-  if (hp.debug_skip & 16u) {                                               // (timing experiments only: contraction without the row steps)
+  if (CDAE_SKIP_ROLE(hp, 16u)) {                                               // (timing experiments only: contraction without the row steps)
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)

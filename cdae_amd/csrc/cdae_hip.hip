@@ -168,7 +168,6 @@ struct cdae_hip {
   // 0.055, 512: 0.083 -> 0.067 / 0.124 -> 0.106, 1024: 0.099 -> 0.088 / 0.145 -> 0.132, 2048: - / 0.197 -> 0.188, 4096: - / 0.327 -> 0.327
   // — a hand-off between two streams costs ~15 us, the recurrence 41 ns per user
   uint32_t full_one_stream_max = 2048;
-  bool full_b_summed = false;           // CDAE_FULL_B_SUMMED (experiment, see hidden_bias_role)
   bool full_bias_unsplit = false;       // CDAE_FULL_BIAS_UNSPLIT: the whole recurrence beside the row launch (A/B)
   bool fused_images = true;             // CDAE_FULL_SEPARATE_COPIES turns it off (developer switch: conversion launches as in round 2)
   hipStream_t aux = nullptr;            // full-output path: the hidden-bias recurrence beside GEMM 3
@@ -230,6 +229,7 @@ struct cdae_hip {
   // data-parallel exchange
   float* d_base = nullptr; float* d_delta = nullptr; float* d_recv = nullptr; float* d_snap = nullptr;   // agreed state, staged delta, all-reduced delta, parameters at the last stage
   void* xchg = nullptr; void (*xchg_free)(void*) = nullptr;   // communicator + schedule of the exchange (cdae_multi.hip)
+  uint32_t delta_combine = CDAE_COMBINE_SUM;                  // cdae_hip_delta_set_combine: how staged deltas are folded in (cdae_exchange_algebra.h)
   // IMF / BPR handles (cdae_hip_create_mf, cdae_mf_kernels.hpp): 0 = CDAE, 1 = IMF, 2 = BPR
   uint32_t mf = 0, mf_bias = 1;
   // IMF / BPR, batch_users = 1 (the library default: the reference's strictly sequential loop): the users are still taken one after the
@@ -315,11 +315,11 @@ int join_aux(cdae_hip* h) {
 // the `released` record and ~3 us at the `ready` wait (profiles/r02_wave_timeline_256.txt: 86 us of kernels in a 100 us step).
 // CDAE_EVENT_SYSTEM_FENCE=1 restores the default.  (The exchange's events in cdae_multi.hip stay system-scope: RCCL peers read.)
 inline unsigned sync_event_flags() {      // (the environment is read at every call: per handle, not per process)
-  const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
+  const bool sys = DEV_ENV("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
   return sys ? (unsigned)hipEventDisableTiming : (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence);
 }
 inline unsigned timing_event_flags() {
-  const bool sys = std::getenv("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
+  const bool sys = DEV_ENV("CDAE_EVENT_SYSTEM_FENCE") != nullptr;
   return sys ? (unsigned)hipEventDefault : (unsigned)hipEventDisableSystemFence;
 }
 
@@ -1138,30 +1138,27 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->NI = cfg->num_dim <= 64 ? 1 : (cfg->num_dim <= 128 ? 2 : (cfg->num_dim <= 256 ? 4 : 8));
   h->Kp = 64u * h->NI;
   h->B = cfg->batch_users ? cfg->batch_users : 1024u;
-  h->one_row_per_wave = std::getenv("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
-  h->full_unfused = std::getenv("CDAE_FULL_UNFUSED") != nullptr;
-  h->gemm_direct = std::getenv("CDAE_GEMM_DIRECT") != nullptr;
-  h->gemm_two_stage = std::getenv("CDAE_GEMM_TWO_STAGE") != nullptr;
-  h->gemm_narrow = std::getenv("CDAE_GEMM_NARROW") != nullptr;
-  h->rows_separate = std::getenv("CDAE_FULL_ROWS_SEPARATE") != nullptr;
-  h->gemm2_nt = std::getenv("CDAE_GEMM2_NT") != nullptr;
-  if (const char* ev = std::getenv("CDAE_GEMM2_STAGES")) h->gemm2_stages = std::max(2, std::min(4, std::atoi(ev)));
-  h->gemm1_tiled = std::getenv("CDAE_GEMM1_TILED") != nullptr;
-  if (const char* e = std::getenv("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
-  h->recommend_per_user = std::getenv("CDAE_RECOMMEND_PER_USER") != nullptr;
-  h->full_bias_unsplit = std::getenv("CDAE_FULL_BIAS_UNSPLIT") != nullptr;
-  if (std::getenv("CDAE_FULL_B_SUMMED")) {        // EXPERIMENT (hidden_bias_role): one summed step of b per full-output block; a sum cannot be hosted in two halves
-    h->full_bias_unsplit = true; h->full_one_stream_max = 0xFFFFFFFFu; h->full_b_summed = true;
-  }
-  if (const char* v = std::getenv("CDAE_FULL_ONE_STREAM_MAX")) h->full_one_stream_max = (uint32_t)std::strtoul(v, nullptr, 10);
-  h->gemm1_whole_tiles = std::getenv("CDAE_GEMM1_PIPE") == nullptr;
-  h->debug_skip_prep = std::getenv("CDAE_DEBUG_SKIP_PREP") != nullptr;
-  h->encode_two_launches = std::getenv("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
-  h->full_separate_copies = std::getenv("CDAE_FULL_SEPARATE_COPIES") != nullptr;
+  h->one_row_per_wave = DEV_ENV("CDAE_DECODE_ONE_ROW_PER_WAVE") != nullptr;
+  h->full_unfused = DEV_ENV("CDAE_FULL_UNFUSED") != nullptr;
+  h->gemm_direct = DEV_ENV("CDAE_GEMM_DIRECT") != nullptr;
+  h->gemm_two_stage = DEV_ENV("CDAE_GEMM_TWO_STAGE") != nullptr;
+  h->gemm_narrow = DEV_ENV("CDAE_GEMM_NARROW") != nullptr;
+  h->rows_separate = DEV_ENV("CDAE_FULL_ROWS_SEPARATE") != nullptr;
+  h->gemm2_nt = DEV_ENV("CDAE_GEMM2_NT") != nullptr;
+  if (const char* ev = DEV_ENV("CDAE_GEMM2_STAGES")) h->gemm2_stages = std::max(2, std::min(4, std::atoi(ev)));
+  h->gemm1_tiled = DEV_ENV("CDAE_GEMM1_TILED") != nullptr;
+  if (const char* e = DEV_ENV("CDAE_FULL_ROWS_KH")) h->rows_fused_kh = std::atoi(e) == 1 ? 1 : 2;
+  h->recommend_per_user = DEV_ENV("CDAE_RECOMMEND_PER_USER") != nullptr;
+  h->full_bias_unsplit = DEV_ENV("CDAE_FULL_BIAS_UNSPLIT") != nullptr;
+  if (const char* v = DEV_ENV("CDAE_FULL_ONE_STREAM_MAX")) h->full_one_stream_max = (uint32_t)std::strtoul(v, nullptr, 10);
+  h->gemm1_whole_tiles = DEV_ENV("CDAE_GEMM1_PIPE") == nullptr;
+  h->debug_skip_prep = DEV_ENV("CDAE_DEBUG_SKIP_PREP") != nullptr;
+  h->encode_two_launches = DEV_ENV("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
+  h->full_separate_copies = DEV_ENV("CDAE_FULL_SEPARATE_COPIES") != nullptr;
   h->fused_images = !h->full_separate_copies;
-  if (const char* ev = std::getenv("CDAE_ENCODE_USERS_MAX")) h->encode_users_max = (uint32_t)std::atoi(ev);
-  if (const char* ev = std::getenv("CDAE_GATHER_HALVES")) h->gather_halves = std::atoi(ev) == 2 ? 2u : 1u;
-  if (const char* ev = std::getenv("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
+  if (const char* ev = DEV_ENV("CDAE_ENCODE_USERS_MAX")) h->encode_users_max = (uint32_t)std::atoi(ev);
+  if (const char* ev = DEV_ENV("CDAE_GATHER_HALVES")) h->gather_halves = std::atoi(ev) == 2 ? 2u : 1u;
+  if (const char* ev = DEV_ENV("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
@@ -1173,7 +1170,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
     // 128 users per batch 0.0972 -> 0.0755 ms per step, 256: 0.0995 -> 0.0942, 512: 0.1409 -> 0.1429 (the prep kernels then
     // only take issue slots from a step that was not waiting for them).  Default "auto": on up to 384 users per batch, on the
     // handle's aux stream (idle in the sampled path; an exchange's collective shares it).  CDAE_PREP2 = off | aux | own | auto.
-    const char* sel = std::getenv("CDAE_PREP2");
+    const char* sel = DEV_ENV("CDAE_PREP2");
     if (sel && !std::strcmp(sel, "own")) { if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep2, hipStreamNonBlocking); h->prep2_own = true; }
     else if (sel && !std::strcmp(sel, "aux")) h->prep2 = h->aux;
     else if (sel && !std::strcmp(sel, "off")) h->prep2 = nullptr;
@@ -1195,13 +1192,12 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   hp.keep_thr = cdae_keep_threshold(cfg->corruption_ratio);
   hp.uid_offset = 0; hp.num_items = 0; hp.K = h->K; hp.Kp = h->Kp;
   hp.own_u0 = 0; hp.own_u1 = ~0ull;
-  if (std::getenv("CDAE_WAVE_TRACE")) {      // developer aid (tools/wave_trace.py): the last training batch's wavefront timeline
+  if (DEV_ENV("CDAE_WAVE_TRACE")) {      // developer aid (tools/wave_trace.py): the last training batch's wavefront timeline
     if (hipMalloc((void**)&hp.trace, 4 * cdae::TRACE_CAP * sizeof(unsigned long long)) != hipSuccess) hp.trace = nullptr;
     if (hp.trace) (void)hipMemset(hp.trace, 0, 4 * cdae::TRACE_CAP * sizeof(unsigned long long));
   }
-  hp.debug_skip = std::getenv("CDAE_DEBUG_SKIP_ROLES") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_SKIP_ROLES"), nullptr, 10) : 0u;
-  if (const char* v = std::getenv("CDAE_FULL_B_SUMMED")) hp.debug_skip |= (std::atoi(v) == 2 ? 192u : std::atoi(v) == 3 ? 320u : std::atoi(v) == 4 ? 832u : 64u);     // 2: summed gradient, per-user accumulator; 3 / 4: a step per 32 / 16 users
-  hp.debug_rank = std::getenv("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(std::getenv("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
+  hp.debug_skip = DEV_ENV("CDAE_DEBUG_SKIP_ROLES") ? (uint32_t)std::strtoul(DEV_ENV("CDAE_DEBUG_SKIP_ROLES"), nullptr, 10) : 0u;
+  hp.debug_rank = DEV_ENV("CDAE_DEBUG_RANK") ? (uint32_t)std::strtoul(DEV_ENV("CDAE_DEBUG_RANK"), nullptr, 10) : 0u;
   *out = h;
   return 0;
 }
@@ -1214,7 +1210,7 @@ int cdae_hip_destroy(cdae_hip_t* h) {
   if (h->hp.trace) {      // records of the LAST batch every slot saw
     std::vector<unsigned long long> rec(4 * cdae::TRACE_CAP);
     (void)hipMemcpy(rec.data(), h->hp.trace, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    if (FILE* f = std::fopen(std::getenv("CDAE_WAVE_TRACE"), "wb")) { std::fwrite(rec.data(), sizeof(unsigned long long), rec.size(), f); std::fclose(f); }
+    if (FILE* f = std::fopen(DEV_ENV("CDAE_WAVE_TRACE"), "wb")) { std::fwrite(rec.data(), sizeof(unsigned long long), rec.size(), f); std::fclose(f); }
     (void)hipFree(h->hp.trace);
     h->hp.trace = nullptr;
   }
@@ -1246,7 +1242,7 @@ int cdae_hip_create_mf(const cdae_mf_config* mc, int device_id, cdae_hip_t** out
   h->mf = mc->pairwise ? 2u : 1u;
   h->mf_bias = mc->using_bias_term ? 1u : 0u;
   h->mf_auto = mc->batch_users == 0u;
-  if (c.batch_users == 1u && std::getenv("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr) { h->mf_seq = true; h->B = MF_SEQ_USERS; }   // (the switch: round 3's launches, A/B)
+  if (c.batch_users == 1u && DEV_ENV("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr) { h->mf_seq = true; h->B = MF_SEQ_USERS; }   // (the switch: round 3's launches, A/B)
   h->hp.loss_type = mc->loss_type;
   h->hp.lambda = (float)(2.0 * mc->lambda);                // imf.hpp:92-95, bpr.hpp:78-82: the gradients regularise with 2 * lambda
   return 0;
@@ -1294,7 +1290,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   if (h->mf && h->mf_auto) {
     const uint32_t b = cdae_hip_mf_default_batch_users(U, h->mf == 2u ? 1u : 0u);
     h->cfg.batch_users = b;
-    h->mf_seq = b == 1u && std::getenv("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr;
+    h->mf_seq = b == 1u && DEV_ENV("CDAE_MF_ONE_LAUNCH_PER_USER") == nullptr;
     h->B = h->mf_seq ? MF_SEQ_USERS : b;
   }
   if (h->mf && !h->mf_seq && h->B > 1 && U > h->B) {
@@ -1360,7 +1356,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     // (256 CUs x 4 SIMDs) several thousand wavefronts: small batches take small units.
     const uint64_t Bu = std::min<uint64_t>(h->B, U);
     uint32_t up = Bu <= 1024 ? 64u : cdae::UNIT_POS_MAX;          // measured at ML-10M shape, batch_users 256 / 512: 64 best (profiles/r02_unit_size.txt)
-    if (const char* ev = std::getenv("CDAE_UNIT_POS")) up = (uint32_t)std::atoi(ev);
+    if (const char* ev = DEV_ENV("CDAE_UNIT_POS")) up = (uint32_t)std::atoi(ev);
     h->hp.unit_pos = std::max<uint32_t>(1u, std::min<uint32_t>(up, cdae::UNIT_POS_MAX));
   }
   h->h_row_ptr.assign(row_ptr, row_ptr + U + 1);
@@ -1384,7 +1380,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   {
     // hot rows: expected positives per batch (popularity x batch share) of at least CDAE_DECODE_HOT_POS (default 48);
     // every row also receives ~ B * mean(n_u) * num_neg / I uniformly spread negatives
-    const char* ev = std::getenv("CDAE_DECODE_HOT_POS");
+    const char* ev = DEV_ENV("CDAE_DECODE_HOT_POS");
     const double hot_pos = ev ? std::atof(ev) : 48.0;
     const double share = (double)std::min<uint64_t>(h->B, U) / (double)U;
     uint32_t hot = 0;
@@ -1460,7 +1456,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   // stream runs beside the training kernels, and what counts there is how much it disturbs them, not its own length
   // (round 4: the tile kernels skip VOID examples, so a sampled item shard can take them too — there the prep chain is NOT hidden
   // behind a look-ahead lane and the library sort's launches and fills are the larger part of it)
-  h->counting_sort = I <= cdae::TILE_SORT_MAX_ITEMS && std::getenv("CDAE_SORT_TILE") != nullptr;
+  h->counting_sort = I <= cdae::TILE_SORT_MAX_ITEMS && DEV_ENV("CDAE_SORT_TILE") != nullptr;
   h->h_unit_ptr.assign(U + 1, 0u);
   for (uint64_t u = 0; u < U; ++u)
     h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + h->hp.unit_pos - 1) / h->hp.unit_pos);
@@ -1518,7 +1514,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     // one correction row per duplicate negative of a batch (~2 % of the examples at ML-10M shape); beyond the
     // capacity decode falls back to atomics.  Zero-filled once: decode's 16-lane path leaves elements >= 64 NV + 16 NT
     // of a row untouched and the gather reads whole rows.
-    const char* ev = std::getenv("CDAE_DUP_CAP");
+    const char* ev = DEV_ENV("CDAE_DUP_CAP");
     const uint64_t want = h->mf ? 1 : (ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4));   // small problems: every example (IMF / BPR have no correction rows)
     h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
     h->dup_stripes = std::max<uint32_t>(1u, std::min<uint32_t>(cdae::DUP_STRIPES, h->dup_cap / 4096u));
@@ -1569,7 +1565,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       // slice adds a [B x Kp] partial of hg)
       const uint32_t tiles = h->Ip / (32 * cdae::FUSED_SUB), ublocks = h->Bp / 128;
       h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>({32u, tiles, (256u + ublocks - 1) / ublocks}));
-      if (const char* ev = std::getenv("CDAE_FULL_SLICES")) h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)std::atoi(ev)));
+      if (const char* ev = DEV_ENV("CDAE_FULL_SLICES")) h->full_slices = std::max<uint32_t>(1, std::min<uint32_t>(tiles, (uint32_t)std::atoi(ev)));
     }
   }
   if (h->cfg.full_output || h->item_shard) {
@@ -2012,6 +2008,14 @@ PipeGeom pipe_geom(const cdae_hip* h) {
 template <int MODE>
 int launch_pipe(cdae_hip* h) {
   const PipeGeom g = pipe_geom(h);
+  if (h->delta_combine == CDAE_COMBINE_GLOBAL_ACC && h->cfg.using_adagrad) {
+    // (parameter, accumulator) pairs: same compact buffers, half the threads of the element-wise pass each moving two elements
+    const size_t n_rows = h->n_matrix / h->Kp, threads = (n_rows / 2) * (g.Kc / 4) + h->I + h->Kp;
+    hipLaunchKernelGGL(cdae::delta_pipe_pair_kernel<MODE>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
+                       h->d_base, h->d_snap, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, (uint32_t)h->I, (float)h->cfg.beta);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(cdae::delta_pipe_kernel<MODE>, dim3((uint32_t)((g.threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                      h->d_base, h->d_snap, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, g.n_tail);
   HIPCHK(hipGetLastError());
@@ -2281,17 +2285,9 @@ int cdae_hip_set_test_rows(cdae_hip_t* h, const int64_t* test_row_ptr, const uin
   if (!h || !h->d_shared || !test_row_ptr) return fail("bad argument (cdae_hip_set_interactions first)");
   HIPCHK(hipSetDevice(h->device));
   const uint64_t U = h->U;
-  if (test_row_ptr[0] != 0) return fail("test_row_ptr[0] must be 0");
   uint64_t with_rows = 0;
-  for (uint64_t u = 0; u < U; ++u) {
-    if (test_row_ptr[u + 1] < test_row_ptr[u]) return fail("test_row_ptr must be non-decreasing");
-    with_rows += test_row_ptr[u + 1] > test_row_ptr[u];
-    for (int64_t p = test_row_ptr[u] + 1; p < test_row_ptr[u + 1]; ++p)
-      if (test_col[p] <= test_col[p - 1]) return fail("test row %llu is not ascending and unique", (unsigned long long)u);
-  }
+  CHK(cdae_internal::validate_test_rows(test_row_ptr, test_col, U, h->item_shard ? h->I_global : h->I, &with_rows));
   const uint64_t nnz = (uint64_t)test_row_ptr[U];
-  if (nnz && !test_col) return fail("bad argument");
-  for (uint64_t p = 0; p < nnz; ++p) if (test_col[p] >= (h->item_shard ? h->I_global : h->I)) return fail("test item id out of range");
   CHK(quiesce(h));
   void** old[] = {(void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out};
   for (void** p : old) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
@@ -2485,6 +2481,13 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule) {
   return 0;
 }
 
+int cdae_hip_delta_set_combine(cdae_hip_t* h, uint32_t combine) {
+  if (!h) return fail("null handle");
+  if (combine > CDAE_COMBINE_GLOBAL_ACC) return fail("unknown combine rule %u", combine);
+  h->delta_combine = combine;      // (takes effect at the next stage: call it between a merge and the following stage)
+  return 0;
+}
+
 // pipelined variant: see delta_pipe_kernel.  The staged / received buffers are compact (no pad columns).
 int cdae_hip_delta_stage(cdae_hip_t* h) {
   if (!h || !h->d_base) return fail("delta_begin must be called first");
@@ -2545,6 +2548,35 @@ bool ready(const cdae_hip_t* h) { return h->d_shared != nullptr; }
 float* send_buf(cdae_hip_t* h) { return h->d_delta; }
 float* recv_buf(cdae_hip_t* h) { return h->d_recv; }
 size_t compact_count(const cdae_hip_t* h) { return pipe_geom(h).n_compact; }
+int validate_test_rows(const int64_t* test_row_ptr, const uint32_t* test_col, uint64_t U, uint64_t I, uint64_t* users_with_rows) {
+  if (!test_row_ptr) return fail("null test_row_ptr");
+  if (test_row_ptr[0] != 0) return fail("test_row_ptr[0] must be 0");
+  for (uint64_t u = 0; u < U; ++u)
+    if (test_row_ptr[u + 1] < test_row_ptr[u]) return fail("test_row_ptr must be non-decreasing");
+  if (test_row_ptr[U] > 0 && !test_col) return fail("null test_col with %lld test interactions", (long long)test_row_ptr[U]);
+  uint64_t with_rows = 0;
+  for (uint64_t u = 0; u < U; ++u) {
+    with_rows += test_row_ptr[u + 1] > test_row_ptr[u];
+    for (int64_t p = test_row_ptr[u]; p < test_row_ptr[u + 1]; ++p) {
+      if (test_col[p] >= I) return fail("test item id %u of user %llu out of range", test_col[p], (unsigned long long)u);
+      if (p > test_row_ptr[u] && test_col[p] <= test_col[p - 1]) return fail("test row %llu is not ascending and unique", (unsigned long long)u);
+    }
+  }
+  if (users_with_rows) *users_with_rows = with_rows;
+  return 0;
+}
+int adopt_shared_block(cdae_hip_t* dst, cdae_hip_t* src) {
+  if (!dst || !src || !dst->d_shared || !src->d_shared || dst->n_shared != src->n_shared) return fail("adopt_shared_block: the handles do not hold the same model");
+  CHK(cdae_hip_synchronize(src));
+  HIPCHK(hipSetDevice(dst->device));
+  CHK(quiesce(dst));
+  dst->db_valid = dst->db_rows_valid = false;      // (full-output path) the bf16 images of the decoder no longer match it
+  if (dst->device == src->device)
+    HIPCHK(hipMemcpyAsync(dst->d_shared, src->d_shared, dst->n_shared * sizeof(float), hipMemcpyDeviceToDevice, dst->stream));
+  else
+    HIPCHK(hipMemcpyPeerAsync(dst->d_shared, dst->device, src->d_shared, src->device, dst->n_shared * sizeof(float), dst->stream));
+  return 0;
+}
 void*& exchange_slot(cdae_hip_t* h) { return h->xchg; }
 void set_exchange_deleter(cdae_hip_t* h, void (*deleter)(void*)) { h->xchg_free = deleter; }
 

@@ -7,6 +7,15 @@
 
 #include "../../include/cdae_hip.h"
 
+// Developer switches (A/B paths the bit-equality tests flip, tuning knobs, timing experiments) are environment variables of the
+// DEVELOPER build only (-DCDAE_DEVELOPER: build/libcdae_hip_dev.so, made by __graft_entry__.build() beside the shipped library and
+// loaded by the tests that need it).  The shipped library reads NO environment variable: the names are not even in its string table.
+#ifdef CDAE_DEVELOPER
+#define DEV_ENV(name) std::getenv(name)
+#else
+#define DEV_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace cdae_internal {
 
 int fail(const char* fmt, ...);                 // sets cdae_hip_last_error(), returns 1
@@ -32,6 +41,14 @@ int shared_penalty(cdae_hip_t* h, double* out);
 // 0.5 * lambda * (|W|^2 + |V|^2 + |b'|^2) (item rows only) and 0.5 * lambda * |b|^2: the pieces an item-sharded model adds up
 int item_rows_penalty(cdae_hip_t* h, double* out);
 int hidden_bias_penalty(cdae_hip_t* h, double* out);
+
+// the validation rows of cdae_hip_set_test_rows / cdae_hip_multi_eval_topn: row_ptr starts at 0 and does not decrease, col is there when
+// there are interactions, every row ascending, unique and inside [0, I) (the metric's binary search needs the order)
+int validate_test_rows(const int64_t* test_row_ptr, const uint32_t* test_col, uint64_t U, uint64_t I, uint64_t* users_with_rows);
+
+// dst's shared block [W | W_ag | (V | V_ag) | b' | b'_ag | b | b_ag] := src's (same model, any two devices of this process); waits for
+// src's work, stream-ordered on dst's main stream.  The relay part of cdae_hip_multi_set_schedule hands the parameters on with it.
+int adopt_shared_block(cdae_hip_t* dst, cdae_hip_t* src);
 
 // exchange state owned by cdae_multi.hip, destroyed with the handle
 void*& exchange_slot(cdae_hip_t* h);

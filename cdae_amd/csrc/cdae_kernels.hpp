@@ -40,6 +40,13 @@ constexpr uint32_t DUP_STRIPES = 64;
 constexpr uint32_t TARGET_BIT = 1u << 30;
 constexpr uint32_t INPUT_BIT = 1u << 31;
 
+// (see HyperParams::debug_skip) — constant false in the shipped build: the tests compile out
+#ifdef CDAE_DEVELOPER
+#define CDAE_SKIP_ROLE(hp, bit) (((hp).debug_skip & (bit)) != 0u)
+#else
+#define CDAE_SKIP_ROLE(hp, bit) false
+#endif
+
 struct HyperParams {
   float lambda, lr, beta, scale;
   uint32_t num_neg;
@@ -54,7 +61,7 @@ struct HyperParams {
   uint32_t debug_rank;       // -DCDAE_DECODE_TIMING builds: the row whose timeline decode_rows_kernel records
   unsigned long long* trace; // CDAE_WAVE_TRACE (developer aid, tools/wave_trace.py): per-wavefront {tag, start, end, extra} records, or nullptr
   uint32_t trace_odd;        // (wave trace) 1 on batches with an odd sequence number
-  uint32_t debug_skip;       // CDAE_DEBUG_SKIP_ROLES (timing experiments only, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows; 64 = CDAE_FULL_B_SUMMED (hidden_bias_role)
+  uint32_t debug_skip;       // -DCDAE_DEVELOPER builds only (CDAE_DEBUG_SKIP_ROLES: timing experiments, WRONG results): 1 hidden-bias role, 2 input-row role, 4 decode hot rows, 8 decode four-per-wave rows, 16 / 32 fused row step; the shipped kernels do not read it (skip_role)
   // users whose private rows (Wu, Wu_ag, Uu, Uu_ag) THIS handle holds, table row 0 = user own_u0.  Everything except an item
   // shard owns every user ([0, 2^64)); an item shard owns a contiguous range (the user node is sharded by user)
   uint64_t own_u0, own_u1;
@@ -1300,7 +1307,7 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
   __shared__ uint32_t rows16_lds[4][ROWS16_LDS_WORDS];
   const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   if (wave < hot_rows) {
-    if (hp.debug_skip & 4u) return;
+    if (CDAE_SKIP_ROLE(hp, 4u)) return;
     const unsigned long long t0 = trace_begin(hp);
 #ifndef CDAE_HOT_PRIO
 #define CDAE_HOT_PRIO 2
@@ -1310,7 +1317,7 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
                                            CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
     trace_end(hp, 3, wave, t0);
   } else {
-    if (hp.debug_skip & 8u) return;
+    if (CDAE_SKIP_ROLE(hp, 8u)) return;
     const unsigned long long t0 = trace_begin(hp);
     decode_rows16<NV, NT, LOSS, ADAGRAD>(hp, hot_rows + (wave - hot_rows) * 4u, rows16_lds[threadIdx.x / WAVE], CDAE_DECODE_PASS);
     trace_end(hp, 4, wave, t0);
@@ -1566,18 +1573,13 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
 // One thread per coordinate; the recurrence is elementwise, the delta loads run 16 users ahead of it.
 // It needs only delta, like the input rows, so it runs as the leading workgroup(s) of input_rows_kernel
 // instead of a launch of its own.
-// FULL (the full-output callers) + debug_skip bit 64 (CDAE_FULL_B_SUMMED=1, an EXPERIMENT of round 4, not a shipped schedule): ONE step of
-// b per block with the block's summed delta — what the decoder and input rows of that schedule take — instead of a step per user.
-// Measured (profiles/r04_full_output_envelope_*_bsummed.txt): at Yelp shape the loop's best Recall@10 in 2-5 epochs instead
-// of 4-27; at ML-10M shape and at K = 512 the blocks then stay BELOW the loop (0.14 against 0.16).  The default stays a step per user.
+// FULL: the full-output callers (same chain; the flag only names the call site).
 template <bool ADAGRAD, bool FULL = false>
 __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uint32_t nb,
                                                  const float* __restrict__ DELTA, float* __restrict__ b,
                                                  float* __restrict__ b_ag) {
   if (k >= hp.Kp || nb == 0) return;
   hp.adagrad = ADAGRAD;
-  const bool summed = FULL && (hp.debug_skip & 64u) != 0u;
-  float sum = 0.f;
   float p = b[k], acc = b_ag[k];
   // One dependent AdaGrad chain per coordinate (7 instructions per user) bounds this role: the loop is branch-free, and
   // the deltas run UN users ahead of it in a register ring — slot j is refilled (index clamped, never guarded) as soon as
@@ -1595,28 +1597,7 @@ __device__ __forceinline__ void hidden_bias_role(HyperParams hp, uint32_t k, uin
 #pragma unroll
   for (uint32_t j = 0; j < UN; ++j) d[j] = delta_of(j);
   uint32_t u = 0;
-  if (FULL && summed) {                                        // (the experiment: its own loop, so that the shipped chain below carries no test)
-    float sq = 0.f;                                            // bit 128 on top: the accumulator grows with the per-user squares, not with the square of the sum
-    const bool chunked = (hp.debug_skip & 256u) != 0u;         // bit 256 on top: one step per 32 users (their summed delta) instead of one per block
-    for (; u + UN <= nb; u += UN) {
-#pragma unroll
-      for (uint32_t j = 0; j < UN; ++j) {
-        sum += d[j]; sq = fmaf(d[j], d[j], sq);
-        d[j] = delta_of(u + UN + j);
-      }
-      if (chunked && (((u / UN) & 1u) || (hp.debug_skip & 512u))) { ada_step(hp, p, acc, fmaf(hp.lambda, p, sum)); sum = 0.f; }     // (bit 512: per 16 users)
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < UN; ++j)
-      if (u + j < nb) { sum += d[j]; sq = fmaf(d[j], d[j], sq); }
-    if (chunked && sum == 0.f && nb % ((hp.debug_skip & 512u) ? UN : 2u * UN) == 0u) {
-      // (every chunk has been stepped)
-    } else if (hp.debug_skip & 128u) {
-      const float g = fmaf(hp.lambda, p, sum);
-      if (ADAGRAD) { acc += sq; p = fmaf(-hp.lr * g, fast_rcp(fast_sqrt(acc) + hp.beta), p); } else p = fmaf(-hp.lr, g, p);
-    } else
-      ada_step(hp, p, acc, fmaf(hp.lambda, p, sum));
-  } else {
+  {
     for (; u + UN <= nb; u += UN) {
 #pragma unroll
       for (uint32_t j = 0; j < UN; ++j) {
@@ -1741,14 +1722,14 @@ input_rows_kernel(HyperParams hp, const uint32_t* __restrict__ item_order,
   const uint32_t bias_blocks = (hp.Kp + blockDim.x - 1) / blockDim.x;     // leading workgroups: K4b
   if (blockIdx.x < bias_blocks) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (hp.debug_skip & 1u) return;
+    if (CDAE_SKIP_ROLE(hp, 1u)) return;
     const unsigned long long t0 = trace_begin(hp);
     if (hp.adagrad) hidden_bias_role<true>(hp, k, nb, DELTA, b, b_ag);
     else hidden_bias_role<false>(hp, k, nb, DELTA, b, b_ag);
     trace_end(hp, 7, k / 64u, t0);
     return;
   }
-  if (hp.debug_skip & 2u) return;
+  if (CDAE_SKIP_ROLE(hp, 2u)) return;
   const uint32_t lane = threadIdx.x % WAVE;
   const uint32_t rank = __builtin_amdgcn_readfirstlane((blockIdx.x - bias_blocks) * (blockDim.x / WAVE) + threadIdx.x / WAVE);
   const unsigned long long t0 = trace_begin(hp);
@@ -2116,5 +2097,64 @@ delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __re
     if (MODE != DELTA_MERGE) { snap[pad_off] = sn; send[cmp_off] = s; recv[cmp_off] = r; }
   }
 }
+
+// The same three passes under the GLOBAL-ACCUMULATOR combine rule (cdae_xa::pipe_pair; cdae_hip_delta_set_combine): a thread takes a
+// parameter element TOGETHER with its AdaGrad accumulator — matrix 2j with matrix 2j + 1 ([W | W_ag | (V | V_ag)]), b' with b'_ag,
+// b with b_ag — same compact send / recv layout as delta_pipe_kernel, so the all-reduce between the passes does not change.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+delta_pipe_pair_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ snap, float* __restrict__ send,
+                       float* __restrict__ recv, size_t n_matrix, uint32_t Kp, uint32_t Kc, uint32_t num_items, float beta) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q_per_row = Kc / 4;
+  const size_t n_rows = n_matrix / Kp, n_pair_rows = n_rows / 2, n_mat4 = n_pair_rows * q_per_row;
+  size_t pp, pa, cpo, cao;                                        // padded / compact float offsets of the parameter and its accumulator
+  int width;
+  if (i < n_mat4) {
+    const size_t prow = i / q_per_row;                            // row of the pair space: (pair index, item)
+    const uint32_t q = (uint32_t)(i - prow * q_per_row);
+    const size_t pair = prow / num_items, r = prow - pair * num_items;
+    const size_t row_p = 2 * pair * num_items + r, row_a = row_p + num_items;
+    pp = row_p * Kp + 4u * q; pa = row_a * Kp + 4u * q; cpo = row_p * Kc + 4u * q; cao = row_a * Kc + 4u * q; width = 4;
+  } else if (i - n_mat4 < (size_t)num_items + Kp) {
+    const size_t j = i - n_mat4;
+    const size_t rel_p = j < num_items ? j : 2 * (size_t)num_items + (j - num_items);
+    const size_t rel_a = rel_p + (j < num_items ? num_items : Kp);
+    pp = n_matrix + rel_p; pa = n_matrix + rel_a; cpo = n_rows * Kc + rel_p; cao = n_rows * Kc + rel_a; width = 1;
+  } else {
+    return;
+  }
+  if (width == 4) {
+    float4 c = *reinterpret_cast<float4*>(cur + pp), ca = *reinterpret_cast<float4*>(cur + pa);
+    float4 A = *reinterpret_cast<float4*>(base + pp), Aa = *reinterpret_cast<float4*>(base + pa);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sn = zero4, sna = zero4, s = zero4, sa = zero4, r = zero4, ra = zero4;
+    if (MODE != DELTA_STAGE) {
+      sn = *reinterpret_cast<float4*>(snap + pp); sna = *reinterpret_cast<float4*>(snap + pa);
+      r = *reinterpret_cast<float4*>(recv + cpo); ra = *reinterpret_cast<float4*>(recv + cao);
+    }
+    cdae_xa::pipe_pair<MODE>(c.x, ca.x, A.x, Aa.x, sn.x, sna.x, s.x, sa.x, r.x, ra.x, beta);
+    cdae_xa::pipe_pair<MODE>(c.y, ca.y, A.y, Aa.y, sn.y, sna.y, s.y, sa.y, r.y, ra.y, beta);
+    cdae_xa::pipe_pair<MODE>(c.z, ca.z, A.z, Aa.z, sn.z, sna.z, s.z, sa.z, r.z, ra.z, beta);
+    cdae_xa::pipe_pair<MODE>(c.w, ca.w, A.w, Aa.w, sn.w, sna.w, s.w, sa.w, r.w, ra.w, beta);
+    if (MODE != DELTA_STAGE) {
+      *reinterpret_cast<float4*>(cur + pp) = c; *reinterpret_cast<float4*>(cur + pa) = ca;
+      *reinterpret_cast<float4*>(base + pp) = A; *reinterpret_cast<float4*>(base + pa) = Aa;
+    }
+    if (MODE != DELTA_MERGE) {
+      *reinterpret_cast<float4*>(snap + pp) = sn; *reinterpret_cast<float4*>(snap + pa) = sna;
+      *reinterpret_cast<float4*>(send + cpo) = s; *reinterpret_cast<float4*>(send + cao) = sa;
+      *reinterpret_cast<float4*>(recv + cpo) = r; *reinterpret_cast<float4*>(recv + cao) = ra;
+    }
+  } else {
+    float c = cur[pp], ca = cur[pa], A = base[pp], Aa = base[pa];
+    float sn = 0.f, sna = 0.f, s = 0.f, sa = 0.f, r = 0.f, ra = 0.f;
+    if (MODE != DELTA_STAGE) { sn = snap[pp]; sna = snap[pa]; r = recv[cpo]; ra = recv[cao]; }
+    cdae_xa::pipe_pair<MODE>(c, ca, A, Aa, sn, sna, s, sa, r, ra, beta);
+    if (MODE != DELTA_STAGE) { cur[pp] = c; cur[pa] = ca; base[pp] = A; base[pa] = Aa; }
+    if (MODE != DELTA_MERGE) { snap[pp] = sn; snap[pa] = sna; send[cpo] = s; send[cao] = sa; recv[cpo] = r; recv[cao] = ra; }
+  }
+}
+
 
 }  // namespace cdae

@@ -103,7 +103,7 @@ local_allreduce_kernel(PeerOuts bufs, int n_peers, size_t n) {
 // the other threads hold the shared side only while they ISSUE a collective and check the flag first, so nobody issues on a
 // communicator that is being aborted.
 struct GroupGuard {
-  std::shared_mutex mu;
+  std::shared_timed_mutex mu;
   std::atomic<int> failed{0};
 };
 
@@ -145,7 +145,7 @@ int make_exchange(cdae_hip_t* h, Exchange** out) {
   // there).  A fourth library stream is poison on this stack: with more than four hardware queues every kernel of the
   // step ran ~3x slower as soon as it existed and carried cross-stream waits (0.132 -> 0.395 ms per 256-user step with no
   // communicator at all; profiles/r02_exchange_streams.txt).  CDAE_XCHG_STREAM = own | main are developer switches.
-  const char* sel = std::getenv("CDAE_XCHG_STREAM");
+  const char* sel = DEV_ENV("CDAE_XCHG_STREAM");
   if (sel && !std::strcmp(sel, "own")) e = hipStreamCreateWithFlags(&x->cstream, hipStreamNonBlocking);
   else if (sel && !std::strcmp(sel, "main")) { x->cstream = cdae_internal::main_stream(h); x->owns_stream = false; }
   else { x->cstream = cdae_internal::aux_stream(h); x->owns_stream = false; }
@@ -202,7 +202,7 @@ int boundary_reduce(Exchange* x) {
   } else {
     HIPCHK(hipStreamWaitEvent(x->cstream, x->ev_staged, 0));
     if (x->guard) {
-      std::shared_lock<std::shared_mutex> lk(x->guard->mu);
+      std::shared_lock<std::shared_timed_mutex> lk(x->guard->mu);
       if (x->guard->failed.load()) return fail("a peer shard failed: epoch abandoned");
       NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
     } else if (x->comm) {
@@ -339,19 +339,31 @@ struct cdae_hip_multi {
   uint64_t U = 0, I = 0;
   int period = 0;
   uint32_t B = 0;
+  // cdae_hip_multi_set_schedule (user-sharded layout): combine rule of the exchange, users per shard of an exchanged step
+  // (0 = B), epochs (fractions allowed) that start with the relay of the single-GPU schedule
+  uint32_t combine = CDAE_COMBINE_SUM, sync_B = 0;
+  double relay_epochs = 0.0;
   // CDAE_LAYOUT_ITEM_ROWS: the shards cut the ITEM rows (W / W_ag / V / V_ag / b' and the decode over them); icut = item ranges
   uint32_t layout = 0;
   std::vector<uint64_t> icut;
   float* d_tmp = nullptr; size_t tmp_cap = 0;      // single-device all-reduce: the sum before it is copied back to every shard
   hipEvent_t ev_done = nullptr;
+  bool one_rank_comms = false;           // (developer build) every shard on its own one-rank communicator, thread-per-shard host logic
+  int fail_shard = -1; uint64_t fail_step = 0;   // (developer build) forced failure of one shard's thread at a step
   bool comm_aborted = false;             // a shard's thread failed inside an epoch: the communicators were aborted so that its peers
                                          // could unwind; the handle answers every later call with that error
   std::string abort_reason;
   GroupGuard guard;
   // called by the failing shard's thread
+  // `failed` goes up FIRST (issuers check it under the shared side before they enqueue a collective).  The exclusive side is then
+  // taken with a TIME LIMIT: a peer may be blocked INSIDE ncclAllReduce holding the shared side (RCCL connects lazily on the first
+  // collective and waits there for the rank that just failed) — waiting for it would be waiting for ourselves, and the abort is
+  // exactly what releases it, so after the limit the abort goes ahead without the lock (ncclCommAbort is the one call RCCL allows
+  // from another thread while a rank is blocked).  ncclCommAbort also frees the communicator: nothing is left to destroy.
   void give_up() {
-    std::unique_lock<std::shared_mutex> lk(guard.mu);
     if (guard.failed.exchange(1)) return;
+    std::unique_lock<std::shared_timed_mutex> lk(guard.mu, std::defer_lock);
+    (void)lk.try_lock_for(std::chrono::milliseconds(200));
     for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
     comm_aborted = true;
   }
@@ -362,13 +374,16 @@ namespace {
 Exchange* xof(cdae_hip_t* h) { return (Exchange*)cdae_internal::exchange_slot(h); }
 
 // one step of every shard's epoch: shard s trains users [a, b) of its own
-struct StepPlan { uint64_t steps; std::vector<uint64_t> per; };
-StepPlan plan_of(const cdae_hip_multi* m) {
+// `first[s]`: users of shard s already trained in this epoch (the relay part of cdae_hip_multi_set_schedule); the plan covers the rest
+struct StepPlan { uint64_t steps; std::vector<uint64_t> per, first; };
+StepPlan plan_of(const cdae_hip_multi* m, const std::vector<uint64_t>& first) {
   StepPlan p;
+  p.first = first;
+  const uint64_t B = m->sync_B ? std::min<uint64_t>(m->sync_B, m->B) : m->B;
   uint64_t longest = 0;
-  for (size_t s = 0; s < m->shard.size(); ++s) longest = std::max(longest, m->cut[s + 1] - m->cut[s]);
-  p.steps = std::max<uint64_t>(1, (longest + m->B - 1) / m->B);
-  for (size_t s = 0; s < m->shard.size(); ++s) p.per.push_back((m->cut[s + 1] - m->cut[s] + p.steps - 1) / p.steps);   // all shards finish together
+  for (size_t s = 0; s < m->shard.size(); ++s) longest = std::max(longest, m->cut[s + 1] - m->cut[s] - first[s]);
+  p.steps = std::max<uint64_t>(1, (longest + B - 1) / B);
+  for (size_t s = 0; s < m->shard.size(); ++s) p.per.push_back((m->cut[s + 1] - m->cut[s] - first[s] + p.steps - 1) / p.steps);   // all shards finish together
   return p;
 }
 
@@ -376,12 +391,13 @@ StepPlan plan_of(const cdae_hip_multi* m) {
 int shard_epoch(cdae_hip_multi* m, size_t s, const StepPlan& pl, uint64_t seed, uint32_t epoch) {
   cdae_hip_t* h = m->shard[s];
   Exchange* x = xof(h);
-  const uint64_t n = m->cut[s + 1] - m->cut[s];
+  const uint64_t n = m->cut[s + 1] - m->cut[s], f = pl.first[s];
   x->period = m->period;
   for (uint64_t t = 0; t < pl.steps; ++t) {
-    const uint64_t a = std::min(n, t * pl.per[s]), b = std::min(n, (t + 1) * pl.per[s]);
+    const uint64_t a = std::min(n, f + t * pl.per[s]), b = std::min(n, f + (t + 1) * pl.per[s]);
+    if ((int)s == m->fail_shard && t == m->fail_step) return fail("forced failure of shard %zu at step %llu (developer build)", s, (unsigned long long)t);
     if (b > a) CHK(cdae_hip_enqueue_users(h, seed, epoch, a, b));
-    const uint64_t a2 = std::min(n, (t + 1) * pl.per[s]), b2 = std::min(n, (t + 2) * pl.per[s]);
+    const uint64_t a2 = std::min(n, f + (t + 1) * pl.per[s]), b2 = std::min(n, f + (t + 2) * pl.per[s]);
     if (b2 > a2) CHK(cdae_hip_prefetch_users(h, seed, epoch, a2, b2));
     CHK(step_single(x));                                   // every shard takes every step: the collective needs all ranks
   }
@@ -400,8 +416,8 @@ int local_epoch(cdae_hip_multi* m, const StepPlan& pl, uint64_t seed, uint32_t e
   uint64_t steps = 0;
   for (uint64_t t = 0; t < pl.steps; ++t) {
     for (size_t s = 0; s < m->shard.size(); ++s) {
-      const uint64_t n = m->cut[s + 1] - m->cut[s];
-      const uint64_t a = std::min(n, t * pl.per[s]), b = std::min(n, (t + 1) * pl.per[s]);
+      const uint64_t n = m->cut[s + 1] - m->cut[s], f = pl.first[s];
+      const uint64_t a = std::min(n, f + t * pl.per[s]), b = std::min(n, f + (t + 1) * pl.per[s]);
       if (b > a) CHK(cdae_hip_enqueue_users(m->shard[s], seed, epoch, a, b));
     }
     ++steps;
@@ -410,6 +426,31 @@ int local_epoch(cdae_hip_multi* m, const StepPlan& pl, uint64_t seed, uint32_t e
   }
   if (m->period != 0 || xof(m->shard[0])->pending) { CHK(local_boundary(m, true)); CHK(local_boundary(m, false)); }
   for (cdae_hip_t* h : m->shard) CHK(cdae_hip_synchronize(h));
+  return 0;
+}
+
+// RELAY part of an epoch (cdae_hip_multi_set_schedule): global users [0, R) on the single-GPU schedule, by the shards that hold them,
+// one after the other; the shared block travels with the training (shard s starts from what shard s - 1 ended with) and ends up on
+// every shard.  first[s] = users of shard s trained here.  Replicas agree on entry (an epoch ends with a flush).
+int relay_part(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t R, std::vector<uint64_t>& first) {
+  const size_t S = m->shard.size();
+  first.assign(S, 0);
+  if (R == 0) return 0;
+  size_t last = 0;
+  for (size_t s = 0; s < S && m->cut[s] < R; ++s) {
+    const uint64_t n = std::min(R, m->cut[s + 1]) - m->cut[s];
+    if (s > 0) CHK(cdae_internal::adopt_shared_block(m->shard[s], m->shard[s - 1]));
+    cdae_hip_stats st;
+    CHK(cdae_hip_train_users(m->shard[s], seed, epoch, 0, n, &st));     // (synchronises: the next shard copies a finished block)
+    first[s] = n;
+    last = s;
+  }
+  for (size_t s = 0; s < S; ++s) if (s != last) CHK(cdae_internal::adopt_shared_block(m->shard[s], m->shard[last]));
+  for (cdae_hip_t* h : m->shard) {
+    CHK(cdae_hip_synchronize(h));
+    Exchange* x = xof(h);
+    if (x) { x->begun = false; x->pending = false; x->steps = 0; }      // the exchange restarts from the relayed parameters
+  }
   return 0;
 }
 
@@ -465,7 +506,7 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
     std::vector<std::string> err(S);
     std::vector<std::thread> th;
     auto all_reduce = [&](size_t s, float* buf, size_t n, hipStream_t st) -> int {
-      std::shared_lock<std::shared_mutex> lk(m->guard.mu);
+      std::shared_lock<std::shared_timed_mutex> lk(m->guard.mu);
       if (m->guard.failed.load()) return fail("item shard %zu: a peer shard failed, epoch abandoned", s);
       NCCLCHK(ncclAllReduce(buf, buf, n, ncclFloat32, ncclSum, m->comms[s], st));
       return 0;
@@ -477,6 +518,7 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
       CHK(cdae_internal::fs_prep(h, seed, epoch, plan[0].s0, plan[0].nb, plan[0].c));
       for (size_t t = 0; t < plan.size(); ++t) {
         const Bt& b = plan[t];
+        if ((int)s == m->fail_shard && t == m->fail_step) return fail("forced failure of item shard %zu at batch %zu (developer build)", s, t);
         CHK(cdae_internal::fs_phase0(h, seed, epoch, b.s0, b.nb, b.c));
         CHK(all_reduce(s, hs[s], (size_t)b.nb * Kp * blocks, st));
         if (t + 1 < plan.size()) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[t + 1].s0, plan[t + 1].nb, plan[t + 1].c));
@@ -528,6 +570,25 @@ int item_encode_chunk(cdae_hip_multi* m, uint64_t u0, uint32_t nu, int mode, uin
   return 0;
 }
 
+// the communicators of a group of shards that each own a device (both layouts): ncclCommInitAll — or, in the developer build's
+// one-rank mode, a communicator of world size 1 per shard
+int init_group_comms(cdae_hip_multi* m) {
+  const size_t S = m->shard.size();
+  if (!m->comms.empty()) return 0;
+  m->comms.assign(S, nullptr);
+  if (m->one_rank_comms) {
+    for (size_t s = 0; s < S; ++s) {
+      ncclUniqueId id;
+      NCCLCHK(ncclGetUniqueId(&id));
+      HIPCHK(hipSetDevice(m->devices[s]));
+      NCCLCHK(ncclCommInitRank(&m->comms[s], 1, id, 0));
+    }
+    return 0;
+  }
+  NCCLCHK(ncclCommInitAll(m->comms.data(), (int)S, m->devices.data()));
+  return 0;
+}
+
 int check_multi(const cdae_hip_multi* m, bool need_data) {
   if (!m) return fail("null multi handle");
   if (m->comm_aborted) return fail("the communicators of this handle were aborted after a shard failed (%s): destroy it", m->abort_reason.c_str());
@@ -545,11 +606,20 @@ int cdae_hip_multi_create(const cdae_hip_config* cfg, int n_shards, const int* d
   std::vector<int> devs(device_ids, device_ids + n_shards), uniq(devs);
   std::sort(uniq.begin(), uniq.end());
   uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-  const bool single = uniq.size() == 1;
-  if (!single && (int)uniq.size() != n_shards)
+  bool single = uniq.size() == 1;
+  // DEVELOPER build only (tests/test_gpu_multi.py): equal device ids, but driven like distinct GPUs — one host thread per shard, each
+  // shard on a ONE-RANK communicator of its own (RCCL refuses two ranks of one communicator on one device).  The collectives are then
+  // identities, so every shard trains as if it were alone: what runs is the thread-per-shard host logic, the guard and the RCCL calls.
+  const bool one_rank_comms = single && n_shards > 1 && DEV_ENV("CDAE_MULTI_ONE_RANK_COMMS") != nullptr;
+  if (one_rank_comms) single = false;
+  if (!single && !one_rank_comms && (int)uniq.size() != n_shards)
     return fail("device_ids must be all distinct (one shard per GPU, RCCL) or all equal (logical shards of one GPU)");
   std::unique_ptr<cdae_hip_multi> m(new cdae_hip_multi());
-  m->cfg = *cfg; m->devices = devs; m->single_device = single;
+  m->cfg = *cfg; m->devices = devs; m->single_device = single; m->one_rank_comms = one_rank_comms;
+  if (const char* f = DEV_ENV("CDAE_MULTI_FAIL_AT")) {        // DEVELOPER build only: "shard:step" — that shard's thread fails there (GroupGuard test)
+    m->fail_shard = std::atoi(f);
+    if (const char* c = std::strchr(f, ':')) m->fail_step = std::strtoull(c + 1, nullptr, 10);
+  }
   for (int s = 0; s < n_shards; ++s) {
     cdae_hip_t* h = nullptr;
     int rc = cdae_hip_create(cfg, devs[s], &h);
@@ -636,10 +706,7 @@ static int set_interactions_item_rows(cdae_hip_multi* m, uint64_t U, uint64_t I,
   m->B = cdae_internal::batch_users(m->shard[0]);
   std::vector<Exchange*> xs(S, nullptr);
   for (size_t s = 0; s < S; ++s) CHK(make_exchange(m->shard[s], &xs[s]));
-  if (S > 1 && !m->single_device && m->comms.empty()) {
-    m->comms.assign(S, nullptr);
-    NCCLCHK(ncclCommInitAll(m->comms.data(), (int)S, m->devices.data()));
-  }
+  if (S > 1 && !m->single_device) CHK(init_group_comms(m));
   return 0;
 }
 
@@ -670,9 +737,8 @@ int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t U, uint64_t I,
   if (S > 1 && m->single_device) {
     for (Exchange* x : xs) { x->local = xs; x->world = (int)S; }
     for (size_t s = 0; s < S; ++s) xs[s]->rank = (int)s;
-  } else if (S > 1 && m->comms.empty()) {
-    m->comms.assign(S, nullptr);
-    NCCLCHK(ncclCommInitAll(m->comms.data(), (int)S, m->devices.data()));
+  } else if (S > 1) {
+    CHK(init_group_comms(m));
     for (size_t s = 0; s < S; ++s) { xs[s]->comm = m->comms[s]; xs[s]->owns_comm = false; xs[s]->world = (int)S; xs[s]->rank = (int)s; }
   }
   for (Exchange* x : xs) { x->begun = false; x->pending = false; x->steps = 0; }
@@ -693,6 +759,19 @@ int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period) {
   return 0;
 }
 
+int cdae_hip_multi_set_schedule(cdae_hip_multi_t* m, const cdae_multi_schedule* sc) {
+  CHK(check_multi(m, false));
+  if (!sc) return fail("null schedule");
+  if (sc->period < 0) return fail("exchange period must be >= 0");
+  if (sc->combine > CDAE_COMBINE_GLOBAL_ACC) return fail("unknown combine rule %u", sc->combine);
+  if (!(sc->relay_epochs >= 0.0)) return fail("relay_epochs must be >= 0");
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS && (sc->combine || sc->sync_batch_users || sc->relay_epochs > 0.0))
+    return fail("the item-rows layout IS the single-GPU schedule: it has no relay, no combine rule and no exchanged steps to size");
+  m->period = sc->period; m->combine = sc->combine; m->sync_B = sc->sync_batch_users; m->relay_epochs = sc->relay_epochs;
+  for (cdae_hip_t* h : m->shard) CHK(cdae_hip_delta_set_combine(h, m->combine));
+  return 0;
+}
+
 int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats) {
   CHK(check_multi(m, true));
   return cdae_hip_multi_train_users(m, seed, epoch, 0, m->U, stats);
@@ -704,7 +783,6 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
   if (m->layout != CDAE_LAYOUT_ITEM_ROWS && (u_begin != 0 || u_end != m->U))
     return fail("the user-sharded layout trains whole epochs (every shard walks its own users): use cdae_hip_multi_train_epoch");
   const auto t0 = std::chrono::steady_clock::now();
-  const StepPlan pl = plan_of(m);
   const size_t S = m->shard.size();
   if (m->layout == CDAE_LAYOUT_ITEM_ROWS) {
     CHK(item_epoch(m, seed, epoch, u_begin, u_end));
@@ -730,7 +808,24 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
     CHK(cdae_hip_train_epoch(m->shard[0], seed, epoch, stats));
     return 0;
   }
-  if (m->single_device) {
+  // relay part: the first (relay_epochs - epoch) epochs' worth of users on the single-GPU schedule
+  std::vector<uint64_t> first(S, 0);
+  const double left = m->relay_epochs - (double)epoch;
+  const uint64_t R = left <= 0.0 ? 0 : (left >= 1.0 ? m->U : std::min<uint64_t>(m->U, (uint64_t)(left * (double)m->U)));
+  cdae_hip_stats relay_stats;
+  std::memset(&relay_stats, 0, sizeof relay_stats);
+  if (R) {
+    CHK(relay_part(m, seed, epoch, R, first));
+    for (cdae_hip_t* h : m->shard) {
+      cdae_hip_stats st;
+      CHK(cdae_hip_collect_stats(h, &st));
+      relay_stats.users += st.users; relay_stats.examples += st.examples; relay_stats.batches += st.batches;
+    }
+  }
+  const StepPlan pl = plan_of(m, first);
+  if (R == m->U) {
+    // the whole epoch was relayed: nothing to exchange
+  } else if (m->single_device) {
     CHK(local_epoch(m, pl, seed, epoch));
   } else {
     // one host thread per device: the launches of a step cost tens of microseconds of host time per shard
@@ -752,7 +847,7 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
       }
   }
   if (stats) {
-    std::memset(stats, 0, sizeof *stats);
+    *stats = relay_stats;
     for (cdae_hip_t* h : m->shard) {
       cdae_hip_stats st;
       CHK(cdae_hip_collect_stats(h, &st));
@@ -849,6 +944,7 @@ int cdae_hip_multi_eval_topn(cdae_hip_multi_t* m, const int64_t* test_row_ptr, c
                              double* rets8, uint64_t* hits3, uint32_t* ids_out) {
   CHK(check_multi(m, true));
   if (!test_row_ptr || !rets8 || topk == 0) return fail("bad argument");
+  CHK(cdae_internal::validate_test_rows(test_row_ptr, test_col, m->U, m->I, nullptr));     // (the single handle's checks: cdae_hip_set_test_rows)
   std::vector<uint32_t> own;
   uint32_t* ids = ids_out;
   if (!ids) { own.resize((size_t)m->U * topk); ids = own.data(); }

@@ -57,8 +57,11 @@ extern "C" {
  * 8: cdae_hip_full_output_plan
  * 9: cdae_hip_set_test_rows, cdae_hip_eval_topn, cdae_hip_multi_eval_topn (TOPN metrics on the device)
  * 10: IMF / BPR handles created with batch_users = 0 train the certified block of their model (cdae_hip_mf_default_batch_users: 16 / 8
- *     users on the BASELINE-sized data sets, was 1); BPR's phase U carries the positive item's row from pair to pair */
-#define CDAE_HIP_ABI_VERSION 10
+ *     users on the BASELINE-sized data sets, was 1); BPR's phase U carries the positive item's row from pair to pair
+ * 11: schedule of the user-sharded layout: cdae_hip_delta_set_combine (CDAE_COMBINE_GLOBAL_ACC), cdae_hip_multi_set_schedule
+ *     (relay warm-up epochs on the single-GPU schedule, users per shard of the exchanged steps, combine rule); the drop-in IMF / BPR
+ *     classes pass batch_users = 1 (the reference loop) unless CDAE_BATCH_USERS says otherwise */
+#define CDAE_HIP_ABI_VERSION 11
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -298,6 +301,15 @@ int cdae_hip_delta_apply(cdae_hip_t* h, uint32_t world_size, uint32_t rule);
  * Stream-ordered on cdae_hip_stream like the calls above.  (cdae_hip_exchange_* below drive these with a library-owned
  * RCCL communicator; these entry points remain for hosts that bring their own collective.) */
 int cdae_hip_delta_stage(cdae_hip_t* h);
+/* How _merge folds the all-reduced buffer in (set it before the first _stage, or between a _merge and the next _stage):
+ *   CDAE_COMBINE_SUM         (default) the algebra above: the replicas' accumulated steps are summed.
+ *   CDAE_COMBINE_GLOBAL_ACC  AdaGrad handles only (others keep the sum): per (parameter, accumulator) pair the replicas exchange their
+ *       accumulator growth — exactly their sum of squared gradients, cdae.hpp:254 — and their step with their own preconditioner taken
+ *       back out, (current - A) * (beta + sqrt(acc)); _merge takes ONE step with the accumulator that has seen every replica:
+ *       A_acc += sum ; A += sum / (beta + sqrt(A_acc))  (cdae_exchange_algebra.h pipe_pair).  Same buffers, same all-reduce. */
+#define CDAE_COMBINE_SUM 0u
+#define CDAE_COMBINE_GLOBAL_ACC 1u
+int cdae_hip_delta_set_combine(cdae_hip_t* h, uint32_t combine);
 int cdae_hip_delta_recv_device_ptr(cdae_hip_t* h, void** device_ptr, size_t* count_floats);
 int cdae_hip_delta_merge(cdae_hip_t* h);
 int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous period then _stage of this one, in one pass */
@@ -313,8 +325,9 @@ int cdae_hip_delta_merge_stage(cdae_hip_t* h);   /* _merge of the previous perio
  * concurrently against the block-start item rows; 1 == the reference's strictly sequential loop.  data_loss / penalty_loss are
  * 0 for these models, as in the reference (ModelBase defaults, model_base.hpp:36-45); cdae_hip_encode, the explicit-input step
  * and the full-output decode do not apply. */
-/* Training order.  A CDAE handle, and an IMF / BPR handle with one user per block (BPR's default), visit the users in id order like the reference.
- * An IMF / BPR handle with batch_users > 1 (the block schedule: IMF's default, a throughput setting beyond it) trains them in ACTIVITY-GROUPED order — users
+/* Training order.  A CDAE handle, and an IMF / BPR handle with one user per block (batch_users = 1: what the drop-in classes
+ * src/model/recsys/imf.hpp / bpr.hpp pass by default), visit the users in id order like the reference.
+ * An IMF / BPR handle with batch_users > 1 (the block schedule: what batch_users = 0 selects on BASELINE-sized data sets, a throughput setting beyond it) trains them in ACTIVITY-GROUPED order — users
  * sorted by train-row length, cut into blocks of batch_users, the blocks visited in a fixed pseudo-random order — because a block
  * lasts as long as its most active user's serial chain.  cdae_hip_user_order returns that order: out[position] = user id
  * (count = num_users; the identity for every other handle).  The random streams, cdae_hip_train_users' range and
@@ -399,6 +412,24 @@ int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t num_users, uin
                                     const uint32_t* col_idx);
 int cdae_hip_multi_init_params(cdae_hip_multi_t* m, uint64_t seed);
 int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period);
+/* The whole schedule of CDAE_LAYOUT_USERS (ABI 11).  An epoch e of `train_epoch` runs in two parts:
+ *   RELAY  the first  R = clamp((relay_epochs - e) * num_users, 0, num_users)  users (fractions of an epoch allowed) are trained on the
+ *          SINGLE-GPU schedule — Solver<CDAE>::train's order (cdae.hpp:136-146): users 0, 1, 2, ... in blocks of the handles'
+ *          batch_users, every item row's chain sequential — by the shard that holds them, and the shared block is handed from shard to
+ *          shard when the range crosses a cut (one device-to-device copy of [W | W_ag | b' | ... ] per shard and epoch; the other GPUs
+ *          wait).  It costs a single GPU's time and has the single-GPU schedule's accuracy: the warm-up that DESIGN.md §7 measured to
+ *          bring the exchanged steps back towards the envelope (young AdaGrad accumulators are what the summed steps overshoot on).
+ *   EXCHANGE  the remaining users of every shard, `sync_batch_users` (0 = the handles' batch_users) per shard and step, deltas
+ *          exchanged every step (period 0) or pipelined (period k), folded in by `combine` (CDAE_COMBINE_*).
+ * cdae_hip_multi_set_exchange(m, p) == set_schedule{p, CDAE_COMBINE_SUM, 0, 0.0}. */
+typedef struct cdae_multi_schedule {
+  int32_t period;
+  uint32_t combine;
+  uint32_t sync_batch_users;
+  uint32_t reserved;
+  double relay_epochs;
+} cdae_multi_schedule;
+int cdae_hip_multi_set_schedule(cdae_hip_multi_t* m, const cdae_multi_schedule* schedule);
 int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
 /* users [u_begin, u_end) only — CDAE_LAYOUT_ITEM_ROWS (every shard sees every user); the user-sharded layout trains whole epochs */
 int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end,

@@ -4,9 +4,10 @@
 //
 //   method (reference lines)                         -> C ABI
 //   reset (57-69)                                     cdae_hip_create_mf, _set_interactions, _init_params
-//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default: blocks of 16 users (BPR: 8) on BASELINE-sized data sets, inside the +-0.002 mean-over-seeds
-//                                                                                    Recall@10 bound against the loop — DESIGN.md §8b; CDAE_BATCH_USERS=1:
-//                                                                                    the reference loop itself; larger blocks: throughput setting)
+//   train_one_iteration (71-86) + train_one_instance  cdae_hip_train_epoch          (default batch_users = 1: the reference's strictly sequential loop, one launch window
+//                                                                                    per 256 users.  CDAE_BATCH_USERS=0 opts into the library's block default — 16 users
+//                                                                                    (BPR: 8) on BASELINE-sized data sets, certified at ONE shape and hyper-parameter set
+//                                                                                    only, DESIGN.md §8b — larger values are throughput settings)
 //   predict_user_item_rating (117-119)                host dot product over parameters fetched once (cdae_hip_get_param)
 //   recommend (RecsysModelBase, 77-104)               cdae_hip_recommend_all in pre_recommend, then table reads
 //   get_user_vecs / get_item_vecs (121-127)           cdae_hip_get_param
@@ -58,7 +59,9 @@ class IMF : public RecsysModelBase {
     c.num_dim = static_cast<uint32_t>(num_dim_); c.num_neg = static_cast<uint32_t>(num_neg_);
     c.loss_type = static_cast<uint32_t>(lt_);                  // the C ABI rejects losses the reference's app does not offer here
     c.using_adagrad = using_adagrad_; c.using_bias_term = using_bias_term_; c.pairwise = pairwise_;
-    c.batch_users = static_cast<uint32_t>(mf_env_u64("CDAE_BATCH_USERS", 0));
+    // the drop-in default IS the reference loop (imf.hpp:71-115, bpr.hpp:56-106): a block schedule changes the trajectory and is
+    // certified at one shape only, so it has to be asked for (CDAE_BATCH_USERS=0: the library's block default; N > 1: N users)
+    c.batch_users = static_cast<uint32_t>(mf_env_u64("CDAE_BATCH_USERS", 1));
     c.lambda = lambda_; c.learn_rate = learn_rate_; c.beta = beta_;
     cdae_hip_t* raw = nullptr;
     CDAE_HIP_CHECK(cdae_hip_create_mf(&c, static_cast<int>(mf_env_u64("CDAE_DEVICE", 0)), &raw));

@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--eval-users", type=int, default=0,
                     help="> 0: Recall@10 over the first N users only (the fp64 top-10 of 480 000 x 17 700 x 200 is ~20 min of one core "
                          "per epoch; training and the reported loss always cover every user)")
+    ap.add_argument("--tag-suffix", default="",
+                    help="appended to the schedule tag of the file name (`literal50` = the app's own horizon, Solver<CDAE>(model, 50), "
+                         "/root/reference/apps/yelp/yelp.cpp:197: kept apart from the 5-epoch six-seed set the default accuracy test globs)")
     args = ap.parse_args()
     if args.full_output_literal:
         args.full_output_batch = 1
@@ -64,6 +67,27 @@ def main():
     o = orc.Oracle(orc.OracleConfig(num_dim=args.num_dim, loss_type=lt, **HYPER), d.num_users, d.num_items, d.train_ptr, d.train_col)
     o.init_params(args.seed)
     rec10, loss, data_loss, metrics, secs = [], [], [], [], []
+    tag = (f"full{args.full_output_batch}" if args.full_output_batch else "literal") + args.tag_suffix
+    name = f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_{tag}_seed{args.seed}" + ("" if args.data_seed is None else f"_data{data_seed}") + ".npz"
+
+    def save(ne):
+        # parameter probes (full-output fixtures compare parameters too: Recall is uninformative on a few hundred users)
+        rng = np.random.default_rng(args.seed)
+        pop = np.bincount(d.train_col, minlength=d.num_items)
+        probe_items = np.unique(np.concatenate([np.argsort(-pop)[:32], rng.choice(d.num_items, 32, replace=False)])).astype(np.int64)
+        probe_users = np.sort(rng.choice(d.num_users, min(16, d.num_users), replace=False)).astype(np.int64)
+        K = args.num_dim
+        probes = dict(probe_items=probe_items, probe_users=probe_users,
+                      W_rows=o.get(ob.P_W).reshape(d.num_items, K)[probe_items], bp_rows=o.get(ob.P_BP)[probe_items],
+                      Wu_rows=o.get(ob.P_WU).reshape(d.num_users, K)[probe_users], b=o.get(ob.P_B),
+                      W_absmax=np.abs(o.get(ob.P_W)).max(), Wu_absmax=np.abs(o.get(ob.P_WU)).max(), bp_absmax=np.abs(o.get(ob.P_BP)).max())
+        tmp = os.path.join(OUT, name + ".tmp.npz")
+        np.savez(tmp, shape=args.shape, seed=args.seed, data_seed=data_seed, num_dim=args.num_dim, loss=args.loss,
+                 full_output_batch=args.full_output_batch, hyper=np.array(sorted(HYPER.items()), dtype=object).astype(str),
+                 recall10=np.array(rec10), train_loss=np.array(loss), data_loss=np.array(data_loss), topn=np.array(metrics),
+                 train_seconds=np.array(secs), nnz_train=d.nnz_train, eval_users=ne, **probes)
+        os.replace(tmp, os.path.join(OUT, name))      # a long run (50 epochs = hours of one core) leaves a usable prefix if it is cut short
+
     for ep in range(args.epochs):
         t0 = time.time()
         if args.full_output_batch:
@@ -78,23 +102,8 @@ def main():
         m = orc.eval_topn(o.recommend(10, 0, ne), d.test_ptr[:ne + 1], d.test_col[:d.test_ptr[ne]])
         metrics.append(m)
         rec10.append(m[5])
+        save(ne)
         print(f"[{args.shape} seed {args.seed}] epoch {ep + 1}: loss {loss[-1]:.1f} recall@10 {rec10[-1]:.5f} ({secs[-1]:.0f} s train)", flush=True)
-    # parameter probes (full-output fixtures compare parameters too: Recall is uninformative on a few hundred users)
-    rng = np.random.default_rng(args.seed)
-    pop = np.bincount(d.train_col, minlength=d.num_items)
-    probe_items = np.unique(np.concatenate([np.argsort(-pop)[:32], rng.choice(d.num_items, 32, replace=False)])).astype(np.int64)
-    probe_users = np.sort(rng.choice(d.num_users, min(16, d.num_users), replace=False)).astype(np.int64)
-    K = args.num_dim
-    probes = dict(probe_items=probe_items, probe_users=probe_users,
-                  W_rows=o.get(ob.P_W).reshape(d.num_items, K)[probe_items], bp_rows=o.get(ob.P_BP)[probe_items],
-                  Wu_rows=o.get(ob.P_WU).reshape(d.num_users, K)[probe_users], b=o.get(ob.P_B),
-                  W_absmax=np.abs(o.get(ob.P_W)).max(), Wu_absmax=np.abs(o.get(ob.P_WU)).max(), bp_absmax=np.abs(o.get(ob.P_BP)).max())
-    tag = f"full{args.full_output_batch}" if args.full_output_batch else "literal"
-    name = f"{args.shape}_k{args.num_dim}_{args.loss.lower()}_{tag}_seed{args.seed}" + ("" if args.data_seed is None else f"_data{data_seed}") + ".npz"
-    np.savez(os.path.join(OUT, name), shape=args.shape, seed=args.seed, data_seed=data_seed, num_dim=args.num_dim, loss=args.loss,
-             full_output_batch=args.full_output_batch, hyper=np.array(sorted(HYPER.items()), dtype=object).astype(str),
-             recall10=np.array(rec10), train_loss=np.array(loss), data_loss=np.array(data_loss), topn=np.array(metrics),
-             train_seconds=np.array(secs), nnz_train=d.nnz_train, eval_users=ne, **probes)
     print("wrote", name)
 
 

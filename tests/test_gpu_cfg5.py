@@ -44,7 +44,7 @@ def run(blocks, users_per_block=1024):
     return out, plan, loss0, loss1, rec
 
 
-def test_config5_item_space_first_block_is_bit_identical_to_the_replaced_launches(built, monkeypatch):
+def test_config5_item_space_first_block_is_bit_identical_to_the_replaced_launches(built, monkeypatch, devlib):
     d = data()
     assert d.num_items == 1_000_000
     new, plan, _, _, _ = run(1)
@@ -58,7 +58,7 @@ def test_config5_item_space_first_block_is_bit_identical_to_the_replaced_launche
     np.testing.assert_allclose(new[cdae_amd.P_BP], old[cdae_amd.P_BP], rtol=1e-5, atol=1e-8)
 
 
-def test_config5_item_space_a_pass_of_blocks(built, monkeypatch):
+def test_config5_item_space_a_pass_of_blocks(built, monkeypatch, devlib):
     d = data()
     blocks = 8
     new, _, loss0, loss1, rec = run(blocks)

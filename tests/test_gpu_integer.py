@@ -160,7 +160,7 @@ def test_user_id_offset_shifts_the_streams_like_a_global_run(built):
 
 
 @pytest.mark.parametrize("tile_sort", [True, False], ids=["tile-counting-sort", "rocprim"])
-def test_both_sort_paths_give_the_same_bit_exact_order(built, monkeypatch, tile_sort):
+def test_both_sort_paths_give_the_same_bit_exact_order(built, monkeypatch, devlib, tile_sort):
     """cdae_sort_kernels.hpp (CDAE_SORT_TILE=1, up to 32 768 items): per-tile LDS counting sort + per-item ordering; default: the
     library radix sort.  Both must equal numpy's stable sort by item, bit for bit."""
     if tile_sort:
@@ -178,7 +178,7 @@ def test_both_sort_paths_give_the_same_bit_exact_order(built, monkeypatch, tile_
     check_batch(m2, o2, d2, 2, 0, 0, 3500, num_neg=1)
 
 
-def test_tile_sort_with_more_than_16384_items(built, monkeypatch):
+def test_tile_sort_with_more_than_16384_items(built, monkeypatch, devlib):
     """per-tile cursors above 64 KiB of LDS (dynamic LDS attribute): 20 000 items"""
     monkeypatch.setenv("CDAE_SORT_TILE", "1")
     d = synth.generate(600, 20_000, 40_000, seed=4)

@@ -407,7 +407,7 @@ def test_item_rows_layout_shards_the_user_node_by_user(built):
 
 
 @pytest.mark.parametrize("K,B,shards,kw", [(24, 48, 1, {}), (24, 48, 3, {}), (200, 64, 4, {}), (24, 300, 5, dict(num_corruptions=2)), (40, 37, 2, dict(asymmetric=True))])
-def test_item_rows_sampled_with_the_tile_counting_sort_changes_no_bit(built, monkeypatch, K, B, shards, kw):
+def test_item_rows_sampled_with_the_tile_counting_sort_changes_no_bit(built, monkeypatch, devlib, K, B, shards, kw):
     """Round 4: a sampled item shard may order its example list with the four tile kernels of cdae_sort_kernels.hpp instead of the
     library radix sort (CDAE_SORT_TILE; the kernels give an example on another shard's row — VOID — no ticket and no place).  The
     item-major order, the segment table and the duplicate marks are the same, so two epochs end on the same bits."""
@@ -429,3 +429,237 @@ def test_item_rows_sampled_with_the_tile_counting_sort_changes_no_bit(built, mon
     tile = run()
     for w in lib:
         np.testing.assert_array_equal(lib[w], tile[w], err_msg=f"parameter {w}")
+
+
+# ---- cdae_hip_multi_set_schedule (ABI 11): relay part + combine rule of the user-sharded layout -----------------------------
+def test_relayed_epochs_are_the_single_gpu_schedule_bit_for_bit(small):
+    """relay_epochs >= the epochs trained: every epoch is the single-GPU schedule — users in Solver<CDAE>::train's order
+    (cdae.hpp:136-146), in blocks of batch_users, the block of shared parameters handed from shard to shard.  ONE handle that holds
+    everybody and is walked range by range over the same cuts takes the same blocks from the same streams: equal bits."""
+    cfg = cfg_of(B=32)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * 3)
+    mm.set_schedule(relay_epochs=2.0)
+    mm.reset(small, seed=11)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(small, seed=11)
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+        assert st.users == small.num_users
+        for a, b in mm.shards():
+            one.train_users(3, ep, a, b)
+    for which in SHARED + [cdae_amd.P_WU, cdae_amd.P_WU_AG]:
+        np.testing.assert_array_equal(mm.get(which), one.get(which))
+    np.testing.assert_array_equal(mm.recommend_all(10), one.recommend_all(10))
+
+
+def test_a_fraction_of_an_epoch_is_relayed_then_the_rest_is_exchanged(small):
+    """relay_epochs = 1.4: epoch 0 is relayed whole, epoch 1 relays global users [0, 0.4 U) — through the cut they cross — and
+    exchanges the rest in steps of sync_batch_users per shard; restated with single handles and the hand-driven protocol."""
+    import torch
+    cfg = cfg_of(B=32)
+    shards, sync_b = 3, 8
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards)
+    mm.set_schedule(period=0, sync_batch_users=sync_b, relay_epochs=1.4)
+    mm.reset(small, seed=11)
+    cuts = mm.shards()
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+        assert st.users == small.num_users
+    # the same by hand
+    dev = torch.device("cuda", 0)
+    ms = []
+    for u0, u1 in cuts:
+        sd = small.user_range(u0, u1)
+        m = cdae_amd.CDAE(cfg)
+        m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
+        m.init_params(11)
+        ms.append(m)
+
+    def hand_on(dst, src):
+        for which in SHARED:
+            dst.set(which, src.get(which))
+
+    U = small.num_users
+    for ep in range(2):
+        R = U if ep == 0 else int(0.4 * U)
+        first, last = [0] * shards, 0
+        for s, (u0, u1) in enumerate(cuts):
+            if u0 >= R:
+                break
+            if s:
+                hand_on(ms[s], ms[s - 1])
+            first[s] = min(R, u1) - u0
+            ms[s].train_users(3, ep, 0, first[s])
+            last = s
+        for s in range(shards):
+            if s != last:
+                hand_on(ms[s], ms[last])
+        if R == U:
+            continue
+        sends, recvs = [], []
+        for m in ms:
+            m.delta_begin(); m.delta_stage(); m.synchronize()
+            ps, _ = m.delta_device_ptr()
+            pr, n = m.delta_recv_device_ptr()
+            sends.append(torch.as_tensor(_DeviceBuffer(ps, n), device=dev))
+            recvs.append(torch.as_tensor(_DeviceBuffer(pr, n), device=dev))
+        rest = [u1 - u0 - f for (u0, u1), f in zip(cuts, first)]
+        steps = max(1, -(-max(rest) // sync_b))
+        per = [-(-n // steps) for n in rest]
+        for t in range(steps):
+            for s, m in enumerate(ms):
+                n = cuts[s][1] - cuts[s][0]
+                a, b = min(n, first[s] + t * per[s]), min(n, first[s] + (t + 1) * per[s])
+                if b > a:
+                    m.enqueue_users(3, ep, a, b)
+            for m in ms:
+                m.delta_stage()
+            for m in ms:
+                m.synchronize()
+            total = sends[0].clone()
+            for x in sends[1:]:
+                total += x
+            for x in recvs:
+                x.copy_(total)
+            torch.cuda.synchronize()
+            for m in ms:
+                m.delta_merge()
+        for m in ms:
+            m.synchronize()
+    for which in SHARED:
+        for m in ms:
+            np.testing.assert_array_equal(mm.get(which), m.get(which))
+    np.testing.assert_array_equal(mm.get(cdae_amd.P_WU), np.concatenate([m.get(cdae_amd.P_WU) for m in ms]))
+
+
+def test_global_accumulator_combine_is_its_statement(small):
+    """CDAE_COMBINE_GLOBAL_ACC (cdae_exchange_algebra.h pipe_pair): per (parameter, accumulator) pair the replicas exchange their
+    accumulator growth and their step with their own preconditioner taken back out; the merge takes one step with the accumulator that
+    has seen everybody.  One synchronous step of three shards against the same formula in numpy (fp32 operations in the same order up
+    to the association of the three-term sum), and the properties that make it a combine RULE: an element only one replica moved
+    ends exactly where that replica put it; replicas agree bit for bit."""
+    cfg = cfg_of(B=16)
+    shards = 3
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0] * shards)
+    mm.set_schedule(period=0, combine=cdae_amd.COMBINE_GLOBAL_ACC)
+    mm.reset(small, seed=11)
+    cuts = mm.shards()
+    before = {w: mm.get(w) for w in SHARED}
+    mm.train_one_iteration(3, 0)
+    # the replicas of every shard agree
+    hs = []
+    for s in range(shards):
+        hs.append({w: mm.shard_get(s, w) for w in SHARED})
+    for w in SHARED:
+        for s in range(1, shards):
+            np.testing.assert_array_equal(hs[0][w], hs[s][w])
+    # one global step by hand: three single handles, each trains ITS first step's users from the common parameters
+    ms = []
+    for u0, u1 in cuts:
+        sd = small.user_range(u0, u1)
+        m = cdae_amd.CDAE(cfg)
+        m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
+        m.init_params(11)
+        ms.append(m)
+    sizes = [u1 - u0 for u0, u1 in cuts]
+    steps = -(-max(sizes) // 16)
+    per = [-(-n // steps) for n in sizes]
+    beta = np.float32(HYPER["beta"])
+    cur = {w: before[w].copy() for w in SHARED}
+    for t in range(steps):
+        after = []
+        for s, m in enumerate(ms):
+            for w in SHARED:
+                m.set(w, cur[w])
+            a, b = min(sizes[s], t * per[s]), min(sizes[s], (t + 1) * per[s])
+            if b > a:
+                m.train_users(3, 0, a, b)
+            after.append({w: m.get(w) for w in SHARED})
+        for p, acc in ((cdae_amd.P_W, cdae_amd.P_W_AG), (cdae_amd.P_B, cdae_amd.P_B_AG), (cdae_amd.P_BP, cdae_amd.P_BP_AG)):
+            da = [x[acc] - cur[acc] for x in after]
+            dp = [(x[p] - cur[p]) * (beta + np.sqrt(x[acc])) for x in after]
+            new_acc = cur[acc] + ((da[0] + da[1]) + da[2])
+            new_p = cur[p] + ((dp[0] + dp[1]) + dp[2]) / (beta + np.sqrt(new_acc))
+            movers = sum((x[p] != cur[p]).astype(np.int32) for x in after)
+            only = movers == 1
+            if only.any():     # an element one replica moved: that replica's value up to the rounding of (x * d) / d
+                mover_val = sum(np.where(x[p] != cur[p], x[p], np.float32(0)) for x in after)
+                assert np.abs(new_p[only] - mover_val[only]).max() <= 4e-7 * max(1.0, np.abs(mover_val[only]).max())
+            cur[acc], cur[p] = new_acc.astype(np.float32), new_p.astype(np.float32)
+    for w in SHARED:
+        scale = max(1e-3, float(np.abs(cur[w]).max()))
+        assert np.abs(hs[0][w] - cur[w]).max() <= 1e-4 * scale, w
+    # and it is a different rule from the sum where several replicas moved an element
+    ms2 = cdae_amd.MultiCDAE(cfg, devices=[0] * shards)
+    ms2.reset(small, seed=11)
+    ms2.train_one_iteration(3, 0)
+    assert np.abs(ms2.get(cdae_amd.P_W) - hs[0][cdae_amd.P_W]).max() > 1e-4
+
+
+# ---- the one-host-thread-per-GPU code paths on a one-GPU box (developer build: every shard on a ONE-RANK communicator) ---------------
+def _plan(sizes, B):
+    steps = max(1, -(-max(sizes) // B))
+    return steps, [-(-n // steps) for n in sizes]
+
+
+@pytest.mark.parametrize("period", [0, 2])
+def test_thread_per_shard_loop_and_rccl_calls_with_one_rank_communicators(small, monkeypatch, devlib, period):
+    """devices = [0, 0, 0] driven like three GPUs: ncclCommInitRank per shard, one host thread per shard for the epoch, every boundary
+    through ncclAllReduce under the group guard, the flush — the code a real N-GPU run executes.  A one-rank all-reduce is the identity,
+    so every shard must end exactly where a single handle ends that trains the same users in the same steps on its own."""
+    monkeypatch.setenv("CDAE_MULTI_ONE_RANK_COMMS", "1")
+    cfg = cfg_of(B=32)
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0, 0, 0], exchange_every=period)
+    mm.reset(small, seed=11)
+    cuts = mm.shards()
+    for ep in range(2):
+        st = mm.train_one_iteration(3, ep)
+        assert st.users == small.num_users
+    sizes = [b - a for a, b in cuts]
+    steps, per = _plan(sizes, 32)
+    for s, (u0, u1) in enumerate(cuts):
+        sd = small.user_range(u0, u1)
+        m = cdae_amd.CDAE(cfg)
+        m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
+        m.init_params(11)
+        for ep in range(2):
+            for t in range(steps):
+                a, b = min(sizes[s], t * per[s]), min(sizes[s], (t + 1) * per[s])
+                if b > a:
+                    m.enqueue_users(3, ep, a, b)
+            m.synchronize()
+        for w in SHARED:
+            np.testing.assert_array_equal(mm.shard_get(s, w), m.get(w))
+        m.close()
+    mm.close()
+
+
+@pytest.mark.parametrize("full_output", [False, True])
+def test_item_rows_thread_per_shard_loop_runs_on_one_rank_communicators(small, monkeypatch, devlib, full_output):
+    """the item-rows layout's one-thread-per-GPU batch loop (phases + two all-reduces per batch on each shard's own communicator):
+    with one-rank communicators the sums stay local — the numbers are not the model's — but every call of the loop executes, returns
+    and leaves finite parameters; evaluation (single-thread group calls) runs behind it"""
+    monkeypatch.setenv("CDAE_MULTI_ONE_RANK_COMMS", "1")
+    mm = cdae_amd.MultiCDAE(cfg_of(B=64, full_output=full_output), devices=[0, 0], item_rows=True)
+    mm.reset(small, seed=11)
+    st = mm.train_one_iteration(3, 0)
+    assert st.users == small.num_users
+    assert np.isfinite(mm.get(cdae_amd.P_W)).all() and np.isfinite(mm.current_loss(5, 0))
+    assert mm.recommend_all(10).shape == (small.num_users, 10)
+    mm.close()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("item_rows", [False, True])
+def test_a_failing_shard_thread_ends_the_epoch_with_an_error_not_a_hang(small, monkeypatch, devlib, item_rows):
+    """GroupGuard: shard 1's thread fails at its fourth step; it aborts the group's communicators, its peers return, the call reports
+    the shard's own message, and the handle answers every later call with the abort — nothing blocks (pytest-timeout is the judge)."""
+    monkeypatch.setenv("CDAE_MULTI_ONE_RANK_COMMS", "1")
+    monkeypatch.setenv("CDAE_MULTI_FAIL_AT", "1:3")
+    mm = cdae_amd.MultiCDAE(cfg_of(B=32), devices=[0, 0, 0], item_rows=item_rows)
+    mm.reset(small, seed=11)
+    with pytest.raises(cdae_amd.CDAEError, match="forced failure"):
+        mm.train_one_iteration(3, 0)
+    with pytest.raises(cdae_amd.CDAEError, match="aborted"):
+        mm.train_one_iteration(3, 1)
+    mm.close()

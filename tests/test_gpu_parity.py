@@ -222,7 +222,7 @@ def test_training_is_bit_deterministic_and_handles_reload(tiny, small):
 @pytest.mark.parametrize("env", [dict(CDAE_PREP_THREAD="0"), dict(CDAE_PREP2="off"), dict(CDAE_PREP2="own"), dict(CDAE_EVENT_SYSTEM_FENCE="1"),
                                  dict(CDAE_ENCODE_TWO_LAUNCHES="1"), dict(CDAE_SORT_TILE="1"), dict(CDAE_GATHER_HALVES="1", CDAE_PREP2="aux")],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
-def test_scheduling_switches_do_not_change_a_single_bit(small, monkeypatch, env):
+def test_scheduling_switches_do_not_change_a_single_bit(small, monkeypatch, devlib, env):
     """The prep worker thread, the second prep lane, device-scope events, the one-launch encode and the tile counting sort change
     WHEN work is issued and by which kernel — never the arithmetic or its order: parameters after two epochs are bit-identical
     to the default configuration's."""
@@ -245,7 +245,33 @@ def test_scheduling_switches_do_not_change_a_single_bit(small, monkeypatch, env)
         assert np.array_equal(base[w], other[w]), (env, w)
 
 
-def test_duplicate_correction_overflow_falls_back_to_atomics(tiny, monkeypatch):
+def test_the_shipped_library_reads_no_developer_switch(small, monkeypatch):
+    """The SHIPPED library (no `devlib` here) under every developer switch that changes results or kernels in the developer build —
+    CDAE_DEBUG_SKIP_ROLES / _SKIP_PREP give WRONG results there by design — trains the same bits as without them."""
+    cfg = cdae_amd.CDAEConfig(num_dim=40, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=64)
+
+    def run(full_output=False):
+        m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=40, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=64, full_output=full_output))
+        assert m.lib is cdae_amd.load_library(cdae_amd.LIB_PATH)
+        m.reset(small, seed=5)
+        for ep in range(2):
+            m.train_one_iteration(5, ep)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        m.close()
+        return out
+
+    base, base_full = run(), run(True)
+    for k, v in dict(CDAE_DEBUG_SKIP_ROLES="63", CDAE_DEBUG_SKIP_PREP="1", CDAE_SORT_TILE="1", CDAE_DUP_CAP="2", CDAE_DECODE_ONE_ROW_PER_WAVE="1",
+                     CDAE_FULL_UNFUSED="1", CDAE_FULL_B_SUMMED="1", CDAE_PREP2="off", CDAE_PREP_THREAD="0", CDAE_UNIT_POS="16",
+                     CDAE_DECODE_HOT_POS="1", CDAE_ENCODE_TWO_LAUNCHES="1", CDAE_FULL_ONE_STREAM_MAX="0").items():
+        monkeypatch.setenv(k, v)
+    other, other_full = run(), run(True)
+    for w in base:
+        assert np.array_equal(base[w], other[w]) and np.array_equal(base_full[w], other_full[w]), w
+    del cfg
+
+
+def test_duplicate_correction_overflow_falls_back_to_atomics(tiny, monkeypatch, devlib):
     """CDAE_DUP_CAP bounds the duplicate-negative correction buffer; examples beyond it take the atomic path and the
     result is the same trajectory (up to the order of a few fp32 additions)."""
     monkeypatch.setenv("CDAE_DUP_CAP", "2")
@@ -525,7 +551,7 @@ def test_more_than_65536_items(built):
 
 
 @pytest.mark.parametrize("K,B,unfused_env", [(300, 48, False), (512, 130, False), (24, 48, True), (200, 64, True), (300, 256, False)])
-def test_full_output_three_gemm_path(tiny, small, monkeypatch, K, B, unfused_env):
+def test_full_output_three_gemm_path(tiny, small, monkeypatch, devlib, K, B, unfused_env):
     """K > 256 (BASELINE configs[4]: K = 512) keeps the three separate matrix-core products — GEMM 1 with the loss epilogue,
     split-K GEMM 2, GEMM 3 — instead of the fused kernel; CDAE_FULL_UNFUSED selects them for any K.  Same oracle as
     test_full_output_mfma_decode_matches_oracle; the bf16 rounding of z and D enters y = D z through K products, so the
@@ -601,7 +627,7 @@ def test_recommend_with_a_rated_set_that_is_not_the_train_row(small):
         model.recommend_user(0, [1, 1, 2], 10)
 
 
-def test_wide_gemm_tiles_change_no_bit(built, monkeypatch):
+def test_wide_gemm_tiles_change_no_bit(built, monkeypatch, devlib):
     """K > 256 full-output path: the 256 x 256-tile kernel (round 3; all three products when rows and columns are multiples of 256)
     against the 256 x 128 / 128 x 128 ones (CDAE_GEMM_NARROW=1).  Every output element is the same sum over k in the same order
     (64-wide slices, four MFMA steps each), whatever the tile: identical G, identical slabs, identical parameters."""
@@ -626,7 +652,7 @@ def test_wide_gemm_tiles_change_no_bit(built, monkeypatch):
 
 
 @pytest.mark.parametrize("adagrad", [True, False])
-def test_fused_rows_kernel_matches_separate_launches(built, monkeypatch, adagrad):
+def test_fused_rows_kernel_matches_separate_launches(built, monkeypatch, devlib, adagrad):
     """K > 256 over >= 32768 items (BASELINE configs[4]'s path): GEMM 3 and the row step in one launch (gemm3_rows_fused_kernel: dD
     stays in the accumulators; the rows some user kept as an input are stepped from their dD pieces by full_rows_inputs_kernel)
     against the two separate launches (CDAE_FULL_ROWS_SEPARATE=1).  One block: every dD element is the same sum over the users in
@@ -670,7 +696,7 @@ def test_fused_rows_kernel_matches_separate_launches(built, monkeypatch, adagrad
 
 
 @pytest.mark.parametrize("asymmetric", [False, True])
-def test_fused_rows_first_block_is_bit_identical(built, monkeypatch, asymmetric):
+def test_fused_rows_first_block_is_bit_identical(built, monkeypatch, devlib, asymmetric):
     """One block from fresh parameters: the decoder rows (W, or V with an asymmetric decoder — then the input rows W of the kept
     items step in the second launch) and their accumulators out of the fused launch are bit-identical to the separate launches'
     (b' differs only in the order its gradient is summed: 1e-6)."""
@@ -696,7 +722,7 @@ def test_fused_rows_first_block_is_bit_identical(built, monkeypatch, asymmetric)
     assert np.abs(fused[0] - w_init).max() > 0      # (the rows moved at all)
 
 
-def test_tn_gemm2_changes_no_bit(built, monkeypatch):
+def test_tn_gemm2_changes_no_bit(built, monkeypatch, devlib):
     """K > 256 full-output path: hg = G D from G^T and the row-major decoder image (gemm_tn_bf16_kernel: contraction-row-major
     operands through gfx950's transposing LDS read; GEMM 1 then writes no G and D^T is never rebuilt) against G and D^T through the
     NT kernel (CDAE_GEMM2_NT=1).  Same products, same 16-wide steps in the same order, same contraction splits: identical slabs,
@@ -723,7 +749,7 @@ def test_tn_gemm2_changes_no_bit(built, monkeypatch):
 
 
 @pytest.mark.parametrize("loss", ["ce", "square"])
-def test_gemm1_zreg_changes_no_bit(built, monkeypatch, loss):
+def test_gemm1_zreg_changes_no_bit(built, monkeypatch, devlib, loss):
     """K = 512 full-output path: GEMM 1 with the z rows of 256 users in registers and only D staged through LDS
     (gemm1_loss_zreg_kernel) against the 256 x 256-tile kernel (CDAE_GEMM1_TILED=1).  Every G^T element is the same sum over k in
     the same order and the same loss expression: identical parameters after two epochs, three blocks each (the last one partly
@@ -787,7 +813,7 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
 
 
 @pytest.mark.parametrize("U,I,B", [(257, 32_768, 256), (700, 40_000, 512), (1030, 65_537, 1024)])
-def test_k512_launches_on_edge_shapes_change_no_bit(built, monkeypatch, U, I, B):
+def test_k512_launches_on_edge_shapes_change_no_bit(built, monkeypatch, devlib, U, I, B):
     """The three K > 256 launches of round 3 together (gemm1_loss_zreg_kernel, gemm_tn_bf16_kernel, gemm3_rows_fused_kernel +
     full_rows_inputs_kernel) against the launches they replace (CDAE_GEMM1_TILED, CDAE_GEMM2_NT, CDAE_FULL_ROWS_SEPARATE) on edge
     shapes: an item count that is exactly the smallest the fused row step takes / not a multiple of anything / one past 65 536 (32-bit
@@ -822,7 +848,7 @@ def test_k512_launches_on_edge_shapes_change_no_bit(built, monkeypatch, U, I, B)
 
 
 @pytest.mark.parametrize("K,B,kw", [(24, 64, {}), (50, 128, dict(asymmetric=True)), (200, 96, dict(lt=cdae_amd.SQUARE, learn_rate=0.02))])
-def test_full_output_one_stream_order_changes_no_bit(built, monkeypatch, K, B, kw):
+def test_full_output_one_stream_order_changes_no_bit(built, monkeypatch, devlib, K, B, kw):
     """Full-output path, small item spaces: the whole block on ONE stream with the b recurrence as the leading workgroups of the row
     launch (CDAE_FULL_ONE_STREAM_MAX users per block and below) against the two-stream order (hidden layer and recurrence on the second
     stream, joined through events).  Same kernels on the same operands in the same order per stream: identical parameters."""

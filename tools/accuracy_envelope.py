@@ -28,9 +28,9 @@ import oracle as orc  # noqa: E402  (test infrastructure: only its metric functi
 HYPER = dict(num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True, learn_rate=0.1, beta=1.0, lambda_=0.01)
 
 
-def fixtures(shape, K, loss, seeds):
+def fixtures(shape, K, loss, seeds, tag="literal"):
     out = []
-    for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", f"{shape}_k{K}_{loss.lower()}_literal_seed*.npz"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", f"{shape}_k{K}_{loss.lower()}_{tag}_seed*.npz"))):
         f = np.load(p, allow_pickle=True)
         if seeds and int(f["seed"]) not in seeds:
             continue
@@ -38,15 +38,16 @@ def fixtures(shape, K, loss, seeds):
     return out
 
 
-def run_single(d, seed, K, lt, B, epochs, full_output=False):
+def run_single(d, seed, K, lt, B, epochs, full_output=False, ne=None):
     m = cdae_amd.CDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=B, full_output=full_output, **HYPER))
     m.reset(d, seed=seed)
     rec, loss, secs = [], [], 0.0
+    ne = d.num_users if ne is None else ne
     for ep in range(epochs):
         st = m.train_one_iteration(seed, ep)
         secs += st.wall_seconds
         loss.append(m.current_loss(seed, ep))
-        rec.append(float(orc.eval_topn(m.recommend_all(10), d.test_ptr, d.test_col)[5]))
+        rec.append(recall10(m, d, ne))
     m.close()
     return rec, loss, d.num_users * epochs / secs
 
@@ -54,6 +55,26 @@ def run_single(d, seed, K, lt, B, epochs, full_output=False):
 def shard_cuts(row_ptr, num_users, shards):
     from cdae_amd.distributed import shard_bounds
     return [shard_bounds(num_users, shards, r, row_ptr) for r in range(shards)]
+
+
+def recall10(m, d, ne):
+    """Recall@10 over the first `ne` users (Netflix-shape fixtures score 60 000 of the 480 000)"""
+    return float(orc.eval_topn(m.recommend_all(10, 0, ne), d.test_ptr[:ne + 1], d.test_col[:d.test_ptr[ne]])[5])
+
+
+def run_schedule(d, seed, K, lt, B, epochs, shards, period, relay_epochs, combine, ne, handle_batch=256):
+    """cdae_hip_multi_set_schedule on `shards` logical shards of GPU 0: `relay_epochs` epochs (fractions allowed) on the single-GPU
+    schedule (blocks of `handle_batch` users, handed from shard to shard), then exchanged steps of B users per shard, `combine` rule."""
+    m = cdae_amd.MultiCDAE(cdae_amd.CDAEConfig(num_dim=K, lt=lt, batch_users=handle_batch, **HYPER), devices=[0] * shards)
+    m.set_schedule(period=period, combine=combine, sync_batch_users=B, relay_epochs=relay_epochs)
+    m.reset(d, seed=seed)
+    rec, loss, secs = [], [], 0.0
+    for ep in range(epochs):
+        secs += m.train_one_iteration(seed, ep).wall_seconds
+        loss.append(m.current_loss(seed, ep))
+        rec.append(recall10(m, d, ne))
+    m.close()
+    return rec, loss, d.num_users * epochs / secs
 
 
 def run_multi(d, seed, K, lt, B, epochs, shards, period, warm_epochs=0, warm_batch=256):
@@ -282,6 +303,11 @@ def main():
     ap.add_argument("--period", type=int, nargs="+", default=[0], help="exchange period of the sharded runs (0 = synchronous)")
     ap.add_argument("--rule", type=int, default=0, help="0 sum, 1 touch-mean (synchronous only)")
     ap.add_argument("--warm-epochs", type=int, default=0, help="sharded runs: first N epochs on the single-GPU schedule (batch_users 256)")
+    ap.add_argument("--relay-epochs", type=float, nargs="+", default=[],
+                    help="--shards N: cdae_hip_multi_set_schedule — this many epochs (fractions allowed) on the single-GPU schedule relayed "
+                         "from shard to shard, then exchanged steps of --batch-users per shard (replaces --warm-epochs, which emulates it)")
+    ap.add_argument("--combine", type=int, nargs="+", default=[0], help="with --relay-epochs: 0 sum, 1 global accumulator (CDAE_COMBINE_*)")
+    ap.add_argument("--fixture-tag", default="literal", help="schedule tag of the fixture files (literal | literal50 | literal20)")
     ap.add_argument("--hybrid-hot", type=int, default=-1, help="--shards N: the hot-row / tail hybrid (run_hybrid) with this many owner-computed "
                     "popular rows (0: only b and the user node are exact)")
     ap.add_argument("--full-output", action="store_true", help="the full-output block schedule against its B = 1 limit (see full_output_envelope)")
@@ -291,12 +317,14 @@ def main():
     lt = cdae_amd.CROSS_ENTROPY if args.loss == "CE" else cdae_amd.SQUARE
     if args.full_output:
         return full_output_envelope(args, lt)
-    fx = fixtures(args.shape, args.num_dim, args.loss, args.seeds)
+    fx = fixtures(args.shape, args.num_dim, args.loss, args.seeds, args.fixture_tag)
     if not fx:
         raise SystemExit("no fixture found (tests/golden/make_literal_curves.py makes them)")
     for f in fx:
         seed = int(f["seed"])
-        d = synth.generate_shape(args.shape, seed=seed)
+        dseed = int(f["data_seed"]) if "data_seed" in f.files else seed
+        d = synth.generate_shape(args.shape, seed=dseed)
+        ne = int(f["eval_users"]) if "eval_users" in f.files else d.num_users
         ep = args.epochs or len(f["recall10"])
         ref_r, ref_l = f["recall10"][:ep], f["train_loss"][:ep]
         print(json.dumps({"run": "fixture literal", "seed": seed, "recall10": [round(float(x), 5) for x in ref_r],
@@ -304,10 +332,21 @@ def main():
         for shards in args.shards:
             for period in (args.period if shards > 1 else [0]):
                 for B in args.batch_users:
+                    if shards > 1 and args.relay_epochs:
+                        for relay in args.relay_epochs:
+                            for combine in args.combine:
+                                rec, loss, ups = run_schedule(d, seed, args.num_dim, lt, B, ep, shards, period, relay, combine, ne)
+                                dr = np.array(rec) - ref_r
+                                dl = np.array(loss) / ref_l - 1.0
+                                print(json.dumps({"run": "hip schedule", "shape": args.shape, "seed": seed, "shards": shards, "period": period, "combine": combine,
+                                                  "relay_epochs": relay, "batch_users": B, "recall10": [round(x, 5) for x in rec],
+                                                  "d_recall": [round(float(x), 5) for x in dr], "max_abs_d_recall_after_relay": round(float(np.abs(dr[int(np.ceil(relay)):]).max()), 5) if int(np.ceil(relay)) < len(dr) else None,
+                                                  "rel_d_loss": [round(float(x), 4) for x in dl], "users_per_s": round(ups)}), flush=True)
+                        continue
                     if shards > 1 and args.hybrid_hot >= 0:
                         rec, loss, ups = run_hybrid(d, seed, args.num_dim, lt, B, ep, shards, args.hybrid_hot)
                     elif shards == 1:
-                        rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep)
+                        rec, loss, ups = run_single(d, seed, args.num_dim, lt, B, ep, ne=ne)
                     elif args.rule == 0:
                         rec, loss, ups = run_multi(d, seed, args.num_dim, lt, B, ep, shards, period, args.warm_epochs)
                     else:

@@ -1,10 +1,13 @@
 #!/bin/bash
 # developer aid: build libcdae_hip.so variants with extra -D flags into build/variants/<name>/ (loaded with CDAE_HIP_LIBRARY=...)
-# usage: tools/build_variant.sh name -DFOO=1 ...
+# usage: tools/build_variant.sh name -DFOO=1 ...      (always with -DCDAE_DEVELOPER: the environment switches are compiled in)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 d=build/variants/$name; mkdir -p $d
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -w "$@" -c cdae_amd/csrc/cdae_hip.hip -o $d/cdae_hip.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/cdae_hip.o build/obj/cdae_multi.hip.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o $d/libcdae_hip.so
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -w -DCDAE_DEVELOPER"
+/opt/rocm/bin/hipcc $F "$@" -c cdae_amd/csrc/cdae_hip.hip -o $d/cdae_hip.o &
+/opt/rocm/bin/hipcc $F "$@" -c cdae_amd/csrc/cdae_multi.hip -o $d/cdae_multi.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/cdae_hip.o $d/cdae_multi.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o $d/libcdae_hip.so
 echo built $d/libcdae_hip.so
