@@ -136,6 +136,7 @@ struct cdae_hip {
     // counting sort (cdae_sort_kernels.hpp): per-item counts / prefix / (unused cursor), item-bucketed values, per-tile counts
     uint32_t* item_count = nullptr; uint32_t* prefix = nullptr; uint32_t* rank = nullptr; uint64_t* bucketed = nullptr;
     uint32_t* tile_hist = nullptr; uint32_t* block_total = nullptr;      // (`rank` holds the in-block item prefix)
+    uint32_t* wg_state = nullptr;                                    // bucket_sort_kernel: one word per item range (cleared by the sample kernel)
     hipEvent_t ready = nullptr, released = nullptr;
   } ex[3];
   static constexpr int NSETS = 3;
@@ -209,6 +210,11 @@ struct cdae_hip {
   bool full_separate_copies = false;    // CDAE_FULL_SEPARATE_COPIES: D and Z bf16 copies as two launches (developer switch)
   bool encode_two_launches = false;     // CDAE_ENCODE_TWO_LAUNCHES: the training encode as encode_partial + encode_finish (developer switch)
   bool debug_skip_prep = false;         // CDAE_DEBUG_SKIP_PREP (timing experiment only: batches reuse stale example lists -> WRONG results)
+  // bucket_sort_kernel (cdae_sort_kernels.hpp): the default item-major ordering — one narrow launch; item ranges cut at set_interactions
+  bool bucket_sort = false;
+  uint32_t bucket_ranges = 0;
+  uint32_t* d_bucket_cut = nullptr;     // [bucket_ranges + 1] item ids
+  bool bucket_attr_set = false;         // dynamic-LDS attribute set on this handle's device
   bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
   bool tile_attr_set = false;           // dynamic LDS above 64 KiB allowed for the two tile kernels (per handle: the attribute is per device)
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
@@ -376,11 +382,11 @@ void free_all(cdae_hip* h) {
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
-                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out};
+                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
-                 b.item_count, b.prefix, b.rank, b.bucketed, b.tile_hist, b.block_total};
+                 b.item_count, b.prefix, b.rank, b.bucketed, b.tile_hist, b.block_total, b.wg_state};
     for (void* p : q) if (p) (void)hipFree(p);
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
@@ -417,11 +423,12 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
                    (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
-                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out};
+                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
-                  (void**)&b.item_count, (void**)&b.prefix, (void**)&b.rank, (void**)&b.bucketed, (void**)&b.tile_hist, (void**)&b.block_total};
+                  (void**)&b.item_count, (void**)&b.prefix, (void**)&b.rank, (void**)&b.bucketed, (void**)&b.tile_hist, (void**)&b.block_total,
+                  (void**)&b.wg_state};
     for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
@@ -456,24 +463,25 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   CHK(pr.begin(h, F_SAMPLE, st, prof_q));
   const bool shs = h->shard_sampled();
   const uint32_t n_units = shs ? gunits_of(h, bt) : units_of(h, bt);
+  const bool bucket = h->bucket_sort && x.key16;      // bucket_sort_kernel writes every entry of the segment tables itself: nothing to clear
   if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
     HIPCHK(hipMemsetAsync(x.seg, 0, 4 * (size_t)I * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), st));
   } else if (h->mf) {
     hipLaunchKernelGGL(mf_sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->mf == 2 ? 1u : 0u, h->d_row_ptr, h->d_col,
-                       h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, seed, epoch, x.item, x.val, x.key16, x.seg, 2u * I, x.dup_count,
-                       x.dup_of_ex, h->d_unit_user);
+                       h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, seed, epoch, x.item, x.val, x.key16, x.seg, bucket ? 0u : 2u * I, x.dup_count,
+                       x.dup_of_ex, h->d_unit_user, x.wg_state);
   } else if (shs) {
     // item shard, sampled decode: the single-GPU example list of the batch from the WHOLE rows, other shards' examples VOID
     hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_grow_ptr, h->d_gcol,
                        h->d_gunit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
-                       x.seg, h->counting_sort ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_gunit_user,
-                       (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t)h->item0, I, (uint32_t)h->I_global);
+                       x.seg, h->counting_sort || bucket ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_gunit_user,
+                       x.wg_state, (const uint32_t*)nullptr, (uint32_t)h->item0, I, (uint32_t)h->I_global);
   } else
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
-                     x.seg, h->counting_sort ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
-                     (uint32_t*)nullptr, (const uint32_t*)h->d_gpos);
+                     x.seg, h->counting_sort || bucket ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
+                     x.wg_state, (const uint32_t*)h->d_gpos);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st, prof_q));
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
@@ -481,6 +489,16 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
     // nothing to order
   } else if (h->mf_seq && !h->prep_force_sort) {
     // the in-place loop reads the user-major list only: no item-major order, no segment table
+  } else if (bucket) {
+    // item-major order, segment tables, duplicate marks: ONE narrow launch (cdae_sort_kernels.hpp bucket_sort_kernel)
+    if (!h->bucket_attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)bucket_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BK_LDS_BYTES));
+      h->bucket_attr_set = true;
+    }
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(h->bucket_ranges), dim3(BK_THREADS), BK_LDS_BYTES, st, (const uint16_t*)x.key16, (const uint64_t*)x.val,
+                       (uint32_t)bt.E, (const uint32_t*)h->d_bucket_cut, x.wg_state, x.seg, x.seg + I, (const uint32_t*)h->d_rank_of,
+                       x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, x.sorted_val, x.bucketed, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex,
+                       h->dup_stripes);
   } else if (h->counting_sort) {
     // item-major order by counting, four launches (cdae_sort_kernels.hpp)
     const uint32_t n_tiles = (uint32_t)((bt.E + TILE_EX - 1) / TILE_EX);
@@ -517,7 +535,6 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
     // built here, beside the previous batch's training, instead of in front of the decode (memset + kernel: 22 us per batch)
     const uint32_t words = (I + 31) / 32;
     uint32_t* bits = h->d_bits_train + (size_t)b * h->bits_stride;
-    HIPCHK(hipMemsetAsync(bits, 0, (size_t)bt.nb * words * sizeof(uint32_t), st));
     hipLaunchKernelGGL(rated_bits_kernel, dim3((bt.nb + 3) / 4), dim3(256), 0, st, h->d_row_ptr, h->d_col, bt.s0, bt.nb, words, bits);
   }
   HIPCHK(hipEventRecord(x.ready, st));
@@ -1457,6 +1474,40 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   // (round 4: the tile kernels skip VOID examples, so a sampled item shard can take them too — there the prep chain is NOT hidden
   // behind a look-ahead lane and the library sort's launches and fills are the larger part of it)
   h->counting_sort = I <= cdae::TILE_SORT_MAX_ITEMS && DEV_ENV("CDAE_SORT_TILE") != nullptr;
+  // DEFAULT since round 5: bucket_sort_kernel — one narrow launch, every workgroup owns a range of item ids cut HERE so that the
+  // ranges expect equal numbers of examples per batch: B * pop[i] / U positives + the uniformly drawn negatives.  It scans the batch's
+  // whole 16-bit key list once per range and pass, so it is for batches up to BUCKET_MAX_EXAMPLES examples (256-512 users at the
+  // BASELINE shapes) over at most 65536 items; beyond that the library sort below stays.  CDAE_SORT_LIBRARY (developer build): the
+  // library sort + segment_kernel everywhere (the A/B side of the bit-equality tests).
+  h->bucket_sort = false; h->bucket_ranges = 0;
+  {
+    constexpr uint64_t BUCKET_MAX_EXAMPLES = 600000;
+    const uint64_t keys = I + (h->shard_sampled() ? 1u : 0u);
+    if (keys <= 65536 && !h->counting_sort && !h->mf_seq && h->Ecap <= BUCKET_MAX_EXAMPLES && h->Ecap > 0 && !DEV_ENV("CDAE_SORT_LIBRARY")) {
+      const double b_share = (double)B / (double)U;
+      const double draw_items = (double)(h->shard_sampled() ? h->I_global : I);
+      const double whole_nnz = h->shard_sampled() ? (double)h->h_grow_ptr[U] : (double)nnz;
+      const uint32_t negs = h->mf == 2 ? 2u * h->hp.num_neg - 0u : h->hp.num_neg;      // (BPR lists the positive once per pair too: weights only balance, any estimate is legal)
+      const double neg_per_item = b_share * whole_nnz * (double)negs / draw_items;
+      std::vector<double> wgt(I);
+      double total = 0.0;
+      for (uint64_t i = 0; i < I; ++i) { wgt[i] = b_share * (double)pop[i] + neg_per_item; total += wgt[i]; }
+      const double per_range = std::max(total / 256.0, std::min(2730.0, total / 8.0));   // ~2.7 K examples per range: half the LDS window
+      std::vector<uint32_t> cut{0u};
+      double acc = 0.0;
+      for (uint64_t i = 0; i < I; ++i) {
+        acc += wgt[i];
+        if (i + 1 < I && (acc >= per_range || (i + 1) - cut.back() == cdae::BK_ITEMS)) { cut.push_back((uint32_t)(i + 1)); acc = 0.0; }
+      }
+      cut.push_back((uint32_t)I);
+      if (cut.size() - 1 <= cdae::BK_MAX_RANGES) {
+        h->bucket_sort = true;
+        h->bucket_ranges = (uint32_t)cut.size() - 1;
+        CHK(dev_alloc(&h->d_bucket_cut, cut.size()));
+        HIPCHK(hipMemcpy(h->d_bucket_cut, cut.data(), cut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      }
+    }
+  }
   h->h_unit_ptr.assign(U + 1, 0u);
   for (uint64_t u = 0; u < U; ++u)
     h->h_unit_ptr[u + 1] = h->h_unit_ptr[u] + (uint32_t)((row_ptr[u + 1] - row_ptr[u] + h->hp.unit_pos - 1) / h->hp.unit_pos);
@@ -1505,7 +1556,10 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       CHK(dev_alloc(&b.rank, (size_t)I)); CHK(dev_alloc(&b.bucketed, h->Ecap));
       CHK(dev_alloc(&b.tile_hist, (size_t)((h->Ecap + cdae::TILE_EX - 1) / cdae::TILE_EX + 1) * I));
       CHK(dev_alloc(&b.block_total, 128));
-    } else if (I + (h->shard_sampled() ? 1u : 0u) <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }   // (a sampled item shard sorts one more key: VOID = I)
+    } else if (I + (h->shard_sampled() ? 1u : 0u) <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap + 8)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }   // (a sampled item shard sorts one more key: VOID = I)
+    if (h->bucket_sort) { CHK(dev_alloc(&b.bucketed, h->Ecap)); }
+    CHK(dev_alloc(&b.wg_state, cdae::BK_MAX_RANGES));
+    HIPCHK(hipMemset(b.wg_state, 0, cdae::BK_MAX_RANGES * sizeof(uint32_t)));
     if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, sync_event_flags())); HIPCHK(hipEventCreateWithFlags(&b.released, sync_event_flags())); }
     HIPCHK(hipEventRecord(b.released, h->stream));
   }
@@ -2122,7 +2176,7 @@ int cdae_hip_debug_sample_batch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, ui
   CHK(out(dup_of_pos, x.dup_of_pos, E * sizeof(uint32_t)));
   CHK(out(dup_of_ex, x.dup_of_ex, E * sizeof(uint32_t)));
   if (sorted_item && E) {
-    if (h->counting_sort) {                               // the counting sort writes no sorted key array: the segments say the same
+    if (h->counting_sort || (h->bucket_sort && x.key16)) {   // the counting / bucket sorts write no sorted key array: the segments say the same
       std::vector<uint32_t> sb(I), se(I);
       HIPCHK(hipMemcpy(sb.data(), x.seg, I * sizeof(uint32_t), hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(se.data(), x.seg + I, I * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -2253,7 +2307,6 @@ int cdae_hip_recommend_all(cdae_hip_t* h, uint64_t u_begin, uint64_t u_end, uint
     for (uint64_t c0 = u_begin; c0 < u_end; c0 += UC) {
       const uint32_t nu = (uint32_t)std::min<uint64_t>(UC, u_end - c0);
       if (!h->mf) CHK(ensure_eval_ws(h, nu, h->h_unit_ptr[c0 + nu] - h->h_unit_ptr[c0]));
-      HIPCHK(hipMemsetAsync(h->d_bits, 0, (size_t)nu * words * sizeof(uint32_t), h->stream));
       hipLaunchKernelGGL(cdae::rated_bits_kernel, dim3((nu + 3) / 4), dim3(256), 0, h->stream, h->d_row_ptr, h->d_col, c0, nu, words, h->d_bits);
       const float* zsrc = h->d_zeval;
       if (h->mf) zsrc = h->d_Wu + (size_t)c0 * h->Kp;      // IMF / BPR: score = ub + ib + uv . iv (imf.hpp:117-119); ub does not rank

@@ -245,7 +245,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               uint32_t* __restrict__ seg /* [seg_words] cleared here for segment_kernel */, uint32_t seg_words,
               uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
               const uint32_t* __restrict__ unit_user /* global unit -> user id */,
-              uint32_t* __restrict__ /* unused (round-2 global-atomic counting sort) */,
+              uint32_t* __restrict__ wg_state /* bucket_sort_kernel's per-range words (BK_MAX_RANGES = 1024), cleared here; or nullptr */,
               const uint32_t* __restrict__ gpos /* item shard: [2 U] (length of the user's WHOLE row, position of the first local item in it); else nullptr */,
               // Item shard of the SAMPLED decode: row_ptr / col are the WHOLE rows with global item ids (negatives are rejected
               // against the whole row and drawn from all `draw_items` items, exactly as on one GPU), the example list keeps the
@@ -257,6 +257,8 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
   if (blockIdx.x == 0 && threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && wg_state)
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) wg_state[i] = 0u;
   const uint32_t wid = threadIdx.x / WAVE;
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;

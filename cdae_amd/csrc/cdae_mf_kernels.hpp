@@ -53,9 +53,11 @@ mf_sample_kernel(HyperParams hp, uint32_t pairwise, const int64_t* __restrict__ 
                  const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb, uint64_t seed, uint32_t epoch,
                  uint32_t* __restrict__ ex_item, uint64_t* __restrict__ ex_val, uint16_t* __restrict__ ex_key16,
                  uint32_t* __restrict__ seg, uint32_t seg_words, uint32_t* __restrict__ dup_count, uint32_t* __restrict__ dup_of_ex,
-                 const uint32_t* __restrict__ unit_user) {
+                 const uint32_t* __restrict__ unit_user, uint32_t* __restrict__ wg_state /* bucket_sort_kernel's per-range words, or nullptr */) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
   if (blockIdx.x == 0 && threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && wg_state)
+    for (uint32_t i = threadIdx.x; i < 1024u; i += blockDim.x) wg_state[i] = 0u;
   const uint32_t unit = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (unit >= n_units) return;

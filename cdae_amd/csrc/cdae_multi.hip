@@ -432,7 +432,7 @@ int local_epoch(cdae_hip_multi* m, const StepPlan& pl, uint64_t seed, uint32_t e
 // RELAY part of an epoch (cdae_hip_multi_set_schedule): global users [0, R) on the single-GPU schedule, by the shards that hold them,
 // one after the other; the shared block travels with the training (shard s starts from what shard s - 1 ended with) and ends up on
 // every shard.  first[s] = users of shard s trained here.  Replicas agree on entry (an epoch ends with a flush).
-int relay_part(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t R, std::vector<uint64_t>& first) {
+int relay_part(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t R, std::vector<uint64_t>& first, cdae_hip_stats* sum) {
   const size_t S = m->shard.size();
   first.assign(S, 0);
   if (R == 0) return 0;
@@ -442,6 +442,7 @@ int relay_part(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t R, std
     if (s > 0) CHK(cdae_internal::adopt_shared_block(m->shard[s], m->shard[s - 1]));
     cdae_hip_stats st;
     CHK(cdae_hip_train_users(m->shard[s], seed, epoch, 0, n, &st));     // (synchronises: the next shard copies a finished block)
+    sum->users += st.users; sum->examples += st.examples; sum->batches += st.batches;
     first[s] = n;
     last = s;
   }
@@ -814,14 +815,7 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
   const uint64_t R = left <= 0.0 ? 0 : (left >= 1.0 ? m->U : std::min<uint64_t>(m->U, (uint64_t)(left * (double)m->U)));
   cdae_hip_stats relay_stats;
   std::memset(&relay_stats, 0, sizeof relay_stats);
-  if (R) {
-    CHK(relay_part(m, seed, epoch, R, first));
-    for (cdae_hip_t* h : m->shard) {
-      cdae_hip_stats st;
-      CHK(cdae_hip_collect_stats(h, &st));
-      relay_stats.users += st.users; relay_stats.examples += st.examples; relay_stats.batches += st.batches;
-    }
-  }
+  if (R) CHK(relay_part(m, seed, epoch, R, first, &relay_stats));
   const StepPlan pl = plan_of(m, first);
   if (R == m->U) {
     // the whole epoch was relayed: nothing to exchange

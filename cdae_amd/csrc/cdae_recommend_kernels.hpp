@@ -26,13 +26,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int REC_TOPK_MAX = 16;       // per-lane list length; larger topk falls back to recommend_kernel
 constexpr int REC_USERS_PER_BLOCK = 128;
 
-// bits[(u - u0) * words + item / 32] |= 1 << (item % 32) for every training item of users [u0, u0 + nu)
+// bits[(u - u0) * words + item / 32] = OR of 1 << (item % 32) over the training items of users [u0, u0 + nu): the wavefront that owns a
+// user's row of words clears it first (no memset launch in front: round 5) — its stores are complete (release fence) before its atomics
 __global__ void __launch_bounds__(256)
 rated_bits_kernel(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, uint64_t u0, uint32_t nu,
                   uint32_t words, uint32_t* __restrict__ bits) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nu) return;
+  for (uint32_t w = lane; w < words; w += WAVE) bits[(size_t)slot * words + w] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   const int64_t r0 = row_ptr[u0 + slot], r1 = row_ptr[u0 + slot + 1];
   for (int64_t p = r0 + lane; p < r1; p += WAVE) {
     const uint32_t item = col[p];

@@ -159,12 +159,15 @@ def test_user_id_offset_shifts_the_streams_like_a_global_run(built):
         np.testing.assert_array_equal(a[k], b[k])
 
 
-@pytest.mark.parametrize("tile_sort", [True, False], ids=["tile-counting-sort", "rocprim"])
-def test_both_sort_paths_give_the_same_bit_exact_order(built, monkeypatch, devlib, tile_sort):
-    """cdae_sort_kernels.hpp (CDAE_SORT_TILE=1, up to 32 768 items): per-tile LDS counting sort + per-item ordering; default: the
-    library radix sort.  Both must equal numpy's stable sort by item, bit for bit."""
-    if tile_sort:
+@pytest.mark.parametrize("path", ["bucket", "tile", "library"])
+def test_every_sort_path_gives_the_same_bit_exact_order(built, monkeypatch, devlib, path):
+    """Default: bucket_sort_kernel (cdae_sort_kernels.hpp: one narrow launch, every workgroup owns a range of item ids).  CDAE_SORT_TILE=1
+    (developer build): the per-tile LDS counting sort + per-item ordering, four launches.  CDAE_SORT_LIBRARY=1: the library radix sort +
+    segment_kernel (what larger batches / item spaces still take).  All three must equal numpy's stable sort by item, bit for bit."""
+    if path == "tile":
         monkeypatch.setenv("CDAE_SORT_TILE", "1")
+    if path == "library":
+        monkeypatch.setenv("CDAE_SORT_LIBRARY", "1")
     d = synth.generate(1200, 500, 60_000, seed=9)
     model, o = make(d, B=96)
     dups = sum(check_batch(model, o, d, 20141119, ep, u0, 96) for ep, u0 in ((0, 0), (3, 96), (1, 1200 - 96)))
@@ -176,6 +179,26 @@ def test_both_sort_paths_give_the_same_bit_exact_order(built, monkeypatch, devli
     d2 = synth.Interactions(len(rows), 400, ptr, np.concatenate(rows), np.zeros(len(rows) + 1, np.int64), np.empty(0, np.uint32))
     m2, o2 = make(d2, B=3500, num_neg=1)
     check_batch(m2, o2, d2, 2, 0, 0, 3500, num_neg=1)
+
+
+def test_bucket_sort_beyond_its_lds_window(built):
+    """bucket_sort_kernel's two slow paths, on the SHIPPED library: (a) ONE item with more examples than the LDS window holds (6144: every
+    one of 7 000 users rated item 0) is ranked in global memory; (b) a range whose batch holds far more examples than the ranges were cut
+    for (the first 200 users all rate the same 60 items, the cut expects the data set's average) is taken in several groups, one more
+    scan of the key list each.  Same bits as numpy's stable sort."""
+    rng = np.random.default_rng(3)
+    rows = [np.unique(np.r_[0, rng.choice(np.arange(1, 400), 30, replace=False)]).astype(np.uint32) for _ in range(7000)]
+    ptr = np.r_[0, np.cumsum([r.size for r in rows])].astype(np.int64)
+    d1 = synth.Interactions(len(rows), 400, ptr, np.concatenate(rows), np.zeros(len(rows) + 1, np.int64), np.empty(0, np.uint32))
+    m1, o1 = make(d1, B=7000, num_neg=1)
+    check_batch(m1, o1, d1, 2, 0, 0, 7000, num_neg=1)
+    rows = [np.arange(60, dtype=np.uint32) if u < 200 else np.sort(rng.choice(np.arange(60, 1000), 20, replace=False)).astype(np.uint32)
+            for u in range(2000)]
+    ptr = np.r_[0, np.cumsum([r.size for r in rows])].astype(np.int64)
+    d2 = synth.Interactions(len(rows), 1000, ptr, np.concatenate(rows), np.zeros(len(rows) + 1, np.int64), np.empty(0, np.uint32))
+    m2, o2 = make(d2, B=200, num_neg=3)
+    assert check_batch(m2, o2, d2, 5, 0, 0, 200, num_neg=3) > 0          # 12 000 positives on 60 items of one range
+    check_batch(m2, o2, d2, 5, 1, 900, 200, num_neg=3)                    # and an ordinary batch of the same handle
 
 
 def test_tile_sort_with_more_than_16384_items(built, monkeypatch, devlib):
