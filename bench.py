@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--exchange-every", type=int, default=-1, help="N > 1: batches between exchanges of the shared-parameter "
                     "deltas (pipelined: the all-reduce overlaps the next period).  -1 (default): chosen at start-up so that one "
                     "period of training covers a measured all-reduce; 0: synchronous exchange after every batch")
+    ap.add_argument("--combine", choices=["sum", "global-acc"], default="global-acc",
+                    help="--layout users: how the all-reduced deltas are folded in (cdae_hip_delta_set_combine).  global-acc (default): one step "
+                         "with the AdaGrad accumulator that has seen every rank; sum: the ranks' accumulated steps are added (rounds 1-4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -214,6 +217,7 @@ def main():
                 model.comm_init_rank(1, 0, cdae_amd.comm_unique_id())      # functional smoke test: RCCL refuses duplicate devices
             else:
                 model.comm_init_rank(world, rank, ids[0])
+        model.delta_set_combine(cdae_amd.COMBINE_GLOBAL_ACC if args.combine == "global-acc" else cdae_amd.COMBINE_SUM)
         model.exchange_configure(max(0, args.exchange_every) if args.exchange_every >= 0 else 1 << 30)
 
     n_batches = (data.num_users + B - 1) // B
@@ -478,7 +482,12 @@ def main():
                    "accuracy": (full_output_accuracy(B, data.num_users, args.shape, K) if args.full_output and args.gpus == 1
                                 else "batch_users within the single-GPU envelope of tests/test_gpu_accuracy.py" if args.gpus == 1 and B <= DEFAULT_BATCH_USERS
                                 else "single GPU, batch_users ABOVE the accuracy envelope (throughput only)" if args.gpus == 1
-                                else "data-parallel delta exchange: OUTSIDE the +-0.002 Recall@10 envelope (DESIGN.md §7 table); throughput only")},
+                                else ("data-parallel delta exchange, synchronous, %s combine: after one relayed epoch (cdae_hip_multi_set_schedule) the "
+                                      "mean-over-seeds Recall@10 is within +-0.002 of the sequential reference at 8 x 64 users per step (ML-10M and Netflix "
+                                      "shape, tests/test_gpu_accuracy.py / test_gpu_netflix.py), single seeds within 0.009 — wider than the single GPU's 0.005; "
+                                      "DESIGN.md §7" % args.combine) if args.exchange_every == 0 and B <= 64
+                                else "data-parallel delta exchange (pipelined, or more than 64 users per rank and step): OUTSIDE the measured envelope "
+                                     "(DESIGN.md §7 table); throughput only")},
         "roofline": roofline,
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
         "profiled_steps": int(acc["launches_decode"]),

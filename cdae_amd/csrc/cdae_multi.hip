@@ -812,7 +812,7 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
   // relay part: the first (relay_epochs - epoch) epochs' worth of users on the single-GPU schedule
   std::vector<uint64_t> first(S, 0);
   const double left = m->relay_epochs - (double)epoch;
-  const uint64_t R = left <= 0.0 ? 0 : (left >= 1.0 ? m->U : std::min<uint64_t>(m->U, (uint64_t)(left * (double)m->U)));
+  const uint64_t R = left <= 0.0 ? 0 : (left >= 1.0 ? m->U : std::min<uint64_t>(m->U, (uint64_t)(left * (double)m->U + 1e-6)));   // (1.4 - 1 is 0.39999...: the fraction a caller wrote, not one user less)
   cdae_hip_stats relay_stats;
   std::memset(&relay_stats, 0, sizeof relay_stats);
   if (R) CHK(relay_part(m, seed, epoch, R, first, &relay_stats));

@@ -26,20 +26,40 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int REC_TOPK_MAX = 16;       // per-lane list length; larger topk falls back to recommend_kernel
 constexpr int REC_USERS_PER_BLOCK = 128;
 
-// bits[(u - u0) * words + item / 32] = OR of 1 << (item % 32) over the training items of users [u0, u0 + nu): the wavefront that owns a
-// user's row of words clears it first (no memset launch in front: round 5) — its stores are complete (release fence) before its atomics
+// bits[(u - u0) * words + item / 32] = OR of 1 << (item % 32) over the training items of users [u0, u0 + nu).  No memset launch in front
+// (round 5): the wavefront that owns a user's row of words builds it in LDS and writes every word once (item spaces up to 65 536: 8 KiB
+// per wavefront); larger rows are cleared in global memory by their wavefront, which waits for its own stores (s_waitcnt: same-wave order
+// is all that is needed — an agent-scope fence here wrote back the L2 under the training kernels of the other stream) before its atomics.
+constexpr uint32_t RATED_LDS_WORDS = 2048;
 __global__ void __launch_bounds__(256)
 rated_bits_kernel(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, uint64_t u0, uint32_t nu,
                   uint32_t words, uint32_t* __restrict__ bits) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  __shared__ uint32_t lrow[4][RATED_LDS_WORDS];
+  const uint32_t wid = threadIdx.x / WAVE;
+  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + wid;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nu) return;
-  for (uint32_t w = lane; w < words; w += WAVE) bits[(size_t)slot * words + w] = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   const int64_t r0 = row_ptr[u0 + slot], r1 = row_ptr[u0 + slot + 1];
+  uint32_t* out = bits + (size_t)slot * words;
+  if (words <= RATED_LDS_WORDS) {
+    uint32_t* w = lrow[wid];
+    for (uint32_t i = lane; i < words; i += WAVE) w[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t p = r0 + lane; p < r1; p += WAVE) {
+      const uint32_t item = col[p];
+      atomicOr(&w[item >> 5], 1u << (item & 31u));                 // LDS
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < words; i += WAVE) out[i] = w[i];
+    return;
+  }
+  for (uint32_t i = lane; i < words; i += WAVE) out[i] = 0u;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int64_t p = r0 + lane; p < r1; p += WAVE) {
     const uint32_t item = col[p];
-    atomicOr(bits + (size_t)slot * words + (item >> 5), 1u << (item & 31u));
+    atomicOr(out + (item >> 5), 1u << (item & 31u));
   }
 }
 

@@ -481,7 +481,7 @@ def test_a_fraction_of_an_epoch_is_relayed_then_the_rest_is_exchanged(small):
 
     U = small.num_users
     for ep in range(2):
-        R = U if ep == 0 else int(0.4 * U)
+        R = U if ep == 0 else int((1.4 - ep) * U + 1e-6)
         first, last = [0] * shards, 0
         for s, (u0, u1) in enumerate(cuts):
             if u0 >= R:

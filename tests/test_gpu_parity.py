@@ -514,13 +514,15 @@ def test_full_output_mfma_decode_matches_oracle(tiny, B, variant):
     """BASELINE configs[1]/[4]: every unrated item is a negative; dense decode on bf16 MFMA with fp32 accumulation.
     The oracle computes the same block-summed schedule in fp64.  Tolerance: operands (z, D) and the loss gradient
     g are rounded to bf16 (relative 2^-9 = 2e-3 each) before the three contractions, so parameters agree to
-    2e-2 of their range after two epochs (measured 5e-4 .. 1e-2), and the loss to 1e-2 relative."""
+    1.2e-2 of their range after two epochs at K = 24 (measured 5e-4 .. 1e-2 over the twelve cases; the bound was 2e-2 through
+    round 4), and the loss to 1e-2 relative."""
     model, o = make_pair(tiny, K=24, B=B, full_output=True, **variant)
     for ep in range(2):
         model.train_one_iteration(seed=4, epoch=ep)
         o.train_full(4, ep, B)
     err, which = max_param_err(model, o)
-    assert err < 2e-2, (err, which)
+    print(f"\nfull-output K=24 B={B} {variant}: max parameter error {err:.2e} of range ({which})")
+    assert err < 1.2e-2, (err, which)
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
 
