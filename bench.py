@@ -307,7 +307,19 @@ def main():
     # training epoch runs in (clocks, caches; DESIGN.md §8: 98 us per step after 5 steps, 94-95 after 300).  The same kind of steps on
     # the same data; the W warm-up steps and the K timed steps follow unchanged.
     prewarm = max(0, 300 - args.warmup)
-    run(0, prewarm)
+    # ... and what the pre-warm hides is reported, not dropped: the first COLD_STEPS steps of the process (device out of idle, cold
+    # caches, first use of every kernel), timed on their own as `cold_start_ms_per_step`
+    COLD_STEPS = min(20, prewarm)
+    cold_ms = None
+    if COLD_STEPS and not exchanging:
+        sync()
+        tc = time.perf_counter()
+        run(0, COLD_STEPS)
+        sync()
+        cold_ms = 1e3 * (time.perf_counter() - tc) / COLD_STEPS
+        run(COLD_STEPS, prewarm - COLD_STEPS)
+    else:
+        run(0, prewarm)
     run(prewarm, args.warmup)
     args_first = prewarm + args.warmup
     model.collect_stats()
@@ -492,6 +504,7 @@ def main():
         "kernel_ms_per_step": {k[3:]: acc[k] / max(1, acc["launches_decode"]) for k in acc if k.startswith("ms_")},
         "profiled_steps": int(acc["launches_decode"]),
         "prewarm_steps": prewarm,          # untimed device pre-warm in front of the W warm-up steps (see the comment at `prewarm`)
+        "cold_start_ms_per_step": cold_ms, # the process's first 20 steps (part of the pre-warm), timed on their own
         "kernel_ms_note": "decode: HIP events inside the timed region; the other families: an untimed pass of 32 steps after it",
     }
     if not args.no_cpu_baseline and args.gpus == 1:          # reported at N = 1 only (rank 0's host cores)

@@ -137,6 +137,8 @@ struct cdae_hip {
     uint32_t* item_count = nullptr; uint32_t* prefix = nullptr; uint32_t* rank = nullptr; uint64_t* bucketed = nullptr;
     uint32_t* tile_hist = nullptr; uint32_t* block_total = nullptr;      // (`rank` holds the in-block item prefix)
     uint32_t* wg_state = nullptr;                                    // bucket_sort_kernel: one word per item range (cleared by the sample kernel)
+    uint32_t* cells = nullptr; uint32_t* cell_flag = nullptr;        // ... and its cells [ranges][units][BKC_SLOTS], filled by sample_kernel; overflow word
+    uint32_t cell_tag = 0;                                           // (host) the tag of the batch last prepared into this set
     hipEvent_t ready = nullptr, released = nullptr;
   } ex[3];
   static constexpr int NSETS = 3;
@@ -215,6 +217,8 @@ struct cdae_hip {
   uint32_t bucket_ranges = 0;
   uint32_t* d_bucket_cut = nullptr;     // [bucket_ranges + 1] item ids
   bool bucket_attr_set = false;         // dynamic-LDS attribute set on this handle's device
+  uint16_t* d_range_of = nullptr;       // [I] item -> range (sample_kernel routes every example into its range's cell); nullptr: the sort scans the key list
+  uint32_t cell_units = 0;              // units the cells are allocated for (the most of any batch)
   bool counting_sort = false;           // tile counting sort on the prep stream (cdae_sort_kernels.hpp) instead of rocPRIM: num_items <= TILE_SORT_MAX_ITEMS
   bool tile_attr_set = false;           // dynamic LDS above 64 KiB allowed for the two tile kernels (per handle: the attribute is per device)
   bool gemm3_attr_set[8] = {false, false, false, false, false, false, false, false};   // launch_gemm_lds: dynamic-LDS attribute set on this handle's device, per epilogue
@@ -382,11 +386,11 @@ void free_all(cdae_hip* h) {
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
-                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut};
+                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut, h->d_range_of};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
-                 b.item_count, b.prefix, b.rank, b.bucketed, b.tile_hist, b.block_total, b.wg_state};
+                 b.item_count, b.prefix, b.rank, b.bucketed, b.tile_hist, b.block_total, b.wg_state, b.cells, b.cell_flag};
     for (void* p : q) if (p) (void)hipFree(p);
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
@@ -423,12 +427,12 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
                    (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
-                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut};
+                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut, (void**)&h->d_range_of};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
                   (void**)&b.item_count, (void**)&b.prefix, (void**)&b.rank, (void**)&b.bucketed, (void**)&b.tile_hist, (void**)&b.block_total,
-                  (void**)&b.wg_state};
+                  (void**)&b.wg_state, (void**)&b.cells, (void**)&b.cell_flag};
     for (void** p : q) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
   }
   for (void** p : ptrs) if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
@@ -464,6 +468,8 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
   const bool shs = h->shard_sampled();
   const uint32_t n_units = shs ? gunits_of(h, bt) : units_of(h, bt);
   const bool bucket = h->bucket_sort && x.key16;      // bucket_sort_kernel writes every entry of the segment tables itself: nothing to clear
+  const bool use_cells = bucket && x.cells && n_units <= h->cell_units;   // sample_kernel routes the examples into the ranges' cells
+  if (use_cells) x.cell_tag = x.cell_tag + 1u ? x.cell_tag + 1u : 1u;     // a fresh non-zero tag per batch: nobody has to clear the overflow word
   if (n_units == 0) {            // (an item shard none of whose rows the batch's users rated: only the per-batch clears)
     HIPCHK(hipMemsetAsync(x.seg, 0, 4 * (size_t)I * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(x.dup_count, 0, cdae::DUP_STRIPES * sizeof(uint32_t), st));
@@ -476,12 +482,16 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
     hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_grow_ptr, h->d_gcol,
                        h->d_gunit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
                        x.seg, h->counting_sort || bucket ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_gunit_user,
-                       x.wg_state, (const uint32_t*)nullptr, (uint32_t)h->item0, I, (uint32_t)h->I_global);
+                       x.wg_state, (const uint32_t*)nullptr, (uint32_t)h->item0, I, (uint32_t)h->I_global,
+                       (const uint16_t*)(use_cells ? h->d_range_of : nullptr), (const uint32_t*)h->d_bucket_cut, h->bucket_ranges,
+                       use_cells ? x.cells : (uint32_t*)nullptr, x.cell_flag, x.cell_tag);
   } else
   hipLaunchKernelGGL(sample_kernel, dim3((n_units + 3) / 4), dim3(256), 0, st, h->hp, h->d_row_ptr, h->d_col,
                      h->d_unit_ptr + bt.s0, n_units, bt.s0, bt.nb, bt.cidx, seed, epoch, x.item, x.val, x.key16,
                      x.seg, h->counting_sort || bucket ? 0u : 4u * I, x.dup_count, x.dup_of_ex, h->d_unit_user,
-                     x.wg_state, (const uint32_t*)h->d_gpos);
+                     x.wg_state, (const uint32_t*)h->d_gpos, 0u, 0u, 0u,
+                     (const uint16_t*)(use_cells ? h->d_range_of : nullptr), (const uint32_t*)h->d_bucket_cut, h->bucket_ranges,
+                     use_cells ? x.cells : (uint32_t*)nullptr, x.cell_flag, x.cell_tag);
   CHK(pr.end());
   CHK(pr.begin(h, F_SORT, st, prof_q));
   const dim3 seg_grid((uint32_t)((bt.E + 256 * SEG_PER_THREAD - 1) / (256 * SEG_PER_THREAD)));
@@ -496,7 +506,8 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
       h->bucket_attr_set = true;
     }
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(h->bucket_ranges), dim3(BK_THREADS), BK_LDS_BYTES, st, (const uint16_t*)x.key16, (const uint64_t*)x.val,
-                       (uint32_t)bt.E, (const uint32_t*)h->d_bucket_cut, x.wg_state, x.seg, x.seg + I, (const uint32_t*)h->d_rank_of,
+                       (uint32_t)bt.E, (const uint32_t*)h->d_bucket_cut, x.wg_state, (const uint32_t*)(use_cells ? x.cells : nullptr), n_units,
+                       (const uint32_t*)x.cell_flag, x.cell_tag, x.seg, x.seg + I, (const uint32_t*)h->d_rank_of,
                        x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, x.sorted_val, x.bucketed, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex,
                        h->dup_stripes);
   } else if (h->counting_sort) {
@@ -1479,7 +1490,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   // whole 16-bit key list once per range and pass, so it is for batches up to BUCKET_MAX_EXAMPLES examples (256-512 users at the
   // BASELINE shapes) over at most 65536 items; beyond that the library sort below stays.  CDAE_SORT_LIBRARY (developer build): the
   // library sort + segment_kernel everywhere (the A/B side of the bit-equality tests).
-  h->bucket_sort = false; h->bucket_ranges = 0;
+  h->bucket_sort = false; h->bucket_ranges = 0; h->cell_units = 0;
   {
     constexpr uint64_t BUCKET_MAX_EXAMPLES = 600000;
     const uint64_t keys = I + (h->shard_sampled() ? 1u : 0u);
@@ -1505,6 +1516,16 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
         h->bucket_ranges = (uint32_t)cut.size() - 1;
         CHK(dev_alloc(&h->d_bucket_cut, cut.size()));
         HIPCHK(hipMemcpy(h->d_bucket_cut, cut.data(), cut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // cells: sample_kernel routes every example into the cell of (its item's range, its unit), so that the sort reads its range's cells
+        // instead of scanning the batch's key list.  The CDAE sampler only; <= 256 ranges (LDS counters per wavefront); example indices must
+        // fit the entry's 20 bits (Ecap <= 600 000 does)
+        if (!h->mf && h->bucket_ranges <= cdae::BKC_MAX_RANGES && h->Ecap < (1ull << (32 - cdae::BKC_ITEM_BITS)) && !DEV_ENV("CDAE_SORT_SCAN")) {
+          std::vector<uint16_t> rof(I);
+          for (uint32_t r = 0; r + 1 < cut.size(); ++r)
+            for (uint32_t i = cut[r]; i < cut[r + 1]; ++i) rof[i] = (uint16_t)r;
+          CHK(dev_alloc(&h->d_range_of, (size_t)I));
+          HIPCHK(hipMemcpy(h->d_range_of, rof.data(), I * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
       }
     }
   }
@@ -1558,6 +1579,17 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       CHK(dev_alloc(&b.block_total, 128));
     } else if (I + (h->shard_sampled() ? 1u : 0u) <= 65536) { CHK(dev_alloc(&b.key16, h->Ecap + 8)); CHK(dev_alloc(&b.sorted_key16, h->Ecap)); }   // (a sampled item shard sorts one more key: VOID = I)
     if (h->bucket_sort) { CHK(dev_alloc(&b.bucketed, h->Ecap)); }
+    b.cell_tag = 0;
+    if (h->bucket_sort && h->d_range_of) {
+      // [ranges][units of the largest batch][BKC_SLOTS] words; beyond 256 MiB per set (or 16 384 units) the sort scans instead
+      const size_t words = (size_t)h->bucket_ranges * h->unit_cap * cdae::BKC_SLOTS;
+      if (h->unit_cap <= cdae::BK_CELL_UNITS_MAX && words * sizeof(uint32_t) <= (256ull << 20)) {
+        CHK(dev_alloc(&b.cells, words));
+        CHK(dev_alloc(&b.cell_flag, 1));
+        HIPCHK(hipMemset(b.cell_flag, 0, sizeof(uint32_t)));
+        h->cell_units = h->unit_cap;
+      }
+    }
     CHK(dev_alloc(&b.wg_state, cdae::BK_MAX_RANGES));
     HIPCHK(hipMemset(b.wg_state, 0, cdae::BK_MAX_RANGES * sizeof(uint32_t)));
     if (!b.ready) { HIPCHK(hipEventCreateWithFlags(&b.ready, sync_event_flags())); HIPCHK(hipEventCreateWithFlags(&b.released, sync_event_flags())); }

@@ -199,6 +199,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // UNITS of at most unit_pos positives of one user: unit k of a user covers positives [k*unit_pos, ...) and the
 // num_neg x as many negatives that belong to them.  `uptr` is the batch's prefix array (nb + 1 entries, any
 // base): user slot s owns units uptr[s] .. uptr[s+1]-1.
+// bucket_sort_kernel's cells (cdae_sort_kernels.hpp): sample_kernel's wavefront (one work unit) drops every example into the cell of
+// (its item's range, the unit): BKC_SLOTS words, word 0 = how many the unit put there, then (example index << BKC_ITEM_BITS | item - range start)
+constexpr uint32_t BKC_SLOTS = 32, BKC_ITEM_BITS = 12, BKC_ITEM_MASK = (1u << BKC_ITEM_BITS) - 1u;
+constexpr uint32_t BKC_MAX_RANGES = 256;      // LDS counters per wavefront in sample_kernel
 constexpr uint32_t UNIT_POS_MAX = 128;     // HyperParams::unit_pos (set per data set / batch size by the host) never exceeds it
 
 struct UnitRef { uint32_t slot, p0, p1; };   // user slot and the positive range [p0, p1) of the unit
@@ -252,8 +256,19 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               // single-GPU layout and numbering, and an example whose item lies outside [shard_item0, shard_item0 + shard_items)
               // is VOID: item = key = shard_items (one past the last local row) — it sorts behind every local row, segment_kernel
               // and hidden_gather_kernel skip it.  shard_items = 0: not a shard (ids pass through).
-              uint32_t shard_item0 = 0, uint32_t shard_items = 0, uint32_t draw_items = 0) {
+              uint32_t shard_item0 = 0, uint32_t shard_items = 0, uint32_t draw_items = 0,
+              // bucket_sort_kernel's cells (nullptr: none): item -> range, the ranges' first items, [ranges][n_units][BKC_SLOTS] words, the
+              // word that receives `cell_tag` when a unit puts more than BKC_SLOTS - 1 examples into one range (the sort then scans instead)
+              const uint16_t* __restrict__ range_of = nullptr, const uint32_t* __restrict__ range_cut = nullptr, uint32_t n_ranges = 0,
+              uint32_t* __restrict__ cells = nullptr, uint32_t* __restrict__ cell_flag = nullptr, uint32_t cell_tag = 0) {
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
+  __shared__ uint32_t cell_cnt[4][BKC_MAX_RANGES];
+  __shared__ uint32_t cell_lo[BKC_MAX_RANGES];
+  if (cells) {
+    for (uint32_t i = threadIdx.x; i < n_ranges; i += blockDim.x) cell_lo[i] = range_cut[i];
+    for (uint32_t i = threadIdx.x; i < 4u * BKC_MAX_RANGES; i += blockDim.x) (&cell_cnt[0][0])[i] = 0u;
+    __syncthreads();
+  }
   // the per-batch clears ride along (no memset launches on the prep stream)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < seg_words; i += gridDim.x * blockDim.x) seg[i] = 0u;
   if (blockIdx.x == 0 && threadIdx.x < DUP_STRIPES) dup_count[threadIdx.x] = 0u;
@@ -272,6 +287,14 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
   const uint32_t p0 = ur.p0, p1 = min(ur.p1, n);
   const uint32_t* row = col + r0;
   const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
+  // the example's cell: an LDS counter per range gives its slot (lanes of the wavefront may meet in one range: the atomic sorts that out)
+  auto cell_add = [&](uint64_t e, uint32_t it /* local item id; >= the local item count: VOID */, uint32_t n_local) {
+    if (!cells || it >= n_local) return;
+    const uint32_t r = range_of[it];
+    const uint32_t slot = 1u + atomicAdd(&cell_cnt[wid][r], 1u);
+    if (slot < BKC_SLOTS) cells[((size_t)r * n_units + unit) * BKC_SLOTS + slot] = ((uint32_t)e << BKC_ITEM_BITS) | (it - cell_lo[r]);
+  };
+  const uint32_t n_local = shard_items ? shard_items : hp.num_items;
   const uint64_t key_c = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_CORRUPT);
   const uint64_t key_n = cdae_rng_key(seed, epoch, uid + hp.uid_offset, CDAE_STREAM_NEGATIVE);
   const bool staged = n <= SAMPLE_LDS_ROW;
@@ -289,6 +312,7 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     if (ex_key16) ex_key16[e] = (uint16_t)it;
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)(slot | TARGET_BIT | (keep ? INPUT_BIT : 0u));
+    cell_add(e, it, n_local);
   }
   const uint32_t n_items = draw_items ? draw_items : hp.num_items;
   // the wavefront's own LDS writes are visible to it once they are issued in order (no cross-wave sharing)
@@ -318,6 +342,19 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
     if (ex_key16) ex_key16[e] = (uint16_t)cand;
     dup_of_ex[e] = DUP_NONE;
     ex_val[e] = (e << 32) | (uint64_t)slot;
+    cell_add(e, cand, n_local);
+  }
+  if (cells) {
+    // the unit's counts, EVERY range (the cells are not cleared between batches); a count beyond the cell raises the batch's tag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool over = false;
+    for (uint32_t r = lane; r < n_ranges; r += WAVE) {
+      const uint32_t c = cell_cnt[wid][r];
+      over = over || c >= BKC_SLOTS;
+      cells[((size_t)r * n_units + unit) * BKC_SLOTS] = min(c, BKC_SLOTS - 1u);
+    }
+    if (over) *cell_flag = cell_tag;
   }
 }
 

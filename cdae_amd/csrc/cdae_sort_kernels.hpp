@@ -273,32 +273,36 @@ segment_sort_kernel(uint32_t num_items, const uint32_t* __restrict__ prefix, con
 // bucket_sort_kernel (round 5): the DEFAULT item-major ordering of a batch — ONE narrow launch behind sample_kernel, no library
 // call, no fill, nothing cleared in front of it.
 //
-// Why narrow.  The prep chain runs beside the previous batch's training kernels; what counts is how little it disturbs them
-// (the tile kernels above are ~1300 workgroups wide and lost to rocPRIM for that reason, r02_tile_sort.txt).  Here <= ~64-128
-// workgroups of 1024 threads each OWN a contiguous range of item ids — cut on the host so that the ranges expect equal numbers of
-// examples (popularity + the uniform negatives; at most BK_ITEMS items) — and do everything for their items:
-//   pass 1   scan the batch's WHOLE key list (16-bit item ids: 350 KB at ML-10M shape / 256 users, an L2 hit for everybody after the
-//            first reader) and count the examples of the own items in LDS;
-//   prefix   publish the range's total, wait for the totals of the ranges in front (one word per range, written once: workgroups
-//            are dispatched in index order, so every range a workgroup waits for is already running or done), scan the counts:
-//            the global item-major position of every own item's segment -> the four segment tables (by item and by rank, every item
-//            of the range, also the empty ones: nobody has to clear the tables);
-//   place    every wavefront walks the list of what it found in pass 1 (example index, item, ticket inside the item: the counting atomic's
-//            return value) and fetches the example words into the items' LDS buckets — the key list is read ONCE; only a range whose
-//            batch overflows a list or the LDS window scans it again, group of items by group of items;
-//   order    inside an item the tickets arrive in any order: rank every word among its item's words (the example index sits in the
-//            high half: user order), all in LDS; flag runs of one user's examples (duplicate negatives), number them (striped
-//            counters, as segment_kernel does), write sorted_val / dup_of_pos / dup_of_ex.
-// Output: bit-identical to a stable sort by item + segment_kernel (tests/test_gpu_integer.py compares both with numpy's stable
-// argsort; VOID examples of a sampled item shard — key >= every range — are simply never picked up).
-// A range whose examples do not fit the LDS window is taken in several GROUPS of consecutive items, one more scan of the key list
-// each; a single item above the window is ranked in global memory (never at the batch sizes in use; correct, slow).
-constexpr uint32_t BK_THREADS = 1024;
-constexpr uint32_t BK_WINDOW = 6144;      // example words of one group held in LDS (x 2: arrival order, sorted)
-constexpr uint32_t BK_ITEMS = 4096;       // most items of one range (LDS counters / cursors)
-constexpr uint32_t BK_WAVE_LIST = BK_WINDOW / (BK_THREADS / 64);   // records per wavefront list (the lists live in the sorted-words array until it is needed)
+// Why narrow, and why it does not scan.  The prep chain runs beside the previous batch's training kernels; what counts is how little it
+// takes from them (round 2's tile kernels, ~1300 workgroups wide, lost to rocPRIM for that reason; this kernel's own first two forms —
+// every workgroup scanning the batch's whole key list once or twice — measured 90 and 51 us on 64 CUs' worth of LDS and lost 3 % of the
+// step to the library sort).  So the routing is done where the examples are BORN: the item ids are cut, on the host, into ranges that
+// expect equal numbers of examples per batch (popularity + the uniform negatives; <= BK_ITEMS items each), and sample_kernel's
+// wavefront (one work unit: <= 384 examples) drops every example into a CELL per (range, unit) — 32 words in global memory, word 0 the
+// count, then (example index << 12 | item - range start) — with an LDS counter per range, no global atomic.  A workgroup here OWNS a range:
+//   gather   read the range's cells (one 128-byte cell per unit of the batch), prefix their counts, copy the entries into an LDS list;
+//   prefix   publish the range's total and wait for the totals of the ranges in front (one word per range, written once; workgroups
+//            are dispatched in index order, so what a workgroup waits for is running or done); count the list per item in LDS — the
+//            counting atomic's return value is the example's ticket inside its item —, scan the counts: the global item-major position
+//            of every segment -> all four segment tables, for every item of the range, also the empty ones (nothing to clear);
+//   place    fetch the example words into the items' LDS buckets (offset + ticket);
+//   order    inside an item the tickets are in arrival order: rank every word among its item's words (the example index sits in the
+//            high half: user order), all in LDS; flag runs of one user's examples (duplicate negatives), number them (striped counters,
+//            as segment_kernel does), write sorted_val / dup_of_pos / dup_of_ex.
+// Output: bit-identical to a stable sort by item + segment_kernel (tests/test_gpu_integer.py: numpy's stable argsort; VOID examples of
+// a sampled item shard belong to no range and are never picked up).
+// SCAN fallback (the first form, kept): when there are no cells (IMF / BPR sampler), a cell overflowed (a unit put > 31 examples into
+// one range: sample_kernel raises the batch's tag in `cell_flag`) or the range holds more than the LDS window, the workgroup scans the
+// batch's 16-bit key list instead — once when its wave lists hold everything, once more per group of items otherwise; a single item above
+// the window is ranked in global memory (correct, slow; never at the batch sizes in use).
+constexpr uint32_t BK_THREADS = 512;
+constexpr uint32_t BK_WINDOW = 4096;      // example words of one group held in LDS (x 2: arrival order, sorted)
+constexpr uint32_t BK_ITEMS = 2048;       // most items of one range (LDS counters: 4 per thread in bk_block_scan)
+constexpr uint32_t BK_WAVE_LIST = BK_WINDOW / (BK_THREADS / 64);   // scan fallback: records per wavefront list (they live in the sorted-words array until it is needed)
 constexpr uint32_t BK_MAX_RANGES = 1024;  // wg_state words (sample_kernel clears them with the other per-batch counters)
+constexpr uint32_t BK_CELL_UNITS_MAX = 16384;   // most units of a batch the cell path takes (their counts, 2 bytes each, fit the `raw` array)
 constexpr size_t BK_LDS_BYTES = (size_t)BK_WINDOW * 8 * 2 + (size_t)BK_WINDOW * 2 + (size_t)(BK_ITEMS + 1) * 4 * 2 + 64 * 4;
+static_assert(BK_ITEMS <= 4 * BK_THREADS && BK_ITEMS <= (1u << BKC_ITEM_BITS), "bk_block_scan takes 4 counters per thread; a cell entry holds the item in BKC_ITEM_BITS bits");
 
 // exclusive scan of v[0 .. n) (n <= 4 * BK_THREADS) in place, v[n] = total; every thread of the workgroup calls it
 __device__ __forceinline__ void bk_block_scan(uint32_t* v, uint32_t n, uint32_t* wave_tot) {
@@ -324,9 +328,8 @@ __device__ __forceinline__ void bk_block_scan(uint32_t* v, uint32_t n, uint32_t*
 }
 
 // f(e, k, valid): example index e carries key k (valid = e < n_ex; f is called by ALL lanes of a wavefront together, so it may use
-// wave-wide operations) — every example of the batch.  8 keys per 16-byte load, BK_UNROLL loads per thread in flight and
-// the next round's requested before this round's keys are looked at: one workgroup reads the whole list (350 KB at ML-10M shape / 256
-// users), and with a load at a time it was a chain of ~22 L2 round trips per pass.
+// wave-wide operations) — every example of the batch.  8 keys per 16-byte load, BK_UNROLL loads per thread in flight and the next
+// round's requested before this round's keys are looked at.
 constexpr uint32_t BK_UNROLL = 4;
 template <typename F>
 __device__ __forceinline__ void bk_scan_keys(const uint16_t* __restrict__ keys, uint32_t n_ex, F&& f) {
@@ -367,6 +370,8 @@ __device__ __forceinline__ void bk_scan_keys(const uint16_t* __restrict__ keys, 
 __global__ void __launch_bounds__(BK_THREADS)
 bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict__ ex_val, uint32_t n_ex,
                    const uint32_t* __restrict__ range_cut /* [ranges + 1] item ids */, uint32_t* __restrict__ wg_state /* [ranges], 0 on entry */,
+                   const uint32_t* __restrict__ cells /* [ranges][cell_units][BKC_SLOTS] written by sample_kernel, or nullptr */, uint32_t cell_units,
+                   const uint32_t* __restrict__ cell_flag /* == cell_tag: a cell of this batch overflowed */, uint32_t cell_tag,
                    uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_end, const uint32_t* __restrict__ rank_of,
                    uint32_t* __restrict__ segr_begin, uint32_t* __restrict__ segr_end, uint64_t* __restrict__ sorted_val,
                    uint64_t* __restrict__ scratch_val /* [n_ex]: only an item above the LDS window uses it */,
@@ -376,34 +381,85 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
   uint64_t* raw = reinterpret_cast<uint64_t*>(bk_lds);                        // [BK_WINDOW] arrival order inside an item
   uint64_t* srt = raw + BK_WINDOW;                                            // [BK_WINDOW] sorted
   uint32_t* off = reinterpret_cast<uint32_t*>(srt + BK_WINDOW);               // [BK_ITEMS + 1] counts -> exclusive prefix (range-relative)
-  uint32_t* cur = off + BK_ITEMS + 1;                                         // [BK_ITEMS + 1] tickets of the group being placed
-  uint32_t* misc = cur + BK_ITEMS + 1;                                        // [64]: wave totals (16) | base | blk_count | blk_base
+  uint32_t* cur = off + BK_ITEMS + 1;                                         // [BK_ITEMS + 1] scan fallback: tickets of the group being placed
+  uint32_t* misc = cur + BK_ITEMS + 1;                                        // [64]: wave totals (16) | base | blk_count | blk_base | overflow | total
   uint16_t* raw_item = reinterpret_cast<uint16_t*>(misc + 64);                // [BK_WINDOW] range-local item of raw[q]
-  const uint32_t t = threadIdx.x, w = blockIdx.x;
+  const uint32_t t = threadIdx.x, w = blockIdx.x, lane = t % WAVE;
   const uint32_t lo = range_cut[w], n_it = range_cut[w + 1] - lo;
   for (uint32_t i = t; i <= n_it; i += BK_THREADS) off[i] = 0u;
   if (t == 0) { misc[16] = 0u; misc[17] = 0u; misc[19] = 0u; }
   __syncthreads();
-  // ---- pass 1: counts of the own items.  The LDS atomic's return value is the example's ticket inside its item, and every wavefront
-  // keeps a list of what it found — (example index, range-local item, ticket), appended with a wave-wide ballot, no atomic — in the
-  // LDS that holds the sorted words later: when everything fits (the common case) the key list is not scanned a second time.
+
+  // ================= front end A: the range's cells ==========================================================================
+  bool listed = false;                                                         // raw / raw_item hold the whole range, off[] is scanned
+  bool scanned = false;                                                        // off[] holds the scanned counts (either front end)
+  if (cells && cell_units <= BK_CELL_UNITS_MAX && *cell_flag != cell_tag) {
+    uint16_t* wcnt = reinterpret_cast<uint16_t*>(raw);                         // [cell_units] counts of the range's cells (raw is free until `place`)
+    uint32_t* lst = reinterpret_cast<uint32_t*>(srt);                          // [BK_WINDOW] entries; tickets behind them
+    uint16_t* tk = reinterpret_cast<uint16_t*>(lst + BK_WINDOW);
+    const uint32_t* mine = cells + (size_t)w * cell_units * BKC_SLOTS;
+    // thread t owns the consecutive units [u0, u1): their counts, then their entries
+    const uint32_t per = (cell_units + BK_THREADS - 1) / BK_THREADS, u0 = min(cell_units, t * per), u1 = min(cell_units, u0 + per);
+    uint32_t sum = 0;
+    for (uint32_t u = u0; u < u1; ++u) { const uint32_t c = mine[(size_t)u * BKC_SLOTS]; wcnt[u] = (uint16_t)c; sum += c; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const uint32_t v = __shfl_up(incl, o, WAVE);
+      if ((int)lane >= o) incl += v;
+    }
+    if (lane == WAVE - 1) misc[t / WAVE] = incl;
+    __syncthreads();
+    uint32_t pos = incl - sum, total = 0;
+    for (uint32_t v = 0; v < BK_THREADS / WAVE; ++v) { if (v < t / WAVE) pos += misc[v]; total += misc[v]; }
+    __syncthreads();                                                           // (misc[0..8) is reused by bk_block_scan)
+    if (total <= BK_WINDOW) {
+      for (uint32_t u = u0; u < u1; ++u) {
+        const uint32_t c = wcnt[u];
+        for (uint32_t j = 0; j < c; ++j) lst[pos + j] = mine[(size_t)u * BKC_SLOTS + 1u + j];
+        pos += c;
+      }
+      __syncthreads();
+      for (uint32_t i = t; i < total; i += BK_THREADS) tk[i] = (uint16_t)atomicAdd(&off[lst[i] & BKC_ITEM_MASK], 1u);
+      __syncthreads();
+      bk_block_scan(off, n_it, misc);
+      for (uint32_t i = t; i < total; i += BK_THREADS) {                       // place: offset of the item + the ticket inside it
+        const uint32_t ent = lst[i], d = ent & BKC_ITEM_MASK, p = off[d] + tk[i];
+        // (wcnt aliases raw: every count was consumed above, before the first barrier of this block)
+        raw[p] = ex_val[ent >> BKC_ITEM_BITS];
+        raw_item[p] = (uint16_t)d;
+      }
+      listed = true; scanned = true;
+    } else {
+      for (uint32_t i = t; i <= n_it; i += BK_THREADS) off[i] = 0u;            // (untouched so far; kept for symmetry) the scan fallback counts from zero
+      __syncthreads();
+    }
+  }
+
+  // ================= front end B: scan the batch's key list ==================================================================
   uint64_t* const wave_list = srt + (t / WAVE) * BK_WAVE_LIST;
   uint32_t wave_n = 0;                                                         // (wave-uniform)
-  bk_scan_keys(keys, n_ex, [&](uint32_t e, uint32_t k, bool valid) {
-    const uint32_t d = k - lo;
-    const bool mine = valid && d < n_it;
-    const uint64_t m = __ballot(mine);
-    if (m == 0ull) return;
-    if (mine) {
-      const uint32_t ticket = atomicAdd(&off[d], 1u);
-      const uint32_t slot = wave_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (slot < BK_WAVE_LIST) wave_list[slot] = ((uint64_t)e << 32) | (uint64_t)(d << 16) | (uint64_t)(ticket & 0xFFFFu);
-    }
-    wave_n += (uint32_t)__popcll(m);
-  });
-  if (wave_n > BK_WAVE_LIST && t % WAVE == 0) misc[19] = 1u;                   // a list ran over: the groups below scan the keys again
-  __syncthreads();
-  bk_block_scan(off, n_it, misc);                                             // off[i] = examples of the range's items before i; off[n_it] = total
+  if (!scanned) {
+    // pass 1: counts of the own items.  The LDS atomic's return value is the example's ticket inside its item, and every wavefront keeps
+    // a list of what it found — (example index, range-local item, ticket), appended with a wave-wide ballot, no atomic — in the LDS
+    // that holds the sorted words later: when everything fits, the key list is not scanned a second time.
+    bk_scan_keys(keys, n_ex, [&](uint32_t e, uint32_t k, bool valid) {
+      const uint32_t d = k - lo;
+      const bool mine = valid && d < n_it;
+      const uint64_t m = __ballot(mine);
+      if (m == 0ull) return;
+      if (mine) {
+        const uint32_t ticket = atomicAdd(&off[d], 1u);
+        const uint32_t slot = wave_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (slot < BK_WAVE_LIST) wave_list[slot] = ((uint64_t)e << 32) | (uint64_t)(d << 16) | (uint64_t)(ticket & 0xFFFFu);
+      }
+      wave_n += (uint32_t)__popcll(m);
+    });
+    if (wave_n > BK_WAVE_LIST && lane == 0) misc[19] = 1u;                     // a list ran over: the groups below scan the keys again
+    __syncthreads();
+    bk_block_scan(off, n_it, misc);                                            // off[i] = examples of the range's items before i; off[n_it] = total
+  }
+
   // ---- the range's place in the item-major list: totals of the ranges in front (one word each: total + 1, 0 = not yet known)
   if (t == 0) __hip_atomic_store(&wg_state[w], off[n_it] + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   for (uint32_t r = t; r < w; r += BK_THREADS) {
@@ -418,40 +474,40 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
     seg_begin[lo + i] = b; seg_end[lo + i] = e;
     if (rank_of) { const uint32_t r = rank_of[lo + i]; segr_begin[r] = b; segr_end[r] = e; }
   }
-  // ---- groups of consecutive items whose examples fit the LDS window
-  const bool listed = misc[19] == 0u && off[n_it] <= BK_WINDOW;               // one group, every example of it in a wave list
+  const bool wave_listed = !listed && misc[19] == 0u && off[n_it] <= BK_WINDOW;   // scan front end, one group, every example of it in a wave list
+
+  // ---- groups of consecutive items whose examples fit the LDS window (ONE group unless the batch is far larger than the cut expected)
   uint32_t ia = 0;
   while (ia < n_it) {
-    // (every thread walks the same few steps: a range is one group unless the batch is far larger than the ranges were cut for)
     uint32_t ib = ia + 1;
     {
-      uint32_t l = ia + 1, h = n_it;                                         // largest ib with off[ib] - off[ia] <= BK_WINDOW
+      uint32_t l = ia + 1, h = n_it;                                           // largest ib with off[ib] - off[ia] <= BK_WINDOW
       while (l < h) { const uint32_t mid = (l + h + 1) >> 1; if (off[mid] - off[ia] <= BK_WINDOW) l = mid; else h = mid - 1; }
       ib = l;
     }
     const uint32_t g0 = off[ia], n = off[ib] - g0;
-    const bool in_lds = n <= BK_WINDOW;                                       // else: ONE oversized item, ranked in global memory
+    const bool in_lds = n <= BK_WINDOW;                                        // else: ONE oversized item, ranked in global memory
     if (n == 0) { ia = ib; continue; }
     if (listed) {
-      // ---- the wave lists: position = the item's offset + the ticket taken in pass 1 (ia = 0, ib = n_it, g0 = 0)
-      for (uint32_t i = t % WAVE; i < wave_n; i += WAVE) {
+      // (front end A placed everything: ia = 0, ib = n_it, g0 = 0)
+    } else if (wave_listed) {
+      for (uint32_t i = lane; i < wave_n; i += WAVE) {
         const uint64_t rec = wave_list[i];
         const uint32_t d = (uint32_t)(rec >> 16) & 0xFFFFu, p = off[d] + ((uint32_t)rec & 0xFFFFu);
         raw[p] = ex_val[(uint32_t)(rec >> 32)];
         raw_item[p] = (uint16_t)d;
       }
     } else {
-    for (uint32_t i = ia + t; i < ib; i += BK_THREADS) cur[i] = off[i] - g0;
-    __syncthreads();
-    // ---- pass 2: tickets
-    bk_scan_keys(keys, n_ex, [&](uint32_t e, uint32_t k, bool valid) {
-      const uint32_t d = k - lo;
-      if (valid && d - ia < ib - ia) {
-        const uint32_t p = atomicAdd(&cur[d], 1u);
-        const uint64_t v = ex_val[e];
-        if (in_lds) { raw[p] = v; raw_item[p] = (uint16_t)d; } else scratch_val[base + g0 + p] = v;
-      }
-    });
+      for (uint32_t i = ia + t; i < ib; i += BK_THREADS) cur[i] = off[i] - g0;
+      __syncthreads();
+      bk_scan_keys(keys, n_ex, [&](uint32_t e, uint32_t k, bool valid) {
+        const uint32_t d = k - lo;
+        if (valid && d - ia < ib - ia) {
+          const uint32_t p = atomicAdd(&cur[d], 1u);
+          const uint64_t v = ex_val[e];
+          if (in_lds) { raw[p] = v; raw_item[p] = (uint16_t)d; } else scratch_val[base + g0 + p] = v;
+        }
+      });
     }
     __threadfence_block();
     __syncthreads();
@@ -460,7 +516,7 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
       if (in_lds) {
         const uint32_t d = raw_item[q], a = off[d] - g0, b = off[d + 1] - g0;
         const uint64_t v = raw[q];
-        uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};                            // eight LDS reads in flight (a popular item holds 100+ examples)
+        uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};                             // eight LDS reads in flight (a popular item holds 100+ examples)
         uint32_t j = a;
         for (; j + 8 <= b; j += 8) {
 #pragma unroll
@@ -481,14 +537,14 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
     uint32_t my_dups = 0;
     for (uint32_t q = t; q < n; q += BK_THREADS) {
       uint32_t a = 0, b = n;
-      if (in_lds) {                                                           // the item of sorted position q: the last one starting at or before it
+      if (in_lds) {                                                            // the item of sorted position q: the last one starting at or before it
         uint32_t l = ia, h = ib - 1;
         while (l < h) { const uint32_t mid = (l + h + 1) >> 1; if (off[mid] - g0 <= q) l = mid; else h = mid - 1; }
         a = off[l] - g0; b = off[l + 1] - g0;
       }
       const uint64_t v = in_lds ? srt[q] : sorted_val[base + g0 + q];
       const uint32_t slot = (uint32_t)v & SLOT_MASK;
-      uint32_t flags = 0;                                                     // neighbours may be mid-update in global memory: only their slot bits are compared
+      uint32_t flags = 0;                                                      // neighbours may be mid-update in global memory: only their slot bits are compared
       if (q > a && ((uint32_t)(in_lds ? srt[q - 1] : sorted_val[base + g0 + q - 1]) & SLOT_MASK) == slot) flags |= DUP_PREV_BIT;
       if (q + 1 < b && ((uint32_t)(in_lds ? srt[q + 1] : sorted_val[base + g0 + q + 1]) & SLOT_MASK) == slot) flags |= DUP_NEXT_BIT;
       if (in_lds || flags) sorted_val[base + g0 + q] = v | flags;
@@ -501,7 +557,7 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
     if (my_dups) {
       o += misc[18];
       const uint32_t stripe_cap = dup_cap / stripes, stripe0 = (w % stripes) * stripe_cap;
-      for (uint32_t q = t; q < n; q += BK_THREADS) {                         // this thread's own positions again
+      for (uint32_t q = t; q < n; q += BK_THREADS) {                          // this thread's own positions again
         const uint64_t v = sorted_val[base + g0 + q];
         if (!((uint32_t)v & DUP_PREV_BIT)) continue;
         const uint32_t idx = o < stripe_cap ? stripe0 + o : DUP_NONE;

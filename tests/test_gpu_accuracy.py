@@ -416,7 +416,8 @@ def test_ml10m_shape_device_literal_loop_is_the_fp64_literal_loop(built):
 
 def test_ml10m_shape_bench_block_reaches_the_literal_loops_quality(built):
     """the accuracy statement of `bench.py --full-output --batch-users 2048` (config.accuracy): blocks of 2048 users reach the literal
-    loop's 25-epoch best Recall@10 within 16 + 2 epochs and stay above it through epoch 25 — one-sided, per seed, two seeds here.  The
+    loop's 25-epoch best Recall@10 within 16 + 2 epochs and stay above it through epoch 25 — one-sided, per seed, all FOUR seeds the
+    envelope file holds literal curves for (two through round 4; the review asked for four at the block size the bench line runs).  The
     literal 25-epoch curves are the device's batch_users = 1 runs recorded in profiles/r04_full_output_envelope_ml10m.txt (tied to the
     fp64 loop by the test above); DESIGN.md §5c has four seeds x six block sizes, and the blocks of <= 512 users that pass the loop
     and then over-train"""
@@ -427,7 +428,7 @@ def test_ml10m_shape_bench_block_reaches_the_literal_loops_quality(built):
         if r.get("run") == "full-output literal":
             lit[int(r["seed"])] = np.array(r["recall10"])
     assert len(lit) >= 4
-    for seed in (20141119, 7):
+    for seed in (20141119, 7, 1234, 42):
         best = float(lit[seed].max())
         rec, _, _ = _ml10m_full_curve(seed, 2048, 25)
         reach = next((i + 1 for i, r in enumerate(rec) if r >= best), None)

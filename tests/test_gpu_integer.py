@@ -159,11 +159,15 @@ def test_user_id_offset_shifts_the_streams_like_a_global_run(built):
         np.testing.assert_array_equal(a[k], b[k])
 
 
-@pytest.mark.parametrize("path", ["bucket", "tile", "library"])
+@pytest.mark.parametrize("path", ["bucket", "scan", "tile", "library"])
 def test_every_sort_path_gives_the_same_bit_exact_order(built, monkeypatch, devlib, path):
-    """Default: bucket_sort_kernel (cdae_sort_kernels.hpp: one narrow launch, every workgroup owns a range of item ids).  CDAE_SORT_TILE=1
+    """Default: bucket_sort_kernel (cdae_sort_kernels.hpp: one narrow launch, every workgroup owns a range of item ids and reads the
+    cells sample_kernel routed its examples into).  CDAE_SORT_SCAN=1 (developer build): the same kernel without cells — every workgroup
+    scans the batch's key list (what IMF / BPR handles and overflowing batches take).  CDAE_SORT_TILE=1
     (developer build): the per-tile LDS counting sort + per-item ordering, four launches.  CDAE_SORT_LIBRARY=1: the library radix sort +
     segment_kernel (what larger batches / item spaces still take).  All three must equal numpy's stable sort by item, bit for bit."""
+    if path == "scan":
+        monkeypatch.setenv("CDAE_SORT_SCAN", "1")
     if path == "tile":
         monkeypatch.setenv("CDAE_SORT_TILE", "1")
     if path == "library":
@@ -182,10 +186,11 @@ def test_every_sort_path_gives_the_same_bit_exact_order(built, monkeypatch, devl
 
 
 def test_bucket_sort_beyond_its_lds_window(built):
-    """bucket_sort_kernel's two slow paths, on the SHIPPED library: (a) ONE item with more examples than the LDS window holds (6144: every
-    one of 7 000 users rated item 0) is ranked in global memory; (b) a range whose batch holds far more examples than the ranges were cut
-    for (the first 200 users all rate the same 60 items, the cut expects the data set's average) is taken in several groups, one more
-    scan of the key list each.  Same bits as numpy's stable sort."""
+    """bucket_sort_kernel's slow paths, on the SHIPPED library: (a) ONE item with more examples than the LDS window holds (4096: every
+    one of 7 000 users rated item 0) is ranked in global memory — the range's cells hold more than the window, so the workgroup scans;
+    (b) a range whose batch holds far more examples than the ranges were cut for (the first 200 users all rate the same 60 items, the cut
+    expects the data set's average): the units' cells overflow (> 31 examples of one unit in one range), sample_kernel raises the batch's
+    tag, every workgroup scans, and the hot range is taken in several groups of items.  Same bits as numpy's stable sort."""
     rng = np.random.default_rng(3)
     rows = [np.unique(np.r_[0, rng.choice(np.arange(1, 400), 30, replace=False)]).astype(np.uint32) for _ in range(7000)]
     ptr = np.r_[0, np.cumsum([r.size for r in rows])].astype(np.int64)

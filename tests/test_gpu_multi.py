@@ -622,11 +622,32 @@ def test_thread_per_shard_loop_and_rccl_calls_with_one_rank_communicators(small,
         m = cdae_amd.CDAE(cfg)
         m.set_interactions(sd.num_users, sd.num_items, sd.train_ptr, sd.train_col, user_id_offset=u0)
         m.init_params(11)
+        # the same boundaries by hand (cdae_multi.hip step_single / flush_single): a one-rank all-reduce leaves the staged delta as it is,
+        # but STAGE / MERGE still run — c = A + (c - snap) after A += (c - A) is c only up to an ulp, so they belong to the expected bits
+        m.delta_begin(); m.delta_stage()
+        st = {"pending": False, "n": 0}
+
+        def boundary(start_next):
+            if st["pending"] and start_next:
+                m.delta_merge_stage()
+            elif st["pending"]:
+                m.delta_merge()
+            elif start_next:
+                m.delta_stage()
+            st["pending"] = start_next
+
         for ep in range(2):
             for t in range(steps):
                 a, b = min(sizes[s], t * per[s]), min(sizes[s], (t + 1) * per[s])
                 if b > a:
                     m.enqueue_users(3, ep, a, b)
+                st["n"] += 1
+                if period == 0:
+                    boundary(True); boundary(False)
+                elif st["n"] % period == 0:
+                    boundary(True)
+            if period != 0 or st["pending"]:
+                boundary(True); boundary(False)
             m.synchronize()
         for w in SHARED:
             np.testing.assert_array_equal(mm.shard_get(s, w), m.get(w))
