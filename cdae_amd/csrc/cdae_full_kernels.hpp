@@ -17,6 +17,7 @@
 // slice of Bm's row n0 + (l & 31).  A wavefront owns a 64 x 64 tile of C (2 x 2 MFMA tiles, 64 accumulator
 // VGPRs), a 256-thread workgroup 128 x 128.  Round 1 feeds the fragments straight from L1/L2 (no LDS staging).
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -856,39 +857,24 @@ gemm1_loss_zreg_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf
 }
 
 // ------------------------------------------------------------------------------------------------
-// GEMM 1 of the K = 512 path, round 4 experiment (CDAE_GEMM1_PIPE=1; NOT the default — it measured no faster): the loss epilogue
-// issued under the matrix cores.
+// GEMM 1 of the K = 512 path, round 5: the two wavefronts of a SIMD in OPPOSITE phases (gemm1_loss_duo_kernel; the default).
 //
-// gemm1_loss_zreg_kernel walks item tiles of 128 and every wavefront reaches a tile's loss epilogue — 64 x (exp, rcp, two packs)
-// per lane — at the same barrier, so ~40 % of the launch ran with the matrix cores idle (rocprofv3: MFMA busy 42 %).  A second
-// accumulator set does not fit beside the 128 registers of z fragments at two wavefronts per SIMD, so the tile is halved instead:
-// HALF-TILES of 64 items (two 32 x 32 accumulator tiles per wavefront) in TWO register sets.  While half-tile h is contracted into
-// one set, one eighth of half-tile h - 1's epilogue (a [4 users] group of one item block: bias, loss', bf16, one 8-byte write into an
-// LDS image) is issued behind every slice's MFMAs from the other set, and one 512-byte row of half-tile h - 2's image leaves for
-// G^T per wavefront and slice.  Staging: slices of 64 items x 64 k (8 KiB: one 1 KiB DMA instruction per wavefront), a ring of eight
-// stages with six slices in flight; per slice a wavefront issues exactly one DMA and (from the third half-tile on) one store, and two
-// bias loads per half-tile, so the counted `s_waitcnt vmcnt(N)` in front of every raw barrier is
-//   N = later slices in flight + stores issued since the awaited slice's DMA + the bias loads in that window.
-// Every element is the same sum over k in the same order as before (16-wide steps ascending) and the same loss expression: G^T is
-// bit-identical (test_gemm1_zreg_changes_no_bit covers this kernel too).
-constexpr int G1P_ITEMS = 64, G1P_STAGES = 8, G1P_AHEAD = 6;
-// developer builds (-DG1P_X_...=1: timing experiments, WRONG results): which part of a step costs what
-#ifndef G1P_X_NOSTAGE
-#define G1P_X_NOSTAGE 0
-#endif
-#ifndef G1P_X_NOMFMA
-#define G1P_X_NOMFMA 0
-#endif
-#ifndef G1P_X_NOEPI
-#define G1P_X_NOEPI 0
-#endif
-#ifndef G1P_X_NOSTORE
-#define G1P_X_NOSTORE 0
-#endif
-constexpr int G1P_STAGE_BYTES = G1P_ITEMS * 64 * 2;              // 8 KiB
-constexpr uint32_t G1P_IMG_RS = 528;                             // image row: 256 users bf16 + 16 B
-constexpr size_t gemm1_pipe_lds_bytes() { return (size_t)G1P_STAGES * G1P_STAGE_BYTES + 2 * (size_t)G1P_ITEMS * G1P_IMG_RS + 2 * 8 * 64 * sizeof(float); }
-
+// gemm1_loss_zreg_kernel runs its eight wavefronts in lockstep: all contract a tile, then all run its loss epilogue — 64 x (exp, rcp,
+// pack) per lane — with the matrix cores idle (rocprofv3: MFMA busy 42 %; 1.15 ms per launch at 1 M items x 1024 users against 0.52 ms
+// for the contraction and its staging alone).  Round 4 tried the epilogue between the MFMAs of one wavefront (no gain: both wavefronts
+// of a SIMD then want the same issue slots at the same time).  Here the workgroup's two halves — wavefronts 0-3 and 4-7, one of each
+// on every SIMD — alternate roles by PERIOD, one workgroup barrier per period:
+//   period p, t = p / 2:   half (p & 1)      contracts item tile t (64 items, two 32 x 32 accumulators per wavefront: 64 MFMAs back to
+//                                            back, nothing else but their LDS reads in its stream)
+//                          the other half    runs the loss epilogue of the tile it contracted in the period before, stores its G^T
+//                                            piece, and issues the LDS DMA of tile t + 1
+// so at any time exactly one wavefront per SIMD feeds the matrix pipe (one stream of independent MFMAs saturates it) and its partner's
+// exp / rcp / packs / stores issue in the gaps.  A tile (64 items x K = 512: 64 KiB, eight slices of 64 k, rows swizzled as GEMM_SLICE)
+// is double-buffered WHOLE: tile t is live for periods 2t (first half reads it) and 2t + 1 (second half), tile t + 1 lands meanwhile
+// in the other buffer — no slice-level hand-shake, no image buffer: a lane holds four consecutive users of an item; v_permlane32_swap
+// pairs it with the lane that holds the next four, and G^T leaves in 16-byte pieces (64 contiguous bytes per item row and wavefront).
+// Every element is the same sum over k in the same order (16-wide steps ascending) and the same loss expression as the kernels above:
+// G^T is bit-identical (test_gemm1_zreg_changes_no_bit).
 __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n) {     // n is wave-uniform
   switch (n) {
     case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
@@ -907,175 +893,222 @@ __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n) {     // n is wav
   }
 }
 
+constexpr int G1D_ITEMS = 64;
+constexpr int G1D_TILE_BYTES = G1D_ITEMS * 512 * 2;              // 64 KiB: [8 slices][64 rows][128 B]
+constexpr int G1D_PIECES = G1D_TILE_BYTES / 1024;                // 64 DMA instructions of 1 KiB (8 rows of one slice)
+// developer builds (tools/build_variant.sh -DG1D_X_...=1: timing experiments, WRONG results): which part of a period costs what
+#ifndef G1D_X_NOEPI
+#define G1D_X_NOEPI 0
+#endif
+#ifndef G1D_X_NOSTORE
+#define G1D_X_NOSTORE 0
+#endif
+#ifndef G1D_X_NODMA
+#define G1D_X_NODMA 0
+#endif
+#ifndef G1D_X_NOMFMA
+#define G1D_X_NOMFMA 0
+#endif
+constexpr int G1D_PIECES_EARLY = 10;                             // per wavefront: issued by the half whose epilogue period comes FIRST (a whole period to land) ...
+constexpr int G1D_PIECES_LATE = G1D_PIECES / 4 - G1D_PIECES_EARLY;   // ... and by the half whose epilogue period ends at the barrier the tile is needed behind
+constexpr size_t gemm1_duo_lds_bytes() { return 2 * (size_t)G1D_TILE_BYTES + 4 * G1D_ITEMS * sizeof(float); }     // two tiles + four tiles' b' values (tile t + 2's
+                                                                                                                  // arrive while the second half still reads tile t's)
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p);
+// step I of a tile's contraction reads rows f_row and 32 + f_row (offset 4096) of slice I / 4 (8 KiB each), 16-byte chunk 2 (I % 4) + f_half
+template <int I>
+__device__ __forceinline__ void g1d_read(bf16x8 (&f)[2], const uint32_t (&va)[4]) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[0]) : "v"(va[I & 3]), "n"((I >> 2) * 8192));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[1]) : "v"(va[I & 3]), "n"((I >> 2) * 8192 + 4096));
+}
+template <int N>
+__device__ __forceinline__ void g1d_wait(bf16x8 (&f)[2]) {       // the MFMAs that take f are ordered behind the wait through its operands
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N));
+}
+template <int I>
+__device__ __forceinline__ void g1d_steps(f32x16 (&acc)[2], const bf16x8 (&zf)[32], bf16x8 (&fd)[3][2], const uint32_t (&va)[4]) {
+  if constexpr (I < 32) {
+    if constexpr (I + 2 < 32) g1d_read<I + 2>(fd[(I + 2) % 3], va);
+    g1d_wait<(I + 2 < 32) ? 4 : ((I + 1 < 32) ? 2 : 0)>(fd[I % 3]);     // LDS reads return in order: what was requested behind step I's pair may stay out
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[I], fd[I % 3][j], acc[j], 0, 0, 0);
+    g1d_steps<I + 1>(acc, zf, fd, va);
+  }
+}
+
 template <int LOSS>
 __global__ void __launch_bounds__(512)
-gemm1_loss_zreg_pipe_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf16* __restrict__ Db /* [Ip][512] */,
-                            const float* __restrict__ bp, __bf16* __restrict__ GT, uint32_t ldgt, uint32_t rows_live, uint32_t cols_live,
-                            uint32_t Ip, uint32_t user_tiles, uint32_t item_groups, uint32_t tiles_per_group) {
-  extern __shared__ __attribute__((aligned(1024))) char smemp[];
-  char* const img0 = smemp + G1P_STAGES * G1P_STAGE_BYTES;
-  char* const bias0 = img0 + 2 * G1P_ITEMS * G1P_IMG_RS;                 // [set][wavefront][64 items] floats: every wavefront keeps its own copy
+gemm1_loss_duo_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf16* __restrict__ Db /* [Ip][512] */,
+                      const float* __restrict__ bp, __bf16* __restrict__ GT, uint32_t ldgt, uint32_t rows_live, uint32_t cols_live,
+                      uint32_t Ip, uint32_t user_tiles, uint32_t item_groups, uint32_t tiles_per_group /* of 128 items */) {
+  extern __shared__ __attribute__((aligned(1024))) char smemd[];
   const uint32_t lane = threadIdx.x % WAVE, wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);      // 0..7
+  const uint32_t half = wid >> 2, hw = wid & 3u;                 // wavefronts w and w + 4 share a SIMD
   uint32_t ut, ig;
   {
     const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     ut = j % user_tiles; ig = (j / user_tiles) * 8u + xcd;
     if (ig >= item_groups) return;
   }
-  const uint32_t n_tiles_all = Ip / 128u;
-  const uint32_t t_begin = ig * tiles_per_group, t_end = min(n_tiles_all, t_begin + tiles_per_group);
+  const uint32_t n_tiles_all = Ip / (uint32_t)G1D_ITEMS;
+  const uint32_t t_begin = ig * tiles_per_group * 2u, t_end = min(n_tiles_all, t_begin + tiles_per_group * 2u);
   if (t_begin >= t_end) return;
-  const uint32_t H = (t_end - t_begin) * 2u, n_slices = H * 8u;          // half-tiles, slices
-  const uint32_t first_item = t_begin * 128u;
+  const uint32_t n_tiles = t_end - t_begin;
   const uint32_t u_tile = ut * 256u;
   const uint32_t f_row = lane & 31u, f_half = lane >> 5;
 
+  // this wavefront's 32 z rows: fragment kk = k in [16 kk, 16 kk + 16), lane holds the 8 of its half
   bf16x8 zf[32];
   {
     const __bf16* zr = Zb + (size_t)(u_tile + wid * 32u + f_row) * 512u + 8u * f_half;
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) zf[kk] = *reinterpret_cast<const bf16x8*>(zr + 16 * kk);
   }
-  // staging: slice sl = (half-tile, ks): wavefront w brings rows 8 w .. 8 w + 7 (one DMA instruction of 1 KiB)
-  const uint32_t st_r = wid * 8u + (lane >> 3), st_slot = lane & 7u;
-  const uint32_t st_col = 8u * (st_slot ^ ((st_r >> 1) & 7u));
-  auto stage = [&](uint32_t sl) {
-    const uint32_t item = first_item + (sl >> 3) * (uint32_t)G1P_ITEMS + st_r, ks = sl & 7u;
-    const __bf16* src = Db + (size_t)min(item, Ip - 1u) * 512u + ks * 64u + st_col;
+  // DMA piece c of a tile: slice c / 8, rows 8 (c % 8) .. + 8 (1 KiB); lane -> (row of the piece, 16-byte slot of its 128-byte line).
+  // Source address = a wave-uniform base (tile, piece) + a 32-bit lane offset that depends on the piece's parity only (the swizzle
+  // term (r >> 1) & 7 of row r = 8 (c % 8) + st_row is 4 (c & 1) + st_row / 2): one scalar add and the DMA per piece.  Tiles are whole
+  // (Ip is a multiple of 256 on this path): no row clamp.
+  const uint32_t st_row = lane >> 3, st_slot = lane & 7u;
+  uint32_t lane_off[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) lane_off[par] = st_row * 1024u + 16u * (st_slot ^ ((4u * par + (st_row >> 1)) & 7u));
+  auto stage_piece = [&](uint32_t tile /* workgroup-local */, uint32_t c /* wave-uniform */) {
+    const char* gbase = reinterpret_cast<const char*>(Db) + (size_t)(t_begin + tile) * (G1D_ITEMS * 1024u) + (c & 7u) * 8192u + (c >> 3) * 128u;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + lane_off[c & 1u]),
+                                     (__attribute__((address_space(3))) void*)(smemd + (tile & 1u) * G1D_TILE_BYTES + c * 1024u), 16, 0, 0);
+  };
+  uint32_t d_off[2], d_sw[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const uint32_t r = j * 32u + f_row; d_off[j] = r * 128u; d_sw[j] = (r >> 1) & 7u; }
+
+  // b' of a tile's 64 items: one 256-byte DMA (4 bytes per lane) beside the tile's pieces
+  auto stage_bias = [&](uint32_t tile) {
+    const float* src = bp + min((t_begin + tile) * (uint32_t)G1D_ITEMS + lane, cols_live - 1u);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(smemp + (sl % (uint32_t)G1P_STAGES) * G1P_STAGE_BYTES + wid * 1024u), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smemd + 2 * G1D_TILE_BYTES + (tile & 3u) * (G1D_ITEMS * 4)), 4, 0, 0);
   };
-  // b' of a half-tile's 64 items: one 4-byte-per-lane DMA instruction into this wavefront's own copy (no global load whose wait the
-  // compiler would place — it put vmcnt(0) in front of every use of a register loaded across the loop's back edge)
-  auto stage_bias = [&](uint32_t item_h, int set) {
-    const float* src = bp + min(item_h + lane, cols_live - 1u);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(bias0 + ((uint32_t)set * 8u + wid) * 256u), 4, 0, 0);
-  };
-  const uint32_t d_sw = (f_row >> 1) & 7u;
-  const uint32_t d_off0 = f_row * 128u, d_off1 = (32u + f_row) * 128u;
-  // bit 4 q + e: user u_tile + 32 wid + 8 q + 4 f_half + e of this lane's accumulator element is a live row of the block
-  uint32_t live_bits = 0;
+  // tile 0: everybody stages an eighth of it
 #pragma unroll
-  for (int i = 0; i < 16; ++i) live_bits |= (u_tile + wid * 32u + 8u * (uint32_t)(i >> 2) + 4u * f_half + (uint32_t)(i & 3) < rows_live ? 1u : 0u) << i;
+  for (int q = 0; q < G1D_PIECES / 8; ++q) stage_piece(0u, wid * (G1D_PIECES / 8) + q);
+  if (wid == 0u) stage_bias(0u);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0), as the builtin: the compiler's wait-count pass then knows the z loads above are complete
+  __builtin_amdgcn_s_barrier();
 
-  __builtin_amdgcn_s_waitcnt(0x0F70);                      // the z fragments have landed: the counted waits below start from zero
+  f32x16 acc[2];
+  const uint32_t n_periods = 2u * n_tiles + 1u;
+  for (uint32_t p = 0; p < n_periods; ++p) {
+    const uint32_t t = p >> 1;
+    if ((p & 1u) == half) {
+      // ---- contraction of tile t ----
+      if (t < n_tiles) {
+        const char* base = smemd + (t & 1u) * G1D_TILE_BYTES;
 #pragma unroll
-  for (int q = 0; q < G1P_AHEAD; ++q) if ((uint32_t)q < n_slices) stage((uint32_t)q);
-
-  f32x16 acc[2][2];                                        // [register set][item block of 32]
-
-  // the loss of one accumulator element, masked to +0 outside the live rows / items (bit masks: v * 0 would leave -0 for y < 0)
-  auto loss_bits = [&](float a, float b, uint32_t mask) -> float {
-    const float y = a + b;
-    const float v = LOSS == 0 ? 2.f * y : fast_rcp(1.f + fast_exp(-y));
-    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & mask);
-  };
-  // one row of a finished image -> G^T (wavefront w, slice ks: row 8 ks + w; 64 lanes x 8 bytes = the 256 users of this workgroup)
-  auto store_row = [&](const char* img, uint32_t item_base, int ks) {
-    const uint32_t row = (uint32_t)ks * 8u + wid;
-    const bf16x4 v = *reinterpret_cast<const bf16x4*>(img + row * G1P_IMG_RS + lane * 8u);
-    *reinterpret_cast<bf16x4*>(GT + (size_t)(item_base + row) * ldgt + u_tile + lane * 4u) = v;
-  };
-
-  // A step of half-tile h in register set CUR: wait for slice sl, barrier, request slice sl + AHEAD, then per 16-wide k step two
-  // fragment reads, two MFMAs and — in program order BETWEEN them, so that it issues while the matrix pipe works — one element of
-  // half-tile h - 1's epilogue group (set PRV, item block ks / 4, user group ks % 4); the group's 8 bytes go to the image, one row
-  // of half-tile h - 2's image goes to G^T.
-#define G1P_PHASE(CUR, PRV)                                                                                                           \
-  do {                                                                                                                                \
-    const uint32_t item_h = first_item + h * (uint32_t)G1P_ITEMS;                                                                     \
-    char* const img_prev = img0 + (PRV) * (G1P_ITEMS * G1P_IMG_RS);           /* half-tile h - 1 is written here */                  \
-    const char* const img_out = img0 + (CUR) * (G1P_ITEMS * G1P_IMG_RS);      /* half-tile h - 2 leaves from here */                 \
-    const bool do_epi = h >= 1u, do_store = h >= 2u;                                                                                  \
-    float bprev[2] = {0.f, 0.f};                                                                                                      \
-    uint32_t nmask[2] = {0u, 0u};                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[CUR][j][r] = 0.f;                \
-    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                                                \
-      const uint32_t sl = h * 8u + (uint32_t)ks;                                                                                      \
-      const uint32_t later = min((uint32_t)G1P_AHEAD - 1u, n_slices - 1u - sl);                                                       \
-      const uint32_t stores = sl > 16u ? min((uint32_t)G1P_AHEAD, sl - 16u) : 0u;                                                     \
-      wait_vmcnt_at_most(later + stores + ((ks >= 1 && ks <= 6) ? 1u : 0u));                                                          \
-      if (ks == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         /* the previous phase's image writes, before anyone reads them */ \
-      __builtin_amdgcn_s_barrier();                                                                                                   \
-      if (!G1P_X_NOSTAGE && sl + (uint32_t)G1P_AHEAD < n_slices) stage(sl + (uint32_t)G1P_AHEAD);                                     \
-      if (ks == 0) {                                                                                                                  \
-        stage_bias(item_h, CUR);                                                                                                      \
-        if (do_epi) {                                                                                                                 \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                             \
-            bprev[j] = *reinterpret_cast<const float*>(bias0 + ((uint32_t)(PRV) * 8u + wid) * 256u + ((uint32_t)j * 32u + f_row) * 4u); \
-            nmask[j] = item_h - (uint32_t)G1P_ITEMS + (uint32_t)j * 32u + f_row < cols_live ? 0xFFFFFFFFu : 0u;                       \
-          }                                                                                                                           \
-        }                                                                                                                             \
-      }                                                                                                                               \
-      const char* base = smemp + (sl % (uint32_t)G1P_STAGES) * G1P_STAGE_BYTES;                                                       \
-      /* the epilogue element of each 16-wide k step sits BETWEEN that step's MFMAs in program order.  (Measured, round 4: this  */    \
-      /* hides nothing — 1.17 ms against the whole-tile kernel's 1.15 at 1 M items x 1024 users, 0.52 ms with the epilogue and the */   \
-      /* stores compiled out; the two blocks in opposite order on the two wavefronts of a SIMD: 2.4 ms.  Kept as an A/B build.)    */   \
-      float g[4] = {0.f, 0.f, 0.f, 0.f};                                                                                              \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                                 \
-        const uint32_t c = ((2u * (uint32_t)s + f_half) ^ d_sw) << 4;                                                                 \
-        const bf16x8 fd0 = *reinterpret_cast<const bf16x8*>(base + d_off0 + c);                                                       \
-        const bf16x8 fd1 = *reinterpret_cast<const bf16x8*>(base + d_off1 + c);                                                       \
-        if (!G1P_X_NOMFMA) {                                                                                                          \
-          acc[CUR][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[ks * 4 + s], fd0, acc[CUR][0], 0, 0, 0);                           \
-          acc[CUR][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf[ks * 4 + s], fd1, acc[CUR][1], 0, 0, 0);                           \
-        } else { acc[CUR][0][s] += (float)fd0[0]; acc[CUR][1][s] += (float)fd1[0]; }                                                  \
-        if (!G1P_X_NOEPI) {                                                                                                           \
-          const uint32_t rmask = (uint32_t)((int32_t)(live_bits << (31 - (4 * (ks & 3) + s))) >> 31);                                 \
-          g[s] = loss_bits(acc[PRV][ks >> 2][4 * (ks & 3) + s], bprev[ks >> 2], nmask[ks >> 2] & rmask);                              \
-        }                                                                                                                             \
-      }                                                                                                                               \
-      if (do_epi && !G1P_X_NOEPI) {                                                                                                   \
-        const bf16x4 hb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};                                                   \
-        *reinterpret_cast<bf16x4*>(img_prev + ((uint32_t)(ks >> 2) * 32u + f_row) * G1P_IMG_RS +                                      \
-                                   (wid * 32u + 8u * (uint32_t)(ks & 3) + 4u * f_half) * 2u) = hb;                                    \
-      }                                                                                                                               \
-      if (do_store && !G1P_X_NOSTORE) store_row(img_out, item_h - 2u * (uint32_t)G1P_ITEMS, ks);                                      \
-    }                                                                                                                                 \
-  } while (0)
-
-  uint32_t h = 0;
-  for (; h + 1u < H; h += 2u) {
-    G1P_PHASE(0, 1);
-    ++h;
-    G1P_PHASE(1, 0);
-    --h;
-  }
-#undef G1P_PHASE
-  // H is even (tiles of 128 items = two half-tiles): the last half-tile H - 1 sits in set 1, H - 2's image (image 0) is complete
-  {
-    const uint32_t item_last = first_item + (H - 1u) * (uint32_t)G1P_ITEMS;
-    char* const img_a = img0;                                  // half-tile H - 2
-    char* const img_b = img0 + G1P_ITEMS * G1P_IMG_RS;         // half-tile H - 1 (half-tile H - 3 left from here during the last phase)
-    __builtin_amdgcn_s_waitcnt(0x0F70);                        // (the last bias row has landed)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                              // H - 2's image is complete; everyone is done reading H - 3's
-    float blast[2];
-    uint32_t nlast[2];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      blast[j] = *reinterpret_cast<const float*>(bias0 + (8u + wid) * 256u + ((uint32_t)j * 32u + f_row) * 4u);
-      nlast[j] = item_last + (uint32_t)j * 32u + f_row < cols_live ? 0xFFFFFFFFu : 0u;
-    }
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // 32 steps of 16 k; the fragments of step i + 2 are requested before the MFMAs of step i — two steps = 128 matrix-pipe cycles
+        // cover the LDS round trip (g1d_steps: asm reads and counted lgkmcnt waits; from the plain loop nest hipcc issued read pair ->
+        // lgkmcnt(0) -> two MFMAs, and with sched_barriers it still drained the queue every third step)
+        uint32_t va[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float g[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t rmask = (uint32_t)((int32_t)(live_bits << (31 - (4 * (c & 3) + e))) >> 31);
-        g[e] = loss_bits(acc[1][c >> 2][4 * (c & 3) + e], blast[c >> 2], nlast[c >> 2] & rmask);
+        for (int s4 = 0; s4 < 4; ++s4) va[s4] = lds_addr_of(base) + d_off[0] + (((2u * s4 + f_half) ^ d_sw[0]) << 4);
+        bf16x8 fd[3][2];
+        g1d_read<0>(fd[0], va);
+        g1d_read<1>(fd[1], va);
+        if (!G1D_X_NOMFMA) g1d_steps<0>(acc, zf, fd, va);
       }
-      const bf16x4 hb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
-      *reinterpret_cast<bf16x4*>(img_b + ((uint32_t)(c >> 2) * 32u + f_row) * G1P_IMG_RS + (wid * 32u + 8u * (uint32_t)(c & 3) + 4u * f_half) * 2u) = hb;
-      store_row(img_a, item_last - (uint32_t)G1P_ITEMS, c);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+      // this half's DMA pieces of the period before (the EARLY ones are needed behind this barrier) and its stores are a period old by
+      // now.  (No vector-memory LOAD into registers anywhere in the loop: the compiler's wait for one — vmcnt(0) — would also wait
+      // for the stores this wavefront issued just before the last barrier; b' comes through LDS with the tile.)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      // ---- epilogue of the tile this half contracted one period ago, and this wavefront's eighth of tile t + 1 ----
+      // p even: this is the second half and its tile is t - 1; p odd: the first half, tile t.  Tile t + 1's buffer was last read in
+      // period 2t - 1 (second half's contraction of t - 1): free in both.
+      const bool early = (p & 1u) == 0u;
+      const uint32_t et = early ? t - 1u : t;                    // (p == 0: no tile yet, wraps to 0xFFFFFFFF)
+      // tile t + 1's pieces: p even — the second half, a whole period before the tile is needed — issues G1D_PIECES_EARLY per wavefront,
+      // p odd — the first half — the rest, FIRST: they are needed behind this period's barrier
+      uint32_t n_dma = 0;
+      if (t + 1u < n_tiles && !G1D_X_NODMA) {
+        if (early) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) store_row(img_b, item_last, c);
+          for (int q = 0; q < G1D_PIECES_EARLY; ++q) stage_piece(t + 1u, hw * G1D_PIECES_EARLY + q);
+          if (hw == 0u) stage_bias(t + 1u);
+          n_dma = G1D_PIECES_EARLY;
+        } else {
+#pragma unroll
+          for (int q = 0; q < G1D_PIECES_LATE; ++q) stage_piece(t + 1u, 4u * G1D_PIECES_EARLY + hw * G1D_PIECES_LATE + q);
+          n_dma = G1D_PIECES_LATE;
+        }
+      }
+      const bool epi = et < n_tiles && !G1D_X_NOEPI;
+      const uint32_t item0 = (t_begin + (epi ? et : 0u)) * (uint32_t)G1D_ITEMS;
+      // lane = item item0 + 32 j + f_row, acc[j][4 q + e] = user u_tile + 32 wid + 8 q + 4 f_half + e.  A tile with all of its items and
+      // all of this wavefront's users live (every tile but the ragged edges) skips the masks: the epilogue's instruction count is
+      // what paces a period (measured: epilogue + stores alone 2670 cycles against the contraction's 2048)
+      const bool interior = item0 + (uint32_t)G1D_ITEMS <= cols_live && u_tile + wid * 32u + 32u <= rows_live;      // wave-uniform
+      uint4 out0, out1;                                          // bf16(g) of item row item0 + 32 j + f_row: this lane's two 16-byte pieces
+      auto pieces = [&](int j, auto masked) {
+        const float bias = *reinterpret_cast<const float*>(smemd + 2 * G1D_TILE_BYTES + (et & 3u) * (G1D_ITEMS * 4) + (j * 32u + f_row) * 4u);
+        const bool n_live = item0 + j * 32u + f_row < cols_live;
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t ul = wid * 32u + 8u * q + 4u * f_half;
+          float g[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = acc[j][4 * q + e] + bias;
+            const float v = LOSS == 0 ? 2.f * y : fast_rcp(1.f + fast_exp(-y));
+            g[e] = (!decltype(masked)::value || (n_live && u_tile + ul + e < rows_live)) ? v : 0.f;
+          }
+          const bf16x4 hb = {(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
+          pk[q] = __builtin_bit_cast(uint2, hb);
+        }
+        // v_permlane32_swap(a, b): a's upper 32 lanes <-> b's lower 32 lanes.  Lane (f_row, 0) holds users 8 q + 0..3, lane
+        // (f_row, 1) users 8 q + 4..7 of item f_row: after swapping (q0, q1) the lower lane holds all eight of q0, the upper of q1
+        {
+          const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+          out0 = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+        {
+          const auto sx = __builtin_amdgcn_permlane32_swap(pk[2].x, pk[3].x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(pk[2].y, pk[3].y, false, false);
+          out1 = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      };
+      auto flush = [&](int j) {                                  // this wavefront's 32 users of the item's row: 64 bytes, 32 of them from this lane pair
+        __bf16* grow = GT + (size_t)(item0 + j * 32u + f_row) * ldgt + u_tile + wid * 32u;
+        if (!G1D_X_NOSTORE || out0.x == 0x12345u) {
+          *reinterpret_cast<uint4*>(grow + 8u * f_half) = out0;
+          *reinterpret_cast<uint4*>(grow + 8u * (2u + f_half)) = out1;
+        }
+      };
+      if (epi) {
+        if (interior) pieces(0, std::false_type{}); else pieces(0, std::true_type{});
+        flush(0);
+        if (interior) pieces(1, std::false_type{}); else pieces(1, std::true_type{});
+        flush(1);
+      }
+      // The pieces went out first and VMEM completes in order: leaving the four stores (and nothing else) outstanding covers them.
+      // Measured at 1 M items x 1024 users (profiles/r05_gemm1_duo_anatomy.txt): 0.98 ms per launch with 10 + 6 pieces per wavefront and
+      // this wait in both halves; 1.06 with 16 + 0 and no wait at all — a wavefront whose DMA finds the CU's queue full stalls at the
+      // ISSUE, so the epilogue waits for the fill either way (the LDS-DMA path delivers ~16 bytes per clock and CU: the same 35-40 GB/s
+      // every staged kernel of this file ran into); 1.31 with the tile staged through registers (global_load_dwordx4 -> ds_write_b128,
+      // two rounds of four pieces under the epilogue's arithmetic: the ~1.2 us load latency is longer than the arithmetic that should
+      // cover it); 0.57 without staging, 0.42 without the epilogue (= the matrix-core floor), 0.78 without the G^T stores.
+      if (n_dma != 0u || !epi) {
+        if (!epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
   }
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // "TN" product for GEMM 2 of the K > 256 path:  C[m][n] = sum_c A[c][m] * Bm[c][n]  with BOTH operands stored contraction-row-major

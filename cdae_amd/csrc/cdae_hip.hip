@@ -226,8 +226,8 @@ struct cdae_hip {
   bool gemm_narrow = false;             // CDAE_GEMM_NARROW: never the 256 x 256-tile kernel (A/B switch)
   bool gemm1_tiled = false;             // CDAE_GEMM1_TILED: GEMM 1 as the 256 x 256-tile kernel where gemm1_loss_zreg_kernel would run (A/B switch)
   bool gemm1_zreg_attr_set[2] = {false, false};   // dynamic-LDS attribute of gemm1_loss_zreg_kernel<LOSS> set on this handle's device
-  bool gemm1_whole_tiles = true;        // false with CDAE_GEMM1_PIPE=1: gemm1_loss_zreg_pipe_kernel (half-tiles, epilogue issued between the MFMAs: bit-identical, measured 2 % slower) where gemm1_loss_zreg_kernel runs (A/B switch)
-  bool gemm1_pipe_attr_set[2] = {false, false};
+  bool gemm1_zreg = false;              // CDAE_GEMM1_ZREG: round 3's gemm1_loss_zreg_kernel (eight wavefronts in lockstep) where gemm1_loss_duo_kernel runs (A/B switch)
+  bool gemm1_duo_attr_set[2] = {false, false};
   bool fused_attr_set = false;          // dynamic-LDS attribute of this handle's full_decode_fused_kernel instance set (one K and loss per handle)
   bool gemm2_nt = false;                // CDAE_GEMM2_NT: hg = G D from G and D^T (gemm_nt_bf16_ldsw_kernel) where gemm_tn_bf16_kernel would read G^T and D (A/B switch)
   int gemm2_stages = 2;                 // CDAE_GEMM2_STAGES: LDS stages of gemm_tn_bf16_kernel (2 = 64-row stages; 3 / 4 = 32-row stages, measured no faster)
@@ -777,18 +777,18 @@ int full_products_k512(cdae_hip* h, hipStream_t st, cdae_hip::ExBuf& x, const Ba
     const uint32_t tiles_per_group = (n_tiles + item_groups - 1) / item_groups;
     const dim3 grid(8u * user_tiles * ((item_groups + 7u) / 8u));
     const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY;
-    if (!h->gemm1_whole_tiles) {
-      // round 4 experiment (CDAE_GEMM1_PIPE=1): half-tiles of 64 items in two accumulator sets, the loss epilogue of one issued between the MFMAs of the next
-      if (!h->gemm1_pipe_attr_set[ce]) {
-        if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_pipe_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_pipe_lds_bytes()));
-        else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_zreg_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_pipe_lds_bytes()));
-        h->gemm1_pipe_attr_set[ce] = true;
+    if (!h->gemm1_zreg) {
+      // round 5 default: the two wavefronts of a SIMD in opposite phases — one contracts while the other runs its loss epilogue (gemm1_loss_duo_kernel)
+      if (!h->gemm1_duo_attr_set[ce]) {
+        if (ce) HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_duo_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_duo_lds_bytes()));
+        else HIPCHK(hipFuncSetAttribute((const void*)gemm1_loss_duo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm1_duo_lds_bytes()));
+        h->gemm1_duo_attr_set[ce] = true;
       }
       if (ce)
-        hipLaunchKernelGGL(gemm1_loss_zreg_pipe_kernel<5>, grid, dim3(512), gemm1_pipe_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+        hipLaunchKernelGGL(gemm1_loss_duo_kernel<5>, grid, dim3(512), gemm1_duo_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
                            (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
       else
-        hipLaunchKernelGGL(gemm1_loss_zreg_pipe_kernel<0>, grid, dim3(512), gemm1_pipe_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
+        hipLaunchKernelGGL(gemm1_loss_duo_kernel<0>, grid, dim3(512), gemm1_duo_lds_bytes(), st, (const __bf16*)h->d_Zb, (const __bf16*)h->d_Db,
                            (const float*)h->P(CDAE_P_BP), h->d_GTb, Bp, nb, I, Ip, user_tiles, item_groups, tiles_per_group);
     } else {
     if (!h->gemm1_zreg_attr_set[ce]) {
@@ -1179,7 +1179,7 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   h->recommend_per_user = DEV_ENV("CDAE_RECOMMEND_PER_USER") != nullptr;
   h->full_bias_unsplit = DEV_ENV("CDAE_FULL_BIAS_UNSPLIT") != nullptr;
   if (const char* v = DEV_ENV("CDAE_FULL_ONE_STREAM_MAX")) h->full_one_stream_max = (uint32_t)std::strtoul(v, nullptr, 10);
-  h->gemm1_whole_tiles = DEV_ENV("CDAE_GEMM1_PIPE") == nullptr;
+  h->gemm1_zreg = DEV_ENV("CDAE_GEMM1_ZREG") != nullptr;
   h->debug_skip_prep = DEV_ENV("CDAE_DEBUG_SKIP_PREP") != nullptr;
   h->encode_two_launches = DEV_ENV("CDAE_ENCODE_TWO_LAUNCHES") != nullptr;
   h->full_separate_copies = DEV_ENV("CDAE_FULL_SEPARATE_COPIES") != nullptr;
@@ -1492,7 +1492,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
   // library sort + segment_kernel everywhere (the A/B side of the bit-equality tests).
   h->bucket_sort = false; h->bucket_ranges = 0; h->cell_units = 0;
   {
-    constexpr uint64_t BUCKET_MAX_EXAMPLES = 600000;
+    // full-output blocks list their positives only and are long (thousands of users).  There the one narrow launch is the wrong shape: its
+    // workgroups (1024 threads, 90 KB of LDS: a CU each) run ~130 us beside a fused decode whose grid wants every CU (ML-10M shape, 2048
+    // users per block: full_decode_fused_kernel 57 -> 93 us, step 0.203 -> 0.24 ms), and from ~300 K examples on it is longer than the
+    // block it prepares (4096 users: 0.43 ms against a 0.33 ms step).  Blocks above 100 K examples keep the library sort's short launches.
+    const uint64_t BUCKET_MAX_EXAMPLES = h->cfg.full_output ? 100000 : 600000;
     const uint64_t keys = I + (h->shard_sampled() ? 1u : 0u);
     if (keys <= 65536 && !h->counting_sort && !h->mf_seq && h->Ecap <= BUCKET_MAX_EXAMPLES && h->Ecap > 0 && !DEV_ENV("CDAE_SORT_LIBRARY")) {
       const double b_share = (double)B / (double)U;
@@ -1645,8 +1649,13 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     CHK(dev_alloc(&h->d_has_in, (size_t)h->Ip));
     HIPCHK(hipMemsetAsync(h->d_has_in, 0, (size_t)h->Ip, h->stream));
     {
-      h->bits_stride = (size_t)B * ((I + 31) / 32);
-      CHK(dev_alloc(&h->d_bits_train, cdae_hip::NSETS * h->bits_stride));     // one per example-buffer set
+      // the rated-items bitmap is read by the fused K <= 256 decode only (the K = 512 launches patch their positives in place:
+      // full_positive_fixup_kernel) — round 5: no longer built where nothing reads it (128 MB and ~1 ms of prep stream per
+      // 1024-user block at 1 M items)
+      if (h->Kp <= 256 && !h->full_unfused) {
+        h->bits_stride = (size_t)B * ((I + 31) / 32);
+        CHK(dev_alloc(&h->d_bits_train, cdae_hip::NSETS * h->bits_stride));     // one per example-buffer set
+      }
       // item slices of the fused decode: slices x Bp/128 workgroups ~ one per CU (measured best at B = 2048: 16 slices; every
       // slice adds a [B x Kp] partial of hg)
       const uint32_t tiles = h->Ip / (32 * cdae::FUSED_SUB), ublocks = h->Bp / 128;

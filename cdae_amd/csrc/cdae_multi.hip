@@ -387,6 +387,18 @@ StepPlan plan_of(const cdae_hip_multi* m, const std::vector<uint64_t>& first) {
   return p;
 }
 
+// which shard's error to report when several threads of a group came back with one: the first that is a CAUSE — the peers of a
+// failing shard return "a peer shard failed" once the group has been abandoned, and which of them has the lower index is chance
+int first_cause(const std::vector<int>& rc, const std::vector<std::string>& err) {
+  int any = -1;
+  for (size_t s = 0; s < rc.size(); ++s)
+    if (rc[s]) {
+      if (err[s].find("a peer shard failed") == std::string::npos) return (int)s;
+      if (any < 0) any = (int)s;
+    }
+  return any;
+}
+
 // the epoch of ONE shard that owns its device (RCCL group): runs on its own host thread
 int shard_epoch(cdae_hip_multi* m, size_t s, const StepPlan& pl, uint64_t seed, uint32_t epoch) {
   cdae_hip_t* h = m->shard[s];
@@ -535,11 +547,10 @@ int item_epoch(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t u_begi
         if (rc[s]) { err[s] = cdae_hip_last_error(); m->give_up(); }
       });
     for (std::thread& t : th) t.join();
-    for (size_t s = 0; s < S; ++s)
-      if (rc[s]) {
-        if (m->comm_aborted) m->abort_reason = err[s];
-        return fail("item shard %zu: %s", s, err[s].c_str());
-      }
+    if (const int s = first_cause(rc, err); s >= 0) {
+      if (m->comm_aborted) m->abort_reason = err[s];
+      return fail("item shard %d: %s", s, err[s].c_str());
+    }
     return 0;
   }
   for (cdae_hip_t* h : m->shard) CHK(cdae_internal::fs_prep(h, seed, epoch, plan[0].s0, plan[0].nb, plan[0].c));
@@ -834,11 +845,10 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
         xof(m->shard[s])->guard = nullptr;
       });
     for (std::thread& t : th) t.join();
-    for (size_t s = 0; s < S; ++s)
-      if (rc[s]) {
-        if (m->comm_aborted) { m->abort_reason = err[s]; for (cdae_hip_t* h : m->shard) xof(h)->comm = nullptr; }
-        return fail("shard %zu: %s", s, err[s].c_str());
-      }
+    if (const int s = first_cause(rc, err); s >= 0) {
+      if (m->comm_aborted) { m->abort_reason = err[s]; for (cdae_hip_t* h : m->shard) xof(h)->comm = nullptr; }
+      return fail("shard %d: %s", s, err[s].c_str());
+    }
   }
   if (stats) {
     *stats = relay_stats;

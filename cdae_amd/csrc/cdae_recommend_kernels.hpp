@@ -55,7 +55,13 @@ rated_bits_kernel(const int64_t* __restrict__ row_ptr, const uint32_t* __restric
     for (uint32_t i = lane; i < words; i += WAVE) out[i] = w[i];
     return;
   }
-  for (uint32_t i = lane; i < words; i += WAVE) out[i] = 0u;
+  {                                                                // 16-byte stores over the aligned middle of the row, words at its ends
+    const uint32_t head = min(words, (uint32_t)((16u - ((uintptr_t)out & 15u)) & 15u) / 4u), quads = (words - head) / 4u;
+    for (uint32_t i = lane; i < head; i += WAVE) out[i] = 0u;
+    uint4* o4 = reinterpret_cast<uint4*>(out + head);
+    for (uint32_t i = lane; i < quads; i += WAVE) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = head + 4u * quads + lane; i < words; i += WAVE) out[i] = 0u;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int64_t p = r0 + lane; p < r1; p += WAVE) {
     const uint32_t item = col[p];
