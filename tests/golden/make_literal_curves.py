@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--tag-suffix", default="",
                     help="appended to the schedule tag of the file name (`literal50` = the app's own horizon, Solver<CDAE>(model, 50), "
                          "/root/reference/apps/yelp/yelp.cpp:197: kept apart from the 5-epoch six-seed set the default accuracy test globs)")
+    ap.add_argument("--checkpoint", default="",
+                    help="directory for a resumable run: after every epoch the oracle's parameters and the curves so far are written there "
+                         "(fp64, ~1.5 GB at Netflix shape: not a fixture, keep it out of the repository) and a later run with the same "
+                         "arguments continues behind the last finished epoch — a 20-epoch Netflix-shape run is ~4.5 h of one core")
     args = ap.parse_args()
     if args.full_output_literal:
         args.full_output_batch = 1
@@ -88,7 +92,36 @@ def main():
                  train_seconds=np.array(secs), nnz_train=d.nnz_train, eval_users=ne, **probes)
         os.replace(tmp, os.path.join(OUT, name))      # a long run (50 epochs = hours of one core) leaves a usable prefix if it is cut short
 
-    for ep in range(args.epochs):
+    first = 0
+    ck = os.path.join(args.checkpoint, name[:-4]) if args.checkpoint else ""
+    if ck and os.path.exists(os.path.join(ck, "curves.npz")):
+        c = np.load(os.path.join(ck, "curves.npz"))
+        rec10, loss, data_loss, secs = list(c["recall10"]), list(c["train_loss"]), list(c["data_loss"]), list(c["train_seconds"])
+        metrics = [np.asarray(m) for m in c["topn"]]
+        for w in range(ob.P_COUNT):
+            f = os.path.join(ck, f"p{w}.npy")
+            if os.path.exists(f):
+                o.set(w, np.load(f))
+        first = len(rec10)
+        print(f"resuming behind epoch {first} from {ck}", flush=True)
+
+    def checkpoint():
+        if not ck:
+            return
+        os.makedirs(ck, exist_ok=True)
+        for w in range(ob.P_COUNT):
+            try:
+                a = o.get(w)
+            except Exception:
+                continue
+            if a is not None and a.size:
+                np.save(os.path.join(ck, f"p{w}.tmp.npy"), a)
+                os.replace(os.path.join(ck, f"p{w}.tmp.npy"), os.path.join(ck, f"p{w}.npy"))
+        np.savez(os.path.join(ck, "curves.tmp.npz"), recall10=np.array(rec10), train_loss=np.array(loss), data_loss=np.array(data_loss),
+                 topn=np.array(metrics), train_seconds=np.array(secs))
+        os.replace(os.path.join(ck, "curves.tmp.npz"), os.path.join(ck, "curves.npz"))     # written last: the parameters above belong to it
+
+    for ep in range(first, args.epochs):
         t0 = time.time()
         if args.full_output_batch:
             o.train_full(args.seed, ep, args.full_output_batch)
@@ -103,6 +136,7 @@ def main():
         metrics.append(m)
         rec10.append(m[5])
         save(ne)
+        checkpoint()
         print(f"[{args.shape} seed {args.seed}] epoch {ep + 1}: loss {loss[-1]:.1f} recall@10 {rec10[-1]:.5f} ({secs[-1]:.0f} s train)", flush=True)
     print("wrote", name)
 
