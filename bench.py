@@ -403,7 +403,7 @@ def main():
             ms_rows = acc["ms_input"] / max(1, acc["launches_decode"])
             fam = {
                 # GEMM 1 (forward + loss', z rows in registers: reads the bf16 image of D, writes G^T) + GEMM 2 (reads G^T and the image)
-                "decode": {"kernels": "gemm1_loss_zreg_kernel + full_positive_fixup_kernel + gemm_tn_bf16_kernel", "ms": ms_per_launch,
+                "decode": {"kernels": "gemm1_loss_duo_kernel + full_positive_fixup_kernel + gemm_tn_bf16_kernel", "ms": ms_per_launch,
                            "flops": 4.0 * K * I_ * users_per_launch, "bytes": 2.0 * (2.0 * I_ * Kp) + 2.0 * (2.0 * I_ * Bp_)},
                 # GEMM 3 + the row steps: D and D_ag read and written once (fp32), the bf16 image written, G^T read once
                 "rows": {"kernels": "gemm3_rows_fused_kernel + full_rows_inputs_kernel", "ms": ms_rows,

@@ -61,7 +61,7 @@ def main():
         name = f"{a.round}_decode_traffic.json"
     else:
         recs = {}
-        for k in ("gemm3_rows_fused_kernel", "gemm1_loss_zreg_kernel", "gemm_tn_bf16_kernel"):
+        for k in ("gemm3_rows_fused_kernel", "gemm1_loss_duo_kernel", "gemm_tn_bf16_kernel"):
             f, w = mean_of(a.fetch, k, "FETCH_SIZE"), mean_of(a.fetch, k, "WRITE_SIZE")
             recs[k] = {"fetch_size_kb_reported": f, "write_size_kb_reported": w, "bytes_per_launch": int((2.0 * f + w) * 1024), "avg_us": avg_us(a.stats, k)}
         out = {"_comment": f"HBM-side traffic per launch of the K > 256 full-output step's three big launches: separate rocprofv3 PMC passes of `python bench.py "
