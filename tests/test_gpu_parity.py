@@ -753,8 +753,8 @@ def test_tn_gemm2_changes_no_bit(built, monkeypatch, devlib):
 @pytest.mark.parametrize("loss", ["ce", "square"])
 def test_gemm1_zreg_changes_no_bit(built, monkeypatch, devlib, loss):
     """K = 512 full-output path: GEMM 1 with the z rows of 256 users in registers and only D staged through LDS — the round-5 default
-    gemm1_loss_duo_kernel (the two wavefronts of a SIMD in opposite phases, tiles staged through registers, 16-byte G^T stores through
-    v_permlane32_swap) and round 3's lockstep gemm1_loss_zreg_kernel (CDAE_GEMM1_ZREG=1) — against the
+    gemm1_loss_duo_kernel (the two wavefronts of a SIMD in opposite phases, whole tiles double-buffered by LDS DMA, 16-byte G^T stores
+    through v_permlane32_swap) and round 3's lockstep gemm1_loss_zreg_kernel (CDAE_GEMM1_ZREG=1) — against the
     256 x 256-tile kernel (CDAE_GEMM1_TILED=1).  Every G^T element is the same sum over k in the same order and the same loss
     expression: identical parameters after two epochs, three blocks each (the last one partly filled: users past the block's end and
     items past the last one are zero in G^T)."""
