@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--tag-suffix", default="",
                     help="appended to the schedule tag of the file name (`literal50` = the app's own horizon, Solver<CDAE>(model, 50), "
                          "/root/reference/apps/yelp/yelp.cpp:197: kept apart from the 5-epoch six-seed set the default accuracy test globs)")
+    ap.add_argument("--out-dir", default="",
+                    help="write the fixture here instead of tests/golden (a long run saves after every epoch: a file that is still short of "
+                         "what a test expects does not belong where the tests glob — copy it over when it is complete)")
     ap.add_argument("--checkpoint", default="",
                     help="directory for a resumable run: after every epoch the oracle's parameters and the curves so far are written there "
                          "(fp64, ~1.5 GB at Netflix shape: not a fixture, keep it out of the repository) and a later run with the same "
@@ -85,12 +88,14 @@ def main():
                       W_rows=o.get(ob.P_W).reshape(d.num_items, K)[probe_items], bp_rows=o.get(ob.P_BP)[probe_items],
                       Wu_rows=o.get(ob.P_WU).reshape(d.num_users, K)[probe_users], b=o.get(ob.P_B),
                       W_absmax=np.abs(o.get(ob.P_W)).max(), Wu_absmax=np.abs(o.get(ob.P_WU)).max(), bp_absmax=np.abs(o.get(ob.P_BP)).max())
-        tmp = os.path.join(OUT, name + ".tmp.npz")
+        out_dir = args.out_dir or OUT
+        os.makedirs(out_dir, exist_ok=True)
+        tmp = os.path.join(out_dir, name + ".tmp.npz")
         np.savez(tmp, shape=args.shape, seed=args.seed, data_seed=data_seed, num_dim=args.num_dim, loss=args.loss,
                  full_output_batch=args.full_output_batch, hyper=np.array(sorted(HYPER.items()), dtype=object).astype(str),
                  recall10=np.array(rec10), train_loss=np.array(loss), data_loss=np.array(data_loss), topn=np.array(metrics),
                  train_seconds=np.array(secs), nnz_train=d.nnz_train, eval_users=ne, **probes)
-        os.replace(tmp, os.path.join(OUT, name))      # a long run (50 epochs = hours of one core) leaves a usable prefix if it is cut short
+        os.replace(tmp, os.path.join(out_dir, name))  # a long run (50 epochs = hours of one core) leaves a usable prefix if it is cut short
 
     first = 0
     ck = os.path.join(args.checkpoint, name[:-4]) if args.checkpoint else ""
