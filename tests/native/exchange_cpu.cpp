@@ -16,6 +16,16 @@ void xa_pipe(int mode, float* cur, float* base, float* snap, float* send, float*
   }
 }
 
+// the same pass under the global-accumulator combine rule, over a (parameter, accumulator) pair of n floats each (delta_pipe_pair_kernel)
+void xa_pipe_pair(int mode, float* cp, float* ca, float* Ap, float* Aa, float* snp, float* sna, float* sp, float* sa, float* rp, float* ra,
+                  float beta, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    if (mode == cdae_xa::STAGE) cdae_xa::pipe_pair<cdae_xa::STAGE>(cp[i], ca[i], Ap[i], Aa[i], snp[i], sna[i], sp[i], sa[i], rp[i], ra[i], beta);
+    else if (mode == cdae_xa::MERGE) cdae_xa::pipe_pair<cdae_xa::MERGE>(cp[i], ca[i], Ap[i], Aa[i], snp[i], sna[i], sp[i], sa[i], rp[i], ra[i], beta);
+    else cdae_xa::pipe_pair<cdae_xa::MERGE_STAGE>(cp[i], ca[i], Ap[i], Aa[i], snp[i], sna[i], sp[i], sa[i], rp[i], ra[i], beta);
+  }
+}
+
 // own_rows_stage_kernel: rows of users [u0, u0 + n) from a table that starts at user own_u0, zeros for users owned elsewhere
 void xa_stage_own_rows(const float* table, uint64_t own_u0, uint64_t own_u1, uint64_t u0, uint32_t n, uint32_t width, float* out) {
   for (uint32_t s = 0; s < n; ++s) {

@@ -46,6 +46,7 @@ def load_slice():
     lib = C.CDLL(build_slice())
     fp, vp = C.POINTER(C.c_float), C.c_void_p
     lib.xa_pipe.argtypes = [C.c_int, fp, fp, fp, fp, fp, C.c_size_t]
+    lib.xa_pipe_pair.argtypes = [C.c_int] + [fp] * 10 + [C.c_float, C.c_size_t]
     lib.xa_stage_own_rows.argtypes = [fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, fp]
     lib.xa_balanced_cuts.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, vp]
     return lib
@@ -67,6 +68,12 @@ class Replica:
         self.recv = np.zeros_like(init)
 
     def apply(self, mode):
+        if getattr(self, "pairs", None):               # global-accumulator combine rule: (parameter, accumulator) regions of the block
+            for p0, a0, n in self.pairs:
+                v = lambda arr, o: fptr(arr[o:o + n])
+                self.lib.xa_pipe_pair(mode, v(self.cur, p0), v(self.cur, a0), v(self.base, p0), v(self.base, a0), v(self.snap, p0), v(self.snap, a0),
+                                      v(self.send, p0), v(self.send, a0), v(self.recv, p0), v(self.recv, a0), self.beta, n)
+            return
         self.lib.xa_pipe(mode, fptr(self.cur), fptr(self.base), fptr(self.snap), fptr(self.send), fptr(self.recv), self.cur.size)
 
 
@@ -202,12 +209,18 @@ def _block_into(o, blk):
         off += n
 
 
-def run_training_schedule(lib, d, world, period, B, all_reduce, rank=None, epochs=2, seed=9):
+def run_training_schedule(lib, d, world, period, B, all_reduce, rank=None, epochs=2, seed=9, global_acc=False):
     """cdae_multi.hip shard_epoch / step_single with the oracle as the shard's training step; rank None: every rank in one process"""
     ranks = [rank] if rank is not None else list(range(world))
     cuts = [shard_bounds(d.num_users, world, r, d.train_ptr) for r in range(world)]
     orcs = {r: _oracle_for(d, seed) for r in ranks}                      # identical shared parameters everywhere; Wu rows by global user id
     reps = {r: Replica(lib, _block_of(orcs[r])) for r in ranks}
+    if global_acc:                                                       # CDAE_COMBINE_GLOBAL_ACC: the block is three (parameter, accumulator) pairs
+        sizes = [orcs[ranks[0]].get(w).size for w in _shared_ids()]
+        offs = np.r_[0, np.cumsum(sizes)]
+        for rep in reps.values():
+            rep.pairs = [(int(offs[i]), int(offs[i + 1]), int(sizes[i])) for i in (0, 2, 4)]
+            rep.beta = 1.0
     for rep in reps.values():
         rep.apply(STAGE)
     pending, n = False, 0
@@ -244,7 +257,7 @@ def run_training_schedule(lib, d, world, period, B, all_reduce, rank=None, epoch
     return reps, orcs
 
 
-def _rank_training(rank, world, port, period, out_dir):
+def _rank_training(rank, world, port, period, out_dir, global_acc=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -254,7 +267,7 @@ def _rank_training(rank, world, port, period, out_dir):
     def all_reduce(reps):
         dist.all_reduce(torch.from_numpy(reps[rank].recv), op=dist.ReduceOp.SUM)
 
-    reps, orcs = run_training_schedule(lib, d, world, period, 16, all_reduce, rank=rank)
+    reps, orcs = run_training_schedule(lib, d, world, period, 16, all_reduce, rank=rank, global_acc=global_acc)
     from oracle import binding as ob
     u0, u1 = shard_bounds(d.num_users, world, rank, d.train_ptr)
     K = 8
@@ -262,8 +275,8 @@ def _rank_training(rank, world, port, period, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("period", [0, 2])
-def test_two_rank_gloo_exchange_around_real_training_steps(tmp_path, period):
+@pytest.mark.parametrize("period,global_acc", [(0, False), (2, False), (0, True)])
+def test_two_rank_gloo_exchange_around_real_training_steps(tmp_path, period, global_acc):
     """two gloo ranks, each training ITS users with the oracle's batched schedule and exchanging the shared block through the shipped
     algebra: replicas bit-identical after every epoch's flush, equal to the one-process restatement, every private Wu row trained by
     its owner only — and the merged model is a trained one: its reported loss over ALL users and its Recall@10 are where one process
@@ -271,7 +284,7 @@ def test_two_rank_gloo_exchange_around_real_training_steps(tmp_path, period):
     import oracle as orc
     from oracle import binding as ob
     world = 2
-    mp.spawn(_rank_training, args=(world, _free_port(), period, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_training, args=(world, _free_port(), period, str(tmp_path), global_acc), nprocs=world, join=True)
     got = [np.load(tmp_path / f"train_{r}.npz") for r in range(world)]
     np.testing.assert_array_equal(got[0]["cur"], got[1]["cur"])
     lib = load_slice()
@@ -282,7 +295,7 @@ def test_two_rank_gloo_exchange_around_real_training_steps(tmp_path, period):
         for rep in reps.values():
             rep.recv[:] = total
 
-    ref, ref_orcs = run_training_schedule(lib, d, world, period, 16, local_sum)
+    ref, ref_orcs = run_training_schedule(lib, d, world, period, 16, local_sum, global_acc=global_acc)
     K = 8
     for r in range(world):
         np.testing.assert_array_equal(got[r]["cur"], ref[r].cur)
@@ -303,7 +316,7 @@ def test_two_rank_gloo_exchange_around_real_training_steps(tmp_path, period):
     for ep in range(2):
         single.train_batched(9, ep, 32)                                  # one replica, 32 users per snapshot = the two ranks' 16 + 16
     l0, lm, ls = init.data_loss(9, 0), merged.data_loss(9, 0), single.data_loss(9, 0)
-    print(f"\nperiod {period}: data loss initial {l0:.2f}, two exchanged shards {lm:.2f}, one replica {ls:.2f}")
+    print(f"\nperiod {period}, global-accumulator rule {global_acc}: data loss initial {l0:.2f}, two exchanged shards {lm:.2f}, one replica {ls:.2f}")
     # (the reported loss counts the positives only, cdae.hpp:78-101: with three negatives per positive it RISES over the first epochs)
     assert abs(lm / l0 - 1.0) > 0.2                                      # the exchanged model has moved a long way from its initial values ...
     assert abs(lm / ls - 1.0) < 0.10                                     # ... to where a single replica gets (measured 1.9 % synchronous, 6.8 % pipelined: the schedules differ, not the model)
