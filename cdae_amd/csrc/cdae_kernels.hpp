@@ -1407,76 +1407,85 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   float acc[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) acc[i] = 0.f;
-  #ifndef CDAE_GATHER_UN
-#define CDAE_GATHER_UN 12
-#endif
-  // rows in flight per trip: a 64-example chunk holds 8 +- 2.6 rows of this partition, so 12 covers a chunk in one L2 round trip
-  // 19 times in 20 (with 8, every other chunk took a second trip for one or two rows)
-  constexpr int UN = CDAE_GATHER_UN;
-  // this lane's (item, g, correction row) of a 64-example chunk; the next chunk is loaded before the current one's rows
-  // are gathered, so a wavefront pays one L2 round trip per chunk, not two
-  auto load_chunk = [&](uint32_t c, uint32_t& item, float& g, uint32_t& di) {
-    const uint32_t v = c + lane;
-    const uint32_t e = v < n_posu ? p0 + v : neg0 + (v - n_posu);
-    const bool in = v < n_ex;
-    item = in ? ex_item[base + e] : 0xFFFFFFFFu;
-    g = in ? G[base + e] : 0.f;
-    di = in ? dup_of_ex[base + e] : DUP_NONE;
+  // Round 5.  Through round 4 a wavefront walked its 64-example chunks one L2 round trip at a time — ballot, up to 12 row loads, wait, FMA —
+  // and the launch moved its ~140 MB of rows at 7-9 TB/s, which was taken for the L2s' limit.  It is not: tools/l2_delivery.hip gathers
+  // random 1 KiB rows out of an XCD-resident region at 30-32 TB/s once 8+ wavefronts per CU keep 8+ rows in flight each
+  // (profiles/r05_l2_delivery.txt).  So the walk is now in two steps: the chunk's rows of this partition (and its duplicate
+  // corrections, rare) are COMPACTED into a per-wavefront LDS list in the order the old loop added them — corrections of a chunk in
+  // lane order, then its rows in lane order — and the list is drained 2 x UN rows per trip, all of a trip's loads issued before the
+  // first FMA.  Same additions in the same order: the partial rows are bit-identical to round 4's.
+  constexpr int TRIP = NI >= 8 ? 4 : 8;                          // rows in flight per trip (registers: TRIP x NI floats; the whole launch must be resident: <= 96 registers)
+  constexpr uint32_t GCAP = 512;                                 // list entries per wavefront; a 128-example step adds at most 256
+  constexpr uint32_t DUP_ROW = 0x80000000u;                      // list entry: a row of dup_corr (added as it is) instead of D0 (times g)
+  __shared__ uint32_t gl_row[4][GCAP];
+  __shared__ float gl_g[4][GCAP];
+  uint32_t* const lrow = gl_row[threadIdx.x / WAVE];
+  float* const lg = gl_g[threadIdx.x / WAVE];
+  // this lane's (item, g, correction row) of two consecutive 64-example chunks; the next pair is requested before this one is compacted
+  struct Meta { uint32_t item[2], di[2]; float g[2]; };
+  auto load_meta = [&](uint32_t c, uint32_t c_end, Meta& m) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const uint32_t v = c + (uint32_t)h2 * WAVE + lane;
+      const uint32_t e = v < n_posu ? p0 + v : neg0 + (v - n_posu);
+      const bool in = v < c_end;
+      m.item[h2] = in ? ex_item[base + e] : 0xFFFFFFFFu;
+      m.g[h2] = in ? G[base + e] : 0.f;
+      m.di[h2] = in ? dup_of_ex[base + e] : DUP_NONE;
+    }
   };
-  // `halves` = 2: two wavefronts share a (unit, partition), each walking half of its 64-example chunks (9 -> 6 dependent round
-  // trips per wavefront, twice the partial sums).  Measured SLOWER (step 0.0935 -> 0.0973 ms at 256 users, 0.140 -> 0.145 at 512):
-  // the launch moves ~140 MB of rows out of L2 in ~15 us and is bound by that, not by the wavefronts' chains; default 1.
+  uint32_t head = 0, len = 0;                                    // list entries [head, len) are waiting (wave-uniform)
+  auto trip = [&](uint32_t n_rows) {                             // the next n_rows <= TRIP entries: every load issued, then the FMAs in list order
+    float vv[TRIP][NI], gg[TRIP];
+#pragma unroll
+    for (int t = 0; t < TRIP; ++t) {
+      if ((uint32_t)t < n_rows) {                                // wave-uniform
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lrow[head + t]);
+        gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lg[head + t])));
+        const float* src = (e & DUP_ROW) ? dup_corr : D0;
+        vload<NI>(vv[t], src + (size_t)(e & ~DUP_ROW) * hp.Kp + lo_ld);
+      } else {
+        gg[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) vv[t][k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TRIP; ++t)
+#pragma unroll
+      for (int k = 0; k < NI; ++k) acc[k] = fmaf(gg[t], vv[t][k], acc[k]);          // (a correction row: g = 1, i.e. acc + row exactly)
+    head += n_rows;
+  };
+  // `halves` = 2: two wavefronts share a (unit, partition), each walking half of its 64-example chunks; measured slower in round 2
+  // (twice the partial sums); default 1.
   const uint32_t chunks_per = ((n_ex + WAVE - 1) / WAVE + halves - 1) / halves;
   const uint32_t c_begin = half * chunks_per * WAVE, c_end = min(n_ex, c_begin + chunks_per * WAVE);
-  uint32_t my_item, my_di, nx_item = 0xFFFFFFFFu, nx_di = DUP_NONE;
-  float my_g, nx_g = 0.f;
-  load_chunk(c_begin, my_item, my_g, my_di);
-  for (uint32_t c0 = c_begin; c0 < c_end; c0 += WAVE) {
-    if (c0 + WAVE < c_end) load_chunk(c0 + WAVE, nx_item, nx_g, nx_di);
-    const bool mine = my_item < hp.num_items && (my_item & 7u) == part;      // (fillers are 0xFFFFFFFF, an item shard's VOID examples num_items)
-    unsigned long long mask = __ballot(mine);
-    // duplicate negatives (rare): add decode's correction rows, in example order
-    unsigned long long dmask = __ballot(mine && my_di != DUP_NONE);
-    while (dmask) {
-      float cr[UN][NI];
+  Meta cur, nxt;
+  load_meta(c_begin, c_end, cur);
+  for (uint32_t c0 = c_begin; c0 < c_end; c0 += 2 * WAVE) {
+    load_meta(c0 + 2 * WAVE, c_end, nxt);                        // (past the end: fillers, no loads)
+    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-      for (int t = 0; t < UN; ++t) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) cr[t][i] = 0.f;
-        if (dmask) {                                           // wave-uniform
-          const int src = __ffsll((long long)dmask) - 1;
-          dmask &= dmask - 1;
-          vload<NI>(cr[t], dup_corr + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_di, src) * hp.Kp + lo_ld);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < UN; ++t)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] += cr[t][i];
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const bool mine = cur.item[h2] < hp.num_items && (cur.item[h2] & 7u) == part;      // (fillers are 0xFFFFFFFF, an item shard's VOID examples num_items)
+      const bool dup = mine && cur.di[h2] != DUP_NONE;           // duplicate negatives (rare): decode's correction rows, in example order
+      const unsigned long long mask = __ballot(mine), dmask = __ballot(dup);
+      const uint32_t n_d = (uint32_t)__popcll(dmask), n_r = (uint32_t)__popcll(mask);
+      if (dup) { const uint32_t k = len + (uint32_t)__popcll(dmask & below); lrow[k] = cur.di[h2] | DUP_ROW; lg[k] = 1.f; }
+      if (mine) { const uint32_t k = len + n_d + (uint32_t)__popcll(mask & below); lrow[k] = cur.item[h2]; lg[k] = cur.g[h2]; }
+      len += n_d + n_r;
     }
-    while (mask) {
-      float vv[UN][NI], gg[UN];
-#pragma unroll
-      for (int t = 0; t < UN; ++t) {
-        if (mask) {                                            // wave-uniform
-          const int src = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)my_item, src);
-          gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_g), src));
-          vload<NI>(vv[t], D0 + (size_t)it * hp.Kp + lo_ld);
-        } else {
-          gg[t] = 0.f;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) vv[t][i] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < UN; ++t)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] = fmaf(gg[t], vv[t][i], acc[i]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the wavefront's own LDS writes, in order)
+    __builtin_amdgcn_wave_barrier();
+    // full trips go out now — their loads fly while the next pair's (item, g) are still on their way; the remainder waits for more
+    const bool last = c0 + 2 * WAVE >= c_end;
+    while (len - head >= (uint32_t)TRIP) trip((uint32_t)TRIP);
+    if (last || len + 4u * WAVE > GCAP) {
+      if (len > head) trip(len - head);
+      head = 0; len = 0;
+      __builtin_amdgcn_wave_barrier();
     }
-    my_item = nx_item; my_g = nx_g; my_di = nx_di;
-    nx_item = 0xFFFFFFFFu; nx_g = 0.f; nx_di = DUP_NONE;
+    cur = nxt;
   }
   if (lo >= hp.K) {
 #pragma unroll
