@@ -1049,8 +1049,10 @@ gemm1_loss_duo_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf1
       // all of this wavefront's users live (every tile but the ragged edges) skips the masks: the epilogue's instruction count is
       // what paces a period (measured: epilogue + stores alone 2670 cycles against the contraction's 2048)
       const bool interior = item0 + (uint32_t)G1D_ITEMS <= cols_live && u_tile + wid * 32u + 32u <= rows_live;      // wave-uniform
-      uint4 out0, out1;                                          // bf16(g) of item row item0 + 32 j + f_row: this lane's two 16-byte pieces
+      uint4 outs[2][2];                                          // [j][piece]: bf16(g) of item row item0 + 32 j + f_row, this lane's two 16-byte pieces
       auto pieces = [&](int j, auto masked) {
+        uint4& out0 = outs[j][0];
+        uint4& out1 = outs[j][1];
         const float bias = *reinterpret_cast<const float*>(smemd + 2 * G1D_TILE_BYTES + (et & 3u) * (G1D_ITEMS * 4) + (j * 32u + f_row) * 4u);
         const bool n_live = item0 + j * 32u + f_row < cols_live;
         uint2 pk[4];
@@ -1082,28 +1084,25 @@ gemm1_loss_duo_kernel(const __bf16* __restrict__ Zb /* [Bp][512] */, const __bf1
       };
       auto flush = [&](int j) {                                  // this wavefront's 32 users of the item's row: 64 bytes, 32 of them from this lane pair
         __bf16* grow = GT + (size_t)(item0 + j * 32u + f_row) * ldgt + u_tile + wid * 32u;
-        if (!G1D_X_NOSTORE || out0.x == 0x12345u) {
-          *reinterpret_cast<uint4*>(grow + 8u * f_half) = out0;
-          *reinterpret_cast<uint4*>(grow + 8u * (2u + f_half)) = out1;
+        if (!G1D_X_NOSTORE || outs[j][0].x == 0x12345u) {
+          *reinterpret_cast<uint4*>(grow + 8u * f_half) = outs[j][0];
+          *reinterpret_cast<uint4*>(grow + 8u * (2u + f_half)) = outs[j][1];
         }
       };
       if (epi) {
-        if (interior) pieces(0, std::false_type{}); else pieces(0, std::true_type{});
-        flush(0);
-        if (interior) pieces(1, std::false_type{}); else pieces(1, std::true_type{});
-        flush(1);
+        if (interior) { pieces(0, std::false_type{}); pieces(1, std::false_type{}); }
+        else { pieces(0, std::true_type{}); pieces(1, std::true_type{}); }
       }
-      // The pieces went out first and VMEM completes in order: leaving the four stores (and nothing else) outstanding covers them.
-      // Measured at 1 M items x 1024 users (profiles/r05_gemm1_duo_anatomy.txt): 0.98 ms per launch with 10 + 6 pieces per wavefront and
-      // this wait in both halves; 1.06 with 16 + 0 and no wait at all — a wavefront whose DMA finds the CU's queue full stalls at the
-      // ISSUE, so the epilogue waits for the fill either way (the LDS-DMA path delivers ~16 bytes per clock and CU: the same 35-40 GB/s
-      // every staged kernel of this file ran into); 1.31 with the tile staged through registers (global_load_dwordx4 -> ds_write_b128,
-      // two rounds of four pieces under the epilogue's arithmetic: the ~1.2 us load latency is longer than the arithmetic that should
-      // cover it); 0.57 without staging, 0.42 without the epilogue (= the matrix-core floor), 0.78 without the G^T stores.
-      if (n_dma != 0u || !epi) {
-        if (!epi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      }
+      // LATE pieces must have landed behind this barrier: they are waited for EXACTLY — vmcnt(0) while they are the only vector-memory
+      // operations this wavefront has outstanding (its previous stores are two periods old) — and the G^T stores go out behind the
+      // wait, so nothing here depends on loads and stores completing in order with each other.  EARLY pieces are waited for by the
+      // vmcnt(0) at the end of this wavefront's next contraction.  Measured at 1 M items x 1024 users
+      // (profiles/r05_gemm1_duo_anatomy.txt): 0.98-1.04 ms per launch with 10 + 6 pieces per wavefront; 1.06 with 16 + 0 and no wait at
+      // all — a wavefront whose DMA finds the CU's queue full stalls at the ISSUE, so the epilogue waits for the fill either way;
+      // 1.31 with the tile staged through registers; 0.57 without staging, 0.42 without the epilogue (= the matrix-core floor), 0.78
+      // without the G^T stores.
+      if (!early && n_dma != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (epi) { flush(0); flush(1); }
       __builtin_amdgcn_s_barrier();
     }
   }
