@@ -195,7 +195,7 @@ def test_netflix_relay_then_exchange_schedule_on_eight_shards(built):
 
 # ---- a longer horizon at Netflix shape: one seed of the literal schedule beyond the three epochs of the fixtures above ---------------------
 # `netflix_k200_ce_literal20_seed*.npz` (make_literal_curves.py --epochs 20 --tag-suffix 20: an epoch of the fp64 loop + its top-10 of
-# 60 000 users is ~1.4 h of one core here, so the file holds as many epochs as the round had time for — the generator saves after each).
+# 60 000 users is ~15 min of one core here; the run is resumable: --checkpoint).
 LONG = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "netflix_k200_ce_literal20_seed*.npz")))
 
 
