@@ -68,6 +68,7 @@ EXPORTS = {
     "cdae_hip_mf_default_batch_users": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "cdae_hip_batch_users": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_full_output_plan": (C.c_uint32, [C.c_void_p]),
+    "cdae_hip_decode_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cdae_hip_user_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_user_id_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
     "cdae_hip_init_params": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -264,6 +265,13 @@ class CDAE:
     def batch_users(self) -> int:
         """users per parameter snapshot the handle is using (the library's choice when the config asked for 0)"""
         return int(self.lib.cdae_hip_batch_users(self.h))
+
+    @property
+    def decode_plan(self) -> dict:
+        """{hot_rows, late_rows, fused} of the sampled step (include/cdae_hip.h cdae_hip_decode_plan)"""
+        a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _chk(self.lib, self.lib.cdae_hip_decode_plan(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(hot_rows=int(a.value), late_rows=int(b.value), fused=bool(c.value))
 
     @property
     def full_output_plan(self) -> int:

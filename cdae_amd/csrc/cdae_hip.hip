@@ -96,6 +96,18 @@ struct cdae_hip {
   uint32_t* d_col = nullptr;
   uint32_t* d_item_order = nullptr;
   uint32_t hot_rows = 0;            // decode: rows [0, hot_rows) of item_order get a wavefront of their own
+  // late rows (cdae_kernels.hpp DecodeLate): the first late_rows of them leave their hidden-gradient terms to hidden_finish_kernel
+  uint32_t late_rows = 0;
+  float* d_Ghot = nullptr;          // [B][LATE_MAX]
+  uint32_t* d_hotdup = nullptr;     // [B][LATE_MAX]
+  uint32_t* d_late_bits = nullptr;  // [(I + 31) / 32] bitmap of the late rows' items
+  uint32_t late_words = 0;
+  bool fused_decode = false;        // decode + gather as ONE launch (decode_gather_kernel); CDAE_DECODE_UNFUSED turns it off (developer switch)
+  bool fused_attr_decode = false;   // its dynamic-LDS attribute has been set on this handle's device
+  uint32_t* d_fused_err = nullptr;  // raised by a gather wavefront of the fused launch that gave up waiting (checked at cdae_hip_synchronize)
+  uint32_t num_cus = 256;
+  cdae::DecodeLate decode_late() const { return cdae::DecodeLate{d_Ghot, d_hotdup, late_rows}; }
+  cdae::LateFinish late_finish() { return cdae::LateFinish{d_Ghot, d_hotdup, d_item_order, d_D0, d_dup_corr, late_rows}; }
   // developer switches, read once in cdae_hip_create (DESIGN.md lists them)
   bool one_row_per_wave = false;    // CDAE_DECODE_ONE_ROW_PER_WAVE: every row on the 64-lane decode path
   bool full_unfused = false;        // CDAE_FULL_UNFUSED: full-output decode as three separate GEMMs
@@ -320,6 +332,19 @@ int join_aux(cdae_hip* h) {
   return 0;
 }
 
+// After the main stream has been synchronised: did a gather wavefront of a fused launch (decode_gather_kernel) give up waiting?
+int fused_check(cdae_hip* h) {
+  if (!h->fused_decode || !h->d_fused_err) return 0;
+  uint32_t err = 0;
+  HIPCHK(hipMemcpy(&err, h->d_fused_err, sizeof err, hipMemcpyDeviceToHost));
+  if (err) {
+    HIPCHK(hipMemset(h->d_fused_err, 0, sizeof err));
+    return fail("fused decode + gather launch: a gather wavefront gave up waiting for its g (workgroups not dispatched in index order?); "
+                "the parameters of this handle are no longer valid");
+  }
+  return 0;
+}
+
 // Events between the library's own streams order work on ONE device: they need no system-scope fence.  A default HIP event
 // writes back and invalidates the caches when it is recorded — measured here as ~14 us of idle main stream per batch around
 // the `released` record and ~3 us at the `ready` wait (profiles/r02_wave_timeline_256.txt: 86 us of kernels in a 100 us step).
@@ -386,7 +411,8 @@ void free_all(cdae_hip* h) {
                   h->d_sort_tmp, h->d_Z, h->d_Dz, h->d_HG, h->d_G, h->d_touched, h->d_scalar, h->d_uids, h->d_rec,
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
-                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut, h->d_range_of};
+                  h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut, h->d_range_of,
+                  h->d_Ghot, h->d_hotdup, h->d_late_bits, h->d_fused_err};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -427,7 +453,8 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Uu, (void**)&h->d_Uu_ag, (void**)&h->d_Ssum, (void**)&h->d_delta_rows, (void**)&h->d_score,
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
                    (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
-                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut, (void**)&h->d_range_of};
+                   (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut, (void**)&h->d_range_of,
+                   (void**)&h->d_Ghot, (void**)&h->d_hotdup, (void**)&h->d_late_bits, (void**)&h->d_fused_err};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -555,7 +582,8 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
 
 // K3 on the main stream: the decode of example-buffer set `x` over this handle's item rows (shared by the single-handle step and
 // the sampled item-shard step)
-int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x) {
+// fused != nullptr: the fused launch (decode_gather_kernel) with these gather arguments; the caller then launches no hidden_gather_kernel
+int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x, const cdae::GatherArgs* fused = nullptr) {
   using namespace cdae;
   hipStream_t st = h->stream;
   const uint32_t I = (uint32_t)h->I;
@@ -579,10 +607,23 @@ int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x) {
   // K <= 256: hot rows one per wavefront, all others four per wavefront (NV float4 pieces + NT tail scalars per lane)
 #define DECODE_HY(NV_, NT_)                                                                                           \
   do {                                                                                                                \
-    if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);   \
-    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
-    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);    \
-    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, 0, st, h->hp, hot, DECODE_TAIL);            \
+    if (fused) {                                                                                                       \
+      if (!h->fused_attr_decode) {                                                                                     \
+        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));   \
+        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));  \
+        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));   \
+        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));  \
+        h->fused_attr_decode = true;                                                                                   \
+      }                                                                                                                \
+      if (ce && ada) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 5, true>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);   \
+      else if (ce) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 5, false>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);    \
+      else if (ada) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 0, true>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);    \
+      else hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 0, false>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);            \
+    }                                                                                                                  \
+    else if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, 0, st, h->hp, hot, late, DECODE_TAIL);   \
+    else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, 0, st, h->hp, hot, late, DECODE_TAIL);    \
+    else if (ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, true>), grid_hy, blk, 0, st, h->hp, hot, late, DECODE_TAIL);    \
+    else hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 0, false>), grid_hy, blk, 0, st, h->hp, hot, late, DECODE_TAIL);            \
   } while (0)
 #define DECODE_HY_NT(NV_)                                                                        \
   do {                                                                                           \
@@ -595,6 +636,15 @@ int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x) {
       const uint32_t hot = std::min<uint32_t>(h->hot_rows, I);
       const uint32_t waves = hot + (I - hot + 3) / 4;
       const dim3 grid_hy((waves + 3) / 4);
+      const DecodeLate late = h->decode_late();
+      // fused launch: [hot rows, four per workgroup] [the other rows: one workgroup per remaining CU] [gather: FUSED_WAVES (unit, partition) wavefronts each]
+      FusedGeom geo{};
+      geo.hot_wgs = (hot + 3) / 4;
+      geo.n_groups = (I - hot + 3) / 4;
+      geo.cold_wgs = std::max<uint32_t>(1u, std::min<uint32_t>(geo.n_groups, h->num_cus > geo.hot_wgs + 8u ? h->num_cus - geo.hot_wgs : 8u));
+      const uint32_t gather_wgs = fused ? 8u * ((fused->n_units + FUSED_WAVES - 1) / FUSED_WAVES) : 0u;
+      const dim3 grid_fu(geo.hot_wgs + geo.cold_wgs + gather_wgs), blk_fu(FUSED_WAVES * WAVE);
+      const size_t fused_lds = (size_t)FUSED_LDS_WORDS * sizeof(uint32_t);
       const uint32_t nv = K / 64, tail = K % 64;
       const uint32_t nt = tail == 0 ? 0u : (tail < 16 ? 1u : (tail < 32 ? 2u : 4u));   // 16 nt > tail: room for b'
       if (nt == 0) {
@@ -635,31 +685,44 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
   const uint32_t n_units = explicit_in ? 1u : units_of(h, bt);
   const uint32_t* uptr = explicit_in ? h->d_uptr_tmp : h->d_unit_ptr + s0;
   const dim3 grid_units((n_units + 3) / 4);
+  // The fused launch (decode + gather, decode_gather_kernel): plain batches of a handle that has late rows.  The batch's encode then
+  // fills G with G_PENDING (the gather wavefronts wait on it), whichever encode form runs.
+  const uint32_t halves = h->gather_halves;
+  const bool fused = h->fused_decode && !explicit_in && halves == 1u && n_units > 0u && bt.E > 0u && bt.E < (1ull << 32);
+  float* const ghot = h->late_rows ? h->d_Ghot : nullptr;
+  uint32_t* const gfill = fused ? reinterpret_cast<uint32_t*>(h->d_G) : nullptr;
+  const uint32_t n_fill = fused ? (uint32_t)bt.E : 0u;
   if (!explicit_in && !h->encode_two_launches && nb <= h->encode_users_max) {
     // one launch: a workgroup per user (encode_users_kernel)
     DISPATCH_NI(h->NI, encode_users_kernel, dim3(nb), dim3(ENC_WAVES * WAVE), 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, s0, nb,
-                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+                bt.cidx, seed, epoch, h->d_Wu, h->P(CDAE_P_B), h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum,
+                (BF16_T*)nullptr, (BF16_T*)nullptr, 0u, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const uint32_t*)nullptr,
+                ghot, h->d_hotdup, gfill, n_fill);
   } else {
     DISPATCH_NI(h->NI, encode_partial_kernel, grid_units, blk, 0, st, h->hp, h->d_row_ptr, h->d_col, h->P(CDAE_P_W), uptr, n_units,
                 (const uint32_t*)nullptr, s0, nb, 1, CDAE_STREAM_CORRUPT, bt.cidx, seed, epoch, h->d_Hpart, explicit_in, n_explicit,
                 explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user);
     DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hpart, uptr, h->d_Wu, h->P(CDAE_P_B),
-                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum);
+                (const uint32_t*)nullptr, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, h->d_Uu, h->d_Ssum,
+                (BF16_T*)nullptr, (BF16_T*)nullptr, 0u, ghot, h->d_hotdup, gfill, n_fill);
   }
   CHK(pr.end());
 
   HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
+  const GatherArgs ga{h->d_row_ptr, uptr, n_units, s0, nb, x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex,
+                      h->d_dup_corr, explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user, halves,
+                      h->late_rows ? (const uint32_t*)h->d_late_bits : (const uint32_t*)nullptr, h->late_words, h->d_fused_err};
   CHK(pr.begin(h, F_DECODE, st));
-  CHK(launch_decode(h, x));
+  CHK(launch_decode(h, x, fused ? &ga : nullptr));
   CHK(pr.end());
 
   CHK(pr.begin(h, F_HIDDEN, st));
-  const uint32_t halves = h->gather_halves;
-  DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_units + 3) / 4)), blk, 0, st, h->hp, h->d_row_ptr, uptr, n_units, s0, nb,
-              x.item, h->d_G, h->d_D0, h->d_HGpart, explicit_in ? (uint32_t)bt.E : 0u, x.dup_of_ex, h->d_dup_corr,
-              explicit_in ? (const uint32_t*)nullptr : (const uint32_t*)h->d_unit_user, halves);
+  if (!fused)
+    DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_units + 3) / 4)), blk, 0, st, h->hp, ga.row_ptr, uptr, n_units, s0, nb,
+                x.item, h->d_G, h->d_D0, h->d_HGpart, ga.explicit_examples, x.dup_of_ex, h->d_dup_corr, ga.unit_user, halves,
+                ga.late_bits, ga.late_words);
   DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
-              h->d_Wu, h->d_Wu_ag, 8u * halves, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
+              h->d_Wu, h->d_Wu_ag, 8u * halves, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, (const float*)nullptr, h->late_finish());
   CHK(pr.end());
   // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
   CHK(pr.begin(h, F_INPUT, st));
@@ -1290,6 +1353,15 @@ int cdae_hip_user_order(cdae_hip_t* h, uint32_t* out, size_t count) {
   for (uint64_t pos = 0; pos < h->U; ++pos) out[pos] = h->user_perm.empty() ? (uint32_t)pos : h->user_perm[pos];
   return 0;
 }
+int cdae_hip_decode_plan(const cdae_hip_t* h, uint32_t* hot_rows, uint32_t* late_rows, uint32_t* fused) {
+  if (!h) return fail("null handle");
+  const bool set = h->d_shared != nullptr;
+  if (hot_rows) *hot_rows = set && h->K <= 256 && !h->one_row_per_wave && !h->mf && !h->cfg.full_output ? h->hot_rows : 0u;
+  if (late_rows) *late_rows = set ? h->late_rows : 0u;
+  if (fused) *fused = set && h->fused_decode ? 1u : 0u;
+  return 0;
+}
+
 uint32_t cdae_hip_batch_users(const cdae_hip_t* h) { return !h || (h->cfg.batch_users == 0 && h->U == 0) ? 0 : (h->mf_seq ? 1u : h->B); }
 uint32_t cdae_hip_full_output_plan(const cdae_hip_t* h) {
   if (!h || !h->cfg.full_output || h->U == 0) return 0;
@@ -1414,6 +1486,37 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     uint32_t hot = 0;
     while (hot < I && (double)pop[order[hot]] * share >= hot_pos) ++hot;
     h->hot_rows = std::min<uint32_t>((hot + 3u) & ~3u, (uint32_t)I);
+  }
+  {
+    // Late rows: the most popular of the hot rows (at most one lane of hidden_finish_kernel each).  Their terms of the hidden gradient are
+    // added by hidden_finish_kernel / hg_raw_kernel from Ghot, not gathered — in EVERY launch order (so that the fused launch, the
+    // separate launches and an item shard of one agree bit for bit); the gather tells them by a bitmap it stages in LDS (item spaces up
+    // to 65 536).  CDAE_NO_LATE_ROWS: round 5's arithmetic (developer switch).
+    const bool hybrid = h->K <= 256 && !h->one_row_per_wave && !h->mf && !h->cfg.full_output;
+    h->late_rows = hybrid && I <= 32u * cdae::LATE_BITS_WORDS && !DEV_ENV("CDAE_NO_LATE_ROWS") ? std::min<uint32_t>(h->hot_rows, cdae::LATE_MAX) : 0u;
+    h->late_words = (uint32_t)((I + 31) / 32);
+    if (h->late_rows) {
+      std::vector<uint32_t> bits(h->late_words, 0u);
+      for (uint32_t r = 0; r < h->late_rows; ++r) bits[order[r] >> 5] |= 1u << (order[r] & 31u);
+      CHK(dev_alloc(&h->d_late_bits, (size_t)h->late_words));
+      HIPCHK(hipMemcpy(h->d_late_bits, bits.data(), h->late_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+      const size_t nB = (size_t)std::max<uint64_t>(std::min<uint64_t>(h->B, U), 1) * cdae::LATE_MAX;
+      CHK(dev_alloc(&h->d_Ghot, nB)); CHK(dev_alloc(&h->d_hotdup, nB));
+      HIPCHK(hipMemset(h->d_Ghot, 0, nB * sizeof(float)));
+      HIPCHK(hipMemset(h->d_hotdup, 0xFF, nB * sizeof(uint32_t)));
+    }
+    CHK(dev_alloc(&h->d_fused_err, 1));
+    HIPCHK(hipMemset(h->d_fused_err, 0, sizeof(uint32_t)));
+    // The fused launch: needs late rows (else the gather would wait for the longest chains); hot rows take a CU per four of them, so
+    // at most half the chip's; the row matrices are addressed through 32-bit buffer offsets.
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = (uint32_t)std::max(prop.multiProcessorCount, 16);
+    h->fused_decode = h->late_rows && h->hot_rows <= 2u * h->num_cus && !h->item_shard && (uint64_t)I * h->Kp * 4u < (1ull << 31) &&
+                      !DEV_ENV("CDAE_DECODE_UNFUSED");
+#ifdef CDAE_DECODE_TIMING
+    h->fused_decode = false;
+#endif
   }
 
   // parameters
@@ -1608,6 +1711,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint64_t want = h->mf ? 1 : (ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4));   // small problems: every example (IMF / BPR have no correction rows)
     h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
     h->dup_stripes = std::max<uint32_t>(1u, std::min<uint32_t>(cdae::DUP_STRIPES, h->dup_cap / 4096u));
+    if ((uint64_t)h->dup_cap * h->Kp * 4u >= (1ull << 31)) h->fused_decode = false;     // (32-bit buffer offsets in the fused launch)
     CHK(dev_alloc(&h->d_dup_corr, (size_t)h->dup_cap * h->Kp));
     HIPCHK(hipMemset(h->d_dup_corr, 0, (size_t)h->dup_cap * h->Kp * sizeof(float)));
   }
@@ -1825,7 +1929,7 @@ int cdae_hip_synchronize(cdae_hip_t* h) {
   HIPCHK(hipSetDevice(h->device));
   CHK(join_aux(h));
   HIPCHK(hipStreamSynchronize(h->stream));
-  return 0;
+  return fused_check(h);
 }
 
 }  // extern "C"
@@ -2127,6 +2231,7 @@ int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t 
   CHK(enqueue_users(h, seed, epoch, u_begin, u_end));
   CHK(join_aux(h));
   HIPCHK(hipStreamSynchronize(h->stream));
+  CHK(fused_check(h));
 #ifdef CDAE_DECODE_TIMING
   {   // developer aid: cycle stamps of row `debug_rank` in the last decode launch (see decode_rows_kernel)
     unsigned long long t[64];
@@ -2812,7 +2917,8 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
   if (!h->cfg.full_output) {
     // ---- sampled decode over the local item rows: the single-GPU step's kernels on this shard's rows / examples ----
     DISPATCH_NI(h->NI, encode_finish_kernel, grid_users, blk, 0, st, h->hp, h->d_Hsum, (const uint32_t*)h->d_iota, wu_b, h->P(CDAE_P_B),
-                (const uint32_t*)h->d_iota, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, uu_b, h->d_Ssum);
+                (const uint32_t*)h->d_iota, s0, nb, 1, h->d_Z, h->d_Dz, h->d_HG, uu_b, h->d_Ssum,
+                (BF16_T*)nullptr, (BF16_T*)nullptr, 0u, h->late_rows ? h->d_Ghot : (float*)nullptr, h->d_hotdup);
     HIPCHK(hipStreamWaitEvent(st, x.ready, 0));
     Prof pr;                                                  // (cdae_hip_set_profiling on a shard's handle: the decode launch of this shard's rows)
     CHK(pr.begin(h, F_DECODE, st, h->seq));
@@ -2823,8 +2929,9 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
     const uint32_t* guptr = h->d_gunit_ptr + s0;
     if (n_gunits)
       DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_gunits + 3) / 4)), blk, 0, st, h->hp, h->d_grow_ptr, guptr, n_gunits, s0, nb,
-                  x.item, h->d_G, h->d_D0, h->d_HGpart, 0u, x.dup_of_ex, h->d_dup_corr, (const uint32_t*)h->d_gunit_user, halves);
-    DISPATCH_NI(h->NI, hg_raw_kernel, grid_users, blk, 0, st, h->hp, guptr, n_gunits, nb, h->d_HGpart, 8u * halves, h->d_HG);
+                  x.item, h->d_G, h->d_D0, h->d_HGpart, 0u, x.dup_of_ex, h->d_dup_corr, (const uint32_t*)h->d_gunit_user, halves,
+                  h->late_rows ? (const uint32_t*)h->d_late_bits : (const uint32_t*)nullptr, h->late_words);
+    DISPATCH_NI(h->NI, hg_raw_kernel, grid_users, blk, 0, st, h->hp, guptr, n_gunits, nb, h->d_HGpart, 8u * halves, h->d_HG, h->late_finish());
     HIPCHK(hipGetLastError());
     return 0;
   }

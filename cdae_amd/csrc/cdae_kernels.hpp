@@ -40,6 +40,35 @@ constexpr uint32_t DUP_STRIPES = 64;
 constexpr uint32_t TARGET_BIT = 1u << 30;
 constexpr uint32_t INPUT_BIT = 1u << 31;
 
+// ---- late rows and the fused decode + gather launch (round 6) ----
+// The `late_rows` (<= LATE_MAX) most popular rows finish last — their serial example chains bound the decode launch — so their terms
+// of the hidden gradient, sum_e g_e D0[j_e] (cdae.hpp:240,248,277,285), are NOT gathered by hidden_gather_kernel: the decode leaves
+// g of (user slot, late row) in Ghot[slot][rank] (one entry per user and row: the sum over a run of the user's duplicate negatives)
+// and hidden_finish_kernel adds  sum_r Ghot[slot][r] D0[item_order[r]]  (+ the runs' correction rows) itself, in rank order, behind
+// the gathered partial rows.  That is what lets the gather of everything else run INSIDE the decode launch, beside the late rows'
+// chains (decode_gather_kernel): a gather wavefront only ever waits for rows that finish early.
+constexpr uint32_t LATE_MAX = 64;               // one lane of hidden_finish_kernel per late row
+struct DecodeLate {
+  float* Ghot;                                  // [batch users][LATE_MAX], zeroed by the batch's encode
+  uint32_t* hotdup;                             // [batch users][LATE_MAX]: correction row of (user, late row)'s duplicate run (DUP_NONE: none)
+  uint32_t late_rows;                           // rows [0, late_rows) of item_order; 0: no late rows (the gather takes every example)
+};
+struct LateFinish {                             // what hidden_finish_kernel / hg_raw_kernel need to add the late rows' terms
+  const float* Ghot; const uint32_t* hotdup; const uint32_t* items /* item_order */; const float* D0; const float* dup_corr;
+  uint32_t late_rows;
+};
+// Fused launch only: G[e] reads G_PENDING (a quiet NaN no loss' produces) until the decode has written it.  The batch's encode fills
+// G with it (a launch boundary earlier); decode writes g THROUGH to memory (sc1 stores: visible to the other XCDs' L2s without a
+// fence), the gather wavefronts poll with sc1 loads — a self-validating 4-byte granule, MI355X_MICROARCH.md "handoff".
+constexpr uint32_t G_PENDING = 0x7FC0DEADu;
+constexpr uint32_t FUSED_SPIN_CAP = 1u << 18;   // polls (>= 1 us each) before a gather wavefront gives up and raises the handle's error word
+
+template <bool SC1>
+__device__ __forceinline__ void store_f32(float* p, float v) {
+  if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+__device__ __forceinline__ float load_f32_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // (see HyperParams::debug_skip) — constant false in the shipped build: the tests compile out
 #ifdef CDAE_DEVELOPER
 #define CDAE_SKIP_ROLE(hp, bit) (((hp).debug_skip & (bit)) != 0u)
@@ -116,6 +145,51 @@ __device__ __forceinline__ void vstore(float* __restrict__ p, const float (&d)[N
 #else
       reinterpret_cast<float4*>(p)[q] = make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
 #endif
+    }
+  }
+}
+
+// Write-through (sc1) forms of the row accesses, through a buffer descriptor (aux bit 4 = sc1 on gfx950): what the fused decode +
+// gather launch uses for everything one workgroup writes and another reads before the launch ends.  Byte offsets stay below 2 GiB
+// (the host checks the matrices' sizes before it selects the fused launch).
+using cdae_b128 = decltype(__builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0), 0, 0, 0));
+using cdae_b64 = decltype(__builtin_amdgcn_raw_buffer_load_b64(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0), 0, 0, 0));
+using cdae_rsrc = decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0));
+__device__ __forceinline__ cdae_rsrc rows_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+constexpr int AUX_SC1 = 16;
+template <int NI>
+__device__ __forceinline__ void vstore_sc1(cdae_rsrc r, uint32_t byte_off, const float (&d)[NI]) {
+  if constexpr (NI == 1) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, d[0]), r, (int)byte_off, 0, AUX_SC1);
+  } else if constexpr (NI == 2) {
+    cdae_b64 v; const float t[2] = {d[0], d[1]};
+    __builtin_memcpy(&v, t, sizeof v);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)byte_off, 0, AUX_SC1);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NI / 4; ++q) {
+      cdae_b128 v; const float t[4] = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+      __builtin_memcpy(&v, t, sizeof v);
+      __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(byte_off + 16u * q), 0, AUX_SC1);
+    }
+  }
+}
+template <int NI>
+__device__ __forceinline__ void vload_sc1(float (&d)[NI], cdae_rsrc r, uint32_t byte_off) {
+  if constexpr (NI == 1) {
+    d[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, AUX_SC1));
+  } else if constexpr (NI == 2) {
+    const cdae_b64 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, AUX_SC1);
+    float t[2]; __builtin_memcpy(t, &v, sizeof t);
+    d[0] = t[0]; d[1] = t[1];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NI / 4; ++q) {
+      const cdae_b128 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(byte_off + 16u * q), 0, AUX_SC1);
+      float t[4]; __builtin_memcpy(t, &v, sizeof t);
+      d[4 * q] = t[0]; d[4 * q + 1] = t[1]; d[4 * q + 2] = t[2]; d[4 * q + 3] = t[3];
     }
   }
 }
@@ -511,11 +585,16 @@ encode_finish_kernel(HyperParams hp, const float* __restrict__ Hpart, const uint
                      const float* __restrict__ Uu /* linear_function only */,
                      float* __restrict__ Ssum /* linear_function training: the unscaled input sums, for the Uu step */,
                      BF16_T* __restrict__ Zb = nullptr /* full-output path: bf16 images of z, [Bp][Kp] and (ZTb) [Kp][Bp], written here */,
-                     BF16_T* __restrict__ ZTb = nullptr, uint32_t Bp = 0) {
+                     BF16_T* __restrict__ ZTb = nullptr, uint32_t Bp = 0,
+                     // training with late rows (DecodeLate): the batch's Ghot / hotdup rows start at 0 / DUP_NONE; fused launch: G starts as G_PENDING
+                     float* __restrict__ Ghot = nullptr, uint32_t* __restrict__ hotdup = nullptr,
+                     uint32_t* __restrict__ Gfill = nullptr, uint32_t n_fill = 0) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_fill; i += gridDim.x * blockDim.x) Gfill[i] = G_PENDING;
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
   const unsigned long long t0 = trace_begin(hp);
+  if (Ghot) { Ghot[(size_t)slot * LATE_MAX + lane] = 0.f; hotdup[(size_t)slot * LATE_MAX + lane] = DUP_NONE; }
   const uint64_t uid = uids ? (uint64_t)uids[slot] : u0 + slot;
   const uint32_t lo = lane * NI;
   float acc[NI];
@@ -588,10 +667,14 @@ encode_users_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const u
                     // `raw_out` [blocks][nb][Kp] — and stage the owner's rows of the private matrices (`raw_a`, then `raw_b`; zeros when
                     // another shard owns the user) behind it: what encode_partial_kernel + unit_sum_stage_kernel wrote, in one launch
                     float* __restrict__ raw_out = nullptr, const float* __restrict__ raw_a = nullptr, const float* __restrict__ raw_b = nullptr,
-                    const uint32_t* __restrict__ gpos = nullptr /* item shard: see encode_partial_kernel */) {
+                    const uint32_t* __restrict__ gpos = nullptr /* item shard: see encode_partial_kernel */,
+                    float* __restrict__ Ghot = nullptr, uint32_t* __restrict__ hotdup = nullptr /* as encode_finish_kernel */,
+                    uint32_t* __restrict__ Gfill = nullptr, uint32_t n_fill = 0) {
   __shared__ float part[ENC_WAVES][64 * NI];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_fill; i += gridDim.x * blockDim.x) Gfill[i] = G_PENDING;
   const uint32_t slot = blockIdx.x, wid = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   const unsigned long long t0 = trace_begin(hp);
+  if (Ghot && wid == 1) { Ghot[(size_t)slot * LATE_MAX + lane] = 0.f; hotdup[(size_t)slot * LATE_MAX + lane] = DUP_NONE; }
   const uint64_t uid = u0 + slot;
   const uint32_t lo = lane * NI;
   const uint32_t n_units = uptr[slot + 1] - uptr[slot];
@@ -751,11 +834,14 @@ constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15 =
 // recurrence (two transcendentals).  Memory images of D and D0 keep their pad elements 0.
 // g_park / park_cap: wave-private LDS words where g is parked until the row is finished (nullptr / 0: written out per 64-example
 // chunk, which costs a store + full vmcnt drain — ~1 us of the row's serial chain — per chunk)
-template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
+// FUSED: the launch that also gathers (decode_gather_kernel) — G, the D0 row and the correction rows are written through (sc1).
+// late: rows below late.late_rows leave their g in late.Ghot and one correction row per duplicate run (late.hotdup), see DecodeLate.
+template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD, bool FUSED = false>
 __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank, float* __restrict__ g_park, const uint32_t park_cap,
-                                             CDAE_DECODE_PARAMS) {
+                                             const DecodeLate late, CDAE_DECODE_PARAMS) {
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
+  const bool is_late = rank < late.late_rows;                     // wave-uniform
   const uint32_t item = item_order[rank];
   const uint32_t beg = seg_begin[rank], end = seg_end[rank];      // (segment tables indexed by rank: read beside item_order[rank])
   hp.loss_type = LOSS;                 // compile-time specialisation of the per-example branches
@@ -777,12 +863,24 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
   vload<NI>(a, D_ag + (size_t)item * hp.Kp + lo);
   float bias = bp[item], bias_ag = bp_ag[item];
   if (beg == end) return;
-  vstore<NI>(D0 + (size_t)item * hp.Kp + lo, w);     // batch-start snapshot of this row for the hidden-gradient gather
+  // batch-start snapshot of this row for the hidden-gradient gather
+  if constexpr (FUSED) {
+    vstore_sc1<NI>(rows_rsrc(D0), (item * hp.Kp + lo) * 4u, w);
+    __builtin_amdgcn_s_waitcnt(WAIT_VM0);            // the row is in memory before any g of it can be (the gather reads the row once it has seen a g)
+  } else {
+    vstore<NI>(D0 + (size_t)item * hp.Kp + lo, w);
+  }
   const bool pad_lane = BIAS_IN_PAD && lane == WAVE - 1;
   const float pad_one = pad_lane ? 1.f : 0.f;
   if (pad_lane) { w[NI - 1] = bias; a[NI - 1] = bias_ag; }
 #pragma unroll
   for (int i = 0; i < NI; ++i) wref[i] = w[i];
+  // late rows: ONE correction row per run of a user's duplicates — the sum of the run's corrections so far, re-written at every
+  // duplicate into the row of the run's first one (hidden_finish_kernel adds it by (user, late row), late.hotdup)
+  uint32_t run_di = DUP_NONE;
+  float csum[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) csum[i] = 0.f;
 
 #ifndef CDAE_DECODE_PF
 #define CDAE_DECODE_PF 8
@@ -852,12 +950,25 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
         if (word & DUP_PREV_BIT) {
           // g * (row now - row at the user's first visit): a plain row store into the correction buffer (the
           // gather adds it to hg_u); fire-and-wait atomics here cost ~25 us per duplicate (measured)
-          const uint32_t di = dup_of_pos[c0 + idx];
+          uint32_t di = dup_of_pos[c0 + idx];
           float corr[NI];
 #pragma unroll
           for (int i = 0; i < NI; ++i) corr[i] = (pad_lane && i == NI - 1) ? 0.f : g * (w[i] - wref[i]);
+          if (is_late && di != DUP_NONE) {                     // (wave-uniform) the run's corrections so far, in the run's first row
+            if (run_di == DUP_NONE) {
+              run_di = di;
+#pragma unroll
+              for (int i = 0; i < NI; ++i) csum[i] = corr[i];
+              if (lane == 0) late.hotdup[(size_t)(word & SLOT_MASK) * LATE_MAX + rank] = di;
+            } else {
+              di = run_di;
+#pragma unroll
+              for (int i = 0; i < NI; ++i) { csum[i] += corr[i]; corr[i] = csum[i]; }
+            }
+          }
           if (di != DUP_NONE) {
-            vstore<NI>(dup_corr + (size_t)di * hp.Kp + lo, corr);
+            if constexpr (FUSED) vstore_sc1<NI>(rows_rsrc(dup_corr), (di * hp.Kp + lo) * 4u, corr);
+            else vstore<NI>(dup_corr + (size_t)di * hp.Kp + lo, corr);
           } else {                                             // correction buffer full: slow path
             float* hc = HGcorr + (size_t)(word & SLOT_MASK) * hp.Kp + lo;
 #pragma unroll
@@ -867,6 +978,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
         } else {                                               // first of a run: remember the row at the user's first visit
 #pragma unroll
           for (int i = 0; i < NI; ++i) wref[i] = w[i];
+          run_di = DUP_NONE;
         }
       }
       if (!deferred) {
@@ -1061,15 +1173,35 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
     if (c0 - beg + WAVE <= park_cap) {                           // wave-uniform: parked in LDS, written out after the row's last example
       g_park[c0 - beg + lane] = gbuf;
     } else {
-      if (lane < cnt) G[cur_e] = gbuf;
-      if (c0 + WAVE < end) __builtin_amdgcn_s_waitcnt(WAIT_VM0);   // (nothing follows the last chunk but the row's own stores)
+      if (lane < cnt) store_f32<FUSED>(G + cur_e, gbuf);
+      if (c0 + WAVE < end || is_late) __builtin_amdgcn_s_waitcnt(WAIT_VM0);   // (nothing follows the last chunk but the row's own stores — and a late row's read-back below)
     }
     CDAE_STAMP();
     cur_w = nxt_w; cur_e = nxt_e; cur_o = nxt_o;
     nxt_w = (uint32_t)far; nxt_e = (uint32_t)(far >> 32); nxt_o = (nxt_w & SLOT_MASK) * row_bytes;
   }
-  for (uint32_t q = lane; q < min(end - beg, park_cap & ~63u); q += WAVE)       // the parked g: example ids are re-read (coalesced)
-    G[(uint32_t)(sorted_val[beg + q] >> 32)] = g_park[q];
+  {
+    // the parked g: example ids are re-read (coalesced).  A late row also leaves g in Ghot[user slot][rank] — for a run of one user's
+    // duplicates ONE entry, the sum of the run's g (the run's first example writes it) — for hidden_finish_kernel's dense sum.
+    const uint32_t n_row = end - beg, n_parked = min(n_row, park_cap & ~63u);
+    for (uint32_t q = lane; q < (is_late ? n_row : n_parked); q += WAVE) {
+      const uint64_t v = sorted_val[beg + q];
+      const uint32_t e = (uint32_t)(v >> 32), word = (uint32_t)v;
+      float g;
+      if (q < n_parked) { g = g_park[q]; store_f32<FUSED>(G + e, g); }
+      else g = load_f32_sc1(G + e);                               // (a row longer than the parking space: written per chunk above)
+      if (is_late && !(word & DUP_PREV_BIT)) {
+        if (word & DUP_NEXT_BIT) {
+          for (uint32_t k = q + 1u; k < n_row; ++k) {
+            const uint64_t v2 = sorted_val[beg + k];
+            if (!((uint32_t)v2 & DUP_PREV_BIT)) break;
+            g += k < n_parked ? g_park[k] : load_f32_sc1(G + (uint32_t)(v2 >> 32));
+          }
+        }
+        late.Ghot[(size_t)(word & SLOT_MASK) * LATE_MAX + rank] = g;
+      }
+    }
+  }
   if (BIAS_IN_PAD) {
     if (pad_lane) {
       bp[item] = w[NI - 1];
@@ -1095,7 +1227,7 @@ template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD>
 __global__ void __launch_bounds__(256)
 decode_rows_kernel(HyperParams hp, CDAE_DECODE_PARAMS) {
   const uint32_t rank = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE);
-  decode_row64<NI, LOSS, ADAGRAD, BIAS_IN_PAD>(hp, rank, nullptr, 0u, CDAE_DECODE_PASS);
+  decode_row64<NI, LOSS, ADAGRAD, BIAS_IN_PAD>(hp, rank, nullptr, 0u, DecodeLate{nullptr, nullptr, 0u}, CDAE_DECODE_PASS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1138,11 +1270,26 @@ __device__ __forceinline__ void row16_store(float* __restrict__ base, const floa
   for (int i = 0; i < NT; ++i) base[64 * NV + l + 16 * i] = r[4 * NV + i];
 }
 
+// the same row image written through (sc1): the fused launch's D0 and correction rows (read by gather wavefronts of the same launch)
+template <int NV, int NT>
+__device__ __forceinline__ void row16_store_sc1(float* __restrict__ matrix, uint32_t row_elem, const float (&r)[4 * NV + NT], uint32_t l) {
+  const cdae_rsrc rs = rows_rsrc(matrix);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    cdae_b128 q; const float t[4] = {r[4 * v], r[4 * v + 1], r[4 * v + 2], r[4 * v + 3]};
+    __builtin_memcpy(&q, t, sizeof q);
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)((row_elem + 64u * v + 4u * l) * 4u), 0, AUX_SC1);
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, r[4 * NV + i]), rs, (int)((row_elem + 64u * NV + l + 16u * i) * 4u), 0, AUX_SC1);
+}
+
 // Wave-private LDS of decode_rows16 (words): example words and example ids of the current and the next 64-example chunk of each
 // of the four groups, and the parked g of the current chunk.
 constexpr uint32_t ROWS16_LDS_WORDS = 4u * 128u + 4u * 128u + 4u * 64u;
 
-template <int NV, int NT, int LOSS, bool ADAGRAD>
+template <int NV, int NT, int LOSS, bool ADAGRAD, bool FUSED = false>
 __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t rank0, uint32_t* __restrict__ lds, CDAE_DECODE_PARAMS) {
   constexpr int GRP = 16, NE = 4 * NV + NT;
   constexpr bool HAS_PAD = NT > 0;
@@ -1175,7 +1322,9 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   if (n) {
     row16_load<NV, NT>(w, D + row_off, l);
     row16_load<NV, NT>(a, D_ag + row_off, l);
-    row16_store<NV, NT>(D0 + row_off, w, l);                     // batch-start snapshot of the row (hidden-gradient gather)
+    // batch-start snapshot of the row (hidden-gradient gather)
+    if constexpr (FUSED) row16_store_sc1<NV, NT>(D0, (uint32_t)row_off, w, l);
+    else row16_store<NV, NT>(D0 + row_off, w, l);
   } else {
 #pragma unroll
     for (int i = 0; i < NE; ++i) { w[i] = 0.f; a[i] = 1.f; }
@@ -1216,9 +1365,10 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t q = c0 + l + GRP * j;
-      if (q < n) G[el[q & 127u]] = gl[q & 63u];
+      if (q < n) store_f32<FUSED>(G + el[q & 127u], gl[q & 63u]);
     }
   };
+  if constexpr (FUSED) __builtin_amdgcn_s_waitcnt(WAIT_VM0);      // the D0 rows are in memory before any g of them can be (decode_row64)
   stage_chunk(0);
   stage_chunk(64);                                               // (unconditional: the look-ahead reads up to PF words past nmax, and LDS starts as garbage)
   const uint32_t shift = 31u - (uint32_t)__builtin_clz(hp.Kp * 4u);      // row stride is a power of two bytes (Kp = 64 NI)
@@ -1285,7 +1435,8 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
 #pragma unroll
             for (int i = 0; i < NE; ++i) corr[i] = (pad_lane && i == NE - 1) ? 0.f : g * (w[i] - wref[i]);
             if (di != DUP_NONE) {
-              row16_store<NV, NT>(dup_corr + (size_t)di * hp.Kp, corr, l);
+              if constexpr (FUSED) row16_store_sc1<NV, NT>(dup_corr, di * hp.Kp, corr, l);
+              else row16_store<NV, NT>(dup_corr + (size_t)di * hp.Kp, corr, l);
             } else {                                             // correction buffer full: slow path
               float* hc = HGcorr + (size_t)(word & SLOT_MASK) * hp.Kp;
 #pragma unroll
@@ -1340,7 +1491,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
 // shortest — and all other rows go four to a wavefront.
 template <int NV, int NT, int LOSS, bool ADAGRAD>
 __global__ void __launch_bounds__(256)
-decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
+decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, DecodeLate late, CDAE_DECODE_PARAMS) {
   constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
   constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
   __shared__ uint32_t rows16_lds[4][ROWS16_LDS_WORDS];
@@ -1352,7 +1503,7 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
 #define CDAE_HOT_PRIO 2
 #endif
     __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
-    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROWS16_LDS_WORDS,
+    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROWS16_LDS_WORDS, late,
                                            CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
     trace_end(hp, 3, wave, t0);
   } else {
@@ -1372,32 +1523,45 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, CDAE_DECODE_PARAMS) {
 // D0 (1.35 MB) and the 684 row reads per user hit L2 instead of the fabric.  The 8 partial sums per user
 // per unit are combined by hidden_finish_kernel.  One wavefront per (unit, partition); ids and g staged 64
 // at a time, matching rows compacted with a ballot, 8 row loads in flight.
-template <int NI>
-__global__ void __launch_bounds__(256)
-hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ uptr,
-                     uint32_t n_units, uint64_t u0, uint32_t nb, const uint32_t* __restrict__ ex_item,
-                     const float* __restrict__ G, const float* __restrict__ D0,
-                     float* __restrict__ HGpart /* [8 * halves][n_units][Kp] */,
-                     uint32_t explicit_examples /* != 0: one user, one unit, that many examples */,
-                     const uint32_t* __restrict__ dup_of_ex, const float* __restrict__ dup_corr,
-                     const uint32_t* __restrict__ unit_user,
-                     uint32_t halves /* 1 or 2: wavefronts per (unit, partition), each walking half of the unit's 64-example chunks */) {
-  const uint32_t part = blockIdx.x & 7u;
-  const uint32_t rest = blockIdx.x >> 3;
-  const uint32_t half = rest % halves;
-  const uint32_t unit = (rest / halves) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+struct GatherArgs {
+  const int64_t* row_ptr; const uint32_t* uptr; uint32_t n_units; uint64_t u0; uint32_t nb;
+  const uint32_t* ex_item; const float* G; const float* D0; float* HGpart;
+  uint32_t explicit_examples;                    // != 0: one user, one unit, that many examples
+  const uint32_t* dup_of_ex; const float* dup_corr; const uint32_t* unit_user;
+  uint32_t halves;                               // 1 or 2: wavefronts per (unit, partition), each walking half of the unit's 64-example chunks
+  const uint32_t* late_bits; uint32_t late_words;   // bitmap over the items: the late rows (DecodeLate), whose examples are NOT gathered; nullptr: none
+  uint32_t* err;                                 // fused launch: raised by a wavefront that gives up waiting for a g
+};
+constexpr uint32_t GATHER_CAP = 512;             // list entries per wavefront; a 128-example step adds at most 256
+constexpr uint32_t LATE_BITS_WORDS = 2048;       // LDS copy of the late-row bitmap: item spaces up to 65 536
+
+// every thread of the workgroup: the late-row bitmap into LDS (before any wavefront leaves)
+__device__ __forceinline__ void stage_late_bits(uint32_t* lbits, const uint32_t* __restrict__ late_bits, uint32_t late_words) {
+  if (late_bits) {
+    for (uint32_t i = threadIdx.x; i < late_words; i += blockDim.x) lbits[i] = late_bits[i];
+    __syncthreads();
+  }
+}
+
+// One wavefront: the partial hidden gradient of (unit, item partition `part`[, half]).
+// FUSED (decode_gather_kernel): the decode of the same launch is still writing G — a g that reads G_PENDING is waited for (sc1
+// polls) — and D0 / correction rows are read past the L1 (sc1), since another CU wrote them during this launch.
+template <int NI, bool FUSED>
+__device__ __forceinline__ void hidden_gather_role(const HyperParams& hp, const GatherArgs& ga, const uint32_t part, const uint32_t half,
+                                                   const uint32_t unit, uint32_t* const lrow, float* const lg,
+                                                   const uint32_t* const lbits /* LDS late-row bitmap, or nullptr */) {
   const uint32_t lane = threadIdx.x % WAVE;
-  if (unit >= n_units) return;
+  const uint32_t halves = ga.halves;
   const unsigned long long t0 = trace_begin(hp);
-  const UnitRef ur = locate_unit(hp.unit_pos, uptr, nb, uptr[0] + unit, unit_user, u0);
-  const uint64_t uid = u0 + ur.slot;
-  const int64_t r0 = row_ptr[uid];
-  const uint32_t n = (uint32_t)(row_ptr[uid + 1] - r0);
-  const uint64_t base = (uint64_t)(r0 - row_ptr[u0]) * (1u + hp.num_neg);
+  const UnitRef ur = locate_unit(hp.unit_pos, ga.uptr, ga.nb, ga.uptr[0] + unit, ga.unit_user, ga.u0);
+  const uint64_t uid = ga.u0 + ur.slot;
+  const int64_t r0 = ga.row_ptr[uid];
+  const uint32_t n = (uint32_t)(ga.row_ptr[uid + 1] - r0);
+  const uint64_t base = (uint64_t)(r0 - ga.row_ptr[ga.u0]) * (1u + hp.num_neg);
   // the unit's examples: positives [p0, p1) then negatives [num_neg*p0, num_neg*p1) (stored after the n positives)
-  const uint32_t p0 = explicit_examples ? 0u : ur.p0, p1 = explicit_examples ? n : min(ur.p1, n);
+  const uint32_t p0 = ga.explicit_examples ? 0u : ur.p0, p1 = ga.explicit_examples ? n : min(ur.p1, n);
   const uint32_t n_posu = p1 - p0;
-  const uint32_t n_negu = explicit_examples ? explicit_examples - n : n_posu * hp.num_neg;
+  const uint32_t n_negu = ga.explicit_examples ? ga.explicit_examples - n : n_posu * hp.num_neg;
   const uint32_t neg0 = n + p0 * hp.num_neg;
   const uint32_t n_ex = n_posu + n_negu;
   const uint32_t lo = lane * NI;
@@ -1414,25 +1578,33 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   // corrections, rare) are COMPACTED into a per-wavefront LDS list in the order the old loop added them — corrections of a chunk in
   // lane order, then its rows in lane order — and the list is drained 2 x UN rows per trip, all of a trip's loads issued before the
   // first FMA.  Same additions in the same order: the partial rows are bit-identical to round 4's.
-  constexpr int TRIP = NI >= 8 ? 4 : 8;                          // rows in flight per trip (registers: TRIP x NI floats; the whole launch must be resident: <= 96 registers)
-  constexpr uint32_t GCAP = 512;                                 // list entries per wavefront; a 128-example step adds at most 256
+  // rows in flight per trip (registers: TRIP x NI floats).  The launch of its own must be resident as a whole: <= 96 registers.  The fused
+  // launch holds three wavefronts per SIMD whatever they need below 168 registers: twice the rows per trip (round 5 measured 16 rows /
+  // 130 registers at 6.6 us per wavefront against 9 us for 8 rows).  The list order, hence every sum, is the same.
+  constexpr int TRIP = NI >= 8 ? 4 : (FUSED ? 16 : 8);
+  constexpr uint32_t GCAP = GATHER_CAP;
   constexpr uint32_t DUP_ROW = 0x80000000u;                      // list entry: a row of dup_corr (added as it is) instead of D0 (times g)
-  __shared__ uint32_t gl_row[4][GCAP];
-  __shared__ float gl_g[4][GCAP];
-  uint32_t* const lrow = gl_row[threadIdx.x / WAVE];
-  float* const lg = gl_g[threadIdx.x / WAVE];
+  const cdae_rsrc d0_rs = rows_rsrc(ga.D0), dc_rs = rows_rsrc(ga.dup_corr);      // (FUSED: sc1 row loads)
   // this lane's (item, g, correction row) of two consecutive 64-example chunks; the next pair is requested before this one is compacted
   struct Meta { uint32_t item[2], di[2]; float g[2]; };
+  auto example_of = [&](uint32_t v) -> uint32_t { return v < n_posu ? p0 + v : neg0 + (v - n_posu); };
   auto load_meta = [&](uint32_t c, uint32_t c_end, Meta& m) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const uint32_t v = c + (uint32_t)h2 * WAVE + lane;
-      const uint32_t e = v < n_posu ? p0 + v : neg0 + (v - n_posu);
+      const uint32_t e = example_of(v);
       const bool in = v < c_end;
-      m.item[h2] = in ? ex_item[base + e] : 0xFFFFFFFFu;
-      m.g[h2] = in ? G[base + e] : 0.f;
-      m.di[h2] = in ? dup_of_ex[base + e] : DUP_NONE;
+      m.item[h2] = in ? ga.ex_item[base + e] : 0xFFFFFFFFu;
+      if constexpr (FUSED) m.g[h2] = in ? load_f32_sc1(ga.G + base + e) : 0.f;
+      else m.g[h2] = in ? ga.G[base + e] : 0.f;
+      m.di[h2] = in ? ga.dup_of_ex[base + e] : DUP_NONE;
     }
+  };
+  // an example of this wavefront: a real item of its partition that is not a late row
+  auto is_mine = [&](uint32_t item) -> bool {
+    bool mine = item < hp.num_items && (item & 7u) == part;      // (fillers are 0xFFFFFFFF, an item shard's VOID examples num_items)
+    if (lbits && mine) mine = ((lbits[item >> 5] >> (item & 31u)) & 1u) == 0u;
+    return mine;
   };
   uint32_t head = 0, len = 0;                                    // list entries [head, len) are waiting (wave-uniform)
   auto trip = [&](uint32_t n_rows) {                             // the next n_rows <= TRIP entries: every load issued, then the FMAs in list order
@@ -1442,8 +1614,12 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
       if ((uint32_t)t < n_rows) {                                // wave-uniform
         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lrow[head + t]);
         gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lg[head + t])));
-        const float* src = (e & DUP_ROW) ? dup_corr : D0;
-        vload<NI>(vv[t], src + (size_t)(e & ~DUP_ROW) * hp.Kp + lo_ld);
+        if constexpr (FUSED) {
+          vload_sc1<NI>(vv[t], (e & DUP_ROW) ? dc_rs : d0_rs, ((e & ~DUP_ROW) * hp.Kp + lo_ld) * 4u);
+        } else {
+          const float* src = (e & DUP_ROW) ? ga.dup_corr : ga.D0;
+          vload<NI>(vv[t], src + (size_t)(e & ~DUP_ROW) * hp.Kp + lo_ld);
+        }
       } else {
         gg[t] = 0.f;
 #pragma unroll
@@ -1464,10 +1640,22 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
   load_meta(c_begin, c_end, cur);
   for (uint32_t c0 = c_begin; c0 < c_end; c0 += 2 * WAVE) {
     load_meta(c0 + 2 * WAVE, c_end, nxt);                        // (past the end: fillers, no loads)
+    if constexpr (FUSED) {
+      // g of a row the decode has not finished yet: wait for it (bounded), re-reading only the lanes that need it
+      for (uint32_t spin = 0;; ++spin) {
+        const bool pend0 = __builtin_bit_cast(uint32_t, cur.g[0]) == G_PENDING && is_mine(cur.item[0]);
+        const bool pend1 = __builtin_bit_cast(uint32_t, cur.g[1]) == G_PENDING && is_mine(cur.item[1]);
+        if (!__ballot(pend0 || pend1)) break;
+        if (spin >= FUSED_SPIN_CAP) { if (lane == 0) atomicOr(ga.err, 1u); break; }
+        __builtin_amdgcn_s_sleep(24);
+        if (pend0) cur.g[0] = load_f32_sc1(ga.G + base + example_of(c0 + lane));
+        if (pend1) cur.g[1] = load_f32_sc1(ga.G + base + example_of(c0 + WAVE + lane));
+      }
+    }
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
-      const bool mine = cur.item[h2] < hp.num_items && (cur.item[h2] & 7u) == part;      // (fillers are 0xFFFFFFFF, an item shard's VOID examples num_items)
+      const bool mine = is_mine(cur.item[h2]);
       const bool dup = mine && cur.di[h2] != DUP_NONE;           // duplicate negatives (rare): decode's correction rows, in example order
       const unsigned long long mask = __ballot(mine), dmask = __ballot(dup);
       const uint32_t n_d = (uint32_t)__popcll(dmask), n_r = (uint32_t)__popcll(mask);
@@ -1491,8 +1679,114 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = 0.f;
   }
-  vstore<NI>(HGpart + ((size_t)(part * halves + half) * n_units + unit) * hp.Kp + lo, acc);
+  vstore<NI>(ga.HGpart + ((size_t)(part * halves + half) * ga.n_units + unit) * hp.Kp + lo, acc);
   trace_end(hp, 5, (unit * 8u + part) * halves + half, t0, n_ex);
+}
+
+template <int NI>
+__global__ void __launch_bounds__(256)
+hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ uptr,
+                     uint32_t n_units, uint64_t u0, uint32_t nb, const uint32_t* __restrict__ ex_item,
+                     const float* __restrict__ G, const float* __restrict__ D0,
+                     float* __restrict__ HGpart /* [8 * halves][n_units][Kp] */,
+                     uint32_t explicit_examples /* != 0: one user, one unit, that many examples */,
+                     const uint32_t* __restrict__ dup_of_ex, const float* __restrict__ dup_corr,
+                     const uint32_t* __restrict__ unit_user,
+                     uint32_t halves /* 1 or 2: wavefronts per (unit, partition), each walking half of the unit's 64-example chunks */,
+                     const uint32_t* __restrict__ late_bits = nullptr /* the late rows (DecodeLate): skipped here, added by hidden_finish_kernel */,
+                     uint32_t late_words = 0) {
+  __shared__ uint32_t gl_row[4][GATHER_CAP];
+  __shared__ float gl_g[4][GATHER_CAP];
+  __shared__ uint32_t lbits[LATE_BITS_WORDS];
+  stage_late_bits(lbits, late_bits, late_words);
+  const uint32_t part = blockIdx.x & 7u;
+  const uint32_t rest = blockIdx.x >> 3;
+  const uint32_t half = rest % halves;
+  const uint32_t unit = (rest / halves) * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  if (unit >= n_units) return;
+  const GatherArgs ga{row_ptr, uptr, n_units, u0, nb, ex_item, G, D0, HGpart, explicit_examples, dup_of_ex, dup_corr, unit_user, halves,
+                      late_bits, late_words, nullptr};
+  hidden_gather_role<NI, false>(hp, ga, part, half, unit, gl_row[threadIdx.x / WAVE], gl_g[threadIdx.x / WAVE], late_bits ? lbits : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 + K4a in ONE launch (round 6).  The decode launch is as long as its most popular row's serial chain (~134 examples x 250 ns at
+// 256 users per batch) while nine tenths of its other wavefronts are done in half that time, and the hidden-gradient gather that
+// follows needs only g — so the gather of everything but the late rows (DecodeLate) runs INSIDE the decode launch, as trailing
+// workgroups that start as the row wavefronts retire and wait, example by example, for the g they need (G_PENDING).
+// Geometry: workgroups of 12 wavefronts with more than half a CU's LDS each, i.e. ONE workgroup per CU —
+//   [hot_wgs]  four popular rows each, one per SIMD (elected by the SIMD the wavefront finds itself on; the other eight leave at
+//              once): the CU belongs to those four chains — through round 5 the four-row wavefronts that shared a SIMD with a
+//              popular row's wavefront (whose chain keeps the SIMD's VALU ~80 % busy) lived as long as the launch;
+//   [cold_wgs] the other rows, four per wavefront (decode_rows16), striped over the workgroups in popularity order;
+//   [gather]   twelve (unit, partition) wavefronts each (hidden_gather_role<FUSED>).
+// Workgroups are dispatched in index order (as bucket_sort_kernel assumes): whatever a gather wavefront waits for is running or done.
+// Everything one role writes and another reads inside the launch is written through (sc1) and read past the L1 (sc1), so no
+// agent-scope fence — a walk of the XCD's whole L2 — is needed (MI355X_MICROARCH.md, inter-workgroup visibility).
+struct FusedGeom { uint32_t hot_wgs, cold_wgs, n_groups; };
+constexpr uint32_t FUSED_WAVES = 12;             // three per SIMD: the row roles need ~145 registers (16 wavefronts = 128 registers each: spills)
+constexpr uint32_t FUSED_LDS_WORDS = 21504;      // 84 KiB of the CU's 160: one workgroup per CU
+static_assert(FUSED_WAVES * ROWS16_LDS_WORDS + 16u <= FUSED_LDS_WORDS, "row roles' LDS");
+static_assert(FUSED_WAVES * 2u * GATHER_CAP + LATE_BITS_WORDS <= FUSED_LDS_WORDS, "gather role's LDS");
+
+template <int NV, int NT, int LOSS, bool ADAGRAD>
+__global__ void __launch_bounds__(FUSED_WAVES * WAVE)
+decode_gather_kernel(HyperParams hp, uint32_t hot_rows, FusedGeom geo, DecodeLate late, GatherArgs ga, CDAE_DECODE_PARAMS) {
+  constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
+  constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
+  extern __shared__ uint32_t fused_lds[];
+  const uint32_t wg = blockIdx.x;
+  const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  if (wg < geo.hot_wgs) {
+    // ---- popular rows: one per SIMD of this CU ----
+    uint32_t* const claim = fused_lds + FUSED_WAVES * ROWS16_LDS_WORDS;       // [4]: 1 + the wavefront that took the SIMD's row
+    if (threadIdx.x < 4) claim[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_ID.SIMD_ID */) & 3u;
+    if (threadIdx.x % WAVE == 0) atomicCAS(&claim[simd], 0u, 1u + wid);
+    __syncthreads();
+    const uint32_t c0 = claim[0], c1 = claim[1], c2 = claim[2], c3 = claim[3];
+    const uint32_t cs[4] = {c0, c1, c2, c3};
+    int mine = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (cs[q] == 1u + wid) mine = q;
+    if (mine < 0) {
+      // a SIMD none of the twelve wavefronts sits on should not happen (they are spread over the CU's four); if it does, the first idle ones take its row
+      uint32_t before = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (cs[q] && cs[q] - 1u < wid) ++before;
+      const uint32_t j = wid - before;
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (!cs[q]) { if (cnt == j) mine = q; ++cnt; }
+    }
+    if (mine < 0) return;
+    const uint32_t row = __builtin_amdgcn_readfirstlane(wg * 4u + (uint32_t)mine);
+    if (row >= hot_rows || CDAE_SKIP_ROLE(hp, 4u)) return;
+    const unsigned long long t0 = trace_begin(hp);
+    __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
+    decode_row64<NI, LOSS, ADAGRAD, false, true>(hp, row, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS), ROWS16_LDS_WORDS, late,
+                                                 CDAE_DECODE_PASS);
+    trace_end(hp, 3, row, t0, simd);
+  } else if (wg < geo.hot_wgs + geo.cold_wgs) {
+    // ---- all other rows, four per wavefront; wavefront w of workgroup c takes the groups w * cold_wgs + c, + 12 cold_wgs, ... ----
+    if (CDAE_SKIP_ROLE(hp, 8u)) return;
+    const uint32_t cw = wg - geo.hot_wgs;
+    for (uint32_t g = wid * geo.cold_wgs + cw; g < geo.n_groups; g += FUSED_WAVES * geo.cold_wgs) {        // (ML-10M shape: 2648 groups on 244 x 12 wavefronts, one each)
+      const unsigned long long t0 = trace_begin(hp);
+      decode_rows16<NV, NT, LOSS, ADAGRAD, true>(hp, hot_rows + g * 4u, fused_lds + wid * ROWS16_LDS_WORDS, CDAE_DECODE_PASS);
+      trace_end(hp, 4, hot_rows + g, t0);
+    }
+  } else {
+    // ---- hidden-gradient gather of the rows that are not late ----
+    uint32_t* const lbits = fused_lds + FUSED_WAVES * 2u * GATHER_CAP;
+    stage_late_bits(lbits, ga.late_bits, ga.late_words);
+    const uint32_t gw = wg - geo.hot_wgs - geo.cold_wgs;
+    const uint32_t part = gw & 7u, unit = (gw >> 3) * FUSED_WAVES + wid;
+    if (unit >= ga.n_units) return;
+    hidden_gather_role<NI, true>(hp, ga, part, 0u, unit, fused_lds + wid * 2u * GATHER_CAP,
+                                 reinterpret_cast<float*>(fused_lds + wid * 2u * GATHER_CAP + GATHER_CAP), ga.late_bits ? lbits : nullptr);
+  }
 }
 
 // hidden_gather_kernel's partial rows of the units [ub, ue) of one user added to hg in a FIXED order (unit-major, then partition):
@@ -1551,6 +1845,56 @@ __device__ __forceinline__ void add_partial_rows(float (&hg)[NI], const float* _
   }
 }
 
+// The late rows' terms of hg_u (DecodeLate; cdae.hpp:240,248,277,285 for the rows hidden_gather_kernel leaves out): lane r of the
+// caller holds row r's entries of the user — gh = Ghot[slot][r] (0: no example), hd = hotdup[slot][r], it = item_order[r].
+// hg += sum_r gh_r D0[it_r] in rank order, eight rows in flight, then the duplicate runs' correction rows in rank order: a fixed
+// order of additions (deterministic; the same in hidden_finish_kernel and hg_raw_kernel).
+template <int NI>
+__device__ __forceinline__ void add_late_rows(float (&hg)[NI], const LateFinish& lf, float gh, uint32_t hd, uint32_t it, uint32_t Kp, uint32_t lo) {
+  constexpr int TR = 8;
+  unsigned long long mask = __ballot(gh != 0.f);
+  while (mask) {
+    float vv[TR][NI], gg[TR];
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+      if (mask) {                                                  // wave-uniform
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        gg[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gh), src));
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readlane((int)it, src);
+        vload<NI>(vv[t], lf.D0 + (size_t)item * Kp + lo);
+      } else {
+        gg[t] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) vv[t][k] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TR; ++t)
+#pragma unroll
+      for (int k = 0; k < NI; ++k) hg[k] = fmaf(gg[t], vv[t][k], hg[k]);
+  }
+  unsigned long long dm = __ballot(hd != DUP_NONE);
+  while (dm) {                                                     // (rare)
+    const int src = __ffsll((long long)dm) - 1;
+    dm &= dm - 1;
+    const uint32_t di = (uint32_t)__builtin_amdgcn_readlane((int)hd, src);
+    float row[NI];
+    vload<NI>(row, lf.dup_corr + (size_t)di * Kp + lo);
+#pragma unroll
+    for (int k = 0; k < NI; ++k) hg[k] += row[k];
+  }
+}
+// the caller's part: this lane's entries of the user's late rows, requested beside everything else the wavefront needs
+__device__ __forceinline__ void load_late_entries(const LateFinish& lf, uint32_t slot, uint32_t lane, float& gh, uint32_t& hd, uint32_t& it) {
+  gh = 0.f; hd = DUP_NONE; it = 0u;
+  if (lane < lf.late_rows) {
+    gh = lf.Ghot[(size_t)slot * LATE_MAX + lane];
+    hd = lf.hotdup[(size_t)slot * LATE_MAX + lane];
+    it = lf.items[lane];
+  }
+}
+
 // K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
 //       and the private user-node step Wu[u]                                      cdae.hpp:317-331
 template <int NI>
@@ -1563,7 +1907,8 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
                      float* __restrict__ Uu, float* __restrict__ Uu_ag, const float* __restrict__ Ssum,
                      float* __restrict__ DELTA_ROWS /* linear_function only: Uu[u] (.) delta_u for the input rows */,
                      const float* __restrict__ Uu_batch = nullptr /* item shard: the batch's gathered Uu rows [nb][Kp] (a user this
-                                                                     shard does not own still needs Uu[u] (.) delta for its input rows) */) {
+                                                                     shard does not own still needs Uu[u] (.) delta for its input rows) */,
+                     LateFinish lf = LateFinish{nullptr, nullptr, nullptr, nullptr, nullptr, 0u} /* the late rows' terms, added behind the partial rows */) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -1579,8 +1924,11 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
   float p[NI], pa[NI];
   vload<NI>(dz, Dz + o);
   if (hp.user_factor && own) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
+  float late_g; uint32_t late_d, late_i;
+  load_late_entries(lf, slot, lane, late_g, late_d, late_i);
   const uint32_t ub = n_parts ? uptr[slot] - uptr[0] : 0u, ue = n_parts ? uptr[slot + 1] - uptr[0] : 0u;
   add_partial_rows<NI>(hg, HGpart, n_units, n_parts, ub, ue, hp.Kp, lo);
+  if (lf.late_rows) add_late_rows<NI>(hg, lf, late_g, late_d, late_i, hp.Kp, lo);
 #pragma unroll
   for (int i = 0; i < NI; ++i) delta[i] = hg[i] * dz[i];
   vstore<NI>(HG + o, delta);
@@ -2038,7 +2386,7 @@ slab_sum_kernel(HyperParams hp, const float* __restrict__ HGpart, uint32_t n_par
 template <int NI>
 __global__ void __launch_bounds__(256)
 hg_raw_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_units, uint32_t nb, const float* __restrict__ HGpart,
-              uint32_t n_parts, float* __restrict__ HG) {
+              uint32_t n_parts, float* __restrict__ HG, LateFinish lf = LateFinish{nullptr, nullptr, nullptr, nullptr, nullptr, 0u}) {
   const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   const uint32_t lane = threadIdx.x % WAVE;
   if (slot >= nb) return;
@@ -2046,8 +2394,11 @@ hg_raw_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_unit
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI];
   vload<NI>(hg, HG + o);
+  float late_g; uint32_t late_d, late_i;
+  load_late_entries(lf, slot, lane, late_g, late_d, late_i);
   const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
   add_partial_rows<NI>(hg, HGpart, n_units, n_parts, ub, ue, hp.Kp, lo);     // (16 partial rows in flight per trip: the loop of single loads was a 15-26 us chain)
+  if (lf.late_rows) add_late_rows<NI>(hg, lf, late_g, late_d, late_i, hp.Kp, lo);
   vstore<NI>(HG + o, hg);
 }
 

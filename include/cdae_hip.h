@@ -60,8 +60,9 @@ extern "C" {
  *     users on the BASELINE-sized data sets, was 1); BPR's phase U carries the positive item's row from pair to pair
  * 11: schedule of the user-sharded layout: cdae_hip_delta_set_combine (CDAE_COMBINE_GLOBAL_ACC), cdae_hip_multi_set_schedule
  *     (relay warm-up epochs on the single-GPU schedule, users per shard of the exchanged steps, combine rule); the drop-in IMF / BPR
- *     classes pass batch_users = 1 (the reference loop) unless CDAE_BATCH_USERS says otherwise */
-#define CDAE_HIP_ABI_VERSION 11
+ *     classes pass batch_users = 1 (the reference loop) unless CDAE_BATCH_USERS says otherwise
+ * 12: cdae_hip_decode_plan (which launches the sampled decode + hidden-gradient step of a handle is made of) */
+#define CDAE_HIP_ABI_VERSION 12
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
 #define CDAE_LOSS_SQUARE 0u
@@ -146,6 +147,15 @@ uint32_t cdae_hip_row_stride(const cdae_hip_t* h);
 #define CDAE_DEFAULT_BATCH_USERS_MAX 256u
 uint32_t cdae_hip_default_batch_users(uint64_t num_users);
 uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
+
+/* Which launches the SAMPLED step's decode (cdae.hpp:225-293) and hidden-gradient sum (cdae.hpp:240,248,277,285) of this handle are
+ * made of, chosen at cdae_hip_set_interactions from the data set and batch_users (0 before it):
+ *   *hot_rows   item rows that take a wavefront of their own (the most popular: >= 48 expected positives per batch);
+ *   *late_rows  the first of them (at most 64) whose hidden-gradient terms the per-user finish adds itself instead of the gather;
+ *   *fused      1: decode and gather are ONE launch (the gather waits, example by example, for the g of rows that finish early
+ *               and never for the late rows); 0: two launches.  Either order gives the same bits.
+ * Any pointer may be NULL. */
+int cdae_hip_decode_plan(const cdae_hip_t* h, uint32_t* hot_rows, uint32_t* late_rows, uint32_t* fused);
 
 /* Which launches the full-output decode (cdae_hip_config.full_output; the reference has no counterpart: its training decode is
  * always sampled, cdae.hpp:217-293) of this handle is made of, once cdae_hip_set_interactions has run — for a caller that prices

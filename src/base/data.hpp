@@ -207,6 +207,17 @@ class Data {
     col.resize(static_cast<size_t>(w));
   }
 
+  // whole-set split (data-inl.hpp:206-229): one shuffle of the positions; the first floor((1 - ratio) * n) go to train, the rest to test
+  void random_split(Data& train, Data& test, double test_ratio) const {
+    CHECK_LT(test_ratio, 1.0);
+    const size_t n = size(), n_train = static_cast<size_t>((1. - test_ratio) * n);
+    std::vector<size_t> pos(n);
+    for (size_t k = 0; k < n; ++k) pos[k] = k;
+    Random::shuffle(pos.begin(), pos.end());
+    train = gather(std::vector<size_t>(pos.begin(), pos.begin() + n_train));
+    test = gather(std::vector<size_t>(pos.begin() + n_train, pos.end()));
+  }
+
   // per id of group fg: shuffle its instances, the first floor(ratio * n) go to test (data-inl.hpp:249-261); ids in ascending
   // order and positions in storage order before each shuffle, so the result is a function of Random's state alone.
   void random_split_by_feature_group(Data& train, Data& test, size_t fg, double test_ratio) const {

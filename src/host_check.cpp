@@ -20,6 +20,7 @@ DEFINE_string(loss_type, "CE", "SQUARE or CE");
 DEFINE_double(cratio, 0.5, "corruption ratio");
 DEFINE_string(csr_only, "", "load this Data cache, time Data::to_csr (what a model's reset() derives for the device) and exit");
 DEFINE_string(dump_csr, "", "write the train / test rows Data::to_csr produces to <path>.train / <path>.test (int64 rows+1, then uint32 cols)");
+DEFINE_string(movielens_sample, "", "a user::item::rating::time file: run the checks of the reference's test/data_test.hpp:17-62 on it and exit");
 
 int main(int argc, char* argv[]) {
   using namespace libcf;
@@ -49,6 +50,40 @@ int main(int argc, char* argv[]) {
     d.to_csr(0, 1, row_ptr, col);
     LOG(INFO) << "csr_only: " << d.size() << " ratings, " << row_ptr.size() - 1 << " rows, " << col.size() << " unique; load "
               << load_s << " s, to_csr " << t_csr.elapsed() << " s";
+    return 0;
+  }
+  if (!FLAGS_movielens_sample.empty()) {
+    // What the reference's own data test asserts (test/data_test.hpp:17-62) on its fixture test/test_data/sample_movielens_data.txt:
+    // the "::" line parser gives four fields per line, every instance has two features (user, item), the file holds 200 instances,
+    // the cache round-trips, and random_split(0.3) leaves size * 0.7 / size * 0.3 instances.
+    auto line_parser = [&](const std::string& line) {
+      auto rets = split_line(line, ": ");
+      CHECK_EQ(rets.size(), size_t(4));
+      return std::vector<std::string>(rets.begin(), rets.begin() + 3);
+    };
+    Data data;
+    data.load(FLAGS_movielens_sample, RECSYS, line_parser);
+    const std::string cache = FLAGS_movielens_sample + ".bin";
+    save(data, cache);
+    Data data1;
+    load(cache, data1);
+    CHECK_EQ(data1.size(), data.size());
+    size_t cnt = 0;
+    double labels = 0.;
+    for (auto it = data1.begin(); it != data1.end(); ++it) {
+      CHECK_EQ((*it).size(), size_t(2));                          // data_test.hpp:48: two features per instance
+      CHECK_EQ((*it).get_feature_group_index(0, 0), data.at(cnt).get_feature_group_index(0, 0));
+      CHECK_EQ((*it).get_feature_group_index(1, 0), data.at(cnt).get_feature_group_index(1, 0));
+      labels += (*it).label();
+      ++cnt;
+    }
+    Data train, test, train2, test2;
+    data.random_split_by_feature_group(train, test, 0, 0.3);     // data_test.hpp:56
+    CHECK_EQ(train.size() + test.size(), data.size());
+    data.random_split(train2, test2, 0.3);                       // data_test.hpp:57-59
+    LOG(INFO) << "movielens sample: instances " << cnt << " users " << data.feature_group_total_dimension(0) << " items "
+              << data.feature_group_total_dimension(1) << " label_sum " << labels << " by_user_split " << train.size() << " " << test.size()
+              << " random_split " << train2.size() << " " << test2.size();
     return 0;
   }
   if (FLAGS_input_file.empty()) { LOG(INFO) << "host layer OK (no input file given)"; return 0; }

@@ -29,9 +29,9 @@ def test_header_symbols_are_all_exported_and_bound(built):
 
 def test_abi_version_and_config_layout(built):
     lib = cdae_amd.load_library()
-    assert lib.cdae_hip_abi_version() == 11
+    assert lib.cdae_hip_abi_version() == 12
     hdr = open(os.path.join(ROOT, "include", "cdae_hip.h")).read()
-    assert "#define CDAE_HIP_ABI_VERSION 11" in hdr
+    assert "#define CDAE_HIP_ABI_VERSION 12" in hdr
     # 14 uint32 + 4 double, naturally aligned
     assert ctypes.sizeof(binding._Config) == 14 * 4 + 4 * 8
     assert ctypes.sizeof(binding.Stats) == 8 * 11
@@ -75,13 +75,13 @@ def test_the_shipped_library_names_no_developer_switch(built):
     exist in the -DCDAE_DEVELOPER build only: the shipped library calls getenv nowhere, so their names are not in its string table; the
     developer build, made from the same sources, has them."""
     switches = [b"CDAE_DEBUG_SKIP_ROLES", b"CDAE_DEBUG_SKIP_PREP", b"CDAE_SORT_TILE", b"CDAE_GEMM1_TILED", b"CDAE_FULL_UNFUSED", b"CDAE_WAVE_TRACE",
-                b"CDAE_PREP2", b"CDAE_DUP_CAP", b"CDAE_XCHG_STREAM", b"CDAE_FULL_B_SUMMED"]
+                b"CDAE_PREP2", b"CDAE_DUP_CAP", b"CDAE_XCHG_STREAM", b"CDAE_FULL_B_SUMMED", b"CDAE_DECODE_UNFUSED", b"CDAE_NO_LATE_ROWS"]
     blob = open(cdae_amd.LIB_PATH, "rb").read()
     assert not [s for s in switches if s in blob]
     names = set(re.findall(rb"CDAE_[A-Z0-9_]{3,}", blob))
     assert len(names) <= 5, sorted(names)         # (error-message text such as a layout's name; no environment variable)
     dev = open(cdae_amd.DEV_LIB_PATH, "rb").read()
-    assert b"CDAE_SORT_TILE" in dev and b"CDAE_GEMM1_TILED" in dev and b"CDAE_FULL_B_SUMMED" not in dev
+    assert b"CDAE_SORT_TILE" in dev and b"CDAE_GEMM1_TILED" in dev and b"CDAE_DECODE_UNFUSED" in dev and b"CDAE_FULL_B_SUMMED" not in dev
 
 
 def test_product_sources_do_not_touch_the_oracle():

@@ -245,6 +245,56 @@ def test_scheduling_switches_do_not_change_a_single_bit(small, monkeypatch, devl
         assert np.array_equal(base[w], other[w]), (env, w)
 
 
+@pytest.mark.parametrize("K,B,kw", [(40, 300, dict()), (200, 300, dict(loss=cdae_amd.SQUARE, asymmetric=True)), (50, 128, dict(using_adagrad=False, learn_rate=0.01)),
+                                    (64, 300, dict(user_factor=False, tanh=True))])
+def test_fused_decode_gather_launch_changes_no_bit(tiny, monkeypatch, devlib, K, B, kw):
+    """Round 6: decode and hidden-gradient gather as ONE launch (decode_gather_kernel: the gather wavefronts wait, example by
+    example, for the g of rows still being decoded; g, D0 and the correction rows written through, sc1) against the SEPARATE
+    launches (CDAE_DECODE_UNFUSED): the same roles, the same sums in the same order — every parameter bit-identical after two
+    epochs.  The 120-item space makes duplicate negatives (correction rows, runs on late rows) the common case."""
+    monkeypatch.setenv("CDAE_DECODE_HOT_POS", "6")       # enough popular ("hot") rows at these sizes: late rows + the fused launch
+
+    def run(expect_fused):
+        m, _ = make_pair(tiny, K=K, B=B, **kw)
+        plan = m.decode_plan
+        assert plan["late_rows"] > 0 and plan["hot_rows"] >= plan["late_rows"] and plan["fused"] == expect_fused, plan
+        for ep in range(2):
+            m.train_one_iteration(seed=4, epoch=ep)
+        out = {w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)}
+        m.close()
+        return out, plan
+
+    fused, plan = run(True)
+    monkeypatch.setenv("CDAE_DECODE_UNFUSED", "1")
+    apart, _ = run(False)
+    for w in fused:
+        assert np.array_equal(fused[w], apart[w]), (w, plan, np.abs(fused[w] - apart[w]).max())
+    assert np.isfinite(fused[0]).all()
+
+
+@pytest.mark.parametrize("B", [64, 300])
+def test_late_rows_track_the_oracle_and_round_fives_arithmetic(tiny, monkeypatch, devlib, B):
+    """The late rows' terms of the hidden gradient are added by hidden_finish_kernel from Ghot (one entry per user and row, one
+    correction row per duplicate run) instead of being gathered: against the oracle's block schedule at the usual 2e-4, and against
+    round 5's arithmetic (CDAE_NO_LATE_ROWS: every example gathered) — a different order of the same fp32 additions, 2e-5."""
+    monkeypatch.setenv("CDAE_DECODE_HOT_POS", "4")
+    m, o = make_pair(tiny, K=40, B=B)
+    assert m.decode_plan["late_rows"] > 0, m.decode_plan
+    for ep in range(2):
+        m.train_one_iteration(seed=1, epoch=ep)
+        o.train_batched(1, ep, B)
+    err, which = max_param_err(m, o)
+    assert err < 2e-4, (err, which)
+    monkeypatch.setenv("CDAE_NO_LATE_ROWS", "1")
+    m5, _ = make_pair(tiny, K=40, B=B)
+    assert m5.decode_plan == dict(hot_rows=m.decode_plan["hot_rows"], late_rows=0, fused=False)
+    for ep in range(2):
+        m5.train_one_iteration(seed=1, epoch=ep)
+    for w in (0, 1, 4, 5, 6, 7, 8, 9):
+        a, b = m.get(w).astype(np.float64), m5.get(w).astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-5 * (1e-3 + np.abs(b).max()), w
+
+
 def test_the_shipped_library_reads_no_developer_switch(small, monkeypatch):
     """The SHIPPED library (no `devlib` here) under every developer switch that changes results or kernels in the developer build —
     CDAE_DEBUG_SKIP_ROLES / _SKIP_PREP give WRONG results there by design — trains the same bits as without them."""
@@ -263,7 +313,7 @@ def test_the_shipped_library_reads_no_developer_switch(small, monkeypatch):
     base, base_full = run(), run(True)
     for k, v in dict(CDAE_DEBUG_SKIP_ROLES="63", CDAE_DEBUG_SKIP_PREP="1", CDAE_SORT_TILE="1", CDAE_DUP_CAP="2", CDAE_DECODE_ONE_ROW_PER_WAVE="1",
                      CDAE_FULL_UNFUSED="1", CDAE_FULL_B_SUMMED="1", CDAE_PREP2="off", CDAE_PREP_THREAD="0", CDAE_UNIT_POS="16",
-                     CDAE_DECODE_HOT_POS="1", CDAE_ENCODE_TWO_LAUNCHES="1", CDAE_FULL_ONE_STREAM_MAX="0").items():
+                     CDAE_DECODE_HOT_POS="1", CDAE_ENCODE_TWO_LAUNCHES="1", CDAE_FULL_ONE_STREAM_MAX="0", CDAE_DECODE_UNFUSED="1", CDAE_NO_LATE_ROWS="1").items():
         monkeypatch.setenv(k, v)
     other, other_full = run(), run(True)
     for w in base:

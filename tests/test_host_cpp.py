@@ -82,6 +82,36 @@ def test_reference_yelp_app_builds_unmodified_and_runs_config1_plumbing(host_bin
     assert rc not in (0, 255) and "truncated" in out, (rc, out[-500:])
 
 
+REF_SAMPLE = "/root/reference/test/test_data/sample_movielens_data.txt"
+
+
+def test_the_references_own_data_fixture_gives_what_its_data_test_asserts(host_bins, tmp_path):
+    """The one data fixture the reference holds (test/test_data/sample_movielens_data.txt) through this repository's ingest, with the
+    assertions of the reference's test/data_test.hpp:17-62: the "::" parser yields four fields per line (CHECK_EQ inside host_check),
+    every instance has two features, 200 instances, the cache round-trips, random_split(0.3) leaves size * 0.7 and size * 0.3.
+    The expected numbers are committed here; the file itself stays in the reference tree (this test runs where that tree exists).
+    Beyond the reference's assertions: 5 users / 175 items / label sum 792 (counted from the file with plain Python below) and the
+    per-user split's floor(0.3 n_u) (data-inl.hpp:249-261): 58 of the users' 22 + 20 + 33 + 38 + 87 ratings."""
+    if not os.path.exists(REF_SAMPLE):
+        pytest.skip("the reference tree is not on this box")
+    rows = [l.strip().split("::") for l in open(REF_SAMPLE) if l.strip()]
+    assert len(rows) == 200 and {len(r) for r in rows} == {4}
+    local = tmp_path / "sample_movielens_data.txt"
+    local.write_text(open(REF_SAMPLE).read())
+    rc, out = run([os.path.join(host_bins, "host_check"), f"--movielens_sample={local}"], tmp_path)
+    assert rc == 0, out
+    m = re.search(r"movielens sample: instances (\d+) users (\d+) items (\d+) label_sum (\S+) by_user_split (\d+) (\d+) random_split (\d+) (\d+)", out)
+    assert m, out
+    inst, users, items, label_sum, utr, ute, rtr, rte = m.groups()
+    assert int(inst) == 200                                             # data_test.hpp:52
+    assert (int(rtr), int(rte)) == (140, 60)                            # data_test.hpp:58-59: size * 0.7, size * 0.3
+    assert int(users) == len({r[0] for r in rows}) == 5 and int(items) == len({r[1] for r in rows}) == 175
+    assert float(label_sum) == sum(float(r[2]) for r in rows) == 792.0
+    per_user = np.unique([r[0] for r in rows], return_counts=True)[1]
+    assert sorted(per_user.tolist()) == [20, 22, 33, 38, 87]
+    assert int(ute) == int(np.floor(0.3 * per_user).sum()) == 58 and int(utr) == 142
+
+
 def test_text_ingest_split_and_csr_are_pinned(host_bins, tmp_path):
     """SURVEY.md §8(f) rank 2, the data path in front of cdae_hip_set_interactions, against an independent numpy derivation:
       * text -> columns: ids in FIRST-SEEN order (instance-inl.hpp:22-37), one (user, item, 1) triple per line, file order
