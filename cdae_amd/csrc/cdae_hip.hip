@@ -103,8 +103,11 @@ struct cdae_hip {
   uint32_t* d_late_bits = nullptr;  // [(I + 31) / 32] bitmap of the late rows' items
   uint32_t late_words = 0;
   bool fused_decode = false;        // decode + gather as ONE launch (decode_gather_kernel); CDAE_DECODE_UNFUSED turns it off (developer switch)
-  bool fused_attr_decode = false;   // its dynamic-LDS attribute has been set on this handle's device
   uint32_t* d_fused_err = nullptr;  // raised by a gather wavefront of the fused launch that gave up waiting (checked at cdae_hip_synchronize)
+  uint32_t* d_hot_cnt = nullptr;    // [hot workgroups] wavefronts of the popular rows finished so far (the fused launch's blockers wait on it)
+  uint32_t fused_seq = 0;           // fused launches so far (wraps with the counters)
+  cdae::FusedGeom fused_geo{};      // geometry of this handle's fused launch (set at the first one)
+  bool fused_geo_set = false;
   uint32_t num_cus = 256;
   cdae::DecodeLate decode_late() const { return cdae::DecodeLate{d_Ghot, d_hotdup, late_rows}; }
   cdae::LateFinish late_finish() { return cdae::LateFinish{d_Ghot, d_hotdup, d_item_order, d_D0, d_dup_corr, late_rows}; }
@@ -412,7 +415,7 @@ void free_all(cdae_hip* h) {
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
                   h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut, h->d_range_of,
-                  h->d_Ghot, h->d_hotdup, h->d_late_bits, h->d_fused_err};
+                  h->d_Ghot, h->d_hotdup, h->d_late_bits, h->d_fused_err, h->d_hot_cnt};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -454,7 +457,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
                    (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
                    (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut, (void**)&h->d_range_of,
-                   (void**)&h->d_Ghot, (void**)&h->d_hotdup, (void**)&h->d_late_bits, (void**)&h->d_fused_err};
+                   (void**)&h->d_Ghot, (void**)&h->d_hotdup, (void**)&h->d_late_bits, (void**)&h->d_fused_err, (void**)&h->d_hot_cnt};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -582,6 +585,31 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
 
 // K3 on the main stream: the decode of example-buffer set `x` over this handle's item rows (shared by the single-handle step and
 // the sampled item-shard step)
+// Geometry of the fused launch, once per handle: how many workgroups of the launch a CU holds decides the blocker rounds.
+template <int NV, int NT>
+int fused_geometry(cdae_hip* h, uint32_t hot, uint32_t I) {
+  using namespace cdae;
+  FusedGeom g{};
+  g.hot_wgs = (hot + 3) / 4;
+  g.stride = h->num_cus;
+  g.blocked = std::min<uint32_t>(g.hot_wgs, FUSED_BLOCK_MAX);
+  int per_cu = 0;
+  const bool ce = h->cfg.loss_type == CDAE_LOSS_CROSS_ENTROPY, ada = h->cfg.using_adagrad != 0;
+  if (ce && ada) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 5, true>, 256, 0));
+  else if (ce) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 5, false>, 256, 0));
+  else if (ada) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 0, true>, 256, 0));
+  else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 0, false>, 256, 0));
+  g.rounds = (uint32_t)std::max(0, std::min(per_cu, 8) - 1);
+  if (const char* ev = DEV_ENV("CDAE_FUSED_BLOCK_ROUNDS")) g.rounds = (uint32_t)std::atoi(ev);     // (developer switch: 0 = no blockers)
+  const uint32_t cold_wgs = ((I - hot + 3) / 4 + 3) / 4;
+  uint32_t b = g.hot_wgs, c = 0;
+  while (c < cold_wgs) { if (!fused_is_blocker(g, b)) ++c; ++b; }
+  g.decode_wgs = b;
+  h->fused_geo = g;
+  h->fused_geo_set = true;
+  return 0;
+}
+
 // fused != nullptr: the fused launch (decode_gather_kernel) with these gather arguments; the caller then launches no hidden_gather_kernel
 int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x, const cdae::GatherArgs* fused = nullptr) {
   using namespace cdae;
@@ -607,18 +635,13 @@ int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x, const cdae::GatherArgs* fused
   // K <= 256: hot rows one per wavefront, all others four per wavefront (NV float4 pieces + NT tail scalars per lane)
 #define DECODE_HY(NV_, NT_)                                                                                           \
   do {                                                                                                                \
+    if (fused && !h->fused_geo_set) { CHK((fused_geometry<NV_, NT_>(h, hot, I))); geo = h->fused_geo; geo.hot_target = 4u * h->fused_seq; geo.hot_cnt = h->d_hot_cnt; \
+                                      grid_fu = dim3(geo.decode_wgs + gather_wgs); }                                  \
     if (fused) {                                                                                                       \
-      if (!h->fused_attr_decode) {                                                                                     \
-        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 5, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));   \
-        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 5, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));  \
-        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));   \
-        HIPCHK(hipFuncSetAttribute((const void*)decode_gather_kernel<NV_, NT_, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds));  \
-        h->fused_attr_decode = true;                                                                                   \
-      }                                                                                                                \
-      if (ce && ada) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 5, true>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);   \
-      else if (ce) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 5, false>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);    \
-      else if (ada) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 0, true>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);    \
-      else hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 0, false>), grid_fu, blk_fu, fused_lds, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);            \
+      if (ce && ada) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 5, true>), grid_fu, blk, 0, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);   \
+      else if (ce) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 5, false>), grid_fu, blk, 0, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);    \
+      else if (ada) hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 0, true>), grid_fu, blk, 0, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);    \
+      else hipLaunchKernelGGL((decode_gather_kernel<NV_, NT_, 0, false>), grid_fu, blk, 0, st, h->hp, hot, geo, late, *fused, DECODE_TAIL);            \
     }                                                                                                                  \
     else if (ce && ada) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, true>), grid_hy, blk, 0, st, h->hp, hot, late, DECODE_TAIL);   \
     else if (ce) hipLaunchKernelGGL((decode_hybrid_kernel<NV_, NT_, 5, false>), grid_hy, blk, 0, st, h->hp, hot, late, DECODE_TAIL);    \
@@ -637,14 +660,14 @@ int launch_decode(cdae_hip* h, cdae_hip::ExBuf& x, const cdae::GatherArgs* fused
       const uint32_t waves = hot + (I - hot + 3) / 4;
       const dim3 grid_hy((waves + 3) / 4);
       const DecodeLate late = h->decode_late();
-      // fused launch: [hot rows, four per workgroup] [the other rows: one workgroup per remaining CU] [gather: FUSED_WAVES (unit, partition) wavefronts each]
-      FusedGeom geo{};
-      geo.hot_wgs = (hot + 3) / 4;
-      geo.n_groups = (I - hot + 3) / 4;
-      geo.cold_wgs = std::max<uint32_t>(1u, std::min<uint32_t>(geo.n_groups, h->num_cus > geo.hot_wgs + 8u ? h->num_cus - geo.hot_wgs : 8u));
-      const uint32_t gather_wgs = fused ? 8u * ((fused->n_units + FUSED_WAVES - 1) / FUSED_WAVES) : 0u;
-      const dim3 grid_fu(geo.hot_wgs + geo.cold_wgs + gather_wgs), blk_fu(FUSED_WAVES * WAVE);
-      const size_t fused_lds = (size_t)FUSED_LDS_WORDS * sizeof(uint32_t);
+      // fused launch (decode_gather_kernel): [popular rows] [the other rows, with the blockers' indices among them] [gather]
+      FusedGeom geo = h->fused_geo;
+      if (fused) {
+        geo.hot_target = 4u * ++h->fused_seq;
+        geo.hot_cnt = h->d_hot_cnt;
+      }
+      const uint32_t gather_wgs = fused ? 8u * ((fused->n_units + 3u) / 4u) : 0u;
+      dim3 grid_fu(geo.decode_wgs + gather_wgs);
       const uint32_t nv = K / 64, tail = K % 64;
       const uint32_t nt = tail == 0 ? 0u : (tail < 16 ? 1u : (tail < 32 ? 2u : 4u));   // 16 nt > tail: room for b'
       if (nt == 0) {
@@ -1252,7 +1275,24 @@ int cdae_hip_create(const cdae_hip_config* cfg, int device_id, cdae_hip_t** out)
   if (const char* ev = DEV_ENV("CDAE_PREP_THREAD")) h->prep_threaded = std::atoi(ev) != 0;
   hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete h; return fail("hipStreamCreate failed: %s", hipGetErrorString(e)); }
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
+  if (const char* ev = DEV_ENV("CDAE_STREAM_PAD")) {     // developer experiment: shift which hardware queues the library's other streams get
+    static std::vector<hipStream_t> pads;                 // (kept for the life of the process)
+    static void* padbuf = nullptr;
+    if (!padbuf) (void)hipMalloc(&padbuf, 256);
+    for (int i = 0, n = std::atoi(ev); i < n && padbuf; ++i) {
+      hipStream_t s;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      (void)hipMemsetAsync(padbuf, 0, 256, s);            // (a stream gets its hardware queue when it is first used)
+      (void)hipStreamSynchronize(s);
+      pads.push_back(s);
+    }
+  }
+  {
+    // the prep stream's queue priority (CDAE_PREP_PRIORITY = 1: the device's highest; developer switch)
+    int prio_lo = 0, prio_hi = 0;
+    const bool high = DEV_ENV("CDAE_PREP_PRIORITY") != nullptr && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
+    if (e == hipSuccess) e = high ? hipStreamCreateWithPriority(&h->prep, hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&h->prep, hipStreamNonBlocking);
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking);
   {
     // Second prep lane.  Sampling + sorting a batch is a chain of ~12 small launches, ~95 us on the prep stream whatever the
@@ -1493,7 +1533,19 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     // separate launches and an item shard of one agree bit for bit); the gather tells them by a bitmap it stages in LDS (item spaces up
     // to 65 536).  CDAE_NO_LATE_ROWS: round 5's arithmetic (developer switch).
     const bool hybrid = h->K <= 256 && !h->one_row_per_wave && !h->mf && !h->cfg.full_output;
-    h->late_rows = hybrid && I <= 32u * cdae::LATE_BITS_WORDS && !DEV_ENV("CDAE_NO_LATE_ROWS") ? std::min<uint32_t>(h->hot_rows, cdae::LATE_MAX) : 0u;
+    h->late_rows = 0;
+    if (hybrid && I <= 32u * cdae::LATE_BITS_WORDS && !DEV_ENV("CDAE_NO_LATE_ROWS")) {
+      // late: at least CDAE_DECODE_LATE_POS (default 48, i.e. the hot rows: measured 16 / 24 / 32 / 48 -> 0.0915 / 0.0918 / 0.0907 / 0.0898 ms per step) expected positives per batch, at most LATE_MAX rows; all of them take a
+      // wavefront of their own (a late row in the four-rows-per-wavefront format would need its own Ghot bookkeeping there)
+      const char* ev = DEV_ENV("CDAE_DECODE_LATE_POS");
+      const double late_pos = ev ? std::atof(ev) : 48.0;
+      const double share = (double)std::min<uint64_t>(h->B, U) / (double)U;
+      uint32_t late = 0;
+      while (late < I && late < cdae::LATE_MAX && (double)pop[order[late]] * share >= late_pos) ++late;
+      // (a batch must have examples enough to make the split worth its bookkeeping: none for tiny batches)
+      h->late_rows = h->hot_rows ? std::min<uint32_t>(std::min<uint32_t>((late + 3u) & ~3u, cdae::LATE_MAX), (uint32_t)I) : 0u;
+      h->hot_rows = std::max(h->hot_rows, h->late_rows);
+    }
     h->late_words = (uint32_t)((I + 31) / 32);
     if (h->late_rows) {
       std::vector<uint32_t> bits(h->late_words, 0u);
@@ -1507,6 +1559,9 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     }
     CHK(dev_alloc(&h->d_fused_err, 1));
     HIPCHK(hipMemset(h->d_fused_err, 0, sizeof(uint32_t)));
+    CHK(dev_alloc(&h->d_hot_cnt, (size_t)h->hot_rows / 4 + 1));
+    HIPCHK(hipMemset(h->d_hot_cnt, 0, ((size_t)h->hot_rows / 4 + 1) * sizeof(uint32_t)));
+    h->fused_seq = 0; h->fused_geo_set = false;
     // The fused launch: needs late rows (else the gather would wait for the longest chains); hot rows take a CU per four of them, so
     // at most half the chip's; the row matrices are addressed through 32-bit buffer offsets.
     hipDeviceProp_t prop;

@@ -104,6 +104,10 @@ constexpr unsigned long long TRACE_CAP = (unsigned long long)TRACE_ROLES * TRACE
 __device__ __forceinline__ unsigned long long trace_begin(const HyperParams& hp) {
   return hp.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 }
+// where a wavefront runs: HW_ID[15:0] (wave 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13) | XCC_ID << 16
+__device__ __forceinline__ uint32_t hw_place() {
+  return (__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) & 0xFFFFu) | ((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xFu) << 16);
+}
 __device__ __forceinline__ void trace_end(const HyperParams& hp, uint32_t tag, uint32_t id, unsigned long long t0, uint32_t extra = 0) {
   if (hp.trace && threadIdx.x % 64 == 0 && id < TRACE_IDS) {
     tag += 16u * hp.trace_odd;                                   // odd batches keep their own records: two consecutive batches survive
@@ -335,6 +339,9 @@ sample_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const uint32_
               // word that receives `cell_tag` when a unit puts more than BKC_SLOTS - 1 examples into one range (the sort then scans instead)
               const uint16_t* __restrict__ range_of = nullptr, const uint32_t* __restrict__ range_cut = nullptr, uint32_t n_ranges = 0,
               uint32_t* __restrict__ cells = nullptr, uint32_t* __restrict__ cell_flag = nullptr, uint32_t cell_tag = 0) {
+#ifdef CDAE_PREP_SETPRIO
+  __builtin_amdgcn_s_setprio(CDAE_PREP_SETPRIO);
+#endif
   __shared__ uint32_t lds_rows[4][SAMPLE_LDS_ROW];
   __shared__ uint32_t cell_cnt[4][BKC_MAX_RANGES];
   __shared__ uint32_t cell_lo[BKC_MAX_RANGES];
@@ -836,9 +843,11 @@ constexpr int WAIT_VM0 = 0x0F70;   // s_waitcnt vmcnt(0) (expcnt 7, lgkmcnt 15 =
 // chunk, which costs a store + full vmcnt drain — ~1 us of the row's serial chain — per chunk)
 // FUSED: the launch that also gathers (decode_gather_kernel) — G, the D0 row and the correction rows are written through (sc1).
 // late: rows below late.late_rows leave their g in late.Ghot and one correction row per duplicate run (late.hotdup), see DecodeLate.
-template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD, bool FUSED = false>
+// ref_lds: 2 NI x 64 wave-private LDS words for the rarely used duplicate-run state (the row at the user's first visit, the run's
+// corrections so far), or nullptr: kept in registers (the K > 256 launch, which has no LDS).
+template <int NI, int LOSS, bool ADAGRAD, bool BIAS_IN_PAD, bool FUSED = false, bool REF_IN_LDS = false>
 __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank, float* __restrict__ g_park, const uint32_t park_cap,
-                                             const DecodeLate late, CDAE_DECODE_PARAMS) {
+                                             const DecodeLate late, CDAE_DECODE_PARAMS, float* __restrict__ ref_lds = nullptr) {
   const uint32_t lane = threadIdx.x % WAVE;
   if (rank >= hp.num_items) return;
   const bool is_late = rank < late.late_rows;                     // wave-uniform
@@ -858,7 +867,12 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
   const bool tied = !hp.asymmetric;
   // the row is requested beside its segment bounds (one round trip of the chain's prologue instead of two); a row without
   // examples leaves here with nothing written
-  float w[NI], a[NI], wref[NI];
+  float w[NI], a[NI];
+  // (REF_IN_LDS: element i of this lane at ref[64 i]; else registers, one "word" apart)
+  float ref_regs[REF_IN_LDS ? 1 : 2 * NI];
+  float* const wref = REF_IN_LDS ? ref_lds + lane : ref_regs;
+  float* const csum = REF_IN_LDS ? ref_lds + 64 * NI + lane : ref_regs + NI;
+  constexpr int RS = REF_IN_LDS ? 64 : 1;                          // stride between a lane's elements
   vload<NI>(w, D + (size_t)item * hp.Kp + lo);
   vload<NI>(a, D_ag + (size_t)item * hp.Kp + lo);
   float bias = bp[item], bias_ag = bp_ag[item];
@@ -873,14 +887,10 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
   const bool pad_lane = BIAS_IN_PAD && lane == WAVE - 1;
   const float pad_one = pad_lane ? 1.f : 0.f;
   if (pad_lane) { w[NI - 1] = bias; a[NI - 1] = bias_ag; }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) wref[i] = w[i];
+  // (a run's first example sets wref before its duplicates read it: no initial value needed)
   // late rows: ONE correction row per run of a user's duplicates — the sum of the run's corrections so far, re-written at every
   // duplicate into the row of the run's first one (hidden_finish_kernel adds it by (user, late row), late.hotdup)
   uint32_t run_di = DUP_NONE;
-  float csum[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) csum[i] = 0.f;
 
 #ifndef CDAE_DECODE_PF
 #define CDAE_DECODE_PF 8
@@ -953,17 +963,17 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
           uint32_t di = dup_of_pos[c0 + idx];
           float corr[NI];
 #pragma unroll
-          for (int i = 0; i < NI; ++i) corr[i] = (pad_lane && i == NI - 1) ? 0.f : g * (w[i] - wref[i]);
+          for (int i = 0; i < NI; ++i) corr[i] = (pad_lane && i == NI - 1) ? 0.f : g * (w[i] - wref[RS * i]);
           if (is_late && di != DUP_NONE) {                     // (wave-uniform) the run's corrections so far, in the run's first row
             if (run_di == DUP_NONE) {
               run_di = di;
 #pragma unroll
-              for (int i = 0; i < NI; ++i) csum[i] = corr[i];
+              for (int i = 0; i < NI; ++i) csum[RS * i] = corr[i];
               if (lane == 0) late.hotdup[(size_t)(word & SLOT_MASK) * LATE_MAX + rank] = di;
             } else {
               di = run_di;
 #pragma unroll
-              for (int i = 0; i < NI; ++i) { csum[i] += corr[i]; corr[i] = csum[i]; }
+              for (int i = 0; i < NI; ++i) { corr[i] += csum[RS * i]; csum[RS * i] = corr[i]; }
             }
           }
           if (di != DUP_NONE) {
@@ -977,7 +987,7 @@ __device__ __forceinline__ void decode_row64(HyperParams hp, const uint32_t rank
           __builtin_amdgcn_s_waitcnt(WAIT_VM0);                // keep the loop's VMEM stream loads-only
         } else {                                               // first of a run: remember the row at the user's first visit
 #pragma unroll
-          for (int i = 0; i < NI; ++i) wref[i] = w[i];
+          for (int i = 0; i < NI; ++i) wref[RS * i] = w[i];
           run_di = DUP_NONE;
         }
       }
@@ -1286,8 +1296,12 @@ __device__ __forceinline__ void row16_store_sc1(float* __restrict__ matrix, uint
 }
 
 // Wave-private LDS of decode_rows16 (words): example words and example ids of the current and the next 64-example chunk of each
-// of the four groups, and the parked g of the current chunk.
-constexpr uint32_t ROWS16_LDS_WORDS = 4u * 128u + 4u * 128u + 4u * 64u;
+// of the four groups, the parked g of the current chunk, and (round 6) the rows as they were at the current user's first visit —
+// read only when that user draws the same negative again: 13-16 registers per lane that the launch's occupancy pays for otherwise.
+constexpr uint32_t ROWS16_WREF_WORDS = 16u * 64u;
+constexpr uint32_t ROWS16_LDS_WORDS = 4u * 128u + 4u * 128u + 4u * 64u + ROWS16_WREF_WORDS;
+// the same words as decode_row64 uses them: g parked until the row's end, then its duplicate-run state (2 x NI x 64 words, NI <= 4)
+constexpr uint32_t ROW64_PARK_WORDS = ROWS16_LDS_WORDS - 512u;
 
 template <int NV, int NT, int LOSS, bool ADAGRAD, bool FUSED = false>
 __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t rank0, uint32_t* __restrict__ lds, CDAE_DECODE_PARAMS) {
@@ -1317,7 +1331,9 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   const bool pad_lane = HAS_PAD && l == GRP - 1;
   const float pad_one = pad_lane ? 1.f : 0.f;
 
-  float w[NE], a[NE], wref[NE];
+  float w[NE], a[NE];
+  static_assert(NE <= 16, "ROWS16_WREF_WORDS");
+  float* const wref = reinterpret_cast<float*>(lds + 1280u) + lane;          // element i of this lane's row: wref[64 i]
   const size_t row_off = (size_t)item * hp.Kp;
   if (n) {
     row16_load<NV, NT>(w, D + row_off, l);
@@ -1331,8 +1347,6 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   }
   float bias = n ? bp[item] : 0.f, bias_ag = n ? bp_ag[item] : 1.f;
   if (pad_lane) { w[NE - 1] = bias; a[NE - 1] = bias_ag; }
-#pragma unroll
-  for (int i = 0; i < NE; ++i) wref[i] = w[i];
 
 #ifndef CDAE_DECODE16_PF
 #define CDAE_DECODE16_PF 4
@@ -1368,6 +1382,16 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
       if (q < n) store_f32<FUSED>(G + el[q & 127u], gl[q & 63u]);
     }
   };
+  // FUSED: g leaves every FLUSH examples instead of every 64 — the gather wavefronts of the same launch take the users in order, and
+  // a row's early examples are the early users' (one more store + drain per 16 steps of a wavefront whose SIMD has other work)
+#ifndef CDAE_FUSED_FLUSH
+#define CDAE_FUSED_FLUSH 64
+#endif
+  constexpr uint32_t FLUSH = FUSED ? (uint32_t)CDAE_FUSED_FLUSH : 64u;
+  auto flush_sixteen = [&](uint32_t c0) {                         // G of the 16 examples starting at c0
+    const uint32_t q = c0 + l;
+    if (q < n) store_f32<FUSED>(G + el[q & 127u], gl[q & 63u]);
+  };
   if constexpr (FUSED) __builtin_amdgcn_s_waitcnt(WAIT_VM0);      // the D0 rows are in memory before any g of them can be (decode_row64)
   stage_chunk(0);
   stage_chunk(64);                                               // (unconditional: the look-ahead reads up to PF words past nmax, and LDS starts as garbage)
@@ -1398,6 +1422,11 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   CDAE_STAMP();
   for (uint32_t t0 = 0; t0 < nmax; t0 += PF) {
     if ((t0 & 15u) == 0u && t0) CDAE_STAMP();
+    if (FLUSH == 16u && (t0 & 15u) == 0u && t0 != 0u) {
+      flush_sixteen(t0 - 16u);
+      __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+      if ((t0 & 63u) == 0u) stage_chunk(t0 + 64u);
+    } else
     if ((t0 & 63u) == 0u && t0 != 0u) {                          // chunk boundary (wave-uniform): write the finished chunk's g, stage the chunk after next
       flush_chunk(t0 - 64u);
       __builtin_amdgcn_s_waitcnt(WAIT_VM0);                      // keep the loop's VMEM stream loads-only
@@ -1433,7 +1462,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
             const uint32_t di = dup_of_pos[beg + t];
             float corr[NE];
 #pragma unroll
-            for (int i = 0; i < NE; ++i) corr[i] = (pad_lane && i == NE - 1) ? 0.f : g * (w[i] - wref[i]);
+            for (int i = 0; i < NE; ++i) corr[i] = (pad_lane && i == NE - 1) ? 0.f : g * (w[i] - wref[64 * i]);
             if (di != DUP_NONE) {
               if constexpr (FUSED) row16_store_sc1<NV, NT>(dup_corr, di * hp.Kp, corr, l);
               else row16_store<NV, NT>(dup_corr + (size_t)di * hp.Kp, corr, l);
@@ -1448,7 +1477,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
             __builtin_amdgcn_s_waitcnt(WAIT_VM0);
           } else {
 #pragma unroll
-            for (int i = 0; i < NE; ++i) wref[i] = w[i];
+            for (int i = 0; i < NE; ++i) wref[64 * i] = w[i];     // (a run's first example always comes before its duplicates: no initial value needed)
           }
         }
         if (!(word & INPUT_BIT) || !tied) {
@@ -1466,7 +1495,8 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
     }
   }
   // g of the chunk the loop ended in (chunks before it were written at their boundary)
-  flush_chunk((nmax - 1u) & ~63u);
+  if (FLUSH == 16u) flush_sixteen((nmax - 1u) & ~15u);
+  else flush_chunk((nmax - 1u) & ~63u);
   if (n) {
     if (HAS_PAD) {
       if (pad_lane) { bp[item] = w[NE - 1]; bp_ag[item] = a[NE - 1]; w[NE - 1] = 0.f; a[NE - 1] = 1.f; }
@@ -1503,8 +1533,9 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, DecodeLate late, CDAE_DE
 #define CDAE_HOT_PRIO 2
 #endif
     __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
-    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROWS16_LDS_WORDS, late,
-                                           CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
+    decode_row64<NI, LOSS, ADAGRAD, false, false, true>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROW64_PARK_WORDS, late,
+                                                        CDAE_DECODE_PASS,   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
+                                                        reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]) + ROW64_PARK_WORDS);
     trace_end(hp, 3, wave, t0);
   } else {
     if (CDAE_SKIP_ROLE(hp, 8u)) return;
@@ -1581,7 +1612,7 @@ __device__ __forceinline__ void hidden_gather_role(const HyperParams& hp, const 
   // rows in flight per trip (registers: TRIP x NI floats).  The launch of its own must be resident as a whole: <= 96 registers.  The fused
   // launch holds three wavefronts per SIMD whatever they need below 168 registers: twice the rows per trip (round 5 measured 16 rows /
   // 130 registers at 6.6 us per wavefront against 9 us for 8 rows).  The list order, hence every sum, is the same.
-  constexpr int TRIP = NI >= 8 ? 4 : (FUSED ? 16 : 8);
+  constexpr int TRIP = NI >= 8 ? 4 : (FUSED ? 12 : 8);
   constexpr uint32_t GCAP = GATHER_CAP;
   constexpr uint32_t DUP_ROW = 0x80000000u;                      // list entry: a row of dup_corr (added as it is) instead of D0 (times g)
   const cdae_rsrc d0_rs = rows_rsrc(ga.D0), dc_rs = rows_rsrc(ga.dup_corr);      // (FUSED: sc1 row loads)
@@ -1713,76 +1744,90 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
 // K3 + K4a in ONE launch (round 6).  The decode launch is as long as its most popular row's serial chain (~134 examples x 250 ns at
 // 256 users per batch) while nine tenths of its other wavefronts are done in half that time, and the hidden-gradient gather that
 // follows needs only g — so the gather of everything but the late rows (DecodeLate) runs INSIDE the decode launch, as trailing
-// workgroups that start as the row wavefronts retire and wait, example by example, for the g they need (G_PENDING).
-// Geometry: workgroups of 12 wavefronts with more than half a CU's LDS each, i.e. ONE workgroup per CU —
-//   [hot_wgs]  four popular rows each, one per SIMD (elected by the SIMD the wavefront finds itself on; the other eight leave at
-//              once): the CU belongs to those four chains — through round 5 the four-row wavefronts that shared a SIMD with a
-//              popular row's wavefront (whose chain keeps the SIMD's VALU ~80 % busy) lived as long as the launch;
-//   [cold_wgs] the other rows, four per wavefront (decode_rows16), striped over the workgroups in popularity order;
-//   [gather]   twelve (unit, partition) wavefronts each (hidden_gather_role<FUSED>).
+// workgroups that are dispatched as the row wavefronts retire and wait, example by example, for the g they need (G_PENDING).
+// Workgroups of four wavefronts, in this order of workgroup index (S = the chip's CU count):
+//   [0, H)                      popular rows (decode_row64), four per workgroup, one per SIMD;
+//   [rS, rS + H), r = 1..rounds BLOCKERS: idle wavefronts that sleep until popular workgroup (index mod S) has finished.  A popular row's
+//                               chain keeps its SIMD's VALU ~80 % busy; through round 5 the four-row wavefronts that shared the SIMD
+//                               lived as long as the launch — harmless then, but here every gather wavefront would end up waiting for
+//                               one of their rows.  Workgroup b runs on the CU that b mod S names while the CUs hold 1 + rounds
+//                               workgroups of this launch each (observed placement, a speed assumption only: wherever a blocker
+//                               lands it just sleeps);
+//   every other index below D   the other rows, four per wavefront (decode_rows16), in popularity order;
+//   [D, ...)                    gather: four (unit, partition) wavefronts each (hidden_gather_role<FUSED>).
 // Workgroups are dispatched in index order (as bucket_sort_kernel assumes): whatever a gather wavefront waits for is running or done.
 // Everything one role writes and another reads inside the launch is written through (sc1) and read past the L1 (sc1), so no
 // agent-scope fence — a walk of the XCD's whole L2 — is needed (MI355X_MICROARCH.md, inter-workgroup visibility).
-struct FusedGeom { uint32_t hot_wgs, cold_wgs, n_groups; };
-constexpr uint32_t FUSED_WAVES = 12;             // three per SIMD: the row roles need ~145 registers (16 wavefronts = 128 registers each: spills)
-constexpr uint32_t FUSED_LDS_WORDS = 21504;      // 84 KiB of the CU's 160: one workgroup per CU
-static_assert(FUSED_WAVES * ROWS16_LDS_WORDS + 16u <= FUSED_LDS_WORDS, "row roles' LDS");
-static_assert(FUSED_WAVES * 2u * GATHER_CAP + LATE_BITS_WORDS <= FUSED_LDS_WORDS, "gather role's LDS");
+struct FusedGeom {
+  uint32_t hot_wgs;        // H
+  uint32_t stride;         // S
+  uint32_t blocked;        // popular workgroups [0, blocked) have blockers (at most FUSED_BLOCK_MAX)
+  uint32_t rounds;         // blocker rounds: workgroups of this launch a CU holds, less one
+  uint32_t decode_wgs;     // D
+  uint32_t hot_target;     // value every popular workgroup's counter reaches when its four wavefronts of THIS launch are done (wraps)
+  uint32_t* hot_cnt;       // [hot_wgs] wavefronts finished since the handle was created
+};
+constexpr uint32_t FUSED_BLOCK_MAX = 16;         // blockers for the workgroups of the 64 most popular rows
+constexpr uint32_t FUSED_LDS_WORDS = 4u * ROWS16_LDS_WORDS;                       // row roles: 36 KiB (the gather role needs 24 KiB)
+static_assert(4u * 2u * GATHER_CAP + LATE_BITS_WORDS <= FUSED_LDS_WORDS, "gather role's LDS");
+// cold workgroup number of workgroup index b (b is neither popular nor a blocker), and the predicate
+__host__ __device__ inline bool fused_is_blocker(const FusedGeom& g, uint32_t b) {
+  return b >= g.stride && b < (1u + g.rounds) * g.stride && b % g.stride < g.blocked;
+}
+__host__ __device__ inline uint32_t fused_cold_index(const FusedGeom& g, uint32_t b) {
+  uint32_t skipped = g.hot_wgs;
+  for (uint32_t r = 1; r <= g.rounds; ++r)
+    if (b > r * g.stride) skipped += (b - r * g.stride < g.blocked ? b - r * g.stride : g.blocked);
+  return b - skipped;
+}
 
+#ifndef CDAE_FUSED_WAVES_PER_SIMD
+#define CDAE_FUSED_WAVES_PER_SIMD 3      // (4 = 128 registers: gather wavefronts resident from the start — measured slower, they take issue slots the row roles need)
+#endif
 template <int NV, int NT, int LOSS, bool ADAGRAD>
-__global__ void __launch_bounds__(FUSED_WAVES * WAVE)
+__global__ void __launch_bounds__(256, CDAE_FUSED_WAVES_PER_SIMD)
 decode_gather_kernel(HyperParams hp, uint32_t hot_rows, FusedGeom geo, DecodeLate late, GatherArgs ga, CDAE_DECODE_PARAMS) {
   constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
   constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
-  extern __shared__ uint32_t fused_lds[];
+  __shared__ uint32_t fused_lds[FUSED_LDS_WORDS];
   const uint32_t wg = blockIdx.x;
   const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   if (wg < geo.hot_wgs) {
-    // ---- popular rows: one per SIMD of this CU ----
-    uint32_t* const claim = fused_lds + FUSED_WAVES * ROWS16_LDS_WORDS;       // [4]: 1 + the wavefront that took the SIMD's row
-    if (threadIdx.x < 4) claim[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_ID.SIMD_ID */) & 3u;
-    if (threadIdx.x % WAVE == 0) atomicCAS(&claim[simd], 0u, 1u + wid);
-    __syncthreads();
-    const uint32_t c0 = claim[0], c1 = claim[1], c2 = claim[2], c3 = claim[3];
-    const uint32_t cs[4] = {c0, c1, c2, c3};
-    int mine = -1;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) if (cs[q] == 1u + wid) mine = q;
-    if (mine < 0) {
-      // a SIMD none of the twelve wavefronts sits on should not happen (they are spread over the CU's four); if it does, the first idle ones take its row
-      uint32_t before = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if (cs[q] && cs[q] - 1u < wid) ++before;
-      const uint32_t j = wid - before;
-      uint32_t cnt = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if (!cs[q]) { if (cnt == j) mine = q; ++cnt; }
-    }
-    if (mine < 0) return;
-    const uint32_t row = __builtin_amdgcn_readfirstlane(wg * 4u + (uint32_t)mine);
-    if (row >= hot_rows || CDAE_SKIP_ROLE(hp, 4u)) return;
-    const unsigned long long t0 = trace_begin(hp);
-    __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
-    decode_row64<NI, LOSS, ADAGRAD, false, true>(hp, row, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS), ROWS16_LDS_WORDS, late,
-                                                 CDAE_DECODE_PASS);
-    trace_end(hp, 3, row, t0, simd);
-  } else if (wg < geo.hot_wgs + geo.cold_wgs) {
-    // ---- all other rows, four per wavefront; wavefront w of workgroup c takes the groups w * cold_wgs + c, + 12 cold_wgs, ... ----
-    if (CDAE_SKIP_ROLE(hp, 8u)) return;
-    const uint32_t cw = wg - geo.hot_wgs;
-    for (uint32_t g = wid * geo.cold_wgs + cw; g < geo.n_groups; g += FUSED_WAVES * geo.cold_wgs) {        // (ML-10M shape: 2648 groups on 244 x 12 wavefronts, one each)
+    // ---- popular rows ----
+    const uint32_t row = wg * 4u + wid;
+    if (row < hot_rows && !CDAE_SKIP_ROLE(hp, 4u)) {
       const unsigned long long t0 = trace_begin(hp);
-      decode_rows16<NV, NT, LOSS, ADAGRAD, true>(hp, hot_rows + g * 4u, fused_lds + wid * ROWS16_LDS_WORDS, CDAE_DECODE_PASS);
-      trace_end(hp, 4, hot_rows + g, t0);
+      __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
+      decode_row64<NI, LOSS, ADAGRAD, false, true, true>(hp, row, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS), ROW64_PARK_WORDS, late,
+                                                         CDAE_DECODE_PASS, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS) + ROW64_PARK_WORDS);
+      __builtin_amdgcn_s_setprio(0);
+      trace_end(hp, 3, row, t0, hp.trace ? hw_place() : 0u);
     }
+    if (threadIdx.x % WAVE == 0) atomicAdd(geo.hot_cnt + wg, 1u);          // (the blockers of this workgroup)
+  } else if (wg < geo.decode_wgs) {
+    if (fused_is_blocker(geo, wg)) {
+      // ---- blocker: hold this CU's slots until the popular workgroup is done ----
+      const uint32_t* cnt = geo.hot_cnt + wg % geo.stride;
+      const unsigned long long t0 = trace_begin(hp);
+      for (uint32_t spin = 0; spin < (1u << 16); ++spin) {
+        if ((int32_t)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - geo.hot_target) >= 0) break;
+        __builtin_amdgcn_s_sleep(127);
+      }
+      trace_end(hp, 10, wg * 4u + wid, t0, hp.trace ? hw_place() : 0u);
+      return;
+    }
+    // ---- all other rows, four per wavefront ----
+    if (CDAE_SKIP_ROLE(hp, 8u)) return;
+    const uint32_t g = fused_cold_index(geo, wg) * 4u + wid;
+    const unsigned long long t0 = trace_begin(hp);
+    decode_rows16<NV, NT, LOSS, ADAGRAD, true>(hp, hot_rows + g * 4u, fused_lds + wid * ROWS16_LDS_WORDS, CDAE_DECODE_PASS);
+    trace_end(hp, 4, hot_rows / 4u + g, t0, hp.trace ? hw_place() : 0u);
   } else {
     // ---- hidden-gradient gather of the rows that are not late ----
-    uint32_t* const lbits = fused_lds + FUSED_WAVES * 2u * GATHER_CAP;
+    uint32_t* const lbits = fused_lds + 4u * 2u * GATHER_CAP;
     stage_late_bits(lbits, ga.late_bits, ga.late_words);
-    const uint32_t gw = wg - geo.hot_wgs - geo.cold_wgs;
-    const uint32_t part = gw & 7u, unit = (gw >> 3) * FUSED_WAVES + wid;
+    const uint32_t gw = wg - geo.decode_wgs;
+    const uint32_t part = gw & 7u, unit = (gw >> 3) * 4u + wid;
     if (unit >= ga.n_units) return;
     hidden_gather_role<NI, true>(hp, ga, part, 0u, unit, fused_lds + wid * 2u * GATHER_CAP,
                                  reinterpret_cast<float*>(fused_lds + wid * 2u * GATHER_CAP + GATHER_CAP), ga.late_bits ? lbits : nullptr);
@@ -1847,11 +1892,11 @@ __device__ __forceinline__ void add_partial_rows(float (&hg)[NI], const float* _
 
 // The late rows' terms of hg_u (DecodeLate; cdae.hpp:240,248,277,285 for the rows hidden_gather_kernel leaves out): lane r of the
 // caller holds row r's entries of the user — gh = Ghot[slot][r] (0: no example), hd = hotdup[slot][r], it = item_order[r].
-// hg += sum_r gh_r D0[it_r] in rank order, eight rows in flight, then the duplicate runs' correction rows in rank order: a fixed
+// hg += sum_r gh_r D0[it_r] in rank order, sixteen rows in flight, then the duplicate runs' correction rows in rank order: a fixed
 // order of additions (deterministic; the same in hidden_finish_kernel and hg_raw_kernel).
 template <int NI>
 __device__ __forceinline__ void add_late_rows(float (&hg)[NI], const LateFinish& lf, float gh, uint32_t hd, uint32_t it, uint32_t Kp, uint32_t lo) {
-  constexpr int TR = 8;
+  constexpr int TR = NI >= 8 ? 8 : 16;
   unsigned long long mask = __ballot(gh != 0.f);
   while (mask) {
     float vv[TR][NI], gg[TR];

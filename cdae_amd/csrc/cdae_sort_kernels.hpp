@@ -377,6 +377,9 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
                    uint64_t* __restrict__ scratch_val /* [n_ex]: only an item above the LDS window uses it */,
                    uint32_t* __restrict__ dup_count, uint32_t dup_cap, uint32_t* __restrict__ dup_of_pos,
                    uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */, uint32_t stripes) {
+#ifdef CDAE_PREP_SETPRIO
+  __builtin_amdgcn_s_setprio(CDAE_PREP_SETPRIO);
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char bk_lds[];
   uint64_t* raw = reinterpret_cast<uint64_t*>(bk_lds);                        // [BK_WINDOW] arrival order inside an item
   uint64_t* srt = raw + BK_WINDOW;                                            // [BK_WINDOW] sorted

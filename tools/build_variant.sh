@@ -6,8 +6,9 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 d=build/variants/$name; mkdir -p $d
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -w -DCDAE_DEVELOPER"
-/opt/rocm/bin/hipcc $F "$@" -c cdae_amd/csrc/cdae_hip.hip -o $d/cdae_hip.o &
-/opt/rocm/bin/hipcc $F "$@" -c cdae_amd/csrc/cdae_multi.hip -o $d/cdae_multi.o &
-wait
+rm -f $d/cdae_hip.o $d/cdae_multi.o $d/libcdae_hip.so            # (never link a stale object behind a failed compile)
+/opt/rocm/bin/hipcc $F "$@" -c cdae_amd/csrc/cdae_hip.hip -o $d/cdae_hip.o & p1=$!
+/opt/rocm/bin/hipcc $F "$@" -c cdae_amd/csrc/cdae_multi.hip -o $d/cdae_multi.o & p2=$!
+wait $p1; wait $p2                                                 # (set -e: either failure ends the script)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/cdae_hip.o $d/cdae_multi.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o $d/libcdae_hip.so
 echo built $d/libcdae_hip.so

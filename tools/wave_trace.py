@@ -20,7 +20,7 @@ import cdae_amd  # noqa: E402
 from cdae_amd import synth  # noqa: E402
 
 ROLES = {1: "encode_partial", 2: "encode_finish", 3: "decode hot row", 4: "decode 4 rows", 5: "hidden_gather", 6: "hidden_finish",
-         7: "input: bias b", 8: "input: hot row", 9: "input: row"}
+         7: "input: bias b", 8: "input: hot row", 9: "input: row", 10: "decode: blocker"}
 
 
 def main():
@@ -37,6 +37,8 @@ def main():
     gc.collect()
     rec = np.fromfile(PATH, dtype=np.uint64).reshape(-1, 4)
     rec = rec[rec[:, 1] != 0]
+    if os.environ.get("CDAE_WAVE_TRACE_DUMP"):
+        np.save(os.environ["CDAE_WAVE_TRACE_DUMP"], rec)
     # slots keep the last batch that wrote them: drop stragglers of earlier batches (ids the last batch did not reach)
     last = rec[:, 2].astype(np.int64).max()
     rec = rec[last - rec[:, 1].astype(np.int64) < 26_000]            # the last two batches (260 us)
