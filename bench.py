@@ -62,6 +62,14 @@ def compulsory_decode_bytes(K, Kp, num_items, examples, batch_users):
     return rows * (5.0 * 4.0 * Kp + 16.0) + batch_users * 4.0 * Kp + examples * 12.0
 
 
+def compulsory_gather_bytes(Kp, num_items, examples, units):
+    """HBM bytes the hidden-gradient gather adds when it runs inside the decode launch (decode_gather_kernel, round 6): the D0 rows come
+    back from memory once (each XCD's L2 then holds its eighth of them: later reads are L2 hits), 12 B of (item, g, correction id)
+    per example, and one partial row per (work unit, item partition) is written."""
+    rows = num_items * (1.0 - np.exp(-examples / num_items))
+    return rows * 4.0 * Kp + examples * 12.0 + 8.0 * units * 4.0 * Kp
+
+
 class Watchdog:
     """N > 1 only.  `with WATCHDOG.stage("what", seconds):` around every step that can wait on ANOTHER rank (communicator set-up,
     collectives, barriers): if it does not return in time this rank prints one parseable JSON line with "error" and exits with
@@ -131,8 +139,13 @@ def main():
                          "ONE data set of the named shape, users sharded over the ranks by interactions (BASELINE configs[3]: "
                          "--shape netflix --scaling strong).  Either way the ranks exchange shared-parameter deltas, which is "
                          "OUTSIDE the single-GPU accuracy envelope (DESIGN.md §7): the N > 1 value is a throughput figure")
-    ap.add_argument("--layout", choices=["users", "item-rows"], default=None,
-                    help="How N > 1 GPUs divide the model.  item-rows (the DEFAULT for N > 1): the GPUs cut the ITEM rows of W / b' and the "
+    ap.add_argument("--layout", choices=["certified", "users", "item-rows"], default=None,
+                    help="How N > 1 GPUs divide the model.  certified (the DEFAULT for N > 1 since round 6): the users are sharded, ONE process "
+                         "(rank 0) drives all N GPUs through cdae_hip_multi_* on the schedule whose accuracy bounds driver-run tests assert — "
+                         "one relayed epoch on the single-GPU schedule (untimed warm-up here; 1 of an application's 50 epochs), then "
+                         "synchronous exchanged steps of 64 users per GPU folded in by the global-accumulator rule (DESIGN.md §7); the line "
+                         "carries the single-GPU and the item-rows figure of the same node beside it in `config` (--no-side-figures skips "
+                         "them).  item-rows: the GPUs cut the ITEM rows of W / b' and the "
                          "decode over them, every GPU sees every user, the user node is sharded by user; two [batch x K] all-reduces per "
                          "batch; it is the single-GPU schedule EXACTLY, so the N > 1 number carries the single-GPU accuracy claim "
                          "(tests/test_gpu_accuracy.py::test_item_rows_sampled_layout_holds_the_accuracy_bounds_at_ml10m_shape).  One "
@@ -140,6 +153,9 @@ def main():
                          "ranks only keep the barriers).  With --full-output it is BASELINE configs[4]'s layout (--shape cfg5_items "
                          "--num-dim 512).  users: user shards + exchange of shared-parameter deltas (one process per GPU, library-owned "
                          "RCCL): scales in throughput but is OUTSIDE the accuracy envelope (DESIGN.md §7) — a throughput figure only")
+    ap.add_argument("--no-side-figures", action="store_true", help="--layout certified: do not measure the single-GPU and item-rows figures beside the line")
+    ap.add_argument("--sync-batch-users", type=int, default=64, help="--layout certified: users per GPU and exchanged step (64 is the certified size)")
+    ap.add_argument("--item-rows-devices", type=int, default=0, help="(internal: the side-figure run of --layout certified) item-rows over this many GPUs from one process")
     ap.add_argument("--users", type=int, default=0, help="--layout item-rows: generate this many users instead of the shape's own count "
                     "(same items and interactions per user), e.g. --shape cfg5_items --users 200000 to see the memory per shard")
     ap.add_argument("--logical-shards", type=int, default=0, help="--layout item-rows on ONE GPU: this many logical shards of cuda:0 "
@@ -174,9 +190,11 @@ def main():
     from cdae_amd.distributed import shard_bounds
 
     if args.layout is None:
-        args.layout = "item-rows" if (world > 1 or args.logical_shards) else "users"
+        args.layout = "item-rows" if (args.logical_shards or args.item_rows_devices or (world > 1 and args.full_output)) else ("certified" if world > 1 else "users")
     if args.layout == "item-rows":
         return bench_item_rows(args, rank, world)
+    if args.layout == "certified":
+        return bench_certified(args, rank, world)
     if args.scaling == "strong" and world > 1:
         whole = synth.generate_shape(args.shape, seed=args.seed)          # the same data set on every rank ...
         u0, u1 = shard_bounds(whole.num_users, world, rank, whole.train_ptr)
@@ -444,6 +462,12 @@ def main():
     else:
         # HBM roofline on the bytes the launch MUST move (never above 1); what actually bounds the kernel is stated beside it
         comp = compulsory_decode_bytes(K, Kp, data.num_items, ex_per_launch, users_per_launch)
+        dplan = model.decode_plan if hasattr(model, "decode_plan") else dict(hot_rows=0, late_rows=0, fused=False)
+        if dplan["fused"]:
+            # the launch also gathers the hidden gradient (one launch since round 6): its compulsory bytes ride along
+            unit_pos = 64 if B <= 1024 else 128
+            units_per_user = float(np.ceil(np.diff(data.train_ptr) / unit_pos).sum()) / data.num_users
+            comp += compulsory_gather_bytes(Kp, data.num_items, ex_per_launch, units_per_user * users_per_launch)
         achieved = comp / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
         traffic, traffic_source = measured_traffic(args.shape, K, B)
         top_share = float(np.bincount(data.train_col, minlength=data.num_items).max()) / data.num_users
@@ -456,7 +480,8 @@ def main():
         CYC_PER_EXAMPLE, CLOCK_GHZ = 420.0, 2.4
         chain_us = 5.0 + chain * CYC_PER_EXAMPLE / (CLOCK_GHZ * 1e3)
         issue_us = 4.0 + (ex_per_launch / 4.0 / 0.85) * 1350.0 / (1024 * CLOCK_GHZ * 1e3)
-        roofline = {"bound": "hbm", "kernel": "decode_hybrid_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "decode_gather_kernel (decode + hidden-gradient gather, one launch)" if dplan["fused"] else "decode_hybrid_kernel",
+                    "decode_plan": dplan, "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     # `traffic` is NOT measured by this run (a process cannot collect PMC counters on itself): it is read back from
                     # the committed rocprofv3 --pmc passes of this same command, when one exists for this exact workload
@@ -494,10 +519,9 @@ def main():
                    "accuracy": (full_output_accuracy(B, data.num_users, args.shape, K) if args.full_output and args.gpus == 1
                                 else "batch_users within the single-GPU envelope of tests/test_gpu_accuracy.py" if args.gpus == 1 and B <= DEFAULT_BATCH_USERS
                                 else "single GPU, batch_users ABOVE the accuracy envelope (throughput only)" if args.gpus == 1
-                                else ("data-parallel delta exchange, synchronous, %s combine: after one relayed epoch (cdae_hip_multi_set_schedule) the "
-                                      "mean-over-seeds Recall@10 is within +-0.002 of the sequential reference at 8 x 64 users per step (ML-10M and Netflix "
-                                      "shape, tests/test_gpu_accuracy.py / test_gpu_netflix.py), single seeds within 0.009 — wider than the single GPU's 0.005; "
-                                      "DESIGN.md §7" % args.combine) if args.exchange_every == 0 and B <= 64
+                                else ("THROUGHPUT ONLY: this multi-process form (--layout users: one process per GPU, synchronous %s exchange) runs NO relayed "
+                                      "epoch — the relay exists only in cdae_hip_multi_set_schedule, i.e. in --layout certified, whose line carries the accuracy "
+                                      "bounds (DESIGN.md §7)" % args.combine) if args.exchange_every == 0 and B <= 64
                                 else "data-parallel delta exchange (pipelined, or more than 64 users per rank and step): OUTSIDE the measured envelope "
                                      "(DESIGN.md §7 table); throughput only")},
         "roofline": roofline,
@@ -534,7 +558,7 @@ def bench_item_rows(args, rank, world):
         dist.barrier(); dist.barrier()
         dist.destroy_process_group()
         return
-    devices = [0] * args.logical_shards if args.logical_shards else list(range(world))
+    devices = [0] * args.logical_shards if args.logical_shards else list(range(args.item_rows_devices or world))
     if args.users >= 2_000_000:          # scale run (configs[4]'s 10 M users): 20 interactions per user, uniform over the items
         u, i, nnz = synth.SHAPES[args.shape]
         t_gen = time.perf_counter()
@@ -649,6 +673,129 @@ def bench_item_rows(args, rank, world):
            "device0_memory_gib": round(used_gib, 3), "shards_on_device0": len(devices) if args.logical_shards else 1,
            "user_node_gib_per_shard": round(2.0 * (data.num_users / len(devices)) * Kp * 4 / 2**30, 3),
            "user_node_gib_if_replicated": round(2.0 * data.num_users * Kp * 4 / 2**30, 3)}
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+
+
+def side_figure(extra, timeout_s=240):
+    """`value` of a short run of this script with other flags, in a fresh process that sees every GPU of the node and no
+    torch.distributed environment (the side figures of --layout certified); None (and the reason) when it fails"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                             "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-side-figures"] + extra, env=env,
+                             capture_output=True, text=True, timeout=timeout_s)
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        return {"users_per_s": line["value"], "ms_per_step": line["ms_per_step"], "batch_users": line["config"].get("batch_users"), "command": "bench.py " + " ".join(extra)}
+    except Exception as e:                                  # noqa: BLE001  (a side figure must never take the line down)
+        return {"users_per_s": None, "error": repr(e)[:200], "command": "bench.py " + " ".join(extra)}
+
+
+def bench_certified(args, rank, world):
+    """--layout certified (the default for N > 1): the user-sharded layout on the schedule whose accuracy bounds are asserted by driver-run
+    tests (tests/test_gpu_accuracy.py::test_relay_then_exchange_schedule_on_eight_shards_at_ml10m_shape, tests/test_gpu_netflix.py::
+    test_netflix_relay_then_exchange_schedule_on_eight_shards): relay epoch, then synchronous exchanged steps of --sync-batch-users users per
+    GPU under the global-accumulator combine rule.  ONE process (rank 0) drives all N GPUs through cdae_hip_multi_* (a host thread per GPU
+    inside the library, RCCL communicators of ncclCommInitAll); a step = one exchanged step = N x sync_batch_users users.  ONE data set
+    (strong scaling).  The relayed epoch runs before the timed region: it costs one single-GPU epoch once per training run."""
+    import torch
+    import cdae_amd
+    from cdae_amd import synth
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with WATCHDOG.stage("gloo rendezvous", WD_INIT_S):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank != 0:                        # the other ranks own no GPU work: they keep the job's barriers
+        dist.barrier(); dist.barrier()
+        dist.destroy_process_group()
+        return
+    n_shards = args.logical_shards or world
+    devices = [0] * n_shards if (args.logical_shards or args.share_device) else list(range(world))
+    side = {}
+    if not args.no_side_figures:
+        # the same node's other two answers to "N GPUs", measured now, in their own processes, before this one holds the devices
+        base = ["--shape", args.shape, "--num-dim", str(args.num_dim), "--seed", str(args.seed)]
+        side["single_gpu"] = side_figure(base + ["--steps", "200", "--warmup", "40"])
+        if len(set(devices)) > 1:
+            side["item_rows_same_gpus"] = side_figure(base + ["--layout", "item-rows", "--item-rows-devices", str(world), "--steps", "100", "--warmup", "20"])
+        else:
+            side["item_rows_same_gpus"] = side_figure(base + ["--layout", "item-rows", "--logical-shards", str(n_shards), "--steps", "60", "--warmup", "10"])
+    data = synth.generate_shape(args.shape, seed=args.seed)
+    K, B1 = args.num_dim, min(args.batch_users, data.num_users)
+    sb = max(1, min(args.sync_batch_users, B1))
+    cfg = cdae_amd.CDAEConfig(num_dim=K, lt=cdae_amd.CROSS_ENTROPY, num_neg=5, num_corruptions=1, corruption_ratio=0.5, scaled=True,
+                              learn_rate=0.1, beta=1.0, lambda_=0.01, using_adagrad=True, user_factor=True, batch_users=B1)
+    model = cdae_amd.MultiCDAE(cfg, devices=devices, exchange_every=0)
+    combine = cdae_amd.COMBINE_GLOBAL_ACC if args.combine == "global-acc" else cdae_amd.COMBINE_SUM
+    model.set_schedule(period=0, combine=combine, sync_batch_users=sb, relay_epochs=1.0)
+    model.reset(data, seed=args.seed)
+    t_r = time.perf_counter()
+    with WATCHDOG.stage("relayed epoch (single-GPU schedule, shard by shard)", WD_SYNC_S):
+        model.train_one_iteration(args.seed, 0)                       # epoch 0: the relay (warm-up; untimed)
+    relay_s = time.perf_counter() - t_r
+    spe = max(1, model.steps_per_epoch)
+
+    def run(first, count):
+        """exchanged steps first .. first + count - 1, counted from the start of epoch 1; returns users trained"""
+        users, i, end = 0, first, first + count
+        while i < end:
+            ep, t = 1 + i // spe, i % spe
+            n = min(end - i, spe - t)
+            users += model.train_steps(args.seed, ep, t, t + n).users
+            i += n
+        return users
+
+    with WATCHDOG.stage("warm-up steps", WD_SYNC_S):
+        run(0, args.warmup)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with WATCHDOG.stage("timed steps", WD_SYNC_S):
+        users = run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    n_gpus = len(set(devices))
+    Kp = 64 * (1 if K <= 64 else 2 if K <= 128 else 4 if K <= 256 else 8)
+    users_step = users / max(1, args.steps)
+    ex_shard_step = data.nnz_train * 6.0 / data.num_users * users_step / n_shards
+    comp = compulsory_decode_bytes(K, Kp, data.num_items, ex_shard_step, users_step / n_shards)
+    achieved = comp / (elapsed / args.steps) / 1e9
+    value = users / elapsed
+    single = (side.get("single_gpu") or {}).get("users_per_s")
+    out = {"metric": ("users/sec (whole node) K=200 ML-10M-shape; Recall@10 parity" if (args.shape == "ml10m" and K == 200)
+                      else f"users/sec (whole node) K={K} {args.shape}-shape"),
+           "value": value, "unit": "users/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.shape}-shape synthetic {data.num_users}x{data.num_items} (ONE data set, users sharded over {n_shards} "
+                                  f"{'logical shards of one GPU' if n_gpus == 1 and n_shards > 1 else 'GPUs'} by interactions), nnz_train={data.nnz_train}, "
+                                  f"K={K}, num_neg=5, CE loss, AdaGrad, q=0.5 scaled",
+                      "batch_users": sb, "global_batch": int(round(users_step)), "parallelism": f"dp{n_shards} (user shards, one process, a host thread per GPU)",
+                      "exchange": f"synchronous: after every step ONE all-reduce(sum) of the accumulated delta of the shared block "
+                                  f"[W | W_ag | b' | b'_ag | b | b_ag] (library-owned RCCL communicators), {args.combine} combine; Wu stays on its shard",
+                      "schedule": {"relay_epochs": 1.0, "relay_epoch_seconds_untimed": relay_s, "sync_batch_users": sb, "steps_per_epoch": spe,
+                                   "note": "the relayed epoch is the single-GPU schedule handed from GPU to GPU (one GPU's time, once per training run: 1 of "
+                                           "apps/yelp's 50 epochs); the timed steps are the exchanged schedule of every later epoch"},
+                      "accuracy": ("relay 1.0 + %d users per GPU and step + %s: mean-over-seeds Recall@10 within +-0.002 of the sequential reference from epoch 2 on at "
+                                   "8 x 64 users per step (ML-10M shape: <= 0.0014; Netflix shape: 0.0020, at the edge), single seeds within 0.009 / 0.005 — "
+                                   "the schedule's OWN bounds, wider than the single GPU's (tests/test_gpu_accuracy.py::test_relay_then_exchange_schedule_on_eight_"
+                                   "shards_at_ml10m_shape, tests/test_gpu_netflix.py::test_netflix_relay_then_exchange_schedule_on_eight_shards; DESIGN.md §7)"
+                                   % (sb, args.combine)) if sb <= 64 and n_shards <= 8 else
+                                  "OUTSIDE the measured envelope (more than 64 users per GPU and step, or more than 8 shards): throughput only",
+                      "same_node_alternatives": side,
+                      "vs_single_gpu": (value / single) if single else None},
+           "roofline": {"bound": "hbm", "kernel": "whole exchanged step per GPU (decode + gather launch of the shard's 64 users, stage, all-reduce, merge)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac_definition": "one shard's compulsory decode bytes / WHOLE step time / HBM peak: the step is bound by the all-reduce of the whole "
+                                           "shared block and the stage / merge passes over it (DESIGN.md §8), not by the decode"}}
     model.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -119,6 +119,8 @@ EXPORTS = {
     "cdae_hip_multi_set_exchange": (C.c_int, [C.c_void_p, C.c_int]),
     "cdae_hip_multi_set_schedule": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cdae_hip_multi_train_epoch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Stats)]),
+    "cdae_hip_multi_steps_per_epoch": (C.c_uint64, [C.c_void_p]),
+    "cdae_hip_multi_train_steps": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "cdae_hip_multi_train_users": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Stats)]),
     "cdae_hip_multi_data_loss": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "cdae_hip_multi_penalty_loss": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
@@ -603,6 +605,17 @@ class MultiCDAE:
     def train_users(self, seed: int, epoch: int, u_begin: int, u_end: int) -> Stats:
         st = Stats()
         _chk(self.lib, self.lib.cdae_hip_multi_train_users(self.h, seed, epoch, u_begin, u_end, C.byref(st)))
+        return st
+
+    @property
+    def steps_per_epoch(self) -> int:
+        """user-sharded layout: exchanged steps of one epoch (cdae_hip_multi_steps_per_epoch)"""
+        return int(self.lib.cdae_hip_multi_steps_per_epoch(self.h))
+
+    def train_steps(self, seed: int, epoch: int, step_begin: int, step_end: int) -> Stats:
+        """steps [step_begin, step_end) of the epoch's exchanged part, no relay, flushed at the end (measurement hook)"""
+        st = Stats()
+        _chk(self.lib, self.lib.cdae_hip_multi_train_steps(self.h, seed, epoch, step_begin, step_end, C.byref(st)))
         return st
 
     def current_loss(self, seed: int, epoch: int) -> float:

@@ -103,11 +103,17 @@ struct cdae_hip {
   uint32_t* d_late_bits = nullptr;  // [(I + 31) / 32] bitmap of the late rows' items
   uint32_t late_words = 0;
   bool fused_decode = false;        // decode + gather as ONE launch (decode_gather_kernel); CDAE_DECODE_UNFUSED turns it off (developer switch)
-  uint32_t* d_fused_err = nullptr;  // raised by a gather wavefront of the fused launch that gave up waiting (checked at cdae_hip_synchronize)
+  // device error word: raised by a gather wavefront of the fused launch (bit 0) or a workgroup of bucket_sort_kernel (bit 1) that gave up
+  // waiting; checked after every synchronisation of the main stream.  HOST memory mapped into the device (the kernels write it on the
+  // error path only): the check is a plain read, not a 30 us device-to-host copy behind every synchronize
+  uint32_t* h_err = nullptr;        // host address
+  uint32_t* d_fused_err = nullptr;  // the same word as the device sees it
   uint32_t* d_hot_cnt = nullptr;    // [hot workgroups] wavefronts of the popular rows finished so far (the fused launch's blockers wait on it)
   uint32_t fused_seq = 0;           // fused launches so far (wraps with the counters)
   cdae::FusedGeom fused_geo{};      // geometry of this handle's fused launch (set at the first one)
   bool fused_geo_set = false;
+  std::vector<float> h_rank_len;    // [I] expected examples per batch of the row of popularity rank r (fused launch: balancing the four-row groups over the SIMDs)
+  uint32_t* d_cold_map = nullptr;   // [decode workgroups x 4] four-row group of every wavefront of the fused launch's row workgroups (0xFFFFFFFF: none)
   uint32_t num_cus = 256;
   cdae::DecodeLate decode_late() const { return cdae::DecodeLate{d_Ghot, d_hotdup, late_rows}; }
   cdae::LateFinish late_finish() { return cdae::LateFinish{d_Ghot, d_hotdup, d_item_order, d_D0, d_dup_corr, late_rows}; }
@@ -335,15 +341,17 @@ int join_aux(cdae_hip* h) {
   return 0;
 }
 
-// After the main stream has been synchronised: did a gather wavefront of a fused launch (decode_gather_kernel) give up waiting?
+// After the main stream has been synchronised: the handle's device error word.  Bit 0: a gather wavefront of a fused launch
+// (decode_gather_kernel) gave up waiting for a g; bit 1: a workgroup of bucket_sort_kernel gave up waiting for the ranges in front of it.
+// Both waits rest on workgroups being dispatched in index order and are bounded, so that a broken assumption is an error, not a hang.
 int fused_check(cdae_hip* h) {
-  if (!h->fused_decode || !h->d_fused_err) return 0;
-  uint32_t err = 0;
-  HIPCHK(hipMemcpy(&err, h->d_fused_err, sizeof err, hipMemcpyDeviceToHost));
+  if (!h->d_fused_err || !(h->fused_decode || h->bucket_sort)) return 0;
+  const uint32_t err = *(volatile uint32_t*)h->h_err;
   if (err) {
-    HIPCHK(hipMemset(h->d_fused_err, 0, sizeof err));
-    return fail("fused decode + gather launch: a gather wavefront gave up waiting for its g (workgroups not dispatched in index order?); "
-                "the parameters of this handle are no longer valid");
+    *(volatile uint32_t*)h->h_err = 0u;
+    return fail("%s%s: workgroups not dispatched in index order, or a launch that was skipped?  The parameters of this handle are no longer valid",
+                (err & 1u) ? "fused decode + gather launch: a gather wavefront gave up waiting for its g; " : "",
+                (err & 2u) ? "bucket_sort_kernel: a workgroup gave up waiting for the ranges in front of it" : "");
   }
   return 0;
 }
@@ -415,7 +423,7 @@ void free_all(cdae_hip* h) {
                   h->d_base, h->d_delta, h->d_recv, h->d_snap, h->d_dup_corr, h->d_unit_user, h->d_zeval, h->d_bits, h->d_hpart_eval, h->d_iota, h->d_bits_train,
                   h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, h->d_score, h->d_Hsum, h->d_hsum_eval, h->d_iota_eval, h->d_rec_score, h->d_gpos, h->d_ub, h->d_ub_ag, h->d_UVpre, h->d_rank_of,
                   h->d_grow_ptr, h->d_gcol, h->d_gunit_ptr, h->d_gunit_user, h->d_test_ptr, h->d_test_col, h->d_topn_pu, h->d_topn_out, h->d_bucket_cut, h->d_range_of,
-                  h->d_Ghot, h->d_hotdup, h->d_late_bits, h->d_fused_err, h->d_hot_cnt};
+                  h->d_Ghot, h->d_hotdup, h->d_late_bits, h->d_hot_cnt, h->d_cold_map};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& b : h->ex) {
     void* q[] = {b.item, b.val, b.sorted_item, b.sorted_val, b.seg, b.dup_of_pos, b.dup_of_ex, b.dup_count, b.key16, b.sorted_key16,
@@ -424,6 +432,7 @@ void free_all(cdae_hip* h) {
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
   }
+  if (h->h_err) { (void)hipHostFree(h->h_err); h->h_err = nullptr; h->d_fused_err = nullptr; }
   if (h->prep) (void)hipStreamDestroy(h->prep);
   if (h->prep2 && h->prep2_own) (void)hipStreamDestroy(h->prep2);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -457,7 +466,7 @@ int free_interaction_state(cdae_hip* h) {
                    (void**)&h->d_Hsum, (void**)&h->d_hsum_eval, (void**)&h->d_iota_eval, (void**)&h->d_rec_score, (void**)&h->d_gpos, (void**)&h->d_ub, (void**)&h->d_ub_ag, (void**)&h->d_UVpre, (void**)&h->d_rank_of,
                    (void**)&h->d_grow_ptr, (void**)&h->d_gcol, (void**)&h->d_gunit_ptr, (void**)&h->d_gunit_user,
                    (void**)&h->d_test_ptr, (void**)&h->d_test_col, (void**)&h->d_topn_pu, (void**)&h->d_topn_out, (void**)&h->d_bucket_cut, (void**)&h->d_range_of,
-                   (void**)&h->d_Ghot, (void**)&h->d_hotdup, (void**)&h->d_late_bits, (void**)&h->d_fused_err, (void**)&h->d_hot_cnt};
+                   (void**)&h->d_Ghot, (void**)&h->d_hotdup, (void**)&h->d_late_bits, (void**)&h->d_hot_cnt, (void**)&h->d_cold_map};
   for (auto& b : h->ex) {
     void** q[] = {(void**)&b.item, (void**)&b.val, (void**)&b.sorted_item, (void**)&b.sorted_val, (void**)&b.seg,
                   (void**)&b.dup_of_pos, (void**)&b.dup_of_ex, (void**)&b.dup_count, (void**)&b.key16, (void**)&b.sorted_key16,
@@ -539,7 +548,7 @@ int prep_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t epoc
                        (uint32_t)bt.E, (const uint32_t*)h->d_bucket_cut, x.wg_state, (const uint32_t*)(use_cells ? x.cells : nullptr), n_units,
                        (const uint32_t*)x.cell_flag, x.cell_tag, x.seg, x.seg + I, (const uint32_t*)h->d_rank_of,
                        x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I, x.sorted_val, x.bucketed, x.dup_count, h->dup_cap, x.dup_of_pos, x.dup_of_ex,
-                       h->dup_stripes);
+                       h->dup_stripes, h->d_fused_err);
   } else if (h->counting_sort) {
     // item-major order by counting, four launches (cdae_sort_kernels.hpp)
     const uint32_t n_tiles = (uint32_t)((bt.E + TILE_EX - 1) / TILE_EX);
@@ -601,10 +610,53 @@ int fused_geometry(cdae_hip* h, uint32_t hot, uint32_t I) {
   else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 0, false>, 256, 0));
   g.rounds = (uint32_t)std::max(0, std::min(per_cu, 8) - 1);
   if (const char* ev = DEV_ENV("CDAE_FUSED_BLOCK_ROUNDS")) g.rounds = (uint32_t)std::atoi(ev);     // (developer switch: 0 = no blockers)
-  const uint32_t cold_wgs = ((I - hot + 3) / 4 + 3) / 4;
-  uint32_t b = g.hot_wgs, c = 0;
-  while (c < cold_wgs) { if (!fused_is_blocker(g, b)) ++c; ++b; }
-  g.decode_wgs = b;
+  // The four-row groups are dealt to (CU, SIMD) bins so that every SIMD gets about the same number of example steps (longest group first,
+  // each to the lightest bin): a group lasts as long as its longest row, the SIMDs are VALU-bound on these wavefronts, and in index
+  // order (round 5) the SIMDs that held the most popular groups finished 10-15 us after the others — which every gather wavefront of
+  // this launch then waits for.  Workgroup b's wavefront w runs on SIMD w of CU b mod S (observed placement: only the balance depends
+  // on it): the k-th group of bin (cu, w) goes to workgroup cu + k S.  The popular rows' CUs (and their blockers') take no group.
+  const uint32_t n_groups = (I - hot + 3) / 4, S = g.stride;
+  std::vector<float> len(n_groups, 0.f);
+  for (uint32_t q = 0; q < n_groups; ++q)
+    for (uint32_t j = 0; j < 4 && hot + 4 * q + j < I; ++j) len[q] = std::max(len[q], h->h_rank_len[hot + 4 * q + j]);
+  std::vector<uint32_t> by_len(n_groups);
+  std::iota(by_len.begin(), by_len.end(), 0u);
+  std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b2) { return len[a] > len[b2]; });
+  const uint32_t cu0 = std::min(g.hot_wgs, S > 8 ? S - 8 : 0u);                 // CUs [0, cu0) belong to the popular rows
+  const uint32_t n_bins = (S - cu0) * 4;
+  std::vector<std::vector<uint32_t>> bin(n_bins);
+  {
+    // lightest bin first: a heap of (load, bin)
+    using Ent = std::pair<float, uint32_t>;
+    std::vector<Ent> heap;
+    for (uint32_t i = 0; i < n_bins; ++i) heap.push_back({0.f, i});
+    auto cmp = [](const Ent& a, const Ent& b2) { return a.first > b2.first || (a.first == b2.first && a.second > b2.second); };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    const bool balance = DEV_ENV("CDAE_FUSED_INDEX_ORDER") == nullptr;                   // (developer switch: round 5's index order)
+    for (uint32_t k = 0; k < n_groups; ++k) {
+      const uint32_t q = balance ? by_len[k] : k;
+      if (!balance) { bin[k % n_bins].push_back(q); continue; }
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      Ent e = heap.back();
+      bin[e.second].push_back(q);
+      e.first += 4.f + len[q];                                                    // (+ a wavefront's fixed cost: prologue, epilogue)
+      heap.back() = e;
+      std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+  }
+  size_t rounds_cold = 0;
+  for (auto& v : bin) rounds_cold = std::max(rounds_cold, v.size());
+  // cold round k of CU cu is workgroup index cu + k S, except that on the popular CUs' indices there are blockers in rounds 1..rounds
+  g.decode_wgs = (uint32_t)std::max<size_t>(rounds_cold, 1) * S;
+  std::vector<uint32_t> map((size_t)g.decode_wgs * 4, 0xFFFFFFFFu);
+  for (uint32_t i = 0; i < n_bins; ++i) {
+    const uint32_t cu = cu0 + i / 4, w = i % 4;
+    for (size_t k = 0; k < bin[i].size(); ++k) map[((size_t)k * S + cu) * 4 + w] = bin[i][k];
+  }
+  if (h->d_cold_map) { HIPCHK(hipFree(h->d_cold_map)); h->d_cold_map = nullptr; }
+  CHK(dev_alloc(&h->d_cold_map, map.size()));
+  HIPCHK(hipMemcpy(h->d_cold_map, map.data(), map.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  g.cold_map = h->d_cold_map;
   h->fused_geo = g;
   h->fused_geo_set = true;
   return 0;
@@ -744,7 +796,7 @@ int compute_batch(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint32_t e
     DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_units + 3) / 4)), blk, 0, st, h->hp, ga.row_ptr, uptr, n_units, s0, nb,
                 x.item, h->d_G, h->d_D0, h->d_HGpart, ga.explicit_examples, x.dup_of_ex, h->d_dup_corr, ga.unit_user, halves,
                 ga.late_bits, ga.late_words);
-  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
+  DISPATCH_NI(h->NI, hidden_finish_kernel, dim3(nb), blk, 0, st, h->hp, uptr, n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG,
               h->d_Wu, h->d_Wu_ag, 8u * halves, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, (const float*)nullptr, h->late_finish());
   CHK(pr.end());
   // input rows + (leading workgroups) the strictly sequential hidden-bias recurrence: both need only delta
@@ -1030,7 +1082,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   if (one_stream) {
     Prof pa;
     CHK(pa.begin(h, F_HIDDEN, st));
-    DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, (const uint32_t*)h->d_iota, hg_rows, s0, nb, h->d_HGpart, h->d_Dz,
+    DISPATCH_NI(h->NI, hidden_finish_kernel, dim3(nb), blk, 0, st, h->hp, (const uint32_t*)h->d_iota, hg_rows, s0, nb, h->d_HGpart, h->d_Dz,
                 h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
     CHK(pa.end());
     GemmEpilogue e3{};
@@ -1073,7 +1125,7 @@ int compute_batch_full(cdae_hip* h, int b, const Batch& bt, uint64_t seed, uint3
   {
     Prof pa;
     CHK(pa.begin(h, F_HIDDEN, h->aux));
-    DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, hg_parts ? (const uint32_t*)h->d_iota : uptr,
+    DISPATCH_NI(h->NI, hidden_finish_kernel, dim3(nb), blk, 0, h->aux, h->hp, hg_parts ? (const uint32_t*)h->d_iota : uptr,
                 hg_parts ? hg_rows : n_units, s0, nb, h->d_HGpart, h->d_Dz, h->d_HG, h->d_Wu, h->d_Wu_ag, hg_parts,
                 h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows);
     CHK(pa.end());
@@ -1547,6 +1599,13 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       h->hot_rows = std::max(h->hot_rows, h->late_rows);
     }
     h->late_words = (uint32_t)((I + 31) / 32);
+    {
+      // expected examples per batch of every row, by popularity rank: positives (popularity x batch share) + the uniformly drawn negatives
+      const double share = (double)std::min<uint64_t>(h->B, U) / (double)U;
+      const double neg_per_item = share * (double)row_ptr[U] * (double)h->hp.num_neg / (double)std::max<uint64_t>(I, 1);
+      h->h_rank_len.resize(I);
+      for (uint32_t r = 0; r < I; ++r) h->h_rank_len[r] = (float)((double)pop[order[r]] * share + neg_per_item);
+    }
     if (h->late_rows) {
       std::vector<uint32_t> bits(h->late_words, 0u);
       for (uint32_t r = 0; r < h->late_rows; ++r) bits[order[r] >> 5] |= 1u << (order[r] & 31u);
@@ -1557,8 +1616,11 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       HIPCHK(hipMemset(h->d_Ghot, 0, nB * sizeof(float)));
       HIPCHK(hipMemset(h->d_hotdup, 0xFF, nB * sizeof(uint32_t)));
     }
-    CHK(dev_alloc(&h->d_fused_err, 1));
-    HIPCHK(hipMemset(h->d_fused_err, 0, sizeof(uint32_t)));
+    if (!h->h_err) {
+      HIPCHK(hipHostMalloc((void**)&h->h_err, sizeof(uint32_t), hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void**)&h->d_fused_err, h->h_err, 0));
+    }
+    *(volatile uint32_t*)h->h_err = 0u;
     CHK(dev_alloc(&h->d_hot_cnt, (size_t)h->hot_rows / 4 + 1));
     HIPCHK(hipMemset(h->d_hot_cnt, 0, ((size_t)h->hot_rows / 4 + 1) * sizeof(uint32_t)));
     h->fused_seq = 0; h->fused_geo_set = false;
@@ -2986,7 +3048,7 @@ int fs_phase1(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
       DISPATCH_NI(h->NI, hidden_gather_kernel, dim3(8 * halves * ((n_gunits + 3) / 4)), blk, 0, st, h->hp, h->d_grow_ptr, guptr, n_gunits, s0, nb,
                   x.item, h->d_G, h->d_D0, h->d_HGpart, 0u, x.dup_of_ex, h->d_dup_corr, (const uint32_t*)h->d_gunit_user, halves,
                   h->late_rows ? (const uint32_t*)h->d_late_bits : (const uint32_t*)nullptr, h->late_words);
-    DISPATCH_NI(h->NI, hg_raw_kernel, grid_users, blk, 0, st, h->hp, guptr, n_gunits, nb, h->d_HGpart, 8u * halves, h->d_HG, h->late_finish());
+    DISPATCH_NI(h->NI, hg_raw_kernel, dim3(nb), blk, 0, st, h->hp, guptr, n_gunits, nb, h->d_HGpart, 8u * halves, h->d_HG, h->late_finish());
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -3045,7 +3107,7 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
   if (!h->cfg.full_output) {
     // ---- sampled decode: delta from the all-reduced hg, the Wu / Uu steps of the users this shard owns, then the local input rows
     // and (replicated, identical everywhere) the b recurrence — the tail of the single-GPU step ----
-    DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, st, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
+    DISPATCH_NI(h->NI, hidden_finish_kernel, dim3(nb), blk, 0, st, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
                 h->d_HG, h->d_Wu, h->d_Wu_ag, 0u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, uu_b);
     const uint32_t bias_blocks = (h->Kp + 255u) / 256u;
     DISPATCH_NI(h->NI, input_rows_kernel, dim3(bias_blocks + (I + 3) / 4), blk, 0, st, h->hp, h->d_item_order, x.seg + 2 * (size_t)I, x.seg + 3 * (size_t)I,
@@ -3060,7 +3122,7 @@ int fs_phase2(cdae_hip_t* h, uint64_t s0, uint32_t nb) {
   HIPCHK(hipEventRecord(h->ev_fork, st));
   HIPCHK(hipStreamWaitEvent(h->aux, h->ev_fork, 0));
   // d_HG holds the all-reduced hg: delta, the Wu steps of the users this shard owns, then the b recurrence (replicated)
-  DISPATCH_NI(h->NI, hidden_finish_kernel, grid_users, blk, 0, h->aux, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
+  DISPATCH_NI(h->NI, hidden_finish_kernel, dim3(nb), blk, 0, h->aux, h->hp, (const uint32_t*)h->d_iota, nb, s0, nb, h->d_HGpart, h->d_Dz,
               h->d_HG, h->d_Wu, h->d_Wu_ag, 0u, h->d_Uu, h->d_Uu_ag, h->d_Ssum, h->d_delta_rows, uu_b);
   HIPCHK(hipEventRecord(h->ev_delta, h->aux));
   hipLaunchKernelGGL(hidden_bias_kernel, dim3((Kp + 255u) / 256u), blk, 0, h->aux, h->hp, nb, h->d_HG, h->P(CDAE_P_B), h->P(CDAE_P_B_AG));

@@ -1677,7 +1677,7 @@ __device__ __forceinline__ void hidden_gather_role(const HyperParams& hp, const 
         const bool pend0 = __builtin_bit_cast(uint32_t, cur.g[0]) == G_PENDING && is_mine(cur.item[0]);
         const bool pend1 = __builtin_bit_cast(uint32_t, cur.g[1]) == G_PENDING && is_mine(cur.item[1]);
         if (!__ballot(pend0 || pend1)) break;
-        if (spin >= FUSED_SPIN_CAP) { if (lane == 0) atomicOr(ga.err, 1u); break; }
+        if (spin >= FUSED_SPIN_CAP) { if (lane == 0) __hip_atomic_store(ga.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // (host memory: a plain store, no PCIe atomic)
         __builtin_amdgcn_s_sleep(24);
         if (pend0) cur.g[0] = load_f32_sc1(ga.G + base + example_of(c0 + lane));
         if (pend1) cur.g[1] = load_f32_sc1(ga.G + base + example_of(c0 + WAVE + lane));
@@ -1753,7 +1753,8 @@ hidden_gather_kernel(HyperParams hp, const int64_t* __restrict__ row_ptr, const 
 //                               one of their rows.  Workgroup b runs on the CU that b mod S names while the CUs hold 1 + rounds
 //                               workgroups of this launch each (observed placement, a speed assumption only: wherever a blocker
 //                               lands it just sleeps);
-//   every other index below D   the other rows, four per wavefront (decode_rows16), in popularity order;
+//   every other index below D   the other rows, four per wavefront (decode_rows16): which group a wavefront takes is the host's table
+//                               (FusedGeom::cold_map: the groups dealt over the SIMDs by expected length, longest first);
 //   [D, ...)                    gather: four (unit, partition) wavefronts each (hidden_gather_role<FUSED>).
 // Workgroups are dispatched in index order (as bucket_sort_kernel assumes): whatever a gather wavefront waits for is running or done.
 // Everything one role writes and another reads inside the launch is written through (sc1) and read past the L1 (sc1), so no
@@ -1766,19 +1767,14 @@ struct FusedGeom {
   uint32_t decode_wgs;     // D
   uint32_t hot_target;     // value every popular workgroup's counter reaches when its four wavefronts of THIS launch are done (wraps)
   uint32_t* hot_cnt;       // [hot_wgs] wavefronts finished since the handle was created
+  const uint32_t* cold_map; // [decode_wgs][4]: the four-row group of every wavefront of a row workgroup, 0xFFFFFFFF = none (balanced by the host)
 };
 constexpr uint32_t FUSED_BLOCK_MAX = 16;         // blockers for the workgroups of the 64 most popular rows
 constexpr uint32_t FUSED_LDS_WORDS = 4u * ROWS16_LDS_WORDS;                       // row roles: 36 KiB (the gather role needs 24 KiB)
 static_assert(4u * 2u * GATHER_CAP + LATE_BITS_WORDS <= FUSED_LDS_WORDS, "gather role's LDS");
-// cold workgroup number of workgroup index b (b is neither popular nor a blocker), and the predicate
+// is workgroup index b a blocker?
 __host__ __device__ inline bool fused_is_blocker(const FusedGeom& g, uint32_t b) {
   return b >= g.stride && b < (1u + g.rounds) * g.stride && b % g.stride < g.blocked;
-}
-__host__ __device__ inline uint32_t fused_cold_index(const FusedGeom& g, uint32_t b) {
-  uint32_t skipped = g.hot_wgs;
-  for (uint32_t r = 1; r <= g.rounds; ++r)
-    if (b > r * g.stride) skipped += (b - r * g.stride < g.blocked ? b - r * g.stride : g.blocked);
-  return b - skipped;
 }
 
 #ifndef CDAE_FUSED_WAVES_PER_SIMD
@@ -1789,7 +1785,7 @@ __global__ void __launch_bounds__(256, CDAE_FUSED_WAVES_PER_SIMD)
 decode_gather_kernel(HyperParams hp, uint32_t hot_rows, FusedGeom geo, DecodeLate late, GatherArgs ga, CDAE_DECODE_PARAMS) {
   constexpr int CH = NT == 0 ? NV : NV + 1;                       // 64-element chunks of the row
   constexpr int NI = CH <= 1 ? 1 : (CH <= 2 ? 2 : 4);
-  __shared__ uint32_t fused_lds[FUSED_LDS_WORDS];
+  __shared__ uint32_t fused_lds[FUSED_LDS_WORDS + 8u];
   const uint32_t wg = blockIdx.x;
   const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   if (wg < geo.hot_wgs) {
@@ -1818,7 +1814,28 @@ decode_gather_kernel(HyperParams hp, uint32_t hot_rows, FusedGeom geo, DecodeLat
     }
     // ---- all other rows, four per wavefront ----
     if (CDAE_SKIP_ROLE(hp, 8u)) return;
-    const uint32_t g = fused_cold_index(geo, wg) * 4u + wid;
+    // the table is by SIMD (the host balanced the SIMDs' loads): a wavefront takes the entry of the SIMD it finds itself on.  The four
+    // wavefronts of a workgroup sit on the CU's four SIMDs; should two ever share one, the entry nobody claimed goes to the loser.
+    uint32_t* const claim = fused_lds + FUSED_LDS_WORDS;
+    if (threadIdx.x < 4) claim[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) /* HW_ID.SIMD_ID */) & 3u;
+    if (threadIdx.x % WAVE == 0) atomicCAS(&claim[simd], 0u, 1u + wid);
+    __syncthreads();
+    const uint32_t cs[4] = {claim[0], claim[1], claim[2], claim[3]};
+    int mine = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (cs[q] == 1u + wid) mine = q;
+    if (mine < 0) {
+      uint32_t before = 0, cnt = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (cs[q] && cs[q] - 1u < wid) ++before;
+      const uint32_t j = wid - before;                            // my place among the wavefronts that claimed nothing
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (!cs[q]) { if (cnt == j) mine = q; ++cnt; }
+    }
+    const uint32_t g = geo.cold_map[wg * 4u + (uint32_t)mine];
+    if (g == 0xFFFFFFFFu) return;
     const unsigned long long t0 = trace_begin(hp);
     decode_rows16<NV, NT, LOSS, ADAGRAD, true>(hp, hot_rows + g * 4u, fused_lds + wid * ROWS16_LDS_WORDS, CDAE_DECODE_PASS);
     trace_end(hp, 4, hot_rows / 4u + g, t0, hp.trace ? hw_place() : 0u);
@@ -1895,9 +1912,10 @@ __device__ __forceinline__ void add_partial_rows(float (&hg)[NI], const float* _
 // hg += sum_r gh_r D0[it_r] in rank order, sixteen rows in flight, then the duplicate runs' correction rows in rank order: a fixed
 // order of additions (deterministic; the same in hidden_finish_kernel and hg_raw_kernel).
 template <int NI>
-__device__ __forceinline__ void add_late_rows(float (&hg)[NI], const LateFinish& lf, float gh, uint32_t hd, uint32_t it, uint32_t Kp, uint32_t lo) {
+__device__ __forceinline__ void add_late_rows(float (&hg)[NI], const LateFinish& lf, float gh, uint32_t hd, uint32_t it, uint32_t Kp, uint32_t lo,
+                                              unsigned long long ranks = ~0ull /* the ranks this wavefront takes */) {
   constexpr int TR = NI >= 8 ? 8 : 16;
-  unsigned long long mask = __ballot(gh != 0.f);
+  unsigned long long mask = __ballot(gh != 0.f) & ranks;
   while (mask) {
     float vv[TR][NI], gg[TR];
 #pragma unroll
@@ -1919,7 +1937,7 @@ __device__ __forceinline__ void add_late_rows(float (&hg)[NI], const LateFinish&
 #pragma unroll
       for (int k = 0; k < NI; ++k) hg[k] = fmaf(gg[t], vv[t][k], hg[k]);
   }
-  unsigned long long dm = __ballot(hd != DUP_NONE);
+  unsigned long long dm = __ballot(hd != DUP_NONE) & ranks;
   while (dm) {                                                     // (rare)
     const int src = __ffsll((long long)dm) - 1;
     dm &= dm - 1;
@@ -1940,8 +1958,58 @@ __device__ __forceinline__ void load_late_entries(const LateFinish& lf, uint32_t
   }
 }
 
+// hg of ONE user by the four wavefronts of its workgroup (round 6; through round 5 one wavefront per user walked all of it, and the
+// launch was as long as the batch's most active user: 7 us against a median of 3).  The user's partial rows — (unit, partition) pairs in
+// unit-major order, numbered 0 .. R-1 — are dealt round-robin: wavefront w adds rows w, w + 4, ... in ascending order, then the late rows
+// of rank = w (mod 4) in rank order and their correction rows; the four sums meet in LDS and wavefront 0 adds them to HG[slot] in
+// wavefront order.  A fixed order of additions: deterministic, and the same in hidden_finish_kernel and hg_raw_kernel (an item shard
+// of one is the single handle bit for bit).  Returns true on wavefront 0, whose `hg` holds the sum; the others are done.
+template <int NI>
+__device__ __forceinline__ bool user_hg(float (&hg)[NI], float* __restrict__ lds /* [3][64 NI] */, const float* __restrict__ HG_in,
+                                        const float* __restrict__ HGpart, uint32_t n_units, uint32_t n_parts, uint32_t ub, uint32_t ue,
+                                        const LateFinish& lf, uint32_t slot, uint32_t Kp) {
+  const uint32_t lane = threadIdx.x % WAVE, wid = threadIdx.x / WAVE, lo = lane * NI;
+  if (wid == 0) vload<NI>(hg, HG_in + (size_t)slot * Kp + lo);           // (requested first: it is added last)
+  float late_g; uint32_t late_d, late_i;
+  load_late_entries(lf, slot, lane, late_g, late_d, late_i);
+  float acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) acc[i] = 0.f;
+  const uint32_t R = (ue - ub) * n_parts;
+  const size_t slab = (size_t)n_units * Kp;
+  constexpr uint32_t TR = NI >= 8 ? 4 : 8;
+  for (uint32_t r0 = wid; r0 < R; r0 += 4u * TR) {
+    float v[TR][NI];
+#pragma unroll
+    for (uint32_t t = 0; t < TR; ++t) {
+      const uint32_t r = min(r0 + 4u * t, R - 1u);                         // (clamped: the surplus is added as 0)
+      vload<NI>(v[t], HGpart + (size_t)(r % n_parts) * slab + (size_t)(ub + r / n_parts) * Kp + lo);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < TR; ++t) {
+      const bool on = r0 + 4u * t < R;                                     // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i] = on ? acc[i] + v[t][i] : acc[i];
+    }
+  }
+  if (lf.late_rows) add_late_rows<NI>(acc, lf, late_g, late_d, late_i, Kp, lo, 0x1111111111111111ull << wid);
+  if (wid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) lds[(wid - 1u) * (64u * NI) + lo + i] = acc[i];
+  }
+  __syncthreads();
+  if (wid) return false;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) hg[i] += acc[i];
+  for (uint32_t w = 0; w < 3u; ++w)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) hg[i] += lds[w * (64u * NI) + lo + i];
+  return true;
+}
+
 // K4a'  delta_u = (sum of the 8 partials + duplicate corrections) (.) act'(z_u)   cdae.hpp:305,321,337
 //       and the private user-node step Wu[u]                                      cdae.hpp:317-331
+// One WORKGROUP per user of the batch (grid = nb): user_hg above, then wavefront 0 finishes.
 template <int NI>
 __global__ void __launch_bounds__(256)
 hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_units, uint64_t u0, uint32_t nb,
@@ -1954,26 +2022,25 @@ hidden_finish_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t
                      const float* __restrict__ Uu_batch = nullptr /* item shard: the batch's gathered Uu rows [nb][Kp] (a user this
                                                                      shard does not own still needs Uu[u] (.) delta for its input rows) */,
                      LateFinish lf = LateFinish{nullptr, nullptr, nullptr, nullptr, nullptr, 0u} /* the late rows' terms, added behind the partial rows */) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  __shared__ float sums[3 * 64 * NI];
+  const uint32_t slot = blockIdx.x;                                 // (grid = nb)
   const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
+  const bool lead = threadIdx.x < WAVE;
   const unsigned long long t0 = trace_begin(hp);
   const uint64_t uid = u0 + slot;
   const bool own = cdae_xa::owns_user(uid, hp.own_u0, hp.own_u1);   // wave-uniform: the private rows of this user live here
   const uint32_t lo = lane * NI;
   const size_t o = (size_t)slot * hp.Kp + lo;
   float hg[NI], dz[NI], delta[NI];
-  vload<NI>(hg, HG + o);
   // everything the tail needs is requested up front, beside the partial rows (it was two more round trips behind them)
   const size_t ou = (size_t)(own ? uid - hp.own_u0 : 0) * hp.Kp + lo;
   float p[NI], pa[NI];
-  vload<NI>(dz, Dz + o);
-  if (hp.user_factor && own) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
-  float late_g; uint32_t late_d, late_i;
-  load_late_entries(lf, slot, lane, late_g, late_d, late_i);
+  if (lead) {
+    vload<NI>(dz, Dz + o);
+    if (hp.user_factor && own) { vload<NI>(p, Wu + ou); vload<NI>(pa, Wu_ag + ou); }
+  }
   const uint32_t ub = n_parts ? uptr[slot] - uptr[0] : 0u, ue = n_parts ? uptr[slot + 1] - uptr[0] : 0u;
-  add_partial_rows<NI>(hg, HGpart, n_units, n_parts, ub, ue, hp.Kp, lo);
-  if (lf.late_rows) add_late_rows<NI>(hg, lf, late_g, late_d, late_i, hp.Kp, lo);
+  if (!user_hg<NI>(hg, sums, HG, HGpart, n_units, n_parts, ub, ue, lf, slot, hp.Kp)) return;
 #pragma unroll
   for (int i = 0; i < NI; ++i) delta[i] = hg[i] * dz[i];
   vstore<NI>(HG + o, delta);
@@ -2432,19 +2499,13 @@ template <int NI>
 __global__ void __launch_bounds__(256)
 hg_raw_kernel(HyperParams hp, const uint32_t* __restrict__ uptr, uint32_t n_units, uint32_t nb, const float* __restrict__ HGpart,
               uint32_t n_parts, float* __restrict__ HG, LateFinish lf = LateFinish{nullptr, nullptr, nullptr, nullptr, nullptr, 0u}) {
-  const uint32_t slot = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  const uint32_t lane = threadIdx.x % WAVE;
-  if (slot >= nb) return;
-  const uint32_t lo = lane * NI;
-  const size_t o = (size_t)slot * hp.Kp + lo;
+  __shared__ float sums[3 * 64 * NI];
+  const uint32_t slot = blockIdx.x;                                 // (grid = nb: one workgroup per user, as hidden_finish_kernel)
+  const uint32_t lo = (threadIdx.x % WAVE) * NI;
   float hg[NI];
-  vload<NI>(hg, HG + o);
-  float late_g; uint32_t late_d, late_i;
-  load_late_entries(lf, slot, lane, late_g, late_d, late_i);
   const uint32_t ub = uptr[slot] - uptr[0], ue = uptr[slot + 1] - uptr[0];
-  add_partial_rows<NI>(hg, HGpart, n_units, n_parts, ub, ue, hp.Kp, lo);     // (16 partial rows in flight per trip: the loop of single loads was a 15-26 us chain)
-  if (lf.late_rows) add_late_rows<NI>(hg, lf, late_g, late_d, late_i, hp.Kp, lo);
-  vstore<NI>(HG + o, hg);
+  if (!user_hg<NI>(hg, sums, HG, HGpart, n_units, n_parts, ub, ue, lf, slot, hp.Kp)) return;
+  vstore<NI>(HG + (size_t)slot * hp.Kp + lo, hg);
 }
 
 // data-parallel exchange helpers (no reference counterpart; DESIGN.md "Multi-GPU")

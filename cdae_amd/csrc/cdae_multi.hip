@@ -375,7 +375,7 @@ Exchange* xof(cdae_hip_t* h) { return (Exchange*)cdae_internal::exchange_slot(h)
 
 // one step of every shard's epoch: shard s trains users [a, b) of its own
 // `first[s]`: users of shard s already trained in this epoch (the relay part of cdae_hip_multi_set_schedule); the plan covers the rest
-struct StepPlan { uint64_t steps; std::vector<uint64_t> per, first; };
+struct StepPlan { uint64_t steps; std::vector<uint64_t> per, first; uint64_t t0 = 0, t1 = ~0ull; /* steps [t0, min(t1, steps)) are run (cdae_hip_multi_train_steps) */ };
 StepPlan plan_of(const cdae_hip_multi* m, const std::vector<uint64_t>& first) {
   StepPlan p;
   p.first = first;
@@ -405,7 +405,7 @@ int shard_epoch(cdae_hip_multi* m, size_t s, const StepPlan& pl, uint64_t seed, 
   Exchange* x = xof(h);
   const uint64_t n = m->cut[s + 1] - m->cut[s], f = pl.first[s];
   x->period = m->period;
-  for (uint64_t t = 0; t < pl.steps; ++t) {
+  for (uint64_t t = pl.t0; t < std::min(pl.t1, pl.steps); ++t) {
     const uint64_t a = std::min(n, f + t * pl.per[s]), b = std::min(n, f + (t + 1) * pl.per[s]);
     if ((int)s == m->fail_shard && t == m->fail_step) return fail("forced failure of shard %zu at step %llu (developer build)", s, (unsigned long long)t);
     if (b > a) CHK(cdae_hip_enqueue_users(h, seed, epoch, a, b));
@@ -426,7 +426,7 @@ int local_boundary(cdae_hip_multi* m, bool start_next) {
 int local_epoch(cdae_hip_multi* m, const StepPlan& pl, uint64_t seed, uint32_t epoch) {
   for (cdae_hip_t* h : m->shard) CHK(begin_if_needed(xof(h)));
   uint64_t steps = 0;
-  for (uint64_t t = 0; t < pl.steps; ++t) {
+  for (uint64_t t = pl.t0; t < std::min(pl.t1, pl.steps); ++t) {
     for (size_t s = 0; s < m->shard.size(); ++s) {
       const uint64_t n = m->cut[s + 1] - m->cut[s], f = pl.first[s];
       const uint64_t a = std::min(n, f + t * pl.per[s]), b = std::min(n, f + (t + 1) * pl.per[s]);
@@ -852,6 +852,57 @@ int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoc
   }
   if (stats) {
     *stats = relay_stats;
+    for (cdae_hip_t* h : m->shard) {
+      cdae_hip_stats st;
+      CHK(cdae_hip_collect_stats(h, &st));
+      stats->users += st.users; stats->examples += st.examples; stats->batches += st.batches;
+    }
+    stats->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return 0;
+}
+
+uint64_t cdae_hip_multi_steps_per_epoch(const cdae_hip_multi_t* m) {
+  if (!m || m->shard.empty() || !m->U || m->layout == CDAE_LAYOUT_ITEM_ROWS) return 0;
+  return plan_of(m, std::vector<uint64_t>(m->shard.size(), 0)).steps;
+}
+
+// Steps [step_begin, step_end) of epoch `epoch`'s EXCHANGED part (no relay), then a flush: what a benchmark times.  Training proper
+// goes through cdae_hip_multi_train_epoch, which runs the relay part first and all the steps.
+int cdae_hip_multi_train_steps(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, uint64_t step_begin, uint64_t step_end, cdae_hip_stats* stats) {
+  CHK(check_multi(m, true));
+  if (m->layout == CDAE_LAYOUT_ITEM_ROWS) return fail("cdae_hip_multi_train_steps: user-sharded layout only (item rows: cdae_hip_multi_train_users)");
+  const size_t S = m->shard.size();
+  StepPlan pl = plan_of(m, std::vector<uint64_t>(S, 0));
+  if (step_begin > step_end || step_begin > pl.steps) return fail("bad step range [%llu, %llu) of %llu", (unsigned long long)step_begin, (unsigned long long)step_end, (unsigned long long)pl.steps);
+  pl.t0 = step_begin; pl.t1 = step_end;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (S == 1) {
+    const uint64_t n = m->U, a = std::min(n, pl.t0 * pl.per[0]), b = std::min(n, std::min(pl.t1, pl.steps) * pl.per[0]);
+    CHK(cdae_hip_train_users(m->shard[0], seed, epoch, a, b, stats));
+    return 0;
+  }
+  if (m->single_device) {
+    CHK(local_epoch(m, pl, seed, epoch));
+  } else {
+    std::vector<int> rc(S, 0);
+    std::vector<std::string> err(S);
+    std::vector<std::thread> th;
+    for (size_t s = 0; s < S; ++s)
+      th.emplace_back([&, s] {
+        xof(m->shard[s])->guard = &m->guard;
+        rc[s] = shard_epoch(m, s, pl, seed, epoch);
+        if (rc[s]) { err[s] = cdae_hip_last_error(); m->give_up(); }
+        xof(m->shard[s])->guard = nullptr;
+      });
+    for (std::thread& t : th) t.join();
+    if (const int s = first_cause(rc, err); s >= 0) {
+      if (m->comm_aborted) { m->abort_reason = err[s]; for (cdae_hip_t* h : m->shard) xof(h)->comm = nullptr; }
+      return fail("shard %d: %s", s, err[s].c_str());
+    }
+  }
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
     for (cdae_hip_t* h : m->shard) {
       cdae_hip_stats st;
       CHK(cdae_hip_collect_stats(h, &st));

@@ -299,6 +299,7 @@ constexpr uint32_t BK_THREADS = 512;
 constexpr uint32_t BK_WINDOW = 4096;      // example words of one group held in LDS (x 2: arrival order, sorted)
 constexpr uint32_t BK_ITEMS = 2048;       // most items of one range (LDS counters: 4 per thread in bk_block_scan)
 constexpr uint32_t BK_WAVE_LIST = BK_WINDOW / (BK_THREADS / 64);   // scan fallback: records per wavefront list (they live in the sorted-words array until it is needed)
+constexpr uint32_t BK_SPIN_CAP = 1u << 21;  // polls (~0.5 us each) of a range's total before bucket_sort_kernel gives up (error bit 1)
 constexpr uint32_t BK_MAX_RANGES = 1024;  // wg_state words (sample_kernel clears them with the other per-batch counters)
 constexpr uint32_t BK_CELL_UNITS_MAX = 16384;   // most units of a batch the cell path takes (their counts, 2 bytes each, fit the `raw` array)
 constexpr size_t BK_LDS_BYTES = (size_t)BK_WINDOW * 8 * 2 + (size_t)BK_WINDOW * 2 + (size_t)(BK_ITEMS + 1) * 4 * 2 + 64 * 4;
@@ -376,7 +377,8 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
                    uint32_t* __restrict__ segr_begin, uint32_t* __restrict__ segr_end, uint64_t* __restrict__ sorted_val,
                    uint64_t* __restrict__ scratch_val /* [n_ex]: only an item above the LDS window uses it */,
                    uint32_t* __restrict__ dup_count, uint32_t dup_cap, uint32_t* __restrict__ dup_of_pos,
-                   uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */, uint32_t stripes) {
+                   uint32_t* __restrict__ dup_of_ex /* pre-filled with DUP_NONE */, uint32_t stripes,
+                   uint32_t* __restrict__ err /* the handle's device error word: bit 1 is raised when the wait below gives up */) {
 #ifdef CDAE_PREP_SETPRIO
   __builtin_amdgcn_s_setprio(CDAE_PREP_SETPRIO);
 #endif
@@ -465,9 +467,14 @@ bucket_sort_kernel(const uint16_t* __restrict__ keys, const uint64_t* __restrict
 
   // ---- the range's place in the item-major list: totals of the ranges in front (one word each: total + 1, 0 = not yet known)
   if (t == 0) __hip_atomic_store(&wg_state[w], off[n_it] + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // (bounded: a range in front that never publishes — its words were not cleared by the batch's sample_kernel, or workgroups are not
+  // dispatched in index order on some future stack — must end in an error the host reports, not in a hung device)
   for (uint32_t r = t; r < w; r += BK_THREADS) {
-    uint32_t v;
-    while ((v = __hip_atomic_load(&wg_state[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
+    uint32_t v, spin = 0;
+    while ((v = __hip_atomic_load(&wg_state[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+      if (++spin > BK_SPIN_CAP) { v = 1u; __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }     // (host memory: a plain store)
+      __builtin_amdgcn_s_sleep(1);
+    }
     atomicAdd(&misc[16], v - 1u);
   }
   __syncthreads();

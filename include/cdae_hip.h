@@ -61,7 +61,8 @@ extern "C" {
  * 11: schedule of the user-sharded layout: cdae_hip_delta_set_combine (CDAE_COMBINE_GLOBAL_ACC), cdae_hip_multi_set_schedule
  *     (relay warm-up epochs on the single-GPU schedule, users per shard of the exchanged steps, combine rule); the drop-in IMF / BPR
  *     classes pass batch_users = 1 (the reference loop) unless CDAE_BATCH_USERS says otherwise
- * 12: cdae_hip_decode_plan (which launches the sampled decode + hidden-gradient step of a handle is made of) */
+ * 12: cdae_hip_decode_plan (which launches the sampled decode + hidden-gradient step of a handle is made of);
+ *     cdae_hip_multi_steps_per_epoch, cdae_hip_multi_train_steps (a range of the exchanged steps of an epoch: what bench.py times) */
 #define CDAE_HIP_ABI_VERSION 12
 
 /* numeric values follow libcf::LossType (/root/reference/src/model/loss.hpp:10-18) */
@@ -427,11 +428,14 @@ int cdae_hip_multi_set_exchange(cdae_hip_multi_t* m, int period);
  *          SINGLE-GPU schedule — Solver<CDAE>::train's order (cdae.hpp:136-146): users 0, 1, 2, ... in blocks of the handles'
  *          batch_users, every item row's chain sequential — by the shard that holds them, and the shared block is handed from shard to
  *          shard when the range crosses a cut (one device-to-device copy of [W | W_ag | b' | ... ] per shard and epoch; the other GPUs
- *          wait).  It costs a single GPU's time and has the single-GPU schedule's accuracy: the warm-up that DESIGN.md §7 measured to
+ *          wait).  The blocks restart at every shard cut (the cuts balance interactions, they are not multiples of batch_users), so the
+ *          trajectory is the single-GPU SCHEDULE — bit for bit one handle walked range by range — not the single handle's own block grid.
+ *          It costs a single GPU's time and has the single-GPU schedule's accuracy: the warm-up that DESIGN.md §7 measured to
  *          bring the exchanged steps back towards the envelope (young AdaGrad accumulators are what the summed steps overshoot on).
  *   EXCHANGE  the remaining users of every shard, `sync_batch_users` (0 = the handles' batch_users) per shard and step, deltas
  *          exchanged every step (period 0) or pipelined (period k), folded in by `combine` (CDAE_COMBINE_*).
- * cdae_hip_multi_set_exchange(m, p) == set_schedule{p, CDAE_COMBINE_SUM, 0, 0.0}. */
+ * cdae_hip_multi_set_exchange(m, p) changes the PERIOD only: combine rule, sync_batch_users and relay_epochs stay as the last
+ * set_schedule left them (a fresh handle: CDAE_COMBINE_SUM, 0, 0.0). */
 typedef struct cdae_multi_schedule {
   int32_t period;
   uint32_t combine;
@@ -443,6 +447,12 @@ int cdae_hip_multi_set_schedule(cdae_hip_multi_t* m, const cdae_multi_schedule* 
 int cdae_hip_multi_train_epoch(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, cdae_hip_stats* stats);
 /* users [u_begin, u_end) only — CDAE_LAYOUT_ITEM_ROWS (every shard sees every user); the user-sharded layout trains whole epochs */
 int cdae_hip_multi_train_users(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, uint64_t u_begin, uint64_t u_end,
+                               cdae_hip_stats* stats);
+/* User-sharded layout: the exchanged part of an epoch is `steps_per_epoch` steps (every shard trains sync_batch_users — or batch_users — of
+ * its users, then the exchange).  cdae_hip_multi_train_steps runs steps [step_begin, step_end) of epoch `epoch` WITHOUT the relay part and
+ * ends with a flush (replicas identical): a measurement hook — bench.py times K steps with it; training goes through train_epoch. */
+uint64_t cdae_hip_multi_steps_per_epoch(const cdae_hip_multi_t* m);
+int cdae_hip_multi_train_steps(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, uint64_t step_begin, uint64_t step_end,
                                cdae_hip_stats* stats);
 int cdae_hip_multi_data_loss(cdae_hip_multi_t* m, uint64_t seed, uint32_t epoch, double* out);
 int cdae_hip_multi_penalty_loss(cdae_hip_multi_t* m, double* out);

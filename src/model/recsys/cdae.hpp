@@ -139,6 +139,14 @@ class CDAE : public RecsysModelBase {
       CDAE_HIP_CHECK(cdae_hip_multi_set_interactions(raw, num_users_, num_items_, csr->row_ptr.data(), csr->col.data()));
       CDAE_HIP_CHECK(cdae_hip_multi_init_params(raw, seed_));
       if (item_rows_) LOG(INFO) << "CDAE: " << devices.size() << " item-row shards (CDAE_DEVICES; CDAE_LAYOUT=item_rows is the default): the single-GPU schedule over item shards";
+      // The sampled decode does NOT get faster in this layout: its two serial chains do not shorten and every batch adds two latency-bound
+      // all-reduces — measured 2 x slower and worse than ONE GPU at the BASELINE shapes.  It is the default because it
+      // is the single-GPU schedule exactly; say so where the user sees it.
+      if (item_rows_ && !c.full_output)
+        LOG(WARNING) << "CDAE: CDAE_DEVICES with the SAMPLED decode in the item-rows layout trains the single-GPU schedule exactly but SLOWER than one GPU "
+                        "(measured 1.3-1.6 M users/s on 8 GPUs against 2.8 M on one at ML-10M shape, DESIGN.md section 7b).  For throughput use one GPU "
+                        "(unset CDAE_DEVICES), or CDAE_LAYOUT=users (relay epoch + exchanged steps: its own, wider accuracy bounds, DESIGN.md section 7); "
+                        "the item-rows layout pays for the full-output decode (CDAE_FULL_OUTPUT=1).";
       else LOG(INFO) << "CDAE: " << devices.size() << " user shards (CDAE_DEVICES, CDAE_LAYOUT=users: relay warm-up + exchanged steps, DESIGN.md section 7), exchange every "
                      << env_u64("CDAE_EXCHANGE_EVERY", 0) << " steps";
     } else {

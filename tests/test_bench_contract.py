@@ -74,9 +74,30 @@ def test_item_rows_layout_line(built):
     assert "item-rows x3" in d["config"]["parallelism"]
 
 
-def test_sampled_item_rows_line_is_the_default_layout_beyond_one_gpu(built):
-    """What `--gpus N` (N > 1) runs by default — the sampled decode in the item-rows layout, the multi-GPU schedule that carries the
-    single-GPU accuracy claim — exercised on one GPU as logical shards (--logical-shards selects the layout like world > 1 does)."""
+def test_certified_schedule_line_is_what_gpus_n_runs_by_default(built):
+    """What `--gpus N` (N > 1) runs by default since round 6 — user shards on the relay + synchronous-exchange + global-accumulator
+    schedule, one process driving every GPU, with the single-GPU and item-rows figures of the same node beside the line — exercised on
+    one GPU as logical shards (the sum kernel in RCCL's place).  K timed steps are exactly K exchanged steps (cdae_hip_multi_train_steps)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shape", "small", "--steps", "20", "--warmup", "3", "--batch-users", "128",
+                          "--num-dim", "32", "--layout", "certified", "--logical-shards", "4", "--sync-batch-users", "32", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    for k, t in REQUIRED.items():
+        assert k in d, k
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["dtype"] == "f32"
+    c = d["config"]
+    assert c["batch_users"] == 32 and 120 <= c["global_batch"] <= 128 and c["schedule"]["relay_epochs"] == 1.0 and c["schedule"]["steps_per_epoch"] > 0   # (shards finish together: a step takes ceil(n_s / steps) of each)
+    assert abs(d["value"] - c["global_batch"] * 1e3 / d["ms_per_step"]) < 0.02 * d["value"]
+    side = c["same_node_alternatives"]
+    assert side["single_gpu"]["users_per_s"] > 0 and side["item_rows_same_gpus"]["users_per_s"] > 0, side
+    assert c["vs_single_gpu"] > 0 and "relay" in c["accuracy"]
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+
+
+def test_sampled_item_rows_line(built):
+    """The sampled decode in the item-rows layout — the multi-GPU schedule that is the single-GPU schedule exactly (the N > 1 default through
+    round 5, now `--layout item-rows`) — exercised on one GPU as logical shards (--logical-shards selects the layout)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--shape", "small", "--steps", "20", "--warmup", "3", "--batch-users", "128",
                           "--num-dim", "32", "--logical-shards", "4", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -253,6 +253,7 @@ def test_fused_decode_gather_launch_changes_no_bit(tiny, monkeypatch, devlib, K,
     launches (CDAE_DECODE_UNFUSED): the same roles, the same sums in the same order — every parameter bit-identical after two
     epochs.  The 120-item space makes duplicate negatives (correction rows, runs on late rows) the common case."""
     monkeypatch.setenv("CDAE_DECODE_HOT_POS", "6")       # enough popular ("hot") rows at these sizes: late rows + the fused launch
+    monkeypatch.setenv("CDAE_DECODE_LATE_POS", "6")
 
     def run(expect_fused):
         m, _ = make_pair(tiny, K=K, B=B, **kw)
@@ -278,6 +279,7 @@ def test_late_rows_track_the_oracle_and_round_fives_arithmetic(tiny, monkeypatch
     correction row per duplicate run) instead of being gathered: against the oracle's block schedule at the usual 2e-4, and against
     round 5's arithmetic (CDAE_NO_LATE_ROWS: every example gathered) — a different order of the same fp32 additions, 2e-5."""
     monkeypatch.setenv("CDAE_DECODE_HOT_POS", "4")
+    monkeypatch.setenv("CDAE_DECODE_LATE_POS", "4")
     m, o = make_pair(tiny, K=40, B=B)
     assert m.decode_plan["late_rows"] > 0, m.decode_plan
     for ep in range(2):

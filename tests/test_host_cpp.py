@@ -352,6 +352,8 @@ def test_reference_yelp_app_trains_the_sampled_decode_in_the_item_rows_layout(ho
                        "--beta=1"], tmp_path, env={"CDAE_SEED": "11", "CDAE_BATCH_USERS": "64", **env})
         assert rc == 0, out[-3000:]
         assert ("item-row shards" in out) == bool(env)
+        # round 6: the user is told that this layout does not speed the SAMPLED decode up (it is the exact schedule, not the fast one)
+        assert ("SLOWER than one GPU" in out) == bool(env)
         rows = [l for l in out.splitlines() if re.search(r"\]\s+\d+\|", l)]
         assert len(rows) == 2 + 51
         tables.append(np.array([[float(x) for x in r.split("|")[2:10]] for r in rows[2:]]))
