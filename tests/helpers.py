@@ -25,6 +25,16 @@ def make_pair(data, *, K=16, B=1, loss=cdae_amd.CROSS_ENTROPY, seed=11, full_out
     return model, o
 
 
+def record_measured(name, **values):
+    """Developer aid for the bf16 guards: with CDAE_RECORD_MEASURED=<file> every guarded quantity is appended to that file as it is measured
+    (one line per call), so that a bound can be set at <= 1.3 x what a full run of the suite actually sees."""
+    import os
+    path = os.environ.get("CDAE_RECORD_MEASURED")
+    if path:
+        with open(path, "a") as f:
+            f.write(name + " " + " ".join(f"{k}={float(v):.5g}" for k, v in values.items()) + "\n")
+
+
 def sync_oracle_from_gpu(model, o):
     for which in PARAMS:
         if o.get(which).size:

@@ -322,6 +322,8 @@ def test_yelp_shape_full_output_k50_curve(built, path):
     assert np.abs(loss / ref_loss - 1.0).max() <= 0.01
     # (parameters at the probes after 40 epochs = 800 block steps on bf16 operands against fp64: measured up to 0.048 of the range on W;
     # the curves above are the claim, this only guards against a gross divergence)
+    from helpers import record_measured
+    record_measured(f"full_output_40_epochs_probes_seed{seed}", W=probes[0], b=probes[1])
     assert probes[0] <= 8e-2 and probes[1] <= 8e-2
 
 
@@ -468,6 +470,8 @@ def test_reduced_config5_k512_131072_items(built, path):
     # bf16 operands at K = 512 (tests/test_gpu_parity.py: 3e-2 of the range).  W after its first two block steps from a 1e-4
     # accumulator is the worst case: a step is lr * grad / (beta + |grad|), so elements whose block-summed gradient is near 0
     # turn the bf16 rounding of g (2^-9 of ~32 = 0.06) into 0.006 of step each; measured max 4.0e-2, mean < 1e-2 of the range
+    from helpers import record_measured
+    record_measured("reduced_config5", **errs)
     assert max(errs["Wu"], errs["bp"], errs["b"]) <= 3e-2 and errs["W"] <= 6e-2 and errs["W_mean"] <= 1e-2, errs
     assert errs["loss"] <= 0.01, errs
     # evaluation at this size goes through the general recommend path (K > 256, 131 072 x 4 B of scores > LDS)

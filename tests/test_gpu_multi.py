@@ -247,6 +247,8 @@ def test_item_rows_layout_tracks_the_oracle_block_schedule(built):
         o.train_full(4, ep, B)
     for which in SHARED + [cdae_amd.P_WU]:
         ref = o.get(which)
+        from helpers import record_measured
+        record_measured("item_rows_full_output_vs_oracle", which=which, err=np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()))
         assert np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()) < 2e-2
 
 

@@ -11,7 +11,7 @@ import cdae_amd
 from cdae_amd import synth
 import oracle as orc
 from oracle import binding as ob
-from helpers import make_pair, max_param_err
+from helpers import make_pair, max_param_err, record_measured
 
 pytestmark = pytest.mark.gpu
 
@@ -109,6 +109,7 @@ def test_linear_function_full_output(tiny):
         model.train_one_iteration(seed=4, epoch=ep)
         o.train_full(4, ep, 48)
     err, which = max_param_err(model, o)
+    record_measured("linear_function_full_output", err=err, which=which)
     assert err < 2e-2, (err, which)                            # bf16 operands, see test_full_output_mfma_decode_matches_oracle
 
 
@@ -601,6 +602,7 @@ def test_more_than_65536_items(built):
     full.train_one_iteration(seed=3, epoch=0)
     of.train_full(3, 0, 32)
     err, which = max_param_err(full, of)
+    record_measured("more_than_65536_items_full", err=err, which=which)
     assert err < 2e-2, (err, which)
 
 
@@ -621,6 +623,7 @@ def test_full_output_three_gemm_path(tiny, small, monkeypatch, devlib, K, B, unf
         model.train_one_iteration(seed=4, epoch=ep)
         o.train_full(4, ep, B)
     err, which = max_param_err(model, o)
+    record_measured(f"three_gemm_path_K{K}_B{B}", err=err, which=which)
     assert err < (3e-2 if K > 64 else 2e-2), (err, which)
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
@@ -858,6 +861,7 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
         if not ref.size:
             continue
         diff = np.abs(model.get(which).astype(np.float64).ravel() - ref) / (1e-3 + np.abs(ref).max())
+        record_measured(f"k512_large_item_space_{variant.get('asymmetric', False)}_{loss}", which=which, max=diff.max(), mean=diff.mean())
         if which in (0, 2):
             assert diff.max() <= 7e-2 and diff.mean() <= 5e-3, (which, diff.max(), diff.mean())
         elif which in (1, 3):

@@ -48,9 +48,10 @@ def main():
     ap.add_argument("--shape", required=True)
     ap.add_argument("--num-dim", type=int, required=True)
     ap.add_argument("--batch-users", type=int, required=True)
+    ap.add_argument("--kernel", default="decode_gather_kernel", help="decode: the launch the roofline is about (decode_hybrid_kernel through round 5)")
     a = ap.parse_args()
     if a.kind == "decode":
-        k = "decode_hybrid_kernel"
+        k = a.kernel
         f, w = mean_of(a.fetch, k), mean_of(a.write, k)
         out = {"_comment": f"HBM-side traffic of cdae::{k} per launch: two separate rocprofv3 PMC passes (--kernel-trace --pmc FETCH_SIZE / WRITE_SIZE) of "
                            f"`python bench.py --no-cpu-baseline --steps 120 --warmup 20` (tools/profile_round.sh {a.round}): {os.path.relpath(a.fetch, ROOT)}, "
