@@ -106,7 +106,8 @@ struct cdae_hip {
   // device error word: raised by a gather wavefront of the fused launch (bit 0) or a workgroup of bucket_sort_kernel (bit 1) that gave up
   // waiting; checked after every synchronisation of the main stream.  HOST memory mapped into the device (the kernels write it on the
   // error path only): the check is a plain read, not a 30 us device-to-host copy behind every synchronize
-  uint32_t* h_err = nullptr;        // host address
+  uint32_t* h_err = nullptr;        // host address (a slot of the process-wide pool below: one mapped page per device, not one per handle)
+  int err_slot = -1;
   uint32_t* d_fused_err = nullptr;  // the same word as the device sees it
   uint32_t* d_hot_cnt = nullptr;    // [hot workgroups] wavefronts of the popular rows finished so far (the fused launch's blockers wait on it)
   uint32_t fused_seq = 0;           // fused launches so far (wraps with the counters)
@@ -341,6 +342,33 @@ int join_aux(cdae_hip* h) {
   return 0;
 }
 
+// Device error words: ONE page of mapped host memory per device and process, a slot per handle (a pinned, mapped allocation per handle
+// is a system-wide resource; hundreds of handles in one process — a test session — should not each hold one).
+struct ErrPool {
+  static constexpr int SLOTS = 1024;
+  uint32_t* host = nullptr; uint32_t* dev = nullptr;
+  std::vector<char> used;
+};
+std::mutex g_err_mu;
+ErrPool g_err_pool[64];
+int err_slot_acquire(int device, uint32_t** host, uint32_t** dev, int* slot) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  if (device < 0 || device >= 64) return fail("device id %d outside the error-word pool", device);
+  ErrPool& p = g_err_pool[device];
+  if (!p.host) {
+    HIPCHK(hipHostMalloc((void**)&p.host, ErrPool::SLOTS * sizeof(uint32_t), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&p.dev, p.host, 0));
+    p.used.assign(ErrPool::SLOTS, 0);
+  }
+  for (int i = 0; i < ErrPool::SLOTS; ++i)
+    if (!p.used[i]) { p.used[i] = 1; p.host[i] = 0u; *host = p.host + i; *dev = p.dev + i; *slot = i; return 0; }
+  return fail("more than %d live handles on device %d", ErrPool::SLOTS, device);
+}
+void err_slot_release(int device, int slot) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  if (device >= 0 && device < 64 && slot >= 0 && g_err_pool[device].host) g_err_pool[device].used[slot] = 0;
+}
+
 // After the main stream has been synchronised: the handle's device error word.  Bit 0: a gather wavefront of a fused launch
 // (decode_gather_kernel) gave up waiting for a g; bit 1: a workgroup of bucket_sort_kernel gave up waiting for the ranges in front of it.
 // Both waits rest on workgroups being dispatched in index order and are bounded, so that a broken assumption is an error, not a hang.
@@ -432,7 +460,7 @@ void free_all(cdae_hip* h) {
     if (b.ready) (void)hipEventDestroy(b.ready);
     if (b.released) (void)hipEventDestroy(b.released);
   }
-  if (h->h_err) { (void)hipHostFree(h->h_err); h->h_err = nullptr; h->d_fused_err = nullptr; }
+  if (h->h_err) { err_slot_release(h->device, h->err_slot); h->h_err = nullptr; h->d_fused_err = nullptr; h->err_slot = -1; }
   if (h->prep) (void)hipStreamDestroy(h->prep);
   if (h->prep2 && h->prep2_own) (void)hipStreamDestroy(h->prep2);
   if (h->aux) (void)hipStreamDestroy(h->aux);
@@ -1616,10 +1644,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
       HIPCHK(hipMemset(h->d_Ghot, 0, nB * sizeof(float)));
       HIPCHK(hipMemset(h->d_hotdup, 0xFF, nB * sizeof(uint32_t)));
     }
-    if (!h->h_err) {
-      HIPCHK(hipHostMalloc((void**)&h->h_err, sizeof(uint32_t), hipHostMallocMapped));
-      HIPCHK(hipHostGetDevicePointer((void**)&h->d_fused_err, h->h_err, 0));
-    }
+    if (!h->h_err) CHK(err_slot_acquire(h->device, &h->h_err, &h->d_fused_err, &h->err_slot));
     *(volatile uint32_t*)h->h_err = 0u;
     CHK(dev_alloc(&h->d_hot_cnt, (size_t)h->hot_rows / 4 + 1));
     HIPCHK(hipMemset(h->d_hot_cnt, 0, ((size_t)h->hot_rows / 4 + 1) * sizeof(uint32_t)));

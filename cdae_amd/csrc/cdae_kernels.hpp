@@ -1296,12 +1296,11 @@ __device__ __forceinline__ void row16_store_sc1(float* __restrict__ matrix, uint
 }
 
 // Wave-private LDS of decode_rows16 (words): example words and example ids of the current and the next 64-example chunk of each
-// of the four groups, the parked g of the current chunk, and (round 6) the rows as they were at the current user's first visit —
-// read only when that user draws the same negative again: 13-16 registers per lane that the launch's occupancy pays for otherwise.
-constexpr uint32_t ROWS16_WREF_WORDS = 16u * 64u;
-constexpr uint32_t ROWS16_LDS_WORDS = 4u * 128u + 4u * 128u + 4u * 64u + ROWS16_WREF_WORDS;
-// the same words as decode_row64 uses them: g parked until the row's end, then its duplicate-run state (2 x NI x 64 words, NI <= 4)
-constexpr uint32_t ROW64_PARK_WORDS = ROWS16_LDS_WORDS - 512u;
+// of the four groups, and the parked g of the current chunk.  (Round 6 tried the rows-at-first-visit state of both row roles in LDS as
+// well — 13-16 registers per lane, wanted for an occupancy of four — and took it back: 36 KiB per workgroup instead of 20 left no
+// room on a CU for bucket_sort_kernel's 88 KiB workgroups beside three of this launch's, and the prep chain's sort went 56 -> 78 us.)
+constexpr uint32_t ROWS16_LDS_WORDS = 4u * 128u + 4u * 128u + 4u * 64u;
+constexpr uint32_t ROW64_PARK_WORDS = ROWS16_LDS_WORDS;          // the same words as decode_row64 uses them: g parked until the row's end
 
 template <int NV, int NT, int LOSS, bool ADAGRAD, bool FUSED = false>
 __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t rank0, uint32_t* __restrict__ lds, CDAE_DECODE_PARAMS) {
@@ -1331,9 +1330,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   const bool pad_lane = HAS_PAD && l == GRP - 1;
   const float pad_one = pad_lane ? 1.f : 0.f;
 
-  float w[NE], a[NE];
-  static_assert(NE <= 16, "ROWS16_WREF_WORDS");
-  float* const wref = reinterpret_cast<float*>(lds + 1280u) + lane;          // element i of this lane's row: wref[64 i]
+  float w[NE], a[NE], wref[NE];
   const size_t row_off = (size_t)item * hp.Kp;
   if (n) {
     row16_load<NV, NT>(w, D + row_off, l);
@@ -1347,6 +1344,8 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
   }
   float bias = n ? bp[item] : 0.f, bias_ag = n ? bp_ag[item] : 1.f;
   if (pad_lane) { w[NE - 1] = bias; a[NE - 1] = bias_ag; }
+#pragma unroll
+  for (int i = 0; i < NE; ++i) wref[i] = w[i];
 
 #ifndef CDAE_DECODE16_PF
 #define CDAE_DECODE16_PF 4
@@ -1462,7 +1461,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
             const uint32_t di = dup_of_pos[beg + t];
             float corr[NE];
 #pragma unroll
-            for (int i = 0; i < NE; ++i) corr[i] = (pad_lane && i == NE - 1) ? 0.f : g * (w[i] - wref[64 * i]);
+            for (int i = 0; i < NE; ++i) corr[i] = (pad_lane && i == NE - 1) ? 0.f : g * (w[i] - wref[i]);
             if (di != DUP_NONE) {
               if constexpr (FUSED) row16_store_sc1<NV, NT>(dup_corr, di * hp.Kp, corr, l);
               else row16_store<NV, NT>(dup_corr + (size_t)di * hp.Kp, corr, l);
@@ -1477,7 +1476,7 @@ __device__ __forceinline__ void decode_rows16(HyperParams hp, const uint32_t ran
             __builtin_amdgcn_s_waitcnt(WAIT_VM0);
           } else {
 #pragma unroll
-            for (int i = 0; i < NE; ++i) wref[64 * i] = w[i];     // (a run's first example always comes before its duplicates: no initial value needed)
+            for (int i = 0; i < NE; ++i) wref[i] = w[i];
           }
         }
         if (!(word & INPUT_BIT) || !tied) {
@@ -1533,9 +1532,8 @@ decode_hybrid_kernel(HyperParams hp, uint32_t hot_rows, DecodeLate late, CDAE_DE
 #define CDAE_HOT_PRIO 2
 #endif
     __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
-    decode_row64<NI, LOSS, ADAGRAD, false, false, true>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROW64_PARK_WORDS, late,
-                                                        CDAE_DECODE_PASS,   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
-                                                        reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]) + ROW64_PARK_WORDS);
+    decode_row64<NI, LOSS, ADAGRAD, false>(hp, wave, reinterpret_cast<float*>(rows16_lds[threadIdx.x / WAVE]), ROW64_PARK_WORDS, late,
+                                           CDAE_DECODE_PASS);   // b' as a scalar: the speculative pipeline needs the row untouched by deferred examples
     trace_end(hp, 3, wave, t0);
   } else {
     if (CDAE_SKIP_ROLE(hp, 8u)) return;
@@ -1563,7 +1561,8 @@ struct GatherArgs {
   const uint32_t* late_bits; uint32_t late_words;   // bitmap over the items: the late rows (DecodeLate), whose examples are NOT gathered; nullptr: none
   uint32_t* err;                                 // fused launch: raised by a wavefront that gives up waiting for a g
 };
-constexpr uint32_t GATHER_CAP = 512;             // list entries per wavefront; a 128-example step adds at most 256
+constexpr uint32_t GATHER_CAP = 448;             // list entries per wavefront; a 128-example step adds at most 256 (flushed when fewer are free).  448,
+                                                 // not 512: three workgroups of the fused launch and one of bucket_sort_kernel (88 KiB) then share a CU's LDS
 constexpr uint32_t LATE_BITS_WORDS = 2048;       // LDS copy of the late-row bitmap: item spaces up to 65 536
 
 // every thread of the workgroup: the late-row bitmap into LDS (before any wavefront leaves)
@@ -1770,8 +1769,9 @@ struct FusedGeom {
   const uint32_t* cold_map; // [decode_wgs][4]: the four-row group of every wavefront of a row workgroup, 0xFFFFFFFF = none (balanced by the host)
 };
 constexpr uint32_t FUSED_BLOCK_MAX = 16;         // blockers for the workgroups of the 64 most popular rows
-constexpr uint32_t FUSED_LDS_WORDS = 4u * ROWS16_LDS_WORDS;                       // row roles: 36 KiB (the gather role needs 24 KiB)
-static_assert(4u * 2u * GATHER_CAP + LATE_BITS_WORDS <= FUSED_LDS_WORDS, "gather role's LDS");
+constexpr uint32_t FUSED_LDS_WORDS = 4u * 2u * GATHER_CAP + LATE_BITS_WORDS;     // gather role: 22 KiB (the row roles need 4 x ROWS16_LDS_WORDS = 20 KiB)
+static_assert(4u * ROWS16_LDS_WORDS <= FUSED_LDS_WORDS, "row roles' LDS");
+static_assert(3u * (FUSED_LDS_WORDS + 8u) * 4u + 90376u <= 160u * 1024u, "three workgroups of this launch + one of bucket_sort_kernel per CU");
 // is workgroup index b a blocker?
 __host__ __device__ inline bool fused_is_blocker(const FusedGeom& g, uint32_t b) {
   return b >= g.stride && b < (1u + g.rounds) * g.stride && b % g.stride < g.blocked;
@@ -1794,8 +1794,8 @@ decode_gather_kernel(HyperParams hp, uint32_t hot_rows, FusedGeom geo, DecodeLat
     if (row < hot_rows && !CDAE_SKIP_ROLE(hp, 4u)) {
       const unsigned long long t0 = trace_begin(hp);
       __builtin_amdgcn_s_setprio(CDAE_HOT_PRIO);
-      decode_row64<NI, LOSS, ADAGRAD, false, true, true>(hp, row, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS), ROW64_PARK_WORDS, late,
-                                                         CDAE_DECODE_PASS, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS) + ROW64_PARK_WORDS);
+      decode_row64<NI, LOSS, ADAGRAD, false, true>(hp, row, reinterpret_cast<float*>(fused_lds + wid * ROWS16_LDS_WORDS), ROW64_PARK_WORDS, late,
+                                                   CDAE_DECODE_PASS);
       __builtin_amdgcn_s_setprio(0);
       trace_end(hp, 3, row, t0, hp.trace ? hw_place() : 0u);
     }

@@ -280,7 +280,8 @@ def test_item_rows_sampled_with_one_shard_is_the_single_handle_bit_for_bit(built
     a, b = _all_params(mm, extra), _all_params(one, extra)
     for w in a:
         np.testing.assert_array_equal(a[w], b[w], err_msg=f"parameter {w}")
-    assert mm.current_loss(5, 0) == one.current_loss(5, 0)
+    la, lb = mm.current_loss(5, 0), one.current_loss(5, 0)      # (bit-equal parameters; the loss pass adds its fp64 terms with atomics: last digits)
+    assert abs(la - lb) <= 1e-12 * abs(lb)
 
 
 @pytest.mark.parametrize("K,B,shards,kw", [(24, 48, 2, {}), (24, 300, 3, {}), (200, 64, 4, {}), (300, 32, 2, {}), (24, 48, 3, dict(asymmetric=True)),

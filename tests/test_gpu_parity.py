@@ -705,7 +705,8 @@ def test_wide_gemm_tiles_change_no_bit(built, monkeypatch, devlib):
     narrow, loss_n = run()
     for w in wide:
         assert np.array_equal(wide[w], narrow[w]), w
-    assert loss_w == loss_n and np.isfinite(loss_w)
+    # (the loss pass adds the users' fp64 terms with atomics: the parameters are bit-equal, the sum of the same terms to the last digit or two)
+    assert abs(loss_w - loss_n) <= 1e-12 * abs(loss_n) and np.isfinite(loss_w)
 
 
 @pytest.mark.parametrize("adagrad", [True, False])
