@@ -636,8 +636,11 @@ int fused_geometry(cdae_hip* h, uint32_t hot, uint32_t I) {
   else if (ce) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 5, false>, 256, 0));
   else if (ada) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 0, true>, 256, 0));
   else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_gather_kernel<NV, NT, 0, false>, 256, 0));
-  g.rounds = (uint32_t)std::max(0, std::min(per_cu, 8) - 1);
-  if (const char* ev = DEV_ENV("CDAE_FUSED_BLOCK_ROUNDS")) g.rounds = (uint32_t)std::atoi(ev);     // (developer switch: 0 = no blockers)
+  // Blockers are OFF in the shipped launch (rounds = 0): measured, they buy nothing (0.0924 with, 0.0919 without: the long-lived four-row
+  // wavefronts are not the popular rows' neighbours), and a blocker that waits in vain is the one wait of this launch that costs time
+  // without raising an error.  CDAE_FUSED_BLOCK_ROUNDS = n (developer switch) brings them back; -1 = one round per resident workgroup.
+  g.rounds = 0;
+  if (const char* ev = DEV_ENV("CDAE_FUSED_BLOCK_ROUNDS")) g.rounds = std::atoi(ev) < 0 ? (uint32_t)std::max(0, std::min(per_cu, 8) - 1) : (uint32_t)std::atoi(ev);
   // The four-row groups are dealt to (CU, SIMD) bins so that every SIMD gets about the same number of example steps (longest group first,
   // each to the lightest bin): a group lasts as long as its longest row, the SIMDs are VALU-bound on these wavefronts, and in index
   // order (round 5) the SIMDs that held the most popular groups finished 10-15 us after the others — which every gather wavefront of
