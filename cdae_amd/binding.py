@@ -68,6 +68,7 @@ EXPORTS = {
     "cdae_hip_mf_default_batch_users": (C.c_uint32, [C.c_uint64, C.c_uint32]),
     "cdae_hip_batch_users": (C.c_uint32, [C.c_void_p]),
     "cdae_hip_full_output_plan": (C.c_uint32, [C.c_void_p]),
+    "cdae_hip_set_decode_fused": (C.c_int, [C.c_void_p, C.c_int]),
     "cdae_hip_decode_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cdae_hip_user_order": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "cdae_hip_set_user_id_offset": (C.c_int, [C.c_void_p, C.c_uint64]),
@@ -267,6 +268,10 @@ class CDAE:
     def batch_users(self) -> int:
         """users per parameter snapshot the handle is using (the library's choice when the config asked for 0)"""
         return int(self.lib.cdae_hip_batch_users(self.h))
+
+    def set_decode_fused(self, allow: bool):
+        """cdae_hip_set_decode_fused: off for handles trained side by side with another handle on the same device"""
+        _chk(self.lib, self.lib.cdae_hip_set_decode_fused(self.h, int(bool(allow))))
 
     @property
     def decode_plan(self) -> dict:

@@ -103,6 +103,8 @@ struct cdae_hip {
   uint32_t* d_late_bits = nullptr;  // [(I + 31) / 32] bitmap of the late rows' items
   uint32_t late_words = 0;
   bool fused_decode = false;        // decode + gather as ONE launch (decode_gather_kernel); CDAE_DECODE_UNFUSED turns it off (developer switch)
+  bool fused_possible = false;      // ... what set_interactions found possible; fused_decode = fused_possible && allow_fused
+  bool allow_fused = true;          // cdae_hip_set_decode_fused: off for handles whose launches may overlap another handle's on the same device
   // device error word: raised by a gather wavefront of the fused launch (bit 0) or a workgroup of bucket_sort_kernel (bit 1) that gave up
   // waiting; checked after every synchronisation of the main stream.  HOST memory mapped into the device (the kernels write it on the
   // error path only): the check is a plain read, not a 30 us device-to-host copy behind every synchronize
@@ -1476,6 +1478,13 @@ int cdae_hip_user_order(cdae_hip_t* h, uint32_t* out, size_t count) {
   for (uint64_t pos = 0; pos < h->U; ++pos) out[pos] = h->user_perm.empty() ? (uint32_t)pos : h->user_perm[pos];
   return 0;
 }
+int cdae_hip_set_decode_fused(cdae_hip_t* h, int allow) {
+  if (!h) return fail("null handle");
+  h->allow_fused = allow != 0;
+  h->fused_decode = h->fused_possible && h->allow_fused;
+  return 0;
+}
+
 int cdae_hip_decode_plan(const cdae_hip_t* h, uint32_t* hot_rows, uint32_t* late_rows, uint32_t* fused) {
   if (!h) return fail("null handle");
   const bool set = h->d_shared != nullptr;
@@ -1657,11 +1666,12 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     h->num_cus = (uint32_t)std::max(prop.multiProcessorCount, 16);
-    h->fused_decode = h->late_rows && h->hot_rows <= 2u * h->num_cus && !h->item_shard && (uint64_t)I * h->Kp * 4u < (1ull << 31) &&
-                      !DEV_ENV("CDAE_DECODE_UNFUSED");
+    h->fused_possible = h->late_rows && h->hot_rows <= 2u * h->num_cus && !h->item_shard && (uint64_t)I * h->Kp * 4u < (1ull << 31) &&
+                        !DEV_ENV("CDAE_DECODE_UNFUSED");
 #ifdef CDAE_DECODE_TIMING
-    h->fused_decode = false;
+    h->fused_possible = false;
 #endif
+    h->fused_decode = h->fused_possible && h->allow_fused;
   }
 
   // parameters
@@ -1856,7 +1866,7 @@ int cdae_hip_set_interactions(cdae_hip_t* h, uint64_t U, uint64_t I, const int64
     const uint64_t want = h->mf ? 1 : (ev ? std::strtoull(ev, nullptr, 10) : std::max<uint64_t>(65536, h->Ecap / 4));   // small problems: every example (IMF / BPR have no correction rows)
     h->dup_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), std::max<uint64_t>(h->Ecap, 1));
     h->dup_stripes = std::max<uint32_t>(1u, std::min<uint32_t>(cdae::DUP_STRIPES, h->dup_cap / 4096u));
-    if ((uint64_t)h->dup_cap * h->Kp * 4u >= (1ull << 31)) h->fused_decode = false;     // (32-bit buffer offsets in the fused launch)
+    if ((uint64_t)h->dup_cap * h->Kp * 4u >= (1ull << 31)) h->fused_possible = h->fused_decode = false;     // (32-bit buffer offsets in the fused launch)
     CHK(dev_alloc(&h->d_dup_corr, (size_t)h->dup_cap * h->Kp));
     HIPCHK(hipMemset(h->d_dup_corr, 0, (size_t)h->dup_cap * h->Kp * sizeof(float)));
   }

@@ -1676,6 +1676,9 @@ __device__ __forceinline__ void hidden_gather_role(const HyperParams& hp, const 
         const bool pend0 = __builtin_bit_cast(uint32_t, cur.g[0]) == G_PENDING && is_mine(cur.item[0]);
         const bool pend1 = __builtin_bit_cast(uint32_t, cur.g[1]) == G_PENDING && is_mine(cur.item[1]);
         if (!__ballot(pend0 || pend1)) break;
+        // (an earlier wavefront or launch has already given up: this handle's parameters are lost, the host will say so — do not make
+        // the rest of the epoch wait for that news)
+        if (spin == 64u && __hip_atomic_load(ga.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
         if (spin >= FUSED_SPIN_CAP) { if (lane == 0) __hip_atomic_store(ga.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // (host memory: a plain store, no PCIe atomic)
         __builtin_amdgcn_s_sleep(24);
         if (pend0) cur.g[0] = load_f32_sc1(ga.G + base + example_of(c0 + lane));

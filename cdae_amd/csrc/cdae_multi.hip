@@ -636,6 +636,8 @@ int cdae_hip_multi_create(const cdae_hip_config* cfg, int n_shards, const int* d
     cdae_hip_t* h = nullptr;
     int rc = cdae_hip_create(cfg, devs[s], &h);
     if (rc) { for (cdae_hip_t* q : m->shard) cdae_hip_destroy(q); return rc; }
+    // shards that share a device run their steps side by side on it: the fused decode + gather launch must not (cdae_hip_set_decode_fused)
+    if ((int)uniq.size() != n_shards) (void)cdae_hip_set_decode_fused(h, 0);
     m->shard.push_back(h);
   }
   *out = m.release();

@@ -61,7 +61,7 @@ extern "C" {
  * 11: schedule of the user-sharded layout: cdae_hip_delta_set_combine (CDAE_COMBINE_GLOBAL_ACC), cdae_hip_multi_set_schedule
  *     (relay warm-up epochs on the single-GPU schedule, users per shard of the exchanged steps, combine rule); the drop-in IMF / BPR
  *     classes pass batch_users = 1 (the reference loop) unless CDAE_BATCH_USERS says otherwise
- * 12: cdae_hip_decode_plan (which launches the sampled decode + hidden-gradient step of a handle is made of);
+ * 12: cdae_hip_decode_plan, cdae_hip_set_decode_fused (which launches the sampled decode + hidden-gradient step of a handle is made of);
  *     cdae_hip_multi_steps_per_epoch, cdae_hip_multi_train_steps (a range of the exchanged steps of an epoch: what bench.py times) */
 #define CDAE_HIP_ABI_VERSION 12
 
@@ -157,6 +157,13 @@ uint32_t cdae_hip_batch_users(const cdae_hip_t* h);
  *               and never for the late rows); 0: two launches.  Either order gives the same bits.
  * Any pointer may be NULL. */
 int cdae_hip_decode_plan(const cdae_hip_t* h, uint32_t* hot_rows, uint32_t* late_rows, uint32_t* fused);
+/* allow = 0: this handle takes the two separate launches (same bits).  REQUIRED for handles whose training calls may be in flight on the
+ * SAME device at the same time as another handle's (two models trained from two threads; the logical shards of cdae_hip_multi_* with
+ * equal device ids, for which the library does it itself): inside the fused launch the gather wavefronts hold their slots while they wait
+ * for rows of the same launch, and with two such launches on one device each can keep the other's row workgroups from being dispatched
+ * — the waits are bounded and end in an error from cdae_hip_synchronize, not in a hang, but the epoch is lost.  One handle per device
+ * at a time (the reference's own use: one model, one training loop) needs nothing. */
+int cdae_hip_set_decode_fused(cdae_hip_t* h, int allow);
 
 /* Which launches the full-output decode (cdae_hip_config.full_output; the reference has no counterpart: its training decode is
  * always sampled, cdae.hpp:217-293) of this handle is made of, once cdae_hip_set_interactions has run — for a caller that prices

@@ -112,6 +112,25 @@ def test_multi_handle_equals_the_hand_driven_protocol_bit_for_bit(small, shards,
     np.testing.assert_array_equal(mm.recommend_all(7, 100, 900), np.concatenate([r.recommend_all(7) for r in ref])[100:900])
 
 
+def test_shards_that_share_a_device_do_not_take_the_fused_launch(built):
+    """Round 6: the fused decode + gather launch must not run side by side with another handle's on one device (its gather wavefronts hold
+    their slots while they wait); the library switches it off for logical shards — and leaves it on for a handle of its own."""
+    import ctypes as C
+    d = synth.generate_shape("tiny", seed=5)
+    cfg = cfg_of(K=40, B=300)
+    one = cdae_amd.CDAE(cfg)
+    one.reset(d, seed=1)
+    assert one.decode_plan["fused"] and one.decode_plan["late_rows"] > 0
+    mm = cdae_amd.MultiCDAE(cfg, devices=[0, 0])
+    mm.reset(d, seed=1)
+    for s in range(2):
+        h, f, l = C.c_void_p(), C.c_uint32(9), C.c_uint32(9)
+        assert mm.lib.cdae_hip_multi_shard(mm.h, s, C.byref(h), None, None) == 0
+        assert mm.lib.cdae_hip_decode_plan(h, None, C.byref(l), C.byref(f)) == 0
+        assert f.value == 0
+    one.close(); mm.close()
+
+
 def test_one_shard_is_the_single_handle(small):
     cfg = cfg_of(B=64)
     mm = cdae_amd.MultiCDAE(cfg, devices=[0])

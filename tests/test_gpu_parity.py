@@ -274,6 +274,23 @@ def test_fused_decode_gather_launch_changes_no_bit(tiny, monkeypatch, devlib, K,
     assert np.isfinite(fused[0]).all()
 
 
+def test_set_decode_fused_switches_the_launch_and_no_bit(tiny):
+    """cdae_hip_set_decode_fused (ABI 12, shipped library): a handle that may train side by side with another one on the same device takes the
+    two separate launches — the same bits.  The logical shards of cdae_hip_multi_* get it from the library (tests/test_gpu_multi.py)."""
+    outs = []
+    for allow in (True, False):
+        m, _ = make_pair(tiny, K=40, B=300)
+        assert m.decode_plan["fused"], m.decode_plan                      # 300 users per batch: tiny's popular rows are hot rows
+        m.set_decode_fused(allow)
+        assert m.decode_plan["fused"] == allow
+        for ep in range(2):
+            m.train_one_iteration(seed=4, epoch=ep)
+        outs.append({w: m.get(w) for w in (0, 1, 4, 5, 6, 7, 8, 9)})
+        m.close()
+    for w in outs[0]:
+        assert np.array_equal(outs[0][w], outs[1][w]), w
+
+
 @pytest.mark.parametrize("B", [64, 300])
 def test_late_rows_track_the_oracle_and_round_fives_arithmetic(tiny, monkeypatch, devlib, B):
     """The late rows' terms of the hidden gradient are added by hidden_finish_kernel from Ghot (one entry per user and row, one
