@@ -324,7 +324,7 @@ def test_yelp_shape_full_output_k50_curve(built, path):
     # the curves above are the claim, this only guards against a gross divergence)
     from helpers import record_measured
     record_measured(f"full_output_40_epochs_probes_seed{seed}", W=probes[0], b=probes[1])
-    assert probes[0] <= 8e-2 and probes[1] <= 8e-2
+    assert probes[0] <= 8e-2 and probes[1] <= 1.1e-2          # measured over the four seeds (round 6): W up to 7.6e-2, b up to 8.5e-3 (b's bound was 8e-2)
 
 
 def test_full_output_block_schedule_reaches_the_literal_loops_quality(built):
@@ -472,7 +472,8 @@ def test_reduced_config5_k512_131072_items(built, path):
     # turn the bf16 rounding of g (2^-9 of ~32 = 0.06) into 0.006 of step each; measured max 4.0e-2, mean < 1e-2 of the range
     from helpers import record_measured
     record_measured("reduced_config5", **errs)
-    assert max(errs["Wu"], errs["bp"], errs["b"]) <= 3e-2 and errs["W"] <= 6e-2 and errs["W_mean"] <= 1e-2, errs
+    # measured (round 6, profiles/r06_measured_bf16_guards.txt): Wu 1.06e-2, b' 5.9e-3, b 1.24e-2, W max 3.98e-2, W mean 5.2e-5; bounds <= 1.3 x (3e-2 / 6e-2 / 1e-2 before)
+    assert max(errs["Wu"], errs["bp"], errs["b"]) <= 1.6e-2 and errs["W"] <= 5.2e-2 and errs["W_mean"] <= 7e-5, errs
     assert errs["loss"] <= 0.01, errs
     # evaluation at this size goes through the general recommend path (K > 256, 131 072 x 4 B of scores > LDS)
     rec = m.recommend_all(10)

@@ -268,7 +268,7 @@ def test_item_rows_layout_tracks_the_oracle_block_schedule(built):
         ref = o.get(which)
         from helpers import record_measured
         record_measured("item_rows_full_output_vs_oracle", which=which, err=np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()))
-        assert np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()) < 2e-2
+        assert np.abs(mm.get(which).astype(np.float64).ravel() - ref).max() / (1e-3 + np.abs(ref).max()) < 3.4e-3      # measured <= 2.63e-3 (round 6; was 2e-2)
 
 
 # ---- the SAMPLED decode in the item-rows layout: the single-GPU schedule itself, over item shards (round 3) ------------------

@@ -110,7 +110,7 @@ def test_linear_function_full_output(tiny):
         o.train_full(4, ep, 48)
     err, which = max_param_err(model, o)
     record_measured("linear_function_full_output", err=err, which=which)
-    assert err < 2e-2, (err, which)                            # bf16 operands, see test_full_output_mfma_decode_matches_oracle
+    assert err < 4.5e-3, (err, which)                          # bf16 operands; measured 3.3e-3 (profiles/r06_measured_bf16_guards.txt; the bound was 2e-2 through round 5)
 
 
 def test_loss_and_recommend_match_oracle(small):
@@ -620,7 +620,7 @@ def test_more_than_65536_items(built):
     of.train_full(3, 0, 32)
     err, which = max_param_err(full, of)
     record_measured("more_than_65536_items_full", err=err, which=which)
-    assert err < 2e-2, (err, which)
+    assert err < 4e-3, (err, which)                            # measured 2.8e-3 (round 6; was 2e-2)
 
 
 @pytest.mark.parametrize("K,B,unfused_env", [(300, 48, False), (512, 130, False), (24, 48, True), (200, 64, True), (300, 256, False)])
@@ -641,7 +641,10 @@ def test_full_output_three_gemm_path(tiny, small, monkeypatch, devlib, K, B, unf
         o.train_full(4, ep, B)
     err, which = max_param_err(model, o)
     record_measured(f"three_gemm_path_K{K}_B{B}", err=err, which=which)
-    assert err < (3e-2 if K > 64 else 2e-2), (err, which)
+    # measured (round 6, profiles/r06_measured_bf16_guards.txt) 2.14e-2 / 2.31e-2 / 4.1e-3 / 5.5e-3 / 1.59e-2 in the order of the cases; each bound <= 1.3 x its
+    # measurement (3e-2 / 2e-2 for all of them through round 5)
+    bound = {(300, 48): 2.8e-2, (512, 130): 3e-2, (24, 48): 5.5e-3, (200, 64): 7.5e-3, (300, 256): 2.1e-2}[(K, B)]
+    assert err < bound, (err, which, bound)
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
 
@@ -880,12 +883,14 @@ def test_k512_path_over_a_large_item_space_matches_oracle(built, variant):
             continue
         diff = np.abs(model.get(which).astype(np.float64).ravel() - ref) / (1e-3 + np.abs(ref).max())
         record_measured(f"k512_large_item_space_{variant.get('asymmetric', False)}_{loss}", which=which, max=diff.max(), mean=diff.mean())
+        # measured over the three variants (round 6, profiles/r06_measured_bf16_guards.txt): W / V max 5.9e-2, mean 4.4e-5; the odd ids (accumulators) up to
+        # 3.1e-2, the other parameters up to 7.3e-3 — the bounds are <= 1.3 x those (7e-2 / 5e-3, 6e-2, 3e-2 through round 5)
         if which in (0, 2):
-            assert diff.max() <= 7e-2 and diff.mean() <= 5e-3, (which, diff.max(), diff.mean())
+            assert diff.max() <= 7e-2 and diff.mean() <= 6e-5, (which, diff.max(), diff.mean())
         elif which in (1, 3):
             continue                                   # (accumulators: the squares of those steps)
         else:                                          # (the other accumulators hold squares: twice the relative error of what they square)
-            assert diff.max() <= (6e-2 if which % 2 else 3e-2), (which, diff.max())
+            assert diff.max() <= (4.1e-2 if which % 2 else 9.5e-3), (which, diff.max())
     lg, lo = model.current_loss(4, 0), o.data_loss(4, 0) + o.penalty_loss()
     assert abs(lg - lo) < 1e-2 * abs(lo)
 
