@@ -122,6 +122,10 @@ struct Exchange {
   uint64_t steps = 0;
   bool pending = false;                  // an all-reduce of a staged delta is in flight / not merged yet
   bool begun = false;
+  // Synchronous exchange of a rank that owns its device (round 6): nothing can overlap the collective — the merge behind it is the next
+  // thing the main stream does — so it is issued ON the main stream: stage -> all-reduce -> merge in order, no event hand-off to the
+  // collective stream and back (two system-scope hops per step, ~10 us each).  Same buffers, same arithmetic.
+  bool reduced_on_main = false;          // the pending all-reduce was issued on the main stream: the merge needs no event wait
 };
 
 void free_exchange(void* p) {
@@ -167,6 +171,9 @@ int begin_if_needed(Exchange* x) {
   return 0;
 }
 
+// the synchronous exchange of a rank that owns its device issues its collective on the main stream (Exchange::reduced_on_main)
+static bool sync_on_main(const Exchange* x) { return x->period == 0 && x->local.empty() && !DEV_ENV("CDAE_XCHG_COLLECTIVE_STREAM"); }
+
 // phase 1 of a boundary, on the handle's main stream: fold the previous period's peers in and / or stage this period's delta
 int boundary_stage(Exchange* x, bool start_next) {
   HIPCHK(hipSetDevice(cdae_internal::device_of(x->h)));
@@ -174,14 +181,14 @@ int boundary_stage(Exchange* x, bool start_next) {
   if (x->pending) {
     // the reduced buffer must be complete; in a local group nobody may restage (overwrite its send buffer) before every
     // peer's sum kernel has read it
-    if (x->local.empty()) HIPCHK(hipStreamWaitEvent(st, x->ev_reduced, 0));
+    if (x->local.empty()) { if (!x->reduced_on_main) HIPCHK(hipStreamWaitEvent(st, x->ev_reduced, 0)); }
     else for (Exchange* p : x->local) HIPCHK(hipStreamWaitEvent(st, p->ev_reduced, 0));
   }
   if (x->pending && start_next) CHK(cdae_hip_delta_merge_stage(x->h));
   else if (x->pending) CHK(cdae_hip_delta_merge(x->h));
   else if (start_next) CHK(cdae_hip_delta_stage(x->h));
   x->pending = false;
-  if (start_next) HIPCHK(hipEventRecord(x->ev_staged, st));
+  if (start_next && !sync_on_main(x)) HIPCHK(hipEventRecord(x->ev_staged, st));
   return 0;
 }
 
@@ -200,14 +207,18 @@ int boundary_reduce(Exchange* x) {
     hipLaunchKernelGGL(local_sum_kernel, dim3((unsigned)((n / 4 + 1 + 255) / 256)), dim3(256), 0, x->cstream, pp, (int)x->local.size(), recv, n);
     HIPCHK(hipGetLastError());
   } else {
-    HIPCHK(hipStreamWaitEvent(x->cstream, x->ev_staged, 0));
+    const bool on_main = sync_on_main(x);      // (CDAE_XCHG_COLLECTIVE_STREAM, developer switch: round 5's hand-off to the collective stream)
+    hipStream_t cs = on_main ? cdae_internal::main_stream(x->h) : x->cstream;
+    if (!on_main) HIPCHK(hipStreamWaitEvent(cs, x->ev_staged, 0));
     if (x->guard) {
       std::shared_lock<std::shared_timed_mutex> lk(x->guard->mu);
       if (x->guard->failed.load()) return fail("a peer shard failed: epoch abandoned");
-      NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));
+      NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, cs));
     } else if (x->comm) {
-      NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, x->cstream));   // (one rank: identity, same stream semantics)
+      NCCLCHK(ncclAllReduce(recv, recv, n, ncclFloat32, ncclSum, x->comm, cs));   // (one rank: identity, same stream semantics)
     }
+    x->reduced_on_main = on_main;
+    if (on_main) { x->pending = true; return 0; }
   }
   HIPCHK(hipEventRecord(x->ev_reduced, x->cstream));
   x->pending = true;
