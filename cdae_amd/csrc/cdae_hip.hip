@@ -2359,18 +2359,19 @@ PipeGeom pipe_geom(const cdae_hip* h) {
   g.threads = n_rows * (g.Kc / 4) + g.n_tail / 4 + g.n_tail % 4;
   return g;
 }
-template <int MODE>
+// SYNC: the synchronous exchange's forms of STAGE / MERGE (cdae_kernels.hpp delta_pipe_kernel: no snap, no send copy)
+template <int MODE, bool SYNC = false>
 int launch_pipe(cdae_hip* h) {
   const PipeGeom g = pipe_geom(h);
   if (h->delta_combine == CDAE_COMBINE_GLOBAL_ACC && h->cfg.using_adagrad) {
     // (parameter, accumulator) pairs: same compact buffers, half the threads of the element-wise pass each moving two elements
     const size_t n_rows = h->n_matrix / h->Kp, threads = (n_rows / 2) * (g.Kc / 4) + h->I + h->Kp;
-    hipLaunchKernelGGL(cdae::delta_pipe_pair_kernel<MODE>, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
+    hipLaunchKernelGGL((cdae::delta_pipe_pair_kernel<MODE, SYNC>), dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                        h->d_base, h->d_snap, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, (uint32_t)h->I, (float)h->cfg.beta);
     HIPCHK(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(cdae::delta_pipe_kernel<MODE>, dim3((uint32_t)((g.threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
+  hipLaunchKernelGGL((cdae::delta_pipe_kernel<MODE, SYNC>), dim3((uint32_t)((g.threads + 255) / 256)), dim3(256), 0, h->stream, h->d_shared,
                      h->d_base, h->d_snap, h->d_delta, h->d_recv, h->n_matrix, h->Kp, g.Kc, g.n_tail);
   HIPCHK(hipGetLastError());
   return 0;
@@ -2919,6 +2920,20 @@ int validate_test_rows(const int64_t* test_row_ptr, const uint32_t* test_col, ui
   if (users_with_rows) *users_with_rows = with_rows;
   return 0;
 }
+int delta_stage_sync(cdae_hip_t* h) {
+  if (!h || !h->d_recv) return fail("delta_stage must have been called once (it allocates the exchange buffers)");
+  HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
+  return launch_pipe<cdae::DELTA_STAGE, true>(h);
+}
+int delta_merge_sync(cdae_hip_t* h) {
+  if (!h || !h->d_recv) return fail("delta_stage must be called first");
+  h->db_valid = h->db_rows_valid = false;
+  HIPCHK(hipSetDevice(h->device));
+  CHK(join_aux(h));
+  return launch_pipe<cdae::DELTA_MERGE, true>(h);
+}
+
 int adopt_shared_block(cdae_hip_t* dst, cdae_hip_t* src) {
   if (!dst || !src || !dst->d_shared || !src->d_shared || dst->n_shared != src->n_shared) return fail("adopt_shared_block: the handles do not hold the same model");
   CHK(cdae_hip_synchronize(src));

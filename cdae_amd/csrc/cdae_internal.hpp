@@ -49,6 +49,10 @@ int validate_test_rows(const int64_t* test_row_ptr, const uint32_t* test_col, ui
 // dst's shared block [W | W_ag | (V | V_ag) | b' | b'_ag | b | b_ag] := src's (same model, any two devices of this process); waits for
 // src's work, stream-ordered on dst's main stream.  The relay part of cdae_hip_multi_set_schedule hands the parameters on with it.
 int adopt_shared_block(cdae_hip_t* dst, cdae_hip_t* src);
+// the synchronous exchange's forms of cdae_hip_delta_stage / _merge (nothing trained between them: no snapshot, no send copy — the
+// all-reduce works in place on recv_buf); a stage_sync must be followed by merge_sync before anything else touches the exchange state
+int delta_stage_sync(cdae_hip_t* h);
+int delta_merge_sync(cdae_hip_t* h);
 
 // exchange state owned by cdae_multi.hip, destroyed with the handle
 void*& exchange_slot(cdae_hip_t* h);

@@ -2561,7 +2561,10 @@ __device__ __forceinline__ void delta_pipe_elem(float& c, float& A, float& snap,
   cdae_xa::pipe_elem<MODE>(c, A, snap, s, r);
 }
 
-template <int MODE>
+// SYNC (round 6): the synchronous exchange of a rank that owns its device — nothing is trained between a STAGE and its MERGE, so
+// c - snap is exactly 0 and c == A after the merge: the STAGE pass writes neither snap nor the send copy (the all-reduce works in place
+// on recv), the MERGE pass reads neither cur nor snap.  Same values (c = A + 0), 7 array passes over the block per step instead of 11.
+template <int MODE, bool SYNC = false>
 __global__ void __launch_bounds__(256)
 delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ snap, float* __restrict__ send,
                   float* __restrict__ recv, size_t n_matrix /* padded floats of all matrices */, uint32_t Kp, uint32_t Kc,
@@ -2586,30 +2589,30 @@ delta_pipe_kernel(float* __restrict__ cur, float* __restrict__ base, float* __re
   }
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (width == 4) {
-    float4 c = *reinterpret_cast<float4*>(cur + pad_off), b = *reinterpret_cast<float4*>(base + pad_off);
-    float4 sn = MODE == DELTA_STAGE ? zero4 : *reinterpret_cast<float4*>(snap + pad_off);
+    float4 c = (SYNC && MODE == DELTA_MERGE) ? zero4 : *reinterpret_cast<float4*>(cur + pad_off), b = *reinterpret_cast<float4*>(base + pad_off);
+    float4 sn = (MODE == DELTA_STAGE || SYNC) ? zero4 : *reinterpret_cast<float4*>(snap + pad_off);
     float4 s = zero4;
     float4 r = MODE == DELTA_STAGE ? zero4 : *reinterpret_cast<float4*>(recv + cmp_off);
     delta_pipe_elem<MODE>(c.x, b.x, sn.x, s.x, r.x); delta_pipe_elem<MODE>(c.y, b.y, sn.y, s.y, r.y);
     delta_pipe_elem<MODE>(c.z, b.z, sn.z, s.z, r.z); delta_pipe_elem<MODE>(c.w, b.w, sn.w, s.w, r.w);
     if (MODE != DELTA_STAGE) { *reinterpret_cast<float4*>(cur + pad_off) = c; *reinterpret_cast<float4*>(base + pad_off) = b; }
     if (MODE != DELTA_MERGE) {
-      *reinterpret_cast<float4*>(snap + pad_off) = sn;
-      *reinterpret_cast<float4*>(send + cmp_off) = s; *reinterpret_cast<float4*>(recv + cmp_off) = r;
+      if (!SYNC) { *reinterpret_cast<float4*>(snap + pad_off) = sn; *reinterpret_cast<float4*>(send + cmp_off) = s; }
+      *reinterpret_cast<float4*>(recv + cmp_off) = r;
     }
   } else {
-    float c = cur[pad_off], b = base[pad_off];
-    float sn = MODE == DELTA_STAGE ? 0.f : snap[pad_off], s = 0.f, r = MODE == DELTA_STAGE ? 0.f : recv[cmp_off];
+    float c = (SYNC && MODE == DELTA_MERGE) ? 0.f : cur[pad_off], b = base[pad_off];
+    float sn = (MODE == DELTA_STAGE || SYNC) ? 0.f : snap[pad_off], s = 0.f, r = MODE == DELTA_STAGE ? 0.f : recv[cmp_off];
     delta_pipe_elem<MODE>(c, b, sn, s, r);
     if (MODE != DELTA_STAGE) { cur[pad_off] = c; base[pad_off] = b; }
-    if (MODE != DELTA_MERGE) { snap[pad_off] = sn; send[cmp_off] = s; recv[cmp_off] = r; }
+    if (MODE != DELTA_MERGE) { if (!SYNC) { snap[pad_off] = sn; send[cmp_off] = s; } recv[cmp_off] = r; }
   }
 }
 
 // The same three passes under the GLOBAL-ACCUMULATOR combine rule (cdae_xa::pipe_pair; cdae_hip_delta_set_combine): a thread takes a
 // parameter element TOGETHER with its AdaGrad accumulator — matrix 2j with matrix 2j + 1 ([W | W_ag | (V | V_ag)]), b' with b'_ag,
 // b with b_ag — same compact send / recv layout as delta_pipe_kernel, so the all-reduce between the passes does not change.
-template <int MODE>
+template <int MODE, bool SYNC = false>
 __global__ void __launch_bounds__(256)
 delta_pipe_pair_kernel(float* __restrict__ cur, float* __restrict__ base, float* __restrict__ snap, float* __restrict__ send,
                        float* __restrict__ recv, size_t n_matrix, uint32_t Kp, uint32_t Kc, uint32_t num_items, float beta) {
@@ -2633,12 +2636,13 @@ delta_pipe_pair_kernel(float* __restrict__ cur, float* __restrict__ base, float*
     return;
   }
   if (width == 4) {
-    float4 c = *reinterpret_cast<float4*>(cur + pp), ca = *reinterpret_cast<float4*>(cur + pa);
-    float4 A = *reinterpret_cast<float4*>(base + pp), Aa = *reinterpret_cast<float4*>(base + pa);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr bool NO_CUR = SYNC && MODE == DELTA_MERGE;            // (c - snap is exactly 0: neither is read)
+    float4 c = NO_CUR ? zero4 : *reinterpret_cast<float4*>(cur + pp), ca = NO_CUR ? zero4 : *reinterpret_cast<float4*>(cur + pa);
+    float4 A = *reinterpret_cast<float4*>(base + pp), Aa = *reinterpret_cast<float4*>(base + pa);
     float4 sn = zero4, sna = zero4, s = zero4, sa = zero4, r = zero4, ra = zero4;
     if (MODE != DELTA_STAGE) {
-      sn = *reinterpret_cast<float4*>(snap + pp); sna = *reinterpret_cast<float4*>(snap + pa);
+      if (!SYNC) { sn = *reinterpret_cast<float4*>(snap + pp); sna = *reinterpret_cast<float4*>(snap + pa); }
       r = *reinterpret_cast<float4*>(recv + cpo); ra = *reinterpret_cast<float4*>(recv + cao);
     }
     cdae_xa::pipe_pair<MODE>(c.x, ca.x, A.x, Aa.x, sn.x, sna.x, s.x, sa.x, r.x, ra.x, beta);
@@ -2650,17 +2654,20 @@ delta_pipe_pair_kernel(float* __restrict__ cur, float* __restrict__ base, float*
       *reinterpret_cast<float4*>(base + pp) = A; *reinterpret_cast<float4*>(base + pa) = Aa;
     }
     if (MODE != DELTA_MERGE) {
-      *reinterpret_cast<float4*>(snap + pp) = sn; *reinterpret_cast<float4*>(snap + pa) = sna;
-      *reinterpret_cast<float4*>(send + cpo) = s; *reinterpret_cast<float4*>(send + cao) = sa;
+      if (!SYNC) {
+        *reinterpret_cast<float4*>(snap + pp) = sn; *reinterpret_cast<float4*>(snap + pa) = sna;
+        *reinterpret_cast<float4*>(send + cpo) = s; *reinterpret_cast<float4*>(send + cao) = sa;
+      }
       *reinterpret_cast<float4*>(recv + cpo) = r; *reinterpret_cast<float4*>(recv + cao) = ra;
     }
   } else {
-    float c = cur[pp], ca = cur[pa], A = base[pp], Aa = base[pa];
+    constexpr bool NO_CUR = SYNC && MODE == DELTA_MERGE;
+    float c = NO_CUR ? 0.f : cur[pp], ca = NO_CUR ? 0.f : cur[pa], A = base[pp], Aa = base[pa];
     float sn = 0.f, sna = 0.f, s = 0.f, sa = 0.f, r = 0.f, ra = 0.f;
-    if (MODE != DELTA_STAGE) { sn = snap[pp]; sna = snap[pa]; r = recv[cpo]; ra = recv[cao]; }
+    if (MODE != DELTA_STAGE) { if (!SYNC) { sn = snap[pp]; sna = snap[pa]; } r = recv[cpo]; ra = recv[cao]; }
     cdae_xa::pipe_pair<MODE>(c, ca, A, Aa, sn, sna, s, sa, r, ra, beta);
     if (MODE != DELTA_STAGE) { cur[pp] = c; cur[pa] = ca; base[pp] = A; base[pa] = Aa; }
-    if (MODE != DELTA_MERGE) { snap[pp] = sn; snap[pa] = sna; send[cpo] = s; send[cao] = sa; recv[cpo] = r; recv[cao] = ra; }
+    if (MODE != DELTA_MERGE) { if (!SYNC) { snap[pp] = sn; snap[pa] = sna; send[cpo] = s; send[cao] = sa; } recv[cpo] = r; recv[cao] = ra; }
   }
 }
 

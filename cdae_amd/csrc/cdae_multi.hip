@@ -126,6 +126,7 @@ struct Exchange {
   // thing the main stream does — so it is issued ON the main stream: stage -> all-reduce -> merge in order, no event hand-off to the
   // collective stream and back (two system-scope hops per step, ~10 us each).  Same buffers, same arithmetic.
   bool reduced_on_main = false;          // the pending all-reduce was issued on the main stream: the merge needs no event wait
+  bool staged_sync = false;              // the pending delta was staged by delta_stage_sync (no snapshot): it must be merged by delta_merge_sync
 };
 
 void free_exchange(void* p) {
@@ -184,8 +185,14 @@ int boundary_stage(Exchange* x, bool start_next) {
     if (x->local.empty()) { if (!x->reduced_on_main) HIPCHK(hipStreamWaitEvent(st, x->ev_reduced, 0)); }
     else for (Exchange* p : x->local) HIPCHK(hipStreamWaitEvent(st, p->ev_reduced, 0));
   }
-  if (x->pending && start_next) CHK(cdae_hip_delta_merge_stage(x->h));
+  if (x->pending && x->staged_sync) {                           // (a synchronous step's merge: directly behind its stage and all-reduce)
+    CHK(cdae_internal::delta_merge_sync(x->h));
+    x->staged_sync = false;
+    if (start_next) CHK(cdae_hip_delta_stage(x->h));
+  }
+  else if (x->pending && start_next) CHK(cdae_hip_delta_merge_stage(x->h));
   else if (x->pending) CHK(cdae_hip_delta_merge(x->h));
+  else if (start_next && sync_on_main(x) && !DEV_ENV("CDAE_XCHG_FULL_PASSES")) { CHK(cdae_internal::delta_stage_sync(x->h)); x->staged_sync = true; }
   else if (start_next) CHK(cdae_hip_delta_stage(x->h));
   x->pending = false;
   if (start_next && !sync_on_main(x)) HIPCHK(hipEventRecord(x->ev_staged, st));
@@ -330,7 +337,7 @@ int cdae_hip_exchange_time_all_reduce(cdae_hip_t* h, int repeats, double* second
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   *seconds = 1e-3 * ms / repeats;
   // the timing runs summed garbage into the receive buffer: restart from a fresh base with a zero staged delta
-  x->begun = false; x->pending = false; x->steps = 0;
+  x->begun = false; x->pending = false; x->staged_sync = false; x->steps = 0;
   CHK(begin_if_needed(x));
   CHK(cdae_hip_synchronize(h));
   return 0;
@@ -473,7 +480,7 @@ int relay_part(cdae_hip_multi* m, uint64_t seed, uint32_t epoch, uint64_t R, std
   for (cdae_hip_t* h : m->shard) {
     CHK(cdae_hip_synchronize(h));
     Exchange* x = xof(h);
-    if (x) { x->begun = false; x->pending = false; x->steps = 0; }      // the exchange restarts from the relayed parameters
+    if (x) { x->begun = false; x->pending = false; x->staged_sync = false; x->steps = 0; }      // the exchange restarts from the relayed parameters
   }
   return 0;
 }
@@ -766,14 +773,14 @@ int cdae_hip_multi_set_interactions(cdae_hip_multi_t* m, uint64_t U, uint64_t I,
     CHK(init_group_comms(m));
     for (size_t s = 0; s < S; ++s) { xs[s]->comm = m->comms[s]; xs[s]->owns_comm = false; xs[s]->world = (int)S; xs[s]->rank = (int)s; }
   }
-  for (Exchange* x : xs) { x->begun = false; x->pending = false; x->steps = 0; }
+  for (Exchange* x : xs) { x->begun = false; x->pending = false; x->staged_sync = false; x->steps = 0; }
   return 0;
 }
 
 int cdae_hip_multi_init_params(cdae_hip_multi_t* m, uint64_t seed) {
   CHK(check_multi(m, true));
   for (cdae_hip_t* h : m->shard) CHK(cdae_hip_init_params(h, seed));     // identical shared blocks; Wu rows by global user id
-  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); if (x) { x->begun = false; x->pending = false; x->steps = 0; } }
+  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); if (x) { x->begun = false; x->pending = false; x->staged_sync = false; x->steps = 0; } }
   return 0;
 }
 
@@ -1104,7 +1111,7 @@ int cdae_hip_multi_set_param(cdae_hip_multi_t* m, uint32_t which, const float* h
     for (size_t s = 0; s < m->shard.size(); ++s)
       CHK(cdae_hip_set_param(m->shard[s], which, host + m->cut[s] * K, (m->cut[s + 1] - m->cut[s]) * K));
   }
-  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); if (x) { x->begun = false; x->pending = false; x->steps = 0; } }
+  for (cdae_hip_t* h : m->shard) { Exchange* x = xof(h); if (x) { x->begun = false; x->pending = false; x->staged_sync = false; x->steps = 0; } }
   return 0;
 }
 

@@ -166,6 +166,30 @@ def test_sharded_init_and_random_streams_are_those_of_the_single_gpu_run(small):
     np.testing.assert_array_equal(mm.recommend_all(10), one.recommend_all(10))
 
 
+def test_synchronous_collective_on_the_main_stream_changes_no_bit(small, monkeypatch, devlib):
+    """Round 6: a rank that owns its device issues the SYNCHRONOUS exchange's all-reduce on its main stream (stage -> all-reduce -> merge in
+    stream order, no event hand-off to the collective stream and back).  Against round 5's hand-off (CDAE_XCHG_COLLECTIVE_STREAM, developer
+    build): the same buffers and kernels in the same order — bit-identical parameters."""
+    def run():
+        a = cdae_amd.CDAE(cfg_of(B=64))
+        a.reset(small, seed=11)
+        a.comm_init_rank(1, 0, cdae_amd.comm_unique_id())
+        a.exchange_configure(0)
+        for lo in range(0, small.num_users, 64):
+            a.enqueue_users(3, 0, lo, min(small.num_users, lo + 64))
+            a.exchange_step()
+        a.exchange_flush()
+        a.synchronize()
+        out = {w: a.get(w) for w in SHARED + [cdae_amd.P_WU]}
+        a.close()
+        return out
+    main = run()
+    monkeypatch.setenv("CDAE_XCHG_COLLECTIVE_STREAM", "1")
+    side = run()
+    for w in main:
+        assert np.array_equal(main[w], side[w]), w
+
+
 @pytest.mark.parametrize("period", [0, 2])
 def test_library_owned_rccl_communicator_with_one_rank(small, period):
     """ncclGetUniqueId / ncclCommInitRank / ncclAllReduce inside the library, beside the training kernels: a one-rank group
