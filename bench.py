@@ -193,6 +193,11 @@ def main():
         args.layout = "item-rows" if (args.logical_shards or args.item_rows_devices or (world > 1 and args.full_output)) else ("certified" if world > 1 else "users")
     if args.layout == "item-rows":
         return bench_item_rows(args, rank, world)
+    if args.layout == "certified" and world > 1 and not (args.logical_shards or args.share_device) and torch.cuda.device_count() < world:
+        # rank 0 drives every GPU of the node in this layout: a launcher that shows each rank only its own device cannot run it
+        print(f"[bench] --layout certified needs all {world} devices visible to rank 0 (this process sees {torch.cuda.device_count()}): "
+              "falling back to --layout users (one process per GPU; THROUGHPUT ONLY, see config.accuracy)", file=sys.stderr)
+        args.layout = "users"
     if args.layout == "certified":
         return bench_certified(args, rank, world)
     if args.scaling == "strong" and world > 1:
