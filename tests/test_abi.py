@@ -75,7 +75,7 @@ def test_the_shipped_library_names_no_developer_switch(built):
     exist in the -DCDAE_DEVELOPER build only: the shipped library calls getenv nowhere, so their names are not in its string table; the
     developer build, made from the same sources, has them."""
     switches = [b"CDAE_DEBUG_SKIP_ROLES", b"CDAE_DEBUG_SKIP_PREP", b"CDAE_SORT_TILE", b"CDAE_GEMM1_TILED", b"CDAE_FULL_UNFUSED", b"CDAE_WAVE_TRACE",
-                b"CDAE_PREP2", b"CDAE_DUP_CAP", b"CDAE_XCHG_STREAM", b"CDAE_FULL_B_SUMMED", b"CDAE_DECODE_UNFUSED", b"CDAE_NO_LATE_ROWS", b"CDAE_XCHG_COLLECTIVE_STREAM", b"CDAE_XCHG_FULL_PASSES", b"CDAE_FUSED_BLOCK_ROUNDS"]
+                b"CDAE_PREP2", b"CDAE_DUP_CAP", b"CDAE_XCHG_STREAM", b"CDAE_FULL_B_SUMMED", b"CDAE_DECODE_UNFUSED", b"CDAE_NO_LATE_ROWS", b"CDAE_XCHG_COLLECTIVE_STREAM", b"CDAE_XCHG_FULL_PASSES", b"CDAE_FUSED_BLOCK_ROUNDS", b"CDAE_HOST_PACE_US"]
     blob = open(cdae_amd.LIB_PATH, "rb").read()
     assert not [s for s in switches if s in blob]
     names = set(re.findall(rb"CDAE_[A-Z0-9_]{3,}", blob))

@@ -221,12 +221,14 @@ def test_training_is_bit_deterministic_and_handles_reload(tiny, small):
 
 
 @pytest.mark.parametrize("env", [dict(CDAE_PREP_THREAD="0"), dict(CDAE_PREP2="off"), dict(CDAE_PREP2="own"), dict(CDAE_EVENT_SYSTEM_FENCE="1"),
-                                 dict(CDAE_ENCODE_TWO_LAUNCHES="1"), dict(CDAE_SORT_TILE="1"), dict(CDAE_SORT_LIBRARY="1"), dict(CDAE_SORT_SCAN="1"), dict(CDAE_GATHER_HALVES="1", CDAE_PREP2="aux")],
+                                 dict(CDAE_ENCODE_TWO_LAUNCHES="1"), dict(CDAE_SORT_TILE="1"), dict(CDAE_SORT_LIBRARY="1"), dict(CDAE_SORT_SCAN="1"), dict(CDAE_GATHER_HALVES="1", CDAE_PREP2="aux"),
+                                 dict(CDAE_HOST_PACE_US="0"), dict(CDAE_HOST_PACE_US="5")],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_scheduling_switches_do_not_change_a_single_bit(small, monkeypatch, devlib, env):
-    """The prep worker thread, the second prep lane, device-scope events, the one-launch encode and the tile counting sort change
-    WHEN work is issued and by which kernel — never the arithmetic or its order: parameters after two epochs are bit-identical
-    to the default configuration's."""
+    """The prep worker thread, the second prep lane, device-scope events, the one-launch encode, the tile counting sort and host pacing
+    (round 6: the caller's thread looks for the prepared lists itself, so that the main stream carries no wait for them; 0 = the device
+    always waits, 5 us = it mostly does) change WHEN work is issued and by which kernel — never the arithmetic or its order: parameters
+    after two epochs are bit-identical to the default configuration's."""
     cfg = cdae_amd.CDAEConfig(num_dim=40, lt=cdae_amd.CROSS_ENTROPY, beta=1.0, batch_users=64)
 
     def run():
