@@ -203,7 +203,10 @@ int cdae_hip_train_epoch(cdae_hip_t* h, uint64_t seed, uint32_t epoch, cdae_hip_
 int cdae_hip_train_users(cdae_hip_t* h, uint64_t seed, uint32_t epoch, uint64_t u_begin,
                          uint64_t u_end, cdae_hip_stats* stats);
 /* Asynchronous forms.  enqueue_users = train_users without the final host synchronisation (several calls
- * queue back to back on the library's stream); prefetch_users runs only the sampling + sorting of the leading
+ * queue back to back on the library's stream; the call returns when its batches are QUEUED, and since round 6 it paces
+ * itself on the side streams: before it queues a batch it looks, for at most 200 us, whether that batch's sampled and
+ * sorted lists are complete, so that the training stream need not wait for them — a call of n batches returns about
+ * two batches before the device has trained them, not n); prefetch_users runs only the sampling + sorting of the leading
  * batch(es) of a range on the side stream(s) — as many as the library looks ahead: one, or two where the second
  * prep lane is on — so that it overlaps whatever the caller does next (e.g. the RCCL all-reduce of the
  * data-parallel exchange); later train/enqueue calls for the same (seed, epoch) starting at the same user
