@@ -378,6 +378,10 @@ struct cdae_hip_multi {
   // collective and waits there for the rank that just failed) — waiting for it would be waiting for ourselves, and the abort is
   // exactly what releases it, so after the limit the abort goes ahead without the lock (ncclCommAbort is the one call RCCL allows
   // from another thread while a rank is blocked).  ncclCommAbort also frees the communicator: nothing is left to destroy.
+  // Known residual window (error path only; round-5 advice): a peer that has passed the `failed` check under the shared side and is then
+  // descheduled for longer than the limit BEFORE it enters ncclAllReduce would call into a freed communicator.  RCCL offers no abort that
+  // keeps the object alive, and waiting without a limit is the deadlock described above; the limit is 200 ms against the nanoseconds
+  // between the check and the call.
   void give_up() {
     if (guard.failed.exchange(1)) return;
     std::unique_lock<std::shared_timed_mutex> lk(guard.mu, std::defer_lock);
